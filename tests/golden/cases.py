@@ -1,0 +1,51 @@
+"""Procedural inputs shared by tests/golden/make_golden.py (which runs the reference on
+them, in the build container) and by the tests (which run the oracle / the HIP path on the
+same inputs anywhere).  Integer permutations + IEEE divisions only: bit-identical on every host."""
+import os
+import sys
+
+import numpy as np
+
+_REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _REPO not in sys.path:
+    sys.path.insert(0, _REPO)
+
+from cim_amd import synthetic  # noqa: E402
+from oracle import mask_iou as oracle_mask_iou  # noqa: E402  (test infrastructure: builds INPUT maps)
+
+THRESHOLDS = [(0.25, 0.5), (0.35, 0.6), (0.45, 0.7)]   # model_builder.py:90-93, step_rate 0.1
+
+MINING_CASES = {
+    # name: N, C, n_pos, mask grid (h, w), seed
+    "n64_c20_k1": dict(n=64, C=20, n_pos=1, hw=(60, 80), seed=11),
+    "n300_c20_k2": dict(n=300, C=20, n_pos=2, hw=(120, 160), seed=12),
+    "n300_c20_k3": dict(n=300, C=20, n_pos=3, hw=(120, 160), seed=13),
+    "n1000_c80_k3": dict(n=1000, C=80, n_pos=3, hw=(150, 200), seed=14),
+}
+
+
+def case_inputs(case):
+    """Procedural inputs of one mining case (shared with tests/test_oracle_mining.py)."""
+    rng = np.random.RandomState(case["seed"])
+    masks, _ = synthetic.make_masks(case["n"], case["hw"][0], case["hw"][1], rng, min_side=8)
+    iou, asy = oracle_mask_iou.mask_iou_maps(masks)
+    pos = np.sort(rng.choice(case["C"], size=case["n_pos"], replace=False))
+    labels = np.zeros((1, case["C"]), dtype=np.float32)
+    labels[0, pos] = 1
+    layers = []
+    for _ in THRESHOLDS:
+        cls, det, iouscore = synthetic.make_scores(case["n"], case["C"], rng)
+        layers.append((cls, det, iouscore))
+    mat = synthetic.make_mat(masks, pos, case["C"], rng)
+    return dict(masks=masks, iou=iou, asy=asy, labels=labels, layers=layers, mat=mat)
+
+
+
+def procedural(shape, salt):
+    """Closed-form pseudo-random weights: identical wherever they are regenerated."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.uint64)
+    h = (i * np.uint64(2654435761) + np.uint64(salt) * np.uint64(40503)) % np.uint64(1 << 20)
+    return ((h.astype(np.float64) / float(1 << 20) - 0.5) * 0.2).astype(np.float32).reshape(shape)
+
+

@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Capture golden vectors by RUNNING THE REFERENCE (/root/reference) in this container.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+The reference cannot travel to the GPU box, so its outputs are committed here as small
+.npz fixtures; inputs are regenerated procedurally (cim_amd/synthetic.py: integer
+permutations + IEEE divisions only, so they are bit-identical on every host) and are also
+stored for the small cases.  Intermediate stages of `CIM_layer` are captured with a
+sys.settrace tap on the reference's own frames (no reference code is edited or copied).
+
+What is captured:
+  mining_<case>.npz   per refinement layer: asy_iou_flag, per-class keep_sort_idx /
+                      keep_nms_idx / res_idx, post-arbitration gt_idxs/labels/weights,
+                      sampling keep-mask, RNG stream position, max_overlap_idx and the three
+                      outputs of CIM_layer.forward (heads.py:410-503)
+  losses_<case>.npz   cls_iou_loss / mil_bag_loss / PCL_loss in fp32 and fp64 (heads.py:10-166)
+  heads_small.npz     cls_iou_model.forward on procedural weights (heads.py:168-219)
+  mask_iou_<n>.npz    mask_iou / mask_asymmetric_iou driven column-by-column as
+                      tools/pre/create_cob_iou.py:43-49 does (lib/utils/mask_utils.py:6-32)
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import _ref_shims  # noqa: E402
+from cim_amd import synthetic  # noqa: E402
+from oracle import mask_iou as oracle_mask_iou  # noqa: E402  (only to build INPUT maps)
+from cases import MINING_CASES, THRESHOLDS, case_inputs, procedural  # noqa: E402
+
+class FrameTap:
+    """sys.settrace tap on heads.py frames: snapshots named locals of CIM_label / MIST_label
+    per class iteration and the locals of CIM_layer.forward at return."""
+    VARS = ("keep_sort_idx", "keep_nms_idx", "res_idx")
+
+    def __init__(self):
+        self.per_class = {}
+        self.order = []
+        self.label_ret = None
+        self.fwd_locals = None
+        self._cur = None
+        self._stale = {}
+        self._last = {}
+
+    def __call__(self, frame, event, arg):
+        co = frame.f_code
+        if co.co_filename.endswith("modeling/heads.py") and co.co_name in ("CIM_label", "MIST_label", "forward"):
+            return self._local
+        return None
+
+    def _local(self, frame, event, arg):
+        name = frame.f_code.co_name
+        loc = frame.f_locals
+        if name in ("CIM_label", "MIST_label"):
+            if "c" in loc and torch.is_tensor(loc["c"]):
+                c = int(loc["c"])
+                if c != self._cur:
+                    self._cur = c
+                    self.order.append(c)
+                    # strong references (not ids): a freed tensor's id can be reused
+                    self._stale = {v: loc.get(v) for v in self.VARS}
+                    self._last = {}
+                rec = self.per_class.setdefault(c, {})
+                for v in self.VARS:
+                    t = loc.get(v)
+                    if torch.is_tensor(t) and t is not self._stale.get(v) and t is not self._last.get(v):
+                        rec[v] = t.clone().numpy()
+                        self._last[v] = t
+            if event == "return" and arg is not None:
+                self.label_ret = [a.clone().numpy() if torch.is_tensor(a) else a for a in arg]
+        elif name == "forward" and event == "return" and "self" in loc and type(loc["self"]).__name__ == "CIM_layer":
+            keep = {}
+            for k in ("gt_idxs", "inds", "max_overlap_idx", "gt_labels", "gt_weights"):
+                if torch.is_tensor(loc.get(k)):
+                    keep[k] = loc[k].clone().numpy()
+            self.fwd_locals = keep
+        return self._local
+
+
+def run_layer(heads, layer, cls, det, labels, iou, asy, using_cim, seed):
+    tap = FrameTap()
+    np.random.seed(seed)
+    rois = torch.zeros(cls.shape[0], 5)
+    sys.settrace(tap)
+    try:
+        out = layer(torch.from_numpy(cls), torch.from_numpy(det) if det is not None else None, rois,
+                    torch.from_numpy(labels), torch.from_numpy(iou), torch.from_numpy(asy), using_CIM=using_cim)
+    finally:
+        sys.settrace(None)
+    rng_probe = np.random.random_sample()          # pins the stream position after the call
+    return out, tap, rng_probe
+
+
+def pack_layer(prefix, out, tap, rng_probe, store):
+    store[prefix + "is_none"] = np.array(out[0] is None)
+    store[prefix + "rng_probe"] = np.array(rng_probe)
+    store[prefix + "class_order"] = np.array(tap.order, dtype=np.int64)
+    for c in tap.order:
+        for v, a in tap.per_class.get(c, {}).items():
+            store["%sc%d_%s" % (prefix, c, v)] = a
+    ret = tap.label_ret
+    # CIM_label returns (boxes, labels, weights, idxs, asy_flag); MIST_label (boxes, labels, weights, idxs)
+    store[prefix + "label_gt_labels"] = ret[1]
+    store[prefix + "label_gt_weights"] = ret[2]
+    store[prefix + "label_gt_idxs"] = ret[3]
+    if len(ret) == 5:
+        store[prefix + "asy_iou_flag"] = ret[4]
+    if out[0] is not None:
+        fl = tap.fwd_locals
+        if "inds" in fl:
+            store[prefix + "sample_keep"] = fl["inds"]
+        store[prefix + "max_overlap_idx"] = fl["max_overlap_idx"]
+        store[prefix + "pseudo_labels"] = out[0].numpy()
+        store[prefix + "pseudo_iou_labels"] = out[1].numpy()
+        store[prefix + "loss_weights"] = out[2].numpy()
+
+
+def gen_mining(heads):
+    for name, case in MINING_CASES.items():
+        inp = case_inputs(case)
+        store = dict(n=np.array(case["n"]), C=np.array(case["C"]), labels=inp["labels"])
+        if case["n"] <= 64:
+            store.update(in_iou=inp["iou"], in_asy=inp["asy"],
+                         in_masks_packed=np.packbits(inp["masks"].reshape(case["n"], -1), axis=1))
+        for li, (cls_thr, iou_thr) in enumerate(THRESHOLDS):
+            cls, det, _ = inp["layers"][li]
+            if case["n"] <= 64:
+                store["in_l%d_cls" % li] = cls
+                store["in_l%d_det" % li] = det
+            layer = heads.CIM_layer(p_seed=0.1, cls_thr=cls_thr, iou_thr=iou_thr, Anti_noise_sampling=True)
+            out, tap, probe = run_layer(heads, layer, cls, det, inp["labels"], inp["iou"], inp["asy"], True, 100 + li)
+            pack_layer("l%d_" % li, out, tap, probe, store)
+        # no anti-noise sampling
+        cls, det, _ = inp["layers"][0]
+        layer = heads.CIM_layer(p_seed=0.1, cls_thr=0.25, iou_thr=0.5, Anti_noise_sampling=False)
+        out, tap, probe = run_layer(heads, layer, cls, det, inp["labels"], inp["iou"], inp["asy"], True, 7)
+        pack_layer("nosample_", out, tap, probe, store)
+        # MIST strategy (using_CIM=False), heads.py:421-427
+        layer = heads.CIM_layer(p_seed=0.1, cls_thr=0.25, iou_thr=0.5, Anti_noise_sampling=True)
+        out, tap, probe = run_layer(heads, layer, cls, det, inp["labels"], inp["iou"], inp["asy"], False, 8)
+        pack_layer("mist_", out, tap, probe, store)
+        np.savez_compressed(os.path.join(HERE, "mining_%s.npz" % name), **store)
+        print("mining", name, "G per layer:",
+              [int(store["l%d_label_gt_idxs" % i].sum()) for i in range(3)],
+              "kept:", [int(store.get("l%d_sample_keep" % i, np.zeros(0)).sum()) for i in range(3)])
+
+    # degenerate: every proposal contains >= 90% of all proposals -> asy_iou_flag all False -> (None,)*3
+    n, C = 16, 20
+    rng = np.random.RandomState(5)
+    masks = np.zeros((n, 20, 20), dtype=bool)
+    masks[:, 2:18, 3:17] = True
+    iou, asy = oracle_mask_iou.mask_iou_maps(masks)
+    cls, det, _ = synthetic.make_scores(n, C, rng)
+    labels = np.zeros((1, C), dtype=np.float32)
+    labels[0, [3, 7]] = 1
+    store = dict(in_iou=iou, in_asy=asy, in_cls=cls, in_det=det, labels=labels)
+    layer = heads.CIM_layer(p_seed=0.1, cls_thr=0.25, iou_thr=0.5, Anti_noise_sampling=True)
+    out, tap, probe = run_layer(heads, layer, cls, det, labels, iou, asy, True, 9)
+    pack_layer("huge_", out, tap, probe, store)
+    # degenerate: no positive image label -> no class loop -> None
+    out, tap, probe = run_layer(heads, layer, cls, det, np.zeros((1, C), dtype=np.float32), iou, asy, True, 9)
+    store["nolabel_is_none"] = np.array(out[0] is None)
+    np.savez_compressed(os.path.join(HERE, "mining_degenerate.npz"), **store)
+    print("mining degenerate: huge none =", out[0] is None)
+
+
+def gen_losses(heads):
+    for name in ("n300_c20_k2", "n1000_c80_k3"):
+        case = MINING_CASES[name]
+        inp = case_inputs(case)
+        gold = np.load(os.path.join(HERE, "mining_%s.npz" % name))
+        labels = torch.from_numpy(inp["labels"])
+        store = {}
+        for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            for li in range(3):
+                lmda = 3 if li == 0 else 1
+                cls, _, iou = inp["layers"][li]
+                pl = torch.from_numpy(gold["l%d_pseudo_labels" % li]).to(dt)
+                pil = torch.from_numpy(gold["l%d_pseudo_iou_labels" % li])     # fp16 like the reference
+                lw = lmda * torch.from_numpy(gold["l%d_loss_weights" % li]).to(dt)
+                c, i, b = heads.cls_iou_loss(torch.from_numpy(cls).to(dt), torch.from_numpy(iou).to(dt),
+                                             pl, pil, lw, labels.to(dt))
+                store["%s_l%d_cls_iou_bag" % (tag, li)] = np.array([float(c), float(i), float(b)], dtype=np.float64)
+            cls, det, _ = inp["layers"][0]
+            store[tag + "_mil_bag"] = np.array(float(heads.mil_bag_loss(
+                torch.from_numpy(cls).to(dt), torch.from_numpy(det).to(dt), labels.to(dt))))
+            store[tag + "_pcl"] = np.array(float(heads.PCL_loss(
+                torch.from_numpy(cls).to(dt), torch.from_numpy(inp["mat"]).to(dt), labels.to(dt))))
+            # branch: no pseudo-labelled row (heads.py:104) and: only background rows (heads.py:117)
+            cls, _, iou = inp["layers"][1]
+            n, C1 = cls.shape
+            zero_pl = torch.zeros(n, C1, dtype=dt)
+            bg_pl = torch.zeros(n, C1, dtype=dt)
+            bg_pl[::3, 0] = 1
+            lw = torch.from_numpy(gold["l1_loss_weights"]).to(dt)
+            pil = torch.from_numpy(gold["l1_pseudo_iou_labels"])
+            c, i, b = heads.cls_iou_loss(torch.from_numpy(cls).to(dt), torch.from_numpy(iou).to(dt),
+                                         bg_pl, pil, lw, labels.to(dt))
+            store["%s_bgonly_cls_iou_bag" % tag] = np.array([float(c), float(i), float(b)], dtype=np.float64)
+            # all-zero pseudo labels: the reference asserts (heads.py:51) before reaching heads.py:104
+            try:
+                heads.cls_iou_loss(torch.from_numpy(cls).to(dt), torch.from_numpy(iou).to(dt),
+                                   zero_pl, pil, lw, labels.to(dt))
+                raised = False
+            except AssertionError:
+                raised = True
+            store["%s_empty_raises_assertion" % tag] = np.array(raised)
+        np.savez_compressed(os.path.join(HERE, "losses_%s.npz" % name), **store)
+        print("losses", name, {k: v.tolist() for k, v in store.items() if k.startswith("f32")})
+
+
+def gen_heads_small(heads):
+    dim_in, C1, n = 64, 21, 50
+    model = heads.cls_iou_model(dim_in, C1, 3)
+    with torch.no_grad():
+        for k, (pname, p) in enumerate(model.named_parameters()):
+            p.copy_(torch.from_numpy(procedural(tuple(p.shape), k + 1)))
+    x = torch.from_numpy(procedural((n, dim_in), 99) * 20)
+    with torch.no_grad():
+        pc, pd, rc, ri = model(x)
+    np.savez_compressed(os.path.join(HERE, "heads_small.npz"),
+                        predict_cls=pc.numpy(), predict_det=pd.numpy(),
+                        refine_cls=np.stack([t.numpy() for t in rc]), refine_iou=np.stack([t.numpy() for t in ri]))
+    print("heads_small ok", pc.shape)
+
+
+def gen_mask_iou():
+    mu = importlib.import_module("utils.mask_utils")
+    for n, hw, seed in ((6, (37, 53), 21), (64, (75, 101), 22)):
+        rng = np.random.RandomState(seed)
+        masks, _ = synthetic.make_masks(n, hw[0], hw[1], rng, min_side=4)
+        masks[n - 1] = False
+        masks[n - 1, hw[0] - 1, hw[1] - 1] = True            # single-pixel mask in the packing tail
+        iou_cols, asy_cols = [], []
+        for j in range(n):                                    # create_cob_iou.py:43-46
+            iou_cols.append(mu.mask_iou(masks, np.expand_dims(masks[j], axis=0)))
+            asy_cols.append(mu.mask_asymmetric_iou(masks, np.expand_dims(masks[j], axis=0)))
+        iou = np.concatenate(iou_cols, axis=1).astype(np.float16)
+        asy = np.concatenate(asy_cols, axis=1).astype(np.float16)
+        np.savez_compressed(os.path.join(HERE, "mask_iou_%d.npz" % n), h=np.array(hw[0]), w=np.array(hw[1]),
+                            masks_packed=np.packbits(masks.reshape(n, -1), axis=1), iou=iou, asy=asy)
+        print("mask_iou", n, iou.shape, float(iou.astype(np.float32).mean()))
+
+
+def main():
+    _ref_shims.install()
+    heads = importlib.import_module("modeling.heads")
+    gen_mining(heads)
+    gen_losses(heads)
+    gen_heads_small(heads)
+    gen_mask_iou()
+
+
+if __name__ == "__main__":
+    main()
