@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the CIM per-image training step (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one synthetic image per GPU through the whole hot path: backbone fwd -> fused
+ROIAlign+mask-cat -> MaskFuse -> 8 heads -> 3 x CIM mining (+ host anti-noise sampling) -> 4 losses
+-> backward -> gradient all-reduce (RCCL) -> SGD step.  Workload at N=1 = BASELINE configs[1]
+(resnet50_voc, bs=1, 1000 proposals, 516x688 image).  Weak scaling: one image per rank.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from cim_amd import _lib, mask_iou, synthetic  # noqa: E402
+from cim_amd.core.config import cfg  # noqa: E402
+from cim_amd.core.presets import apply_preset  # noqa: E402
+from cim_amd.modeling.model_builder import Generalized_RCNN  # noqa: E402
+from cim_amd.nn import DataParallel  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+class KernelTimer:
+    """HIP events around selected C-ABI launches / module calls, recorded on the launch stream
+    inside the timed region (torch.cuda.Event records on torch's current stream, which is the
+    stream every launch here uses)."""
+
+    def __init__(self):
+        self.spans = {}
+        self.enabled = False
+
+    def span(self, name):
+        timer = self
+
+        class _Ctx:
+            def __enter__(self):
+                if timer.enabled:
+                    self.a = torch.cuda.Event(enable_timing=True)
+                    self.b = torch.cuda.Event(enable_timing=True)
+                    self.a.record()
+
+            def __exit__(self, *exc):
+                if timer.enabled:
+                    self.b.record()
+                    timer.spans.setdefault(name, []).append((self.a, self.b))
+        return _Ctx()
+
+    def mean_ms(self, name):
+        ev = self.spans.get(name, [])
+        return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+
+
+def instrument(model, timer):
+    orig_call = _lib.call
+
+    def call(name, *args):
+        if name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_bwd"):
+            with timer.span(name):
+                return orig_call(name, *args)
+        return orig_call(name, *args)
+
+    _lib.call = call
+    import cim_amd.ops.roi_align as ra
+    ra._lib.call = call
+    conv = model.Box_Head.mask_branch[0]
+    orig_fwd = conv.forward
+
+    def fwd(x):
+        with timer.span("maskfuse_conv_fwd"):
+            return orig_fwd(x)
+
+    conv.forward = fwd
+
+
+def make_optimizer(model):
+    """Param groups of tools/train.py:282-311 (bias: lr x2, no weight decay), SGD momentum 0.9."""
+    bias, nonbias = [], []
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            (bias if "bias" in name else nonbias).append(p)
+    lr, wd = 0.0005, 0.0005                                   # configs/resnet50_voc.yaml SOLVER
+    return torch.optim.SGD([dict(params=nonbias, lr=lr, weight_decay=wd),
+                            dict(params=bias, lr=2 * lr, weight_decay=0.0)], lr=lr, momentum=0.9, foreach=True)
+
+
+def cpu_baseline(config, budget_n=64):
+    """The oracle's CPU restatement of the same step, timed on this host (bounded sample)."""
+    from oracle import cpu_step, mask_iou as omi
+    apply_preset(config)
+    torch.manual_seed(3)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    model = Generalized_RCNN().train()
+    inp = synthetic.make_image_inputs(config, seed=3)
+    n = inp["rois"].shape[0]
+    iou, asy = omi.mask_iou_maps(inp["full_masks"])
+    tm = {}
+    t0 = time.perf_counter()
+    cpu_step.step(model, inp, iou, asy, n_sub=budget_n, seed=3, timings=tm)
+    wall = time.perf_counter() - t0
+    # backbone + mining run on the full workload inside the sample; the proposal-linear phases
+    # (ROIAlign, MaskFuse, heads, losses and their backward) ran on n_sub of n proposals.
+    scale = n / float(budget_n)
+    fixed = tm["backbone_fwd"] + tm["backbone_bwd"]
+    linear = tm["roialign_fwd"] + tm["head_fwd"] + tm["losses_fwd"] + tm["head_bwd"] + tm["mining"]
+    est = fixed + linear * scale
+    return dict(value=1.0 / est, unit="images/s", cores=threads, kind="port",
+                sample="oracle/cpu_step.py fwd+bwd of %s: backbone on the full image, ROIAlign/MaskFuse/heads/"
+                       "mining/losses/backward on the first %d of %d proposals, proposal-linear phases scaled x%.1f "
+                       "(measured %.1f s; phases %s)" % (config, budget_n, n, scale, wall,
+                                                         {k: round(v, 2) for k, v in tm.items()}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="resnet50_voc")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=64)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    _lib.load()                                                # no HIP extension -> fail loudly
+
+    apply_preset(args.config)
+    torch.manual_seed(cfg.RNG_SEED)                            # identical initial weights on every rank
+    model = Generalized_RCNN().to(dev).train()
+    timer = KernelTimer()
+    instrument(model, timer)
+    dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True)
+    opt = make_optimizer(model)
+
+    inp = synthetic.make_image_inputs(args.config, seed=cfg.RNG_SEED + rank)     # one image per rank
+    n = inp["rois"].shape[0]
+    iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
+    t = lambda a: [torch.from_numpy(a).unsqueeze(0).to(dev)]
+    batch = dict(data=[torch.from_numpy(inp["data"]).to(dev)], rois=t(inp["rois"]), masks=t(inp["masks"]),
+                 labels=t(inp["labels"]), gtrois=[None], mat=t(inp["mat"]), index=t(inp["index"]),
+                 iou_map=[iou], asy_iou_map=[asy])
+    np.random.seed(cfg.RNG_SEED + rank)                        # the anti-noise sampling stream
+
+    def step():
+        dp.zero_grad()
+        out = dp(**batch)
+        loss = sum(v.sum() for v in out["losses"].values()) * dp.loss_scale()
+        loss.backward()
+        dp.finish_gradient_sync()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer.enabled = True
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    assert torch.isfinite(loss), "non-finite loss in the timed region"
+
+    if rank == 0:
+        H, W = inp["image_hw"]
+        Cf = model.Conv_Body.dim_out
+        Hf, Wf = -(-H // 16), -(-W // 16)
+        # dominant kernel: MaskFuse 3x3 conv forward (a-2), 2*49*N*(2Cf*9)*Cf flops
+        conv_ms = timer.mean_ms("maskfuse_conv_fwd")
+        conv_flops = 2.0 * 49 * n * (2 * Cf * 9) * Cf
+        roofline = dict(bound="mfma", kernel="maskfuse_conv3x3_fwd", achieved=conv_flops / (conv_ms * 1e-3) / 1e12,
+                        peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None)
+        roofline["frac"] = roofline["achieved"] / roofline["peak"]
+        # HBM-bound hand-written kernels: fused ROIAlign+mask-cat fwd / bwd
+        ra_bytes = 4.0 * (Cf * Hf * Wf + 5 * n + 49 * n) + 4.0 * n * 2 * Cf * 49
+        hbm = []
+        for name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_bwd"):
+            ms = timer.mean_ms(name)
+            if ms:
+                ach = ra_bytes / (ms * 1e-3) / 1e9
+                hbm.append(dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=ach / HBM_PEAK_GBS, ms=ms, traffic=None))
+        line = dict(metric="images/sec training step (ResNet-50 VOC, ~1k proposals/img)",
+                    value=world * args.steps / elapsed, unit="images/s", n_gpus=world, steps=args.steps,
+                    warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+                    scaling="weak", vs_baseline=None, dtype="fp32", data="synthetic",
+                    config=dict(workload="%s bs=1/GPU, %d proposals, image 3x%dx%d, feature %dx%dx%d, iter_size=1"
+                                         % (args.config, n, H, W, Cf, Hf, Wf), parallelism="dp%d" % world),
+                    roofline=roofline, roofline_hbm=hbm)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

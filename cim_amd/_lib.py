@@ -1,0 +1,68 @@
+"""ctypes binding of libcim_hip.so (include/cim_hip.h).  There is NO fallback: if the HIP
+library is missing or a call fails, this raises."""
+import ctypes
+import os
+
+from ctypes import c_float, c_int, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcim_hip.so")
+
+# name -> argtypes (all return int)
+_P = c_void_p
+SIGNATURES = {
+    "cim_roi_align_fwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
+    "cim_roi_align_bwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
+    "cim_roi_align_maskcat_fwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
+    "cim_roi_align_maskcat_bwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
+    "cim_mask_pack": [_P, _P, c_int, c_int, _P],
+    "cim_mask_iou_pair": [_P, c_int, c_int, _P, _P, _P, _P],
+    "cim_asy_flag": [_P, c_int, c_float, _P, _P],
+    "cim_seed_select": [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P],
+    "cim_contain_argmax": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P],
+    "cim_arbitrate": [_P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P],
+    "cim_assign": [_P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P],
+}
+
+_lib = None
+
+
+class CimHipError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CimHipError(
+            "libcim_hip.so not found at %s - build it with `python -m cim_amd.build` "
+            "(there is no CPU fallback for the CIM hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.cim_last_error.restype = ctypes.c_char_p
+    lib.cim_last_error.argtypes = []
+    lib.cim_abi_version.restype = c_int
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise CimHipError("%s failed (rc=%d): %s" % (name, rc, lib.cim_last_error().decode()))
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a dense tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

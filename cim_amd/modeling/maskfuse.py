@@ -1,0 +1,44 @@
+"""`MaskFuse` box head: ROIAlign -> (box_x, box_x * mask) -> 3x3 conv 2C->C -> FC 49C->4096 -> FC.
+
+Mirrors MaskFuse of /root/reference/lib/modeling/resnet50.py:94-138 (vgg16.py:135-179,
+HRNet.py:588-632): same constructor `(dim_in, roi_xform_func, spatial_scale)`, same parameter
+names (`mask_branch.0`, `seg_fc.0`, `seg_fc.2`) and the same (c, h, w) flatten order into
+`seg_fc.0`, so reference checkpoints load unchanged.
+
+MI355X design: the ROIAlign output, the mask product and the channel concat are produced by
+ONE fused HIP kernel straight into the conv input (channels-last), instead of three
+materialised tensors (box_x, mask_x, cat) as in the reference.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..core.config import cfg
+from ..ops import roi_align_maskcat
+
+
+class MaskFuse(nn.Module):
+    def __init__(self, dim_in, roi_xform_func, spatial_scale):
+        super().__init__()
+        self.dim_in = dim_in
+        self.roi_xform = roi_xform_func
+        self.spatial_scale = spatial_scale
+        self.dim_out = hidden_dim = 4096
+        roi_size = cfg.FAST_RCNN.ROI_XFORM_RESOLUTION
+        self.mask_branch = nn.Sequential(nn.Conv2d(dim_in * 2, dim_in, kernel_size=3, padding=1), nn.ReLU())
+        self.seg_fc = nn.Sequential(nn.Linear(dim_in * roi_size ** 2, hidden_dim), nn.ReLU(),
+                                    nn.Linear(hidden_dim, hidden_dim), nn.ReLU())
+
+    def detectron_weight_mapping(self):
+        return {name: name for name, _ in self.named_parameters()}, []
+
+    def forward(self, x, rois, masks):
+        method = cfg.FAST_RCNN.ROI_XFORM_METHOD
+        if method != "RoIAlign":
+            raise NotImplementedError("MaskFuse: only ROI_XFORM_METHOD=RoIAlign is on the CIM path (got %s)" % method)
+        cat = roi_align_maskcat(x, rois, masks, cfg.FAST_RCNN.ROI_XFORM_RESOLUTION, self.spatial_scale,
+                                cfg.FAST_RCNN.ROI_XFORM_SAMPLING_RATIO, aligned=True)
+        y = self.mask_branch(cat)
+        n = y.size(0)
+        # (c, h, w) flatten order of the reference's `.view(batch, -1)` on an NCHW tensor
+        return self.seg_fc(y.contiguous(memory_format=torch.contiguous_format).view(n, -1))

@@ -1,0 +1,177 @@
+"""`Generalized_RCNN`: the CIM per-image training / inference forward on MI355X.
+
+Mirrors /root/reference/lib/modeling/model_builder.py (`Generalized_RCNN` :71-263, `get_func`
+:16-34, `testing_function` :60-68): constructor without arguments reading the global `cfg`;
+`forward(data, rois, masks, labels, gtrois, mat, path=None, index=None)` returning
+`{'blob_conv', 'losses': {bag_loss, pcl_loss, cls_loss, iou_loss}}` (each loss shape [1]) in
+training and `{'blob_conv', 'refine_score'}` in eval; attributes `Conv_Body`, `Box_Head`,
+`cls_iou_model`, `CIM_layer_list`, `using_CIM`; `roi_feature_transform`, `convbody_net`,
+`detectron_weight_mapping`.
+
+Extension: `forward` also accepts `iou_map=` / `asy_iou_map=` float16 device
+tensors [N,N] (e.g. built on device by cim_amd.mask_iou) so that no disk I/O happens inside
+the step; when absent the reference's pickle path (model_builder.py:147-159) is used.
+"""
+import importlib
+import logging
+import os
+import pickle
+from functools import wraps
+
+import torch
+import torch.nn as nn
+
+from ..core.config import cfg
+from ..ops import RoIAlign, RoIPool
+from . import heads
+
+logger = logging.getLogger(__name__)
+
+
+def get_func(func_name):
+    """Resolve 'resnet50.MaskFuse'-style names relative to this `modeling` package
+    (reference model_builder.py:16-34)."""
+    if func_name == "":
+        return None
+    try:
+        parts = func_name.split(".")
+        if len(parts) == 1:
+            return globals()[parts[0]]
+        module = importlib.import_module(__package__ + "." + ".".join(parts[:-1]))
+        return getattr(module, parts[-1])
+    except Exception:
+        logger.error("Failed to find function: %s", func_name)
+        raise
+
+
+def check_inference(net_func):
+    @wraps(net_func)
+    def wrapper(self, *args, **kwargs):
+        if self.training:
+            raise ValueError("You should call this function only on inference."
+                             "Set the network in inference mode by net.eval().")
+        with torch.no_grad():
+            return net_func(self, *args, **kwargs)
+    return wrapper
+
+
+def testing_function(predict_cls, predict_det, ref_cls_score, ref_iou_score, return_dict):
+    return_dict["refine_score"] = [(c * i)[:, 1:] for c, i in zip(ref_cls_score, ref_iou_score)]
+    return return_dict
+
+
+def _load_map(directory, stem, what, device, index):
+    """The reference's per-step pickle path (model_builder.py:147-159)."""
+    path = os.path.join(directory, stem + ".pkl")
+    try:
+        with open(path, "rb") as f:
+            m = pickle.load(f)
+        return torch.tensor(m, device=device)[index][:, index]
+    except Exception:
+        print(what + " lose " + path)
+        raise NotImplementedError("Please generate or download " + what)
+
+
+class Generalized_RCNN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mapping_to_detectron = None
+        self.orphans_in_detectron = None
+        cls_num = cfg.MODEL.NUM_CLASSES + 1
+        self.Conv_Body = get_func(cfg.MODEL.CONV_BODY)()
+        self.Box_Head = get_func(cfg.FAST_RCNN.ROI_BOX_HEAD)(self.Conv_Body.dim_out, self.roi_feature_transform,
+                                                            self.Conv_Body.spatial_scale)
+        self.cls_iou_model = heads.cls_iou_model(self.Box_Head.dim_out, cls_num, cfg.REFINE_TIMES, class_agnostic=False)
+        # a plain list like the reference (no parameters, not in state_dict) - model_builder.py:88-94
+        self.CIM_layer_list = [heads.CIM_layer(p_seed=cfg.p_seed,
+                                               cls_thr=0.25 + cfg.step_rate * t,
+                                               iou_thr=0.5 + cfg.step_rate * t,
+                                               Anti_noise_sampling=cfg.Anti_noise_sampling)
+                               for t in range(cfg.REFINE_TIMES)]
+        self.using_CIM = [True, True, True]
+        if cfg.TRAIN.FREEZE_CONV_BODY:
+            for p in self.Conv_Body.parameters():
+                p.requires_grad = False
+
+    def forward(self, data, rois, masks, labels, gtrois=None, mat=None, path=None, index=None,
+                iou_map=None, asy_iou_map=None):
+        with torch.set_grad_enabled(self.training):
+            im_data = data
+            labels_host = None
+            if self.training:
+                if not labels.is_cuda:
+                    labels_host = labels.detach().reshape(-1).numpy().copy()
+                dev, dt = im_data.device, im_data.dtype
+                rois = rois.squeeze(dim=0).to(device=dev, dtype=dt)
+                masks = masks.squeeze(dim=0).to(device=dev, dtype=dt)
+                labels = labels.squeeze(dim=0).to(device=dev, dtype=dt)
+                mat = mat.squeeze(dim=0).to(device=dev, dtype=dt)
+                if index is not None:
+                    index = index.squeeze(dim=0).to(device=dev).long()
+            return_dict = {}
+            blob_conv = self.Conv_Body(im_data)
+            return_dict["blob_conv"] = blob_conv
+            seg_x = self.Box_Head(blob_conv, rois, masks.detach())
+            predict_cls, predict_det, ref_cls_score, ref_iou_score = self.cls_iou_model(seg_x)
+
+            if not self.training:
+                return testing_function(predict_cls, predict_det, ref_cls_score, ref_iou_score, return_dict)
+
+            if iou_map is None or asy_iou_map is None:
+                stem = os.path.splitext(os.path.split(path)[1])[0]
+                iou_map = _load_map(cfg.iou_dir, stem, "iou_map", labels.device, index)
+                asy_iou_map = _load_map(cfg.asy_iou_dir, stem, "asy_iou_map", labels.device, index)
+
+            n = predict_cls.shape[0]
+            ctx = heads.MiningContext(labels, n, predict_cls.device, labels_host=labels_host)
+            zero = seg_x.new_zeros(())
+            losses = dict(bag_loss=zero.clone(), pcl_loss=zero.clone(), cls_loss=zero.clone(), iou_loss=zero.clone())
+            for i, (cls_score, iou_score, layer) in enumerate(zip(ref_cls_score, ref_iou_score, self.CIM_layer_list)):
+                lmda = 3 if i == 0 else 1                                   # model_builder.py:172
+                src_cls, src_det = (predict_cls, predict_det) if i == 0 else (ref_cls_score[i - 1], ref_iou_score[i - 1])
+                pseudo_labels, pseudo_iou_labels, loss_weights = layer(src_cls, src_det, rois, labels, iou_map,
+                                                                       asy_iou_map, using_CIM=self.using_CIM[i],
+                                                                       _ctx=ctx)
+                if pseudo_labels is None:
+                    continue
+                loss_weights = lmda * loss_weights
+                cls_loss, iou_loss, bag_loss = heads.cls_iou_loss(cls_score, iou_score, pseudo_labels,
+                                                                  pseudo_iou_labels, loss_weights, labels)
+                losses["cls_loss"] = losses["cls_loss"] + cls_loss
+                losses["iou_loss"] = losses["iou_loss"] + 3 * iou_loss        # model_builder.py:199
+                losses["bag_loss"] = losses["bag_loss"] + bag_loss
+            losses["bag_loss"] = losses["bag_loss"] + heads.mil_bag_loss(predict_cls, predict_det, labels)
+            losses["pcl_loss"] = losses["pcl_loss"] + heads.PCL_loss(predict_cls, mat, labels)
+            return_dict["losses"] = {k: v.unsqueeze(0) for k, v in losses.items()}
+            return return_dict
+
+    def roi_feature_transform(self, blobs_in, rois, method="RoIPoolF", resolution=7, spatial_scale=1.0 / 16.0,
+                              sampling_ratio=0):
+        """Same dispatch as model_builder.py:215-233 (kept for API compatibility; MaskFuse uses the
+        fused ROIAlign+mask-cat kernel directly)."""
+        assert method in {"RoIPoolF", "RoICrop", "RoIAlign"}, "Unknown pooling method: {}".format(method)
+        if method == "RoIPoolF":
+            return RoIPool(resolution, spatial_scale)(blobs_in, rois)
+        if method == "RoIAlign":
+            return RoIAlign(resolution, spatial_scale, sampling_ratio)(blobs_in.contiguous(), rois.contiguous())
+
+    @check_inference
+    def convbody_net(self, data):
+        return self.Conv_Body(data)
+
+    @property
+    def detectron_weight_mapping(self):
+        if self.mapping_to_detectron is None:
+            d_wmap, d_orphan = {}, []
+            for name, child in self.named_children():
+                if list(child.parameters()):
+                    child_map, child_orphan = child.detectron_weight_mapping()
+                    d_orphan.extend(child_orphan)
+                    for key, value in child_map.items():
+                        d_wmap[name + "." + key] = value
+            self.mapping_to_detectron = d_wmap
+            self.orphans_in_detectron = d_orphan
+        return self.mapping_to_detectron, self.orphans_in_detectron
+
+    def _add_loss(self, return_dict, key, value):
+        return_dict["losses"][key] = value

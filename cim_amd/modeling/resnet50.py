@@ -1,0 +1,103 @@
+"""ResNet-50 C4 body + MaskFuse head (mirror of /root/reference/lib/modeling/resnet50.py).
+
+The reference wraps `torchvision.models.resnet50` (resnet50.py:20-33); torchvision is not in
+this image, so the architecture (ResNet-50 v1.5: conv1-bn-relu-maxpool, layer1..layer3) is
+defined here with torchvision's state_dict key names so that ImageNet / reference checkpoints
+load unchanged: `res1.0`=conv1, `res1.1`=bn1, `res2|res3|res4.<i>.{conv1,bn1,conv2,bn2,conv3,
+bn3,downsample.0,downsample.1}`.  All BatchNorm layers stay in eval mode and res1-2 are frozen,
+as resnet50.py:53-77 does.
+"""
+import torch.nn as nn
+
+from ..core.config import cfg
+from .maskfuse import MaskFuse  # noqa: F401  (resolved as "resnet50.MaskFuse" by get_func)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+def _make_layer(inplanes, planes, blocks, stride):
+    downsample = None
+    if stride != 1 or inplanes != planes * 4:
+        downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                   nn.BatchNorm2d(planes * 4))
+    layers = [Bottleneck(inplanes, planes, stride, downsample)]
+    for _ in range(1, blocks):
+        layers.append(Bottleneck(planes * 4, planes))
+    return nn.Sequential(*layers)
+
+
+def freeze_params(m):
+    for p in m.parameters():
+        p.requires_grad = False
+
+
+class resnet(nn.Module):
+    def __init__(self, block_counts=4):
+        super().__init__()
+        if block_counts != 4:
+            raise AssertionError
+        self.res1 = nn.Sequential(nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False),
+                                  nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+                                  nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
+        self.res2 = _make_layer(64, 64, 3, 1)
+        self.res3 = _make_layer(256, 128, 4, 2)
+        self.res4 = _make_layer(512, 256, 6, 2)
+        self.spatial_scale = 1 / 16
+        self.dim_out = 1024
+        self.block_counts = block_counts
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._init_modules()
+
+    def _init_modules(self):
+        assert cfg.ResNet.FREEZE_AT in [0, 2, 3, 4, 5]
+        for i in range(1, cfg.ResNet.FREEZE_AT + 1):
+            freeze_params(getattr(self, "res%d" % i))
+        self.freeze(self)
+
+    def freeze(self, m):
+        for k in m.modules():
+            if isinstance(k, nn.BatchNorm2d):
+                k.eval()
+
+    def train(self, mode=True):
+        self.training = mode
+        for i in range(cfg.ResNet.FREEZE_AT + 1, self.block_counts + 1):
+            getattr(self, "res%d" % i).train(mode)
+        self.freeze(self)
+        return self
+
+    def detectron_weight_mapping(self):
+        return {name: name for name, _ in self.named_parameters()}, []
+
+    def forward(self, x):
+        for i in range(self.block_counts):
+            x = getattr(self, "res%d" % (i + 1))(x)
+        return x
+
+
+def torch_resnet50():
+    return resnet()

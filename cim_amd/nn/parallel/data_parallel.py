@@ -1,0 +1,125 @@
+"""Data-parallel wrapper for the CIM training step: one process per MI355X, gradient
+all-reduce on RCCL over xGMI.
+
+Keeps the constructor / call surface of /root/reference/lib/nn/parallel/data_parallel.py:9-116
+(`DataParallel(module, cpu_keywords=[...], minibatch=True)`, list-valued kwargs with one entry
+per local device, `.module`), which tools/train.py:344,432 uses.  The reference runs one Python
+thread per GPU inside one process, re-broadcasts all parameters every forward and gathers
+outputs (broken for >1 GPU, S7).  Here each rank owns ONE device and one image;
+the only collective is the gradient all-reduce:
+
+  * gradients live in ONE flat fp32 buffer (param.grad are views into it), so zeroing is one
+    memset and the all-reduce needs no packing copies;
+  * the buffer is cut into buckets in reverse parameter order (= backward completion order);
+    a bucket's all-reduce is launched from a post-accumulate-grad hook as soon as its last
+    gradient is written, so RCCL traffic overlaps the rest of backward;
+  * sum-all-reduce of (loss / world) gradients == the reference's `loss.mean(dim=0)` over GPUs
+    (lib/utils/training_stats.py:100).
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class DataParallel(nn.Module):
+    def __init__(self, module, device_ids=None, output_device=None, dim=0, cpu_keywords=(), minibatch=False,
+                 batch_outputs=True, bucket_bytes=256 << 20, process_group=None):
+        super().__init__()
+        self.module = module
+        self.cpu_keywords = list(cpu_keywords)
+        self.minibatch = minibatch
+        self.batch_outputs = batch_outputs
+        self.dim = dim
+        self.process_group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.device = next(module.parameters()).device
+        self.device_ids = [self.device.index] if self.device.type == "cuda" else []
+        self.output_device = self.device
+        self._sync = True
+        self._pending = []
+        self._build_flat_grads(bucket_bytes)
+
+    # ------------------------------------------------------------------ flat gradient storage
+    def _build_flat_grads(self, bucket_bytes):
+        params = [p for p in self.module.parameters() if p.requires_grad]
+        self._params = params
+        total = sum(p.numel() for p in params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        # reverse registration order ~ order in which backward produces gradients
+        off = 0
+        spans = []
+        for p in reversed(params):
+            n = p.numel()
+            p.grad = self.flat_grad[off:off + n].view_as(p)
+            spans.append((p, off, off + n))
+            off += n
+        # buckets: contiguous spans of ~bucket_bytes; a huge tensor (seg_fc.0: 822 MB) is one bucket
+        self.buckets = []
+        cur = None
+        for p, a, b in spans:
+            if cur is None or (cur["end"] - cur["start"]) * 4 >= bucket_bytes:
+                cur = dict(start=a, end=b, params=[p], ready=0)
+                self.buckets.append(cur)
+            else:
+                cur["end"] = b
+                cur["params"].append(p)
+        self._bucket_of = {}
+        for bi, bk in enumerate(self.buckets):
+            for p in bk["params"]:
+                self._bucket_of[p] = bi
+        if self.world_size > 1:
+            for p in params:
+                p.register_post_accumulate_grad_hook(self._on_grad_ready)
+
+    def _on_grad_ready(self, p):
+        if not self._sync:
+            return
+        bk = self.buckets[self._bucket_of[p]]
+        bk["ready"] += 1
+        if bk["ready"] == len(bk["params"]):
+            bk["ready"] = 0
+            if p.grad.data_ptr() < self.flat_grad.data_ptr() or \
+                    p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * 4:
+                raise RuntimeError("DataParallel: a .grad was replaced (use zero_grad(set_to_none=False) / "
+                                   "DataParallel.zero_grad())")
+            self._pending.append(dist.all_reduce(self.flat_grad[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM,
+                                                 group=self.process_group, async_op=True))
+
+    def zero_grad(self, set_to_none=False):
+        """One memset of the flat buffer (param.grad stay views into it)."""
+        self.flat_grad.zero_()
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (tools/train.py --iter_size): skip the all-reduce inside."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    def finish_gradient_sync(self):
+        """Wait for the in-flight bucket all-reduces (call after backward, before optimizer.step)."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def loss_scale(self):
+        return 1.0 / self.world_size
+
+    # ------------------------------------------------------------------ forward
+    def _to_device(self, k, v):
+        if k in self.cpu_keywords or not torch.is_tensor(v) or self.device.type != "cuda":
+            return v
+        return v.to(self.device, non_blocking=True)
+
+    def forward(self, *inputs, **kwargs):
+        if self.minibatch:
+            # the reference passes one list entry per local GPU; this process owns exactly one
+            inputs = [x[0] if isinstance(x, (list, tuple)) else x for x in inputs]
+            kwargs = {k: (v[0] if isinstance(v, (list, tuple)) else v) for k, v in kwargs.items()}
+        inputs = [self._to_device(None, x) for x in inputs]
+        kwargs = {k: self._to_device(k, v) for k, v in kwargs.items()}
+        return self.module(*inputs, **kwargs)

@@ -1,0 +1,132 @@
+/*
+ * cim_hip.h - C ABI of libcim_hip.so, the MI355X (gfx950) kernel library behind the
+ * per-image training step of ZechengLi19/CIM.
+ *
+ * Conventions (every entry point):
+ *   - returns 0 on success, a positive hipError_t on a HIP failure, -1 on bad arguments;
+ *     cim_last_error() returns a thread-local description of the last failure;
+ *   - every pointer is a caller-owned DEVICE pointer to a dense array of the stated dtype
+ *     (the Python host passes torch.Tensor.data_ptr()); nothing is allocated or freed,
+ *     no host synchronisation happens, no global state is kept (re-entrant);
+ *   - the last argument is the hipStream_t to launch on, passed as void*
+ *     (torch.cuda.current_stream().cuda_stream);
+ *   - "f16" arrays hold IEEE binary16 bit patterns (uint16_t).  Python-float thresholds are
+ *     rounded to binary16 inside the library before comparing against f16 maps, which is
+ *     what the reference's fp16-tensor-vs-Python-scalar compares do.
+ *
+ * Each entry cites the reference interface it replaces (paths under /root/reference).
+ */
+#ifndef CIM_HIP_H
+#define CIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* cim_last_error(void);
+int cim_abi_version(void);
+
+/* ------------------------------------------------------------------ ROIAlign (a-1, a-2 prologue)
+ * Replaces mmcv.ops.RoIAlign(output_size=P, spatial_scale, sampling_ratio, 'avg', aligned)
+ * as imported by lib/ops/__init__.py:6 and called at lib/modeling/model_builder.py:229-231
+ * (forward) and by autograd (backward).  Arithmetic: SURVEY.md App. D.
+ *
+ * Layout is channels-last: feat [B,H,W,C] f32, rois [K,5] f32 = (batch, x1, y1, x2, y2) in
+ * input-image pixels, out [K,P,P,C] f32.  (The Python wrapper exposes these as logical NCHW
+ * tensors in torch.channels_last memory format, so the reference's NCHW API is unchanged.)
+ */
+int cim_roi_align_fwd(const float* feat, const float* rois, float* out,
+                      int B, int C, int H, int W, int K, int P,
+                      float spatial_scale, int sampling_ratio, int aligned, void* stream);
+
+/* grad_in [B,H,W,C] is fully overwritten (zero-filled on `stream`, then accumulated). */
+int cim_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in,
+                      int B, int C, int H, int W, int K, int P,
+                      float spatial_scale, int sampling_ratio, int aligned, void* stream);
+
+/* Fused ROIAlign + mask multiply + channel concat: the input of MaskFuse.mask_branch,
+ * lib/modeling/resnet50.py:121-134 (vgg16.py:162-175, HRNet.py:615-628):
+ *   cat[k,ph,pw,0:C]  = roi_align(feat)[k,ph,pw,:]
+ *   cat[k,ph,pw,C:2C] = roi_align(feat)[k,ph,pw,:] * masks[k,ph,pw]
+ * masks [K,P,P] f32; cat [K,P,P,2C] f32.  box_x / mask_x are never materialised. */
+int cim_roi_align_maskcat_fwd(const float* feat, const float* rois, const float* masks, float* cat,
+                              int B, int C, int H, int W, int K, int P,
+                              float spatial_scale, int sampling_ratio, int aligned, void* stream);
+
+int cim_roi_align_maskcat_bwd(const float* grad_cat, const float* rois, const float* masks, float* grad_in,
+                              int B, int C, int H, int W, int K, int P,
+                              float spatial_scale, int sampling_ratio, int aligned, void* stream);
+
+/* ------------------------------------------------------------------ mask IoU / containment maps (a-7)
+ * Replaces lib/utils/mask_utils.py:6-18 (mask_iou) and :20-32 (mask_asymmetric_iou) as driven
+ * by tools/pre/create_cob_iou.py:43-49 / create_cob_asy_iou.py:43-53, and the per-step
+ * pickle.load + H2D at lib/modeling/model_builder.py:147-159.
+ *   iou[i,j] = |m_i & m_j| / |m_i | m_j|      asy[i,j] = |m_i & m_j| / |m_j|
+ * with the reference's rounding chain int64 -> f64 divide -> f32 -> f16.
+ */
+/* masks_u8 [N, HW] (non-zero = inside) -> packed [words, N] uint64 (WORD-MAJOR: packed[w*N + n]),
+ * words = ceil(HW/64), bit b of word w = pixel 64*w+b, tail bits zero. */
+int cim_mask_pack(const uint8_t* masks_u8, uint64_t* packed, int N, int HW, void* stream);
+
+/* packed [words,N] (word-major) -> area [N] int32, iou_f16 [N,N], asy_f16 [N,N]. */
+int cim_mask_iou_pair(const uint64_t* packed, int N, int words, int32_t* area,
+                      uint16_t* iou_f16, uint16_t* asy_f16, void* stream);
+
+/* ------------------------------------------------------------------ CIM mining (a-4)
+ * Replaces CIM_layer.CIM_label / MIST_label / instance_nms, lib/modeling/heads.py:237-407.
+ * All index outputs are bit-identical to the reference CPU path.
+ */
+/* heads.py:338: flag[i] = (#{j : asy[i,j] > con_thr}) < 0.9*N     (flag: uint8 [N]) */
+int cim_asy_flag(const uint16_t* asy_f16, int N, float con_thr, uint8_t* flag, void* stream);
+
+/* Step 1 (heads.py:354-380 / 279-304): for each of the n_cls image classes (class ids in
+ * `classes`, ascending), stable-descending top-K of seed_score[:, c] and greedy NMS over
+ * the K x K sub-block of iou (keep dst iff iou < nms_thr, fp16 compare).
+ *   seed_score: f32, element (i, c) at seed_score[i*score_ld + score_off + c]
+ *   topk_idx  [n_cls, K] int32  (keep_sort_idx)
+ *   seeds     [n_cls, K] int32  (keep_nms_idx, selection order; entries >= n_seeds are -1)
+ *   n_seeds   [n_cls]    int32
+ * Limits: N <= 8192, K <= 1024. */
+int cim_seed_select(const float* seed_score, int score_ld, int score_off, const uint16_t* iou_f16, int N,
+                    const int32_t* classes, int n_cls, int K, float nms_thr,
+                    int32_t* topk_idx, int32_t* seeds, int32_t* n_seeds, void* stream);
+
+/* Step 2 (heads.py:386-395): for every seed s of class c, among proposals i with
+ * asy[i,s] > con_thr and flag[i], the first index maximising det[i,c]
+ * (det: element (i,c) at det[i*det_ld + det_off + c*det_cstride]; det_cstride = 0 selects the
+ * class-agnostic detector, heads.py:346-347).  res_idx [n_cls,K] int32, -1 where the seed
+ * has no containing proposal (column dropped at heads.py:392) or s >= n_seeds. */
+int cim_contain_argmax(const uint16_t* asy_f16, const uint8_t* flag, const float* det, int det_ld, int det_off,
+                       int det_cstride, int N, const int32_t* classes, int n_cls, int K, float con_thr,
+                       const int32_t* seeds, const int32_t* n_seeds, int32_t* res_idx, void* stream);
+
+/* Cross-class arbitration + compaction (heads.py:397-405 for CIM, :306-314 for MIST).
+ * cand [n_cls,K] int32 candidate proposals per class (-1 = none; duplicates allowed),
+ * weight element (i,c) = wa[i*wa_ld + wa_off + c] * (wb ? wb[i*wb_ld + wb_off + c*wb_cstride] : 1).
+ * Classes are applied sequentially in ascending order with the strict '>' rule.
+ * Outputs: gt_class [N] int32 (0 = not a pseudo GT, else class id + 1), gt_weight [N] f32
+ * (-1 where unset), and gt_pack [1 + 3N] int32 = { G, idx[N], class[N], weight_bits[N] } with
+ * the G pseudo GTs compacted in ascending proposal order (one D2H copy feeds the host-side
+ * anti-noise sampling of heads.py:447-473). */
+int cim_arbitrate(const int32_t* cand, const int32_t* classes, int n_cls, int K, int N,
+                  const float* wa, int wa_ld, int wa_off,
+                  const float* wb, int wb_ld, int wb_off, int wb_cstride,
+                  int32_t* gt_class, float* gt_weight, int32_t* gt_pack, void* stream);
+
+/* ------------------------------------------------------------------ assignment (a-6)
+ * Replaces lib/modeling/heads.py:435,477-501.  gt_idx [G] int32 ascending proposal indices of
+ * the surviving pseudo GTs (after anti-noise sampling, done on the host with NumPy's global
+ * RNG exactly as heads.py:447-473), gt_cls [G] int32 (class id + 1), gt_w [G] f32.
+ * Outputs: pseudo_labels [N, C1] f32 one-hot rows (C1 = classes + 1), pseudo_iou_f16 [N]
+ * ({0,1} in binary16, like the reference), loss_weights [N] f32, max_idx [N] int32. */
+int cim_assign(const uint16_t* iou_f16, int N, const int32_t* gt_idx, const int32_t* gt_cls, const float* gt_w,
+               int G, int C1, float cls_thr, float iou_thr,
+               float* pseudo_labels, uint16_t* pseudo_iou_f16, float* loss_weights, int32_t* max_idx,
+               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIM_HIP_H */

@@ -1,0 +1,311 @@
+"""-m gpu: the HIP path (through the C ABI of include/cim_hip.h) against the oracle and the
+golden vectors captured from the reference.  Bit-exact for indices / fp16 maps / ROIAlign
+forward; stated tolerances for fp32 reductions with a different summation order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cases import MINING_CASES, THRESHOLDS, case_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from cim_amd import _lib
+    _lib.load()          # fail loudly if the HIP extension is missing
+    return torch.device("cuda:0")
+
+
+def _cl(x_nchw, dev):
+    return torch.from_numpy(x_nchw).to(dev).contiguous(memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------ ROIAlign (a-1, a-2 prologue)
+def _roi_case(seed, C, H, W, K, img_scale=16.0):
+    rng = np.random.RandomState(seed)
+    feat = rng.randn(1, C, H, W).astype(np.float32)
+    x1 = rng.uniform(-20, W * img_scale * 0.8, K)
+    y1 = rng.uniform(-20, H * img_scale * 0.8, K)
+    w = rng.uniform(1, W * img_scale, K)
+    h = rng.uniform(1, H * img_scale, K)
+    rois = np.stack([np.zeros(K), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    rois[0, 1:] = (0, 0, W * img_scale, H * img_scale)             # full image
+    rois[1, 1:] = (40, 40, 40.5, 40.25)                            # < 1 feature px
+    rois[2, 1:] = (W * img_scale + 500, 10, W * img_scale + 900, 200)   # outside
+    return feat, rois
+
+
+@pytest.mark.parametrize("C,H,W,K,aligned", [(8, 13, 17, 24, True), (3, 9, 11, 16, True), (64, 33, 43, 40, True),
+                                              (8, 13, 17, 24, False)])
+def test_roi_align_fwd_bwd_vs_oracle(dev, C, H, W, K, aligned):
+    from cim_amd.ops import roi_align
+    from oracle import roi_align as oracle
+    feat, rois = _roi_case(C * 7 + K, C, H, W, K)
+    ref = oracle.roi_align_fwd(feat, rois, P=7, scale=1 / 16.0, aligned=aligned)
+    x = _cl(feat, dev).requires_grad_(True)
+    out = roi_align(x, torch.from_numpy(rois).to(dev), 7, 1 / 16.0, 0, "avg", aligned)
+    assert out.shape == (K, C, 7, 7)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)         # bit-exact forward
+    rng = np.random.RandomState(1)
+    go = rng.randn(K, C, 7, 7).astype(np.float32)
+    out.backward(torch.from_numpy(go).to(dev))
+    gref = oracle.roi_align_bwd(go, rois, feat.shape, P=7, scale=1 / 16.0, aligned=aligned)
+    # fp32 atomics in arbitrary order vs exact fp64 accumulation
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gref, rtol=1e-4, atol=1e-4)
+
+
+def test_roi_align_module_matches_reference_call_convention(dev):
+    """model_builder.py:230-231: RoIAlign(resolution, spatial_scale, sampling_ratio)(feat, rois)."""
+    from cim_amd.ops import RoIAlign
+    from oracle import roi_align as oracle
+    feat, rois = _roi_case(5, 16, 12, 15, 10)
+    out = RoIAlign(7, 1.0 / 16.0, 0)(torch.from_numpy(feat).to(dev).contiguous(), torch.from_numpy(rois).to(dev).contiguous())
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.roi_align_fwd(feat, rois))
+    out2 = RoIAlign(7, 1.0 / 16.0, 2)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev))
+    np.testing.assert_array_equal(out2.cpu().numpy(), oracle.roi_align_fwd(feat, rois, sampling_ratio=2))
+
+
+def test_roi_align_maskcat_fused_vs_oracle(dev):
+    from cim_amd.ops import roi_align_maskcat
+    from oracle import roi_align as oracle
+    C, H, W, K = 32, 20, 25, 30
+    feat, rois = _roi_case(77, C, H, W, K)
+    rng = np.random.RandomState(2)
+    masks = (rng.rand(K, 7, 7) > 0.4).astype(np.float32)
+    box = oracle.roi_align_fwd(feat, rois)
+    ref = np.concatenate([box, box * masks[:, None]], axis=1)
+    x = _cl(feat, dev).requires_grad_(True)
+    cat = roi_align_maskcat(x, torch.from_numpy(rois).to(dev), torch.from_numpy(masks).to(dev), 7, 1 / 16.0, 0, True)
+    assert cat.shape == (K, 2 * C, 7, 7)
+    np.testing.assert_array_equal(cat.detach().cpu().numpy(), ref)
+    g = rng.randn(K, 2 * C, 7, 7).astype(np.float32)
+    cat.backward(torch.from_numpy(g).to(dev))
+    g_box = g[:, :C] + g[:, C:] * masks[:, None]
+    gref = oracle.roi_align_bwd(g_box, rois, feat.shape)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gref, rtol=1e-4, atol=1e-4)
+
+
+def test_roi_align_empty_and_bad_args(dev):
+    from cim_amd import _lib
+    from cim_amd.ops import roi_align
+    feat = torch.randn(1, 8, 5, 5, device=dev).contiguous(memory_format=torch.channels_last)
+    out = roi_align(feat, torch.zeros(0, 5, device=dev), 7, 1 / 16.0)
+    assert out.shape == (0, 8, 7, 7)
+    with pytest.raises(_lib.CimHipError):
+        _lib.call("cim_roi_align_fwd", feat.data_ptr(), None, None, 1, 8, 5, 5, 3, 7, 0.0625, 0, 1, None)
+    with pytest.raises(_lib.CimHipError):
+        roi_align(torch.randn(1, 8, 5, 5), torch.zeros(1, 5), 7, 1 / 16.0)     # CPU tensors: no fallback
+
+
+def test_roi_align_full_size_properties(dev):
+    """BASELINE cfg2 size (1024 x 33 x 43, 1000 ROIs): linearity and the constant-map identity."""
+    from cim_amd.ops import roi_align
+    from cim_amd import synthetic
+    inp = synthetic.make_image_inputs("resnet50_voc", seed=3, with_image=False)
+    rois = torch.from_numpy(inp["rois"]).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    a = torch.randn(1, 1024, 33, 43, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(1, 1024, 33, 43, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    fa, fb, fab = (roi_align(t, rois, 7, 1 / 16.0) for t in (a, b, 2 * a + b))
+    assert fa.shape == (1000, 1024, 7, 7)
+    torch.testing.assert_close(fab, 2 * fa + fb, rtol=1e-4, atol=1e-4)
+    ones = roi_align(torch.ones_like(a), rois, 7, 1 / 16.0)
+    inside = (ones - 1).abs().max()
+    assert inside < 1e-5 or ones.min() >= 0         # bins partly outside the map average in zeros
+    assert torch.isfinite(fa).all()
+
+
+# ------------------------------------------------------------------ mask IoU maps (a-7)
+@pytest.mark.parametrize("n", [6, 64])
+def test_mask_iou_matches_reference_golden(dev, n, golden_dir):
+    from cim_amd import mask_iou
+    g = np.load(os.path.join(golden_dir, "mask_iou_%d.npz" % n))
+    h, w = int(g["h"]), int(g["w"])
+    masks = np.unpackbits(g["masks_packed"], axis=1)[:, :h * w].reshape(n, h, w).astype(bool)
+    iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(masks).to(dev))
+    assert iou.dtype == torch.float16
+    np.testing.assert_array_equal(iou.cpu().numpy(), g["iou"])
+    np.testing.assert_array_equal(asy.cpu().numpy(), g["asy"])
+
+
+def test_mask_iou_vs_oracle_ragged_and_full_size(dev):
+    from cim_amd import mask_iou, synthetic
+    from oracle import mask_iou as oracle
+    rng = np.random.RandomState(4)
+    masks, _ = synthetic.make_masks(301, 67, 93, rng, min_side=4)      # N, H*W not multiples of 64
+    iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(masks).to(dev))
+    ri, ra = oracle.mask_iou_maps(masks)
+    np.testing.assert_array_equal(iou.cpu().numpy(), ri)
+    np.testing.assert_array_equal(asy.cpu().numpy(), ra)
+    # cfg2 size: 1000 masks of 375 x 500
+    inp = synthetic.make_image_inputs("resnet50_voc", seed=3, with_image=False)
+    iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
+    ri, ra = oracle.mask_iou_maps(inp["full_masks"])
+    np.testing.assert_array_equal(iou.cpu().numpy(), ri)
+    np.testing.assert_array_equal(asy.cpu().numpy(), ra)
+    assert torch.equal(iou, iou.t()) and bool((iou.diagonal() == 1).all()) and bool((asy.diagonal() == 1).all())
+
+
+# ------------------------------------------------------------------ mining + assignment (a-4..a-6)
+def _run_layer(dev, g, prefix, cls, det, labels, iou, asy, cls_thr, iou_thr, seed, sampling=True, using_cim=True):
+    from cim_amd.modeling import heads
+    layer = heads.CIM_layer(p_seed=0.1, cls_thr=cls_thr, iou_thr=iou_thr, Anti_noise_sampling=sampling)
+    np.random.seed(seed)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = layer(t(cls), t(det), torch.zeros(cls.shape[0], 5, device=dev), t(labels), t(iou), t(asy), using_CIM=using_cim)
+    probe = np.random.random_sample()
+    assert bool(g[prefix + "is_none"]) == (out[0] is None)
+    assert probe == float(g[prefix + "rng_probe"]), "NumPy RNG stream position differs from the reference"
+    last = layer.last
+    order = g[prefix + "class_order"]
+    K = int(np.ceil(0.1 * cls.shape[0]))
+    for k, c in enumerate(order):
+        np.testing.assert_array_equal(last["topk"][k].cpu().numpy(), g["%sc%d_keep_sort_idx" % (prefix, c)])
+        ns = int(last["n_seeds"][k])
+        np.testing.assert_array_equal(last["seeds"][k, :ns].cpu().numpy(), g["%sc%d_keep_nms_idx" % (prefix, c)])
+        assert (last["seeds"][k, ns:] == -1).all()
+        if using_cim:
+            res = last["res"][k, :ns].cpu().numpy()
+            key = "%sc%d_res_idx" % (prefix, c)
+            got = np.unique(res[res >= 0])
+            if key in g.files:
+                np.testing.assert_array_equal(got, g[key])
+            else:
+                assert got.size == 0
+    gt_idxs = (last["gt_class"] > 0).cpu().numpy()
+    np.testing.assert_array_equal(gt_idxs, g[prefix + "label_gt_idxs"])
+    gl = g[prefix + "label_gt_labels"]
+    np.testing.assert_array_equal(last["gt_class"].cpu().numpy()[gt_idxs], gl.argmax(1) if gl.size else np.zeros(0))
+    np.testing.assert_array_equal(last["gt_weight"].cpu().numpy()[gt_idxs], g[prefix + "label_gt_weights"])
+    if using_cim:
+        np.testing.assert_array_equal(last["asy_flag"].cpu().numpy().astype(bool)[:, None], g[prefix + "asy_iou_flag"])
+    if out[0] is None:
+        return
+    if sampling:
+        np.testing.assert_array_equal(last["sample_keep"], g[prefix + "sample_keep"])
+    np.testing.assert_array_equal(last["max_overlap_idx"].cpu().numpy(), g[prefix + "max_overlap_idx"])
+    np.testing.assert_array_equal(out[0].cpu().numpy(), g[prefix + "pseudo_labels"])
+    assert out[1].dtype == torch.float16
+    np.testing.assert_array_equal(out[1].cpu().numpy(), g[prefix + "pseudo_iou_labels"])
+    np.testing.assert_array_equal(out[2].cpu().numpy(), g[prefix + "loss_weights"])
+
+
+@pytest.mark.parametrize("name", list(MINING_CASES))
+def test_cim_layer_bit_identical_to_reference(dev, name, golden_dir):
+    g = np.load(os.path.join(golden_dir, "mining_%s.npz" % name))
+    inp = case_inputs(MINING_CASES[name])
+    for li, (cls_thr, iou_thr) in enumerate(THRESHOLDS):
+        cls, det, _ = inp["layers"][li]
+        _run_layer(dev, g, "l%d_" % li, cls, det, inp["labels"], inp["iou"], inp["asy"], cls_thr, iou_thr, 100 + li)
+    cls, det, _ = inp["layers"][0]
+    _run_layer(dev, g, "nosample_", cls, det, inp["labels"], inp["iou"], inp["asy"], 0.25, 0.5, 7, sampling=False)
+    _run_layer(dev, g, "mist_", cls, det, inp["labels"], inp["iou"], inp["asy"], 0.25, 0.5, 8, using_cim=False)
+
+
+def test_cim_layer_degenerate_cases(dev, golden_dir):
+    from cim_amd.modeling import heads
+    g = np.load(os.path.join(golden_dir, "mining_degenerate.npz"))
+    _run_layer(dev, g, "huge_", g["in_cls"], g["in_det"], g["labels"], g["in_iou"], g["in_asy"], 0.25, 0.5, 9)
+    layer = heads.CIM_layer()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = layer(t(g["in_cls"]), t(g["in_det"]), None, t(np.zeros_like(g["labels"])), t(g["in_iou"]), t(g["in_asy"]))
+    assert out == (None, None, None)
+    with pytest.raises(NotImplementedError):                      # missing maps: model_builder.py:150-152
+        layer(t(g["in_cls"]), t(g["in_det"]), None, t(g["labels"]), None, None)
+
+
+def test_cim_layer_full_size_vs_oracle(dev):
+    """cfg2 / cfg4 sizes against the NumPy oracle on the same seeded inputs (index-exact)."""
+    from cim_amd import synthetic
+    from cim_amd.modeling import heads
+    from oracle import mask_iou as omi, mining as om
+    for config, n in (("resnet50_voc", 1000), ("resnet50_coco2017", 2000)):
+        inp = synthetic.make_image_inputs(config, seed=3, with_image=False)
+        iou, asy = omi.mask_iou_maps(inp["full_masks"])
+        C = inp["labels"].shape[1]
+        rng = np.random.RandomState(0)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        for li, (cls_thr, iou_thr) in enumerate(THRESHOLDS):
+            cls, det, _ = synthetic.make_scores(n, C, rng)
+            np.random.seed(50 + li)
+            ref = om.cim_layer_forward(cls, det, inp["labels"], iou, asy, cls_thr=cls_thr, iou_thr=iou_thr)
+            probe_ref = np.random.random_sample()
+            np.random.seed(50 + li)
+            layer = heads.CIM_layer(cls_thr=cls_thr, iou_thr=iou_thr)
+            out = layer(t(cls), t(det), None, t(inp["labels"]), t(iou), t(asy))
+            assert np.random.random_sample() == probe_ref
+            assert (out[0] is None) == (ref[0] is None)
+            if ref[0] is not None:
+                np.testing.assert_array_equal(out[0].cpu().numpy(), ref[0])
+                np.testing.assert_array_equal(out[1].cpu().numpy(), ref[1])
+                np.testing.assert_array_equal(out[2].cpu().numpy(), ref[2])
+
+
+# ------------------------------------------------------------------ heads + losses (a-3, a-8..a-10)
+@pytest.mark.parametrize("name", ["n300_c20_k2", "n1000_c80_k3"])
+def test_losses_on_device_match_reference(dev, name, golden_dir):
+    from cim_amd.modeling import heads
+    g = np.load(os.path.join(golden_dir, "losses_%s.npz" % name))
+    m = np.load(os.path.join(golden_dir, "mining_%s.npz" % name))
+    inp = case_inputs(MINING_CASES[name])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    rtol = 2e-5       # fp32 reductions in a different order; |f32 - f64| of the reference itself is ~1e-6
+    for li in range(3):
+        lmda = 3 if li == 0 else 1
+        cls, _, iou = inp["layers"][li]
+        got = heads.cls_iou_loss(t(cls), t(iou), t(m["l%d_pseudo_labels" % li]), t(m["l%d_pseudo_iou_labels" % li]),
+                                 lmda * t(m["l%d_loss_weights" % li]), t(inp["labels"]))
+        np.testing.assert_allclose([float(x) for x in got], g["f64_l%d_cls_iou_bag" % li], rtol=rtol)
+    cls, det, _ = inp["layers"][0]
+    np.testing.assert_allclose(float(heads.mil_bag_loss(t(cls), t(det), t(inp["labels"]))), g["f64_mil_bag"], rtol=rtol)
+    np.testing.assert_allclose(float(heads.PCL_loss(t(cls), t(inp["mat"]), t(inp["labels"]))), g["f64_pcl"], rtol=rtol)
+
+
+# ------------------------------------------------------------------ end to end (a-11, a-12): model vs oracle/cpu_step.py
+@pytest.mark.parametrize("config", ["resnet50_voc", "vgg16_voc"])
+def test_training_step_matches_cpu_oracle(dev, config):
+    """Same weights, same synthetic image: the 4 losses and the parameter gradients of the HIP
+    model against the host restatement (torch CPU ops + oracle ROIAlign + oracle mining).
+    fp32 conv/GEMM summation order differs between MIOpen/hipBLASLt and the CPU, hence a
+    tolerance; the pseudo labels are index-exact, so the same loss terms are active."""
+    import copy
+    from cim_amd import mask_iou, synthetic
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    from oracle import cpu_step, mask_iou as omi
+    apply_preset(config)
+    torch.manual_seed(0)
+    n = 48
+    inp = synthetic.make_image_inputs(config, seed=5, n=n)
+    inp["data"] = inp["data"][:, :, :192, :256].copy()
+    inp["rois"][:, 1:] *= np.float32(0.35)
+    cpu_model = Generalized_RCNN().train()
+    gpu_model = copy.deepcopy(cpu_model).to(dev).train()
+    iou, asy = omi.mask_iou_maps(inp["full_masks"])
+    ref = cpu_step.step(cpu_model, inp, iou, asy, seed=11)
+    t = lambda a: torch.from_numpy(a).unsqueeze(0).to(dev)
+    np.random.seed(11)
+    diou, dasy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
+    out = gpu_model(data=torch.from_numpy(inp["data"]).to(dev), rois=t(inp["rois"]), masks=t(inp["masks"]),
+                    labels=t(inp["labels"]), gtrois=None, mat=t(inp["mat"]), index=t(inp["index"]),
+                    iou_map=diou, asy_iou_map=dasy)
+    sum(v.sum() for v in out["losses"].values()).backward()
+    for k, v in ref.items():
+        assert out["losses"][k].shape == (1,)
+        np.testing.assert_allclose(float(out["losses"][k]), v, rtol=2e-3, atol=1e-5, err_msg=k)
+    cpu_p = dict(cpu_model.named_parameters())
+    checked = 0
+    for name, p in gpu_model.named_parameters():
+        if not p.requires_grad:
+            assert cpu_p[name].grad is None
+            continue
+        g_ref = cpu_p[name].grad
+        g = p.grad.cpu()
+        denom = float(g_ref.norm()) + 1e-12
+        assert float((g - g_ref).norm()) / denom < 2e-2, "gradient mismatch at %s" % name
+        checked += 1
+    assert checked > 20

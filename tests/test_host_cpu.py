@@ -1,0 +1,100 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/cim_hip.h declares,
+the config loader, and the torch-level losses / heads against the reference goldens."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from cases import MINING_CASES, case_inputs, procedural
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cim_amd import _lib, build
+    build.build()
+    header = open(os.path.join(REPO, "include", "cim_hip.h")).read()
+    declared = set(re.findall(r"\b(cim_[a-z0-9_]+)\s*\(", header))
+    assert {"cim_roi_align_fwd", "cim_assign", "cim_mask_iou_pair", "cim_seed_select"} <= declared
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "missing export: " + name
+    assert declared - {"cim_last_error", "cim_abi_version"} == set(_lib.SIGNATURES), "ctypes table out of sync with the header"
+    assert _lib.load().cim_abi_version() >= 1
+
+
+def test_no_cpu_fallback():
+    from cim_amd import _lib
+    from cim_amd.modeling import heads
+    from cim_amd.ops import roi_align
+    with pytest.raises(_lib.CimHipError):
+        roi_align(torch.randn(1, 4, 5, 5), torch.zeros(1, 5), 7, 0.0625)
+    with pytest.raises(_lib.CimHipError):
+        heads.CIM_layer()(torch.rand(8, 21), torch.rand(8, 21), None, torch.zeros(1, 20), None, None)
+
+
+def test_presets_and_model_construction():
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    cfg = apply_preset("vgg16_voc")
+    m = Generalized_RCNN()
+    keys = set(m.state_dict().keys())
+    assert {"Conv_Body.conv5.4.weight", "Box_Head.mask_branch.0.weight", "Box_Head.seg_fc.0.weight",
+            "Box_Head.seg_fc.2.bias", "cls_iou_model.refine_iou.2.weight", "cls_iou_model.detector.bias"} <= keys
+    assert m.Box_Head.mask_branch[0].weight.shape == (512, 1024, 3, 3)
+    assert not any(k.startswith("CIM_layer_list") for k in keys)
+    thr = [(l.cls_thr, l.iou_thr) for l in m.CIM_layer_list]
+    np.testing.assert_allclose(thr, [(0.25, 0.5), (0.35, 0.6), (0.45, 0.7)])
+    assert not m.Conv_Body.conv1[0].weight.requires_grad and m.Conv_Body.conv3[0].weight.requires_grad
+    wmap, orphans = m.detectron_weight_mapping
+    assert "Conv_Body.conv1.0.weight" in wmap and orphans == []
+    apply_preset("resnet50_voc")
+    assert cfg.MODEL.CONV_BODY == "resnet50.torch_resnet50"
+
+
+@pytest.mark.parametrize("name", ["n300_c20_k2", "n1000_c80_k3"])
+def test_torch_losses_match_reference(name, golden_dir):
+    from cim_amd.modeling import heads
+    g = np.load(os.path.join(golden_dir, "losses_%s.npz" % name))
+    m = np.load(os.path.join(golden_dir, "mining_%s.npz" % name))
+    inp = case_inputs(MINING_CASES[name])
+    t = torch.from_numpy
+    for dt, tag, rtol in ((torch.float32, "f32", 2e-5), (torch.float64, "f64", 1e-10)):
+        labels = t(inp["labels"]).to(dt)
+        for li in range(3):
+            lmda = 3 if li == 0 else 1
+            cls, _, iou = inp["layers"][li]
+            got = heads.cls_iou_loss(t(cls).to(dt), t(iou).to(dt), t(m["l%d_pseudo_labels" % li]).to(dt),
+                                     t(m["l%d_pseudo_iou_labels" % li]), lmda * t(m["l%d_loss_weights" % li]).to(dt), labels)
+            np.testing.assert_allclose([float(x) for x in got], g["%s_l%d_cls_iou_bag" % (tag, li)], rtol=rtol)
+        cls, det, _ = inp["layers"][0]
+        np.testing.assert_allclose(float(heads.mil_bag_loss(t(cls).to(dt), t(det).to(dt), labels)), g[tag + "_mil_bag"], rtol=rtol)
+        np.testing.assert_allclose(float(heads.PCL_loss(t(cls).to(dt), t(inp["mat"]).to(dt), labels)), g[tag + "_pcl"],
+                                   rtol=max(rtol, 2e-7))
+        cls, _, iou = inp["layers"][1]
+        bg = torch.zeros(cls.shape, dtype=dt)
+        bg[::3, 0] = 1
+        got = heads.cls_iou_loss(t(cls).to(dt), t(iou).to(dt), bg, t(m["l1_pseudo_iou_labels"]),
+                                 t(m["l1_loss_weights"]).to(dt), labels)
+        np.testing.assert_allclose([float(x) for x in got], g[tag + "_bgonly_cls_iou_bag"], rtol=rtol, atol=1e-12)
+        with pytest.raises(AssertionError):           # same error behaviour as heads.py:51
+            heads.cls_iou_loss(t(cls).to(dt), t(iou).to(dt), torch.zeros(cls.shape, dtype=dt),
+                               t(m["l1_pseudo_iou_labels"]), t(m["l1_loss_weights"]).to(dt), labels)
+
+
+def test_cls_iou_model_matches_reference(golden_dir):
+    from cim_amd.modeling import heads
+    g = np.load(os.path.join(golden_dir, "heads_small.npz"))
+    model = heads.cls_iou_model(64, 21, 3)
+    with torch.no_grad():
+        for k, (_, p) in enumerate(model.named_parameters()):
+            p.copy_(torch.from_numpy(procedural(tuple(p.shape), k + 1)))
+        pc, pd, rc, ri = model(torch.from_numpy(procedural((50, 64), 99) * 20))
+    np.testing.assert_allclose(pc.numpy(), g["predict_cls"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pd.numpy(), g["predict_det"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(torch.stack(rc).numpy(), g["refine_cls"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(torch.stack(ri).numpy(), g["refine_iou"], rtol=1e-5, atol=1e-7)
+    assert [n for n, _ in model.named_parameters()][:4] == ["classifier.weight", "classifier.bias", "detector.weight", "detector.bias"]
