@@ -73,9 +73,7 @@ def instrument(model, timer):
                 return orig_call(name, *args)
         return orig_call(name, *args)
 
-    _lib.call = call
-    import cim_amd.ops.roi_align as ra
-    ra._lib.call = call
+    _lib.call = call          # every wrapper resolves `_lib.call` at call time
     conv = model.Box_Head.mask_branch[0]
     orig_fwd = conv.forward
 
@@ -132,7 +130,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="resnet50_voc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=64)
+    ap.add_argument("--cpu-sample", type=int, default=128)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -35,6 +35,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime of this process, so
+    # import torch BEFORE dlopen-ing our library (otherwise /opt/rocm's copy is loaded first and
+    # the two runtimes do not share devices / streams).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CimHipError(
             "libcim_hip.so not found at %s - build it with `python -m cim_amd.build` "

@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void mask_area_kernel(const unsigned long long
 
 __device__ __forceinline__ uint16_t ratio_f16(int num, int den) {
     const double q = (double)num / (double)den;       // int64 / int64 -> float64 (numpy true_divide)
-    const float f = (float)q;                         // stored into a float32 array (mask_utils.py:12)
+    float f = (float)q;                               // stored into a float32 array (mask_utils.py:12)
+    // Keep the two roundings separate: without this barrier LLVM folds f64->f32->f16 into one
+    // direct f64->f16 truncation, which differs from the reference in ~4e-5 of the entries
+    // (values whose f32 rounding lands on an f16 tie).
+    asm volatile("" : "+v"(f));
     return __half_as_ushort(__float2half_rn(f));      // .astype(float16) (create_cob_iou.py:48)
 }
 

@@ -250,6 +250,39 @@ def gen_mask_iou():
         print("mask_iou", n, iou.shape, float(iou.astype(np.float32).mean()))
 
 
+def gen_mask_iou_witness():
+    """Pairs whose IoU rounds differently through f64->f32->f16 (the reference's chain) than
+    through a direct f64->f16 conversion: pins the DOUBLE rounding (needs unions > 8192 px)."""
+    mu = importlib.import_module("utils.mask_utils")
+    h, w = 150, 200
+    found = []
+    b = h * w - 7
+    while len(found) < 24 and b > 8192:
+        a = np.arange(1, b, dtype=np.int64)
+        q = a.astype(np.float64) / float(b)
+        diff = np.nonzero(q.astype(np.float32).astype(np.float16) != q.astype(np.float16))[0]
+        for i in diff[:2]:
+            found.append((int(a[i]), b))
+        b -= 37
+    masks = np.zeros((2 * len(found), h * w), dtype=bool)
+    for k, (inter, union) in enumerate(found):
+        # m1 = [0, x), m2 = [x - inter, union)  ->  |m1 & m2| = inter, |m1 | m2| = union
+        x = (union + inter) // 2
+        masks[2 * k, :x] = True
+        masks[2 * k + 1, x - inter:union] = True
+    masks = masks.reshape(-1, h, w)
+    n = masks.shape[0]
+    iou = np.concatenate([mu.mask_iou(masks, masks[j:j + 1]) for j in range(n)], axis=1).astype(np.float16)
+    asy = np.concatenate([mu.mask_asymmetric_iou(masks, masks[j:j + 1]) for j in range(n)], axis=1).astype(np.float16)
+    direct = np.array([np.float16(a / b) for a, b in found])
+    chained = np.array([iou[2 * k, 2 * k + 1] for k in range(len(found))])
+    assert (direct != chained).all(), "witnesses must distinguish the two rounding chains"
+    np.savez_compressed(os.path.join(HERE, "mask_iou_witness.npz"), h=np.array(h), w=np.array(w),
+                        masks_packed=np.packbits(masks.reshape(n, -1), axis=1), iou=iou, asy=asy,
+                        pairs=np.array(found))
+    print("mask_iou witness pairs:", len(found))
+
+
 def main():
     _ref_shims.install()
     heads = importlib.import_module("modeling.heads")
@@ -257,6 +290,7 @@ def main():
     gen_losses(heads)
     gen_heads_small(heads)
     gen_mask_iou()
+    gen_mask_iou_witness()
 
 
 if __name__ == "__main__":

@@ -59,9 +59,10 @@ def test_head_activations_match_reference(golden_dir):
     np.testing.assert_allclose(np.stack(act["refine_iou"]), g["refine_iou"], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("n", [6, 64])
+@pytest.mark.parametrize("n", [6, 64, "witness"])
 def test_mask_iou_matches_reference(n, golden_dir):
-    g = np.load(os.path.join(golden_dir, "mask_iou_%d.npz" % n))
+    g = np.load(os.path.join(golden_dir, "mask_iou_%s.npz" % n))
+    n = g["iou"].shape[0]
     h, w = int(g["h"]), int(g["w"])
     masks = np.unpackbits(g["masks_packed"], axis=1)[:, :h * w].reshape(n, h, w).astype(bool)
     iou, asy = mask_iou.mask_iou_maps(masks)
