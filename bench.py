@@ -84,6 +84,17 @@ def instrument(model, timer):
     conv.forward = fwd
 
 
+def init_for_synthetic(model):
+    """Random-init weights of the same architecture (no checkpoints on the box).  The ResNet body
+    keeps BatchNorm in eval mode (resnet50.py:63-68), so with untrained running statistics it is an
+    identity and the residual sum would grow ~2x in variance per block; damp the last BN scale of
+    every bottleneck (as zero-init-residual schemes do) so activations stay O(1) and the
+    synthetic training steps stay finite.  Architecture and work per step are unchanged."""
+    for m in model.modules():
+        if hasattr(m, "bn3"):
+            torch.nn.init.constant_(m.bn3.weight, 0.25)
+
+
 def make_optimizer(model):
     """Param groups of tools/train.py:282-311 (bias: lr x2, no weight decay), SGD momentum 0.9."""
     bias, nonbias = [], []
@@ -145,7 +156,9 @@ def main():
 
     apply_preset(args.config)
     torch.manual_seed(cfg.RNG_SEED)                            # identical initial weights on every rank
-    model = Generalized_RCNN().to(dev).train()
+    model = Generalized_RCNN()
+    init_for_synthetic(model)
+    model = model.to(dev).train()
     timer = KernelTimer()
     instrument(model, timer)
     dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True)

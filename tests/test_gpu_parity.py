@@ -254,16 +254,19 @@ def test_losses_on_device_match_reference(dev, name, golden_dir):
     m = np.load(os.path.join(golden_dir, "mining_%s.npz" % name))
     inp = case_inputs(MINING_CASES[name])
     t = lambda a: torch.from_numpy(a).to(dev)
-    rtol = 2e-5       # fp32 reductions in a different order; |f32 - f64| of the reference itself is ~1e-6
+    # against the reference's own fp32 results (its fp64 results differ by up to 1e-3 where the
+    # 1e-6 clamp saturates: 1 - 1e-6 is not representable in fp32); fp32 reductions run in a
+    # different order on the device, hence 2e-5.
+    rtol = 2e-5
     for li in range(3):
         lmda = 3 if li == 0 else 1
         cls, _, iou = inp["layers"][li]
         got = heads.cls_iou_loss(t(cls), t(iou), t(m["l%d_pseudo_labels" % li]), t(m["l%d_pseudo_iou_labels" % li]),
                                  lmda * t(m["l%d_loss_weights" % li]), t(inp["labels"]))
-        np.testing.assert_allclose([float(x) for x in got], g["f64_l%d_cls_iou_bag" % li], rtol=rtol)
+        np.testing.assert_allclose([float(x) for x in got], g["f32_l%d_cls_iou_bag" % li], rtol=rtol)
     cls, det, _ = inp["layers"][0]
-    np.testing.assert_allclose(float(heads.mil_bag_loss(t(cls), t(det), t(inp["labels"]))), g["f64_mil_bag"], rtol=rtol)
-    np.testing.assert_allclose(float(heads.PCL_loss(t(cls), t(inp["mat"]), t(inp["labels"]))), g["f64_pcl"], rtol=rtol)
+    np.testing.assert_allclose(float(heads.mil_bag_loss(t(cls), t(det), t(inp["labels"]))), g["f32_mil_bag"], rtol=rtol)
+    np.testing.assert_allclose(float(heads.PCL_loss(t(cls), t(inp["mat"]), t(inp["labels"]))), g["f32_pcl"], rtol=rtol)
 
 
 # ------------------------------------------------------------------ end to end (a-11, a-12): model vs oracle/cpu_step.py
@@ -306,7 +309,9 @@ def test_training_step_matches_cpu_oracle(dev, config):
             continue
         g_ref = cpu_p[name].grad
         g = p.grad.cpu()
-        denom = float(g_ref.norm()) + 1e-12
-        assert float((g - g_ref).norm()) / denom < 2e-2, "gradient mismatch at %s" % name
+        # relative to the gradient's own norm, with an absolute floor for vanishing gradients
+        # (the detector head: softmax over proposals, |g| ~ 1e-9)
+        tol = 2e-2 * float(g_ref.norm()) + 1e-7 * (g_ref.numel() ** 0.5)
+        assert float((g - g_ref).norm()) < tol, "gradient mismatch at %s" % name
         checked += 1
     assert checked > 20
