@@ -168,6 +168,174 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward, LDS-resident formulation (the default).
+//
+// ROIAlign is linear and separable: with per-ROI weight tables
+//   WY[ph][y] = sum over the bin-row's y-samples of the bilinear weight that sample puts on row y
+//   WX[pw][x] = likewise for columns
+// (a sample is dropped when either coordinate is out of range, which factorises too),
+//   grad_in[y,x,c] += (1/count) * sum_ph WY[ph][y] * sum_pw WX[pw][x] * g[ph,pw,c].
+// A workgroup OWNS a chunk of CH channels of the WHOLE feature map as an fp32 tile in LDS
+// (33x43x16x4 B = 91 KB of the CU's 160 KB), walks its share of the ROIs, accumulates into the
+// tile with plain LDS read-modify-writes (every (pixel, channel) is touched by exactly one lane
+// per ROI), and flushes the tile once.  HBM traffic = grad_out read once + the map written
+// once per ROI group; no global atomics in the ROI loop (the v1 kernel issued ~1.8 G of them).
+// grid = (C/CH, RG); block = 256.
+constexpr int TILE_THREADS = 1024;   // 16 waves: the tile pins one workgroup per CU, so hide LDS latency inside it
+
+// conservative [lo, hi] range of bins whose samples can touch position `pos` along one axis
+__device__ __forceinline__ void bin_range(float start, float bin, int P, int pos, int& lo, int& hi) {
+    if (bin > 0.0f) {
+        const float inv = 1.0f / bin;
+        lo = (int)floorf(((float)pos - 1.0f - start) * inv) - 1;
+        hi = (int)floorf(((float)pos + 1.0f - start) * inv) + 1;
+        lo = max(lo, 0);
+        hi = min(hi, P - 1);
+    } else {  // degenerate ROI: every bin sits at `start`
+        lo = 0;
+        hi = P - 1;
+    }
+}
+
+template <int CH, bool MASKCAT>
+__global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_tile_kernel(const float* __restrict__ grad_out,
+                                                                          const float* __restrict__ rois,
+                                                                          const float* __restrict__ masks,
+                                                                          float* __restrict__ grad_in, int B, int C,
+                                                                          int H, int W, int K, int P, float scale,
+                                                                          int sampling_ratio, int aligned,
+                                                                          int use_atomic) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CG = CH / 4;
+    constexpr int NT = TILE_THREADS;
+    const int HW = H * W;
+    const int tab = P * (H + W);
+    float* tile = lds;                        // [HW][CH]
+    float* gbuf = tile + (size_t)HW * CH;     // 2 x [P*P][CH]   (already divided by count), double-buffered
+    float* wtab = gbuf + 2 * P * P * CH;      // 2 x ([P][H] + [P][W]), double-buffered
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * CH;
+    const int OC = MASKCAT ? 2 * C : C;
+
+    for (int b = 0; b < B; ++b) {
+        for (int i = tid; i < HW * CG; i += NT) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int buf = 0;
+        for (int k = blockIdx.y; k < K; k += gridDim.y) {
+            const RoiGeom g = roi_geom(rois + 5 * (size_t)k, scale, P, sampling_ratio, aligned);
+            if (g.b != b) continue;                               // block-uniform
+            float* gb_ = gbuf + buf * P * P * CH;
+            float* wy = wtab + buf * tab;
+            float* wx = wy + P * H;
+            // weight tables: one entry per lane, loop over the bin's samples
+            for (int e = tid; e < tab; e += NT) {
+                const bool isy = e < P * H;
+                const int e2 = isy ? e : e - P * H;
+                const int size = isy ? H : W;
+                const int pb = e2 / size, pos = e2 % size;
+                const int gn = isy ? g.gh : g.gw;
+                const float start = isy ? g.y1 : g.x1, bin = isy ? g.bh : g.bw;
+                float acc = 0.0f;
+                for (int is = 0; is < gn; ++is) {
+                    const float v = start + pb * bin + (is + 0.5f) * bin / (float)gn;
+                    const Tap t = make_tap(v, size);
+                    if (!t.valid) continue;
+                    if (t.lo == pos) acc += t.h;
+                    if (t.hi == pos) acc += t.l;
+                }
+                (isy ? wy : wx)[e2] = acc;
+            }
+            // gradient of this ROI for our channel chunk, pre-divided by count
+            for (int e = tid; e < P * P * CG; e += NT) {
+                const int bin = e / CG, cg = e % CG;
+                const float* src = grad_out + ((size_t)k * P * P + bin) * OC + c0 + cg * 4;
+                float4 v = *reinterpret_cast<const float4*>(src);
+                if (MASKCAT) {
+                    const float m = masks[(size_t)k * P * P + bin];
+                    const float4 v2 = *reinterpret_cast<const float4*>(src + C);
+                    v = make_float4(v.x + m * v2.x, v.y + m * v2.y, v.z + m * v2.z, v.w + m * v2.w);
+                }
+                reinterpret_cast<float4*>(gb_)[e] = make_float4(v.x / g.count, v.y / g.count, v.z / g.count, v.w / g.count);
+            }
+            // one barrier per ROI: tables/gradient of ROI k are double-buffered, and the tile
+            // read-modify-writes of ROI k-1 (issued before this barrier by every lane) are complete.
+            __syncthreads();
+            // conservative bounding box of the pixels the ROI's samples can touch
+            const float ylast = g.y1 + (float)P * g.bh, xlast = g.x1 + (float)P * g.bw;
+            const int ylo = max(0, (int)floorf(fminf(g.y1, ylast)) - 1), yhi = min(H - 1, (int)floorf(fmaxf(g.y1, ylast)) + 2);
+            const int xlo = max(0, (int)floorf(fminf(g.x1, xlast)) - 1), xhi = min(W - 1, (int)floorf(fmaxf(g.x1, xlast)) + 2);
+            if (yhi >= ylo && xhi >= xlo) {
+                const int rw = xhi - xlo + 1, items = (yhi - ylo + 1) * rw * CG;
+                for (int it = tid; it < items; it += NT) {
+                    const int cg = it % CG, pix = it / CG;
+                    const int y = ylo + pix / rw, x = xlo + pix % rw;
+                    int phl, phh, pwl, pwh;
+                    bin_range(g.y1, g.bh, P, y, phl, phh);
+                    bin_range(g.x1, g.bw, P, x, pwl, pwh);
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int ph = phl; ph <= phh; ++ph) {
+                        const float a = wy[ph * H + y];
+                        if (a == 0.0f) continue;
+                        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int pw = pwl; pw <= pwh; ++pw) {
+                            const float bw_ = wx[pw * W + x];
+                            const float4 gv = reinterpret_cast<const float4*>(gb_)[(ph * P + pw) * CG + cg];
+                            row.x += bw_ * gv.x; row.y += bw_ * gv.y; row.z += bw_ * gv.z; row.w += bw_ * gv.w;
+                        }
+                        acc.x += a * row.x; acc.y += a * row.y; acc.z += a * row.z; acc.w += a * row.w;
+                    }
+                    float4* t4 = reinterpret_cast<float4*>(tile) + (size_t)(y * W + x) * CG + cg;
+                    float4 cur = *t4;
+                    cur.x += acc.x; cur.y += acc.y; cur.z += acc.z; cur.w += acc.w;
+                    *t4 = cur;
+                }
+            }
+            buf ^= 1;
+        }
+        __syncthreads();
+        float* gb = grad_in + (size_t)b * HW * C;
+        for (int i = tid; i < HW * CG; i += NT) {
+            const int pix = i / CG, cg = i % CG;
+            const float4 v = reinterpret_cast<const float4*>(tile)[i];
+            float* dst = gb + (size_t)pix * C + c0 + cg * 4;
+            if (use_atomic) {
+                atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+            } else {
+                *reinterpret_cast<float4*>(dst) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// LDS bytes of the tile kernel for a channel chunk of CH
+static size_t bwd_tile_lds(int CH, int H, int W, int P) {
+    return sizeof(float) * ((size_t)H * W * CH + 2 * (size_t)P * P * CH + 2 * (size_t)P * (H + W));
+}
+
+template <int CH, bool MASKCAT>
+static int launch_bwd_tile(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H,
+                           int W, int K, int P, float scale, int sr, int aligned, hipStream_t st) {
+    const size_t lds = bwd_tile_lds(CH, H, W, P);
+    auto kern = roi_align_bwd_tile_kernel<CH, MASKCAT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int chunks = C / CH;
+    int rg = (256 + chunks - 1) / chunks;          // >= one workgroup per CU (1 resident per CU at ~96 KB LDS)
+    if (rg > K) rg = K;
+    if (rg < 1) rg = 1;
+    if (rg > 1) {
+        hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * (size_t)B * H * W * C, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(chunks, rg), dim3(TILE_THREADS), lds, st, go, rois, masks, gin, B, C, H, W, K, P, scale,
+                       sr, aligned, rg > 1 ? 1 : 0);
+    return 0;
+}
+
 template <bool MASKCAT>
 int launch_fwd(const float* feat, const float* rois, const float* masks, float* out, int B, int C, int H, int W, int K,
                int P, float scale, int sr, int aligned, hipStream_t st) {
@@ -185,6 +353,16 @@ int launch_fwd(const float* feat, const float* rois, const float* masks, float* 
 template <bool MASKCAT>
 int launch_bwd(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W, int K,
                int P, float scale, int sr, int aligned, hipStream_t st) {
+    const size_t budget = 150 * 1024;
+    if (K > 0 && P <= 16 && C % 4 == 0) {
+        if (C % 16 == 0 && bwd_tile_lds(16, H, W, P) <= budget)
+            return launch_bwd_tile<16, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, st);
+        if (C % 8 == 0 && bwd_tile_lds(8, H, W, P) <= budget)
+            return launch_bwd_tile<8, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, st);
+        if (bwd_tile_lds(4, H, W, P) <= budget)
+            return launch_bwd_tile<4, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, st);
+    }
+    // generic fallback (odd channel counts, maps too large for an LDS tile): global atomics
     hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * (size_t)B * H * W * C, st);
     if (e != hipSuccess) return (int)e;
     if (K == 0) return 0;
