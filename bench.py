@@ -67,21 +67,23 @@ class KernelTimer:
 def instrument(model, timer):
     orig_call = _lib.call
 
+    state = {"conv": 0}
+
     def call(name, *args):
         if name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_bwd"):
+            state["conv"] = 0
             with timer.span(name):
+                return orig_call(name, *args)
+        if name == "cim_conv3x3_f32":       # per step: 1st launch = forward, 2nd = data gradient
+            state["conv"] += 1
+            with timer.span("maskfuse_conv_fwd" if state["conv"] == 1 else "maskfuse_conv_dgrad"):
+                return orig_call(name, *args)
+        if name == "cim_conv3x3_wgrad_f32":
+            with timer.span("maskfuse_conv_wgrad"):
                 return orig_call(name, *args)
         return orig_call(name, *args)
 
     _lib.call = call          # every wrapper resolves `_lib.call` at call time
-    conv = model.Box_Head.mask_branch[0]
-    orig_fwd = conv.forward
-
-    def fwd(x):
-        with timer.span("maskfuse_conv_fwd"):
-            return orig_fwd(x)
-
-    conv.forward = fwd
 
 
 def init_for_synthetic(model):
@@ -211,7 +213,7 @@ def main():
         # dominant kernel: MaskFuse 3x3 conv forward (a-2), 2*49*N*(2Cf*9)*Cf flops
         conv_ms = timer.mean_ms("maskfuse_conv_fwd")
         conv_flops = 2.0 * 49 * n * (2 * Cf * 9) * Cf
-        roofline = dict(bound="mfma", kernel="maskfuse_conv3x3_fwd", achieved=conv_flops / (conv_ms * 1e-3) / 1e12,
+        roofline = dict(bound="mfma", kernel="gemm_f32_kernel<A_CONV_K,B_NCONTIG> (MaskFuse conv3x3 fwd)", achieved=conv_flops / (conv_ms * 1e-3) / 1e12,
                         peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None)
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         # HBM-bound hand-written kernels: fused ROIAlign+mask-cat fwd / bwd

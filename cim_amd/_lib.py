@@ -21,6 +21,10 @@ SIGNATURES = {
     "cim_seed_select": [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P],
     "cim_contain_argmax": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P],
     "cim_arbitrate": [_P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P],
+    "cim_gemm_f32_splits": [c_int, c_int, c_int],
+    "cim_gemm_f32": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P],
+    "cim_conv3x3_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "cim_conv3x3_wgrad_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "cim_assign": [_P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P],
 }
 
@@ -55,9 +59,14 @@ def load():
     return lib
 
 
+VALUE_RETURNING = {"cim_gemm_f32_splits"}      # return a count, not a status
+
+
 def call(name, *args):
     lib = load()
     rc = getattr(lib, name)(*args)
+    if name in VALUE_RETURNING:
+        return rc
     if rc != 0:
         raise CimHipError("%s failed (rc=%d): %s" % (name, rc, lib.cim_last_error().decode()))
 

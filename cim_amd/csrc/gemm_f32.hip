@@ -1,0 +1,432 @@
+// fp32 MFMA GEMM family for the MaskFuse head (~98 % of the step's FLOPs).
+//
+// Replaces the dense contractions of MaskFuse.forward / backward,
+// /root/reference/lib/modeling/resnet50.py:104-110,135-136: the 3x3 conv 2C->C on N x 7 x 7
+// (as an implicit GEMM: the im2col matrix is never materialised), Linear(49C->4096),
+// Linear(4096->4096), and their data / weight gradients.
+//
+// Arithmetic: exact fp32 - v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bitwise a k-ordered
+// fmaf chain), 157.3 TFLOP/s dense peak on MI355X.  No reduced-precision path.
+//
+// Tiling (64-wide waves): workgroup tile BM x BN = 256 x 256, 8 waves as 2(M) x 4(N), each wave
+// 128 x 64 = 4 x 2 MFMA tiles of 32 x 32 (128 accumulator VGPRs).  K is consumed in slabs of
+// BK = 16 staged through LDS as [k][m] / [k][n] (row stride +4 floats), so each MFMA operand
+// fetch is one conflict-free ds_read_b32 of 32 consecutive floats per half-wave.  Global->LDS is
+// register-staged and double-buffered: the loads of slab t+1 are issued before the MFMAs of
+// slab t and written to the other LDS buffer afterwards (one barrier per slab).
+// Operand layouts are template parameters (no runtime dispatch inside the loop):
+//   A: K-contiguous rows (activations [M,K], optionally gathered as 3x3-conv patches) or
+//      M-contiguous rows ([K,M], e.g. dY^T / im2col^T for weight gradients)
+//   B: N-contiguous rows ([K,N]) or K-contiguous rows ([N,K], nn.Linear weights)
+#include "common.h"
+#include "../../include/cim_hip.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 256, BN = 256, BK = 16;
+constexpr int WAVES_M = 2, WAVES_N = 4;
+constexpr int NT = 64 * WAVES_M * WAVES_N;      // 512 threads
+constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // 128 x 64 per wave
+constexpr int MI = WM / 32, NI = WN / 32;        // 4 x 2 MFMA tiles
+constexpr int LDS_A = BM + 4, LDS_B = BN + 4;    // padded row strides (floats)
+constexpr int SLAB = BK * (LDS_A + LDS_B);       // floats per LDS buffer
+
+enum ALayout { A_KCONTIG = 0, A_MCONTIG = 1, A_CONV_K = 2, A_CONV_M = 3 };
+enum BLayout { B_NCONTIG = 0, B_KCONTIG = 1 };
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;   // [N] or null
+    int M, N, K;
+    int lda, ldb, ldc;
+    int relu;
+    int k_per_split;     // multiple of BK
+    long long c_split_stride;   // elements between split-K partial outputs
+    // implicit 3x3 conv geometry (A_CONV_*): A is X[R, P, P, Cin] (NHWC)
+    int P, Cin;
+};
+
+// ---- A operand -------------------------------------------------------------------------------
+// K-contiguous: each thread owns float4 pieces (row, 4 consecutive k); BM*BK/4/NT = 2 pieces.
+template <int AL>
+struct ALoaderK {
+    static constexpr int PIECES = BM * BK / 4 / NT;
+    const float* ptr[PIECES];   // row base (+ q*4), null when the row is out of range
+    int row[PIECES];
+    int oh[PIECES], ow[PIECES];
+    int q;
+
+    __device__ __forceinline__ void init(const GemmArgs& g, int m0, int tid) {
+        q = tid & 3;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            row[i] = (tid >> 2) + i * (NT / 4);
+            const int m = m0 + row[i];
+            if (AL == A_CONV_K) {
+                const int pp = g.P * g.P;
+                const int p = m % pp;
+                oh[i] = p / g.P;
+                ow[i] = p % g.P;
+                ptr[i] = (m < g.M) ? g.A + (size_t)m * g.Cin + q * 4 : nullptr;
+            } else {
+                ptr[i] = (m < g.M) ? g.A + (size_t)m * g.lda + q * 4 : nullptr;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const GemmArgs& g, int k0, float4 (&v)[PIECES]) const {
+        int dy = 0, dx = 0, ci0 = k0;
+        if (AL == A_CONV_K) {   // slab = 16 channels of one tap (Cin % BK == 0)
+            const int tap = k0 / g.Cin;
+            ci0 = k0 - tap * g.Cin;
+            dy = tap / 3 - 1;
+            dx = tap % 3 - 1;
+        }
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ptr[i] == nullptr) continue;
+            if (AL == A_CONV_K) {
+                const int y = oh[i] + dy, x = ow[i] + dx;
+                if ((unsigned)y < (unsigned)g.P && (unsigned)x < (unsigned)g.P)
+                    v[i] = *reinterpret_cast<const float4*>(ptr[i] + (ptrdiff_t)(dy * g.P + dx) * g.Cin + ci0);
+            } else if (k0 + q * 4 < g.K) {
+                v[i] = *reinterpret_cast<const float4*>(ptr[i] + k0);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* as, const float4 (&v)[PIECES]) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            float* d = as + (q * 4) * LDS_A + row[i];
+            d[0 * LDS_A] = v[i].x;
+            d[1 * LDS_A] = v[i].y;
+            d[2 * LDS_A] = v[i].z;
+            d[3 * LDS_A] = v[i].w;
+        }
+    }
+};
+
+// M-contiguous: element (m, k) at A[k*lda + m]; thread owns float4 pieces (k row, 4 consecutive m).
+template <int AL>
+struct ALoaderM {
+    static constexpr int PIECES = BM * BK / 4 / NT;
+    int mq, krow0;
+    const float* base;   // column base (A + m), null when out of range
+    int dy, dx;
+
+    __device__ __forceinline__ void init(const GemmArgs& g, int m0, int tid) {
+        mq = tid & 63;
+        krow0 = tid >> 6;
+        const int m = m0 + mq * 4;
+        if (AL == A_CONV_M) {   // m = (tap, ci); 4 consecutive m share the tap (Cin % 4 == 0)
+            const int tap = m / g.Cin;
+            dy = tap / 3 - 1;
+            dx = tap % 3 - 1;
+            base = (m < g.M) ? g.A + (m - tap * g.Cin) : nullptr;
+        } else {
+            dy = dx = 0;
+            base = (m < g.M) ? g.A + m : nullptr;
+        }
+    }
+    __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int k = k0 + krow0 + i * (NT / 64);
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (base == nullptr || k >= kend) continue;
+            if (AL == A_CONV_M) {   // k = output pixel row (roi, oh, ow); gather the tap-shifted input pixel
+                const int pp = g.P * g.P;
+                const int p = k % pp;
+                const int y = p / g.P + dy, x = p % g.P + dx;
+                if ((unsigned)y < (unsigned)g.P && (unsigned)x < (unsigned)g.P)
+                    v[i] = *reinterpret_cast<const float4*>(base + (size_t)(k + dy * g.P + dx) * g.Cin);
+            } else {
+                v[i] = *reinterpret_cast<const float4*>(base + (size_t)k * g.lda);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* as, const float4 (&v)[PIECES]) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i)
+            *reinterpret_cast<float4*>(as + (krow0 + i * (NT / 64)) * LDS_A + mq * 4) = v[i];
+    }
+};
+
+// ---- B operand -------------------------------------------------------------------------------
+struct BLoaderN {   // element (k, n) at B[k*ldb + n]
+    static constexpr int PIECES = BN * BK / 4 / NT;
+    int nq, krow0;
+    const float* base;
+    __device__ __forceinline__ void init(const GemmArgs& g, int n0, int tid) {
+        nq = tid & 63;
+        krow0 = tid >> 6;
+        const int n = n0 + nq * 4;
+        base = (n < g.N) ? g.B + n : nullptr;
+    }
+    __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int k = k0 + krow0 + i * (NT / 64);
+            v[i] = (base != nullptr && k < kend) ? *reinterpret_cast<const float4*>(base + (size_t)k * g.ldb)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float* bs, const float4 (&v)[PIECES]) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i)
+            *reinterpret_cast<float4*>(bs + (krow0 + i * (NT / 64)) * LDS_B + nq * 4) = v[i];
+    }
+};
+
+struct BLoaderK {   // element (k, n) at B[n*ldb + k]  (nn.Linear weight [N, K])
+    static constexpr int PIECES = BN * BK / 4 / NT;
+    const float* ptr[PIECES];
+    int row[PIECES];
+    int q;
+    __device__ __forceinline__ void init(const GemmArgs& g, int n0, int tid) {
+        q = tid & 3;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            row[i] = (tid >> 2) + i * (NT / 4);
+            const int n = n0 + row[i];
+            ptr[i] = (n < g.N) ? g.B + (size_t)n * g.ldb + q * 4 : nullptr;
+        }
+    }
+    __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i)
+            v[i] = (ptr[i] != nullptr && k0 + q * 4 < kend) ? *reinterpret_cast<const float4*>(ptr[i] + k0)
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ void store(float* bs, const float4 (&v)[PIECES]) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            float* d = bs + (q * 4) * LDS_B + row[i];
+            d[0 * LDS_B] = v[i].x;
+            d[1 * LDS_B] = v[i].y;
+            d[2 * LDS_B] = v[i].z;
+            d[3 * LDS_B] = v[i].w;
+        }
+    }
+};
+
+template <int AL> struct ASel { using type = ALoaderK<AL>; };
+template <> struct ASel<A_MCONTIG> { using type = ALoaderM<A_MCONTIG>; };
+template <> struct ASel<A_CONV_M> { using type = ALoaderM<A_CONV_M>; };
+template <int BL> struct BSel { using type = BLoaderN; };
+template <> struct BSel<B_KCONTIG> { using type = BLoaderK; };
+
+template <int AL, class L>
+__device__ __forceinline__ void a_load(const L& l, const GemmArgs& g, int k0, int kend, float4 (&v)[L::PIECES]) {
+    if constexpr (AL == A_KCONTIG || AL == A_CONV_K) l.load(g, k0, v);
+    else l.load(g, k0, kend, v);
+}
+
+// grid = (tiles_n, tiles_m, splits); block = 512
+template <int AL, int BL>
+__global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    typename ASel<AL>::type la;
+    typename BSel<BL>::type lb;
+    la.init(g, m0, tid);
+    lb.init(g, n0, tid);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[ASel<AL>::type::PIECES], rb[BSel<BL>::type::PIECES];
+    a_load<AL>(la, g, kbeg, kend, ra);
+    lb.load(g, kbeg, kend, rb);
+    la.store(smem, ra);
+    lb.store(smem + BK * LDS_A, rb);
+    __syncthreads();
+
+    const int nslab = (kend - kbeg + BK - 1) / BK;
+    const int lk = lane >> 5, l31 = lane & 31;
+    for (int t = 0; t < nslab; ++t) {
+        float* cur = smem + (t & 1) * SLAB;
+        float* nxt = smem + ((t + 1) & 1) * SLAB;
+        const bool more = (t + 1 < nslab);
+        if (more) {   // issue the next slab's global loads before the MFMAs of this one
+            a_load<AL>(la, g, kbeg + (t + 1) * BK, kend, ra);
+            lb.load(g, kbeg + (t + 1) * BK, kend, rb);
+        }
+        const float* as = cur + wm * WM + l31;
+        const float* bs = cur + BK * LDS_A + wn * WN + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = as[(kk + lk) * LDS_A + i * 32];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = bs[(kk + lk) * LDS_B + j * 32];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            la.store(nxt, ra);
+            lb.store(nxt + BK * LDS_A, rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* C = g.C + (size_t)blockIdx.z * g.c_split_stride;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n >= g.N) continue;
+        const float bv = (g.bias != nullptr) ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (g.relu) v = fmaxf(v, 0.0f);
+                C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// sum split-K partials (fixed order: deterministic), add bias, optional ReLU.  One float4 per lane.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
+                                                            const float* __restrict__ bias, int M, int N, int ldc,
+                                                            int splits, long long stride, int relu) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (long long)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    float4 s = *reinterpret_cast<const float4*>(ws + i);
+    for (int k = 1; k < splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + k * stride + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (relu) {
+        s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = s;
+}
+
+template <int AL, int BL>
+int launch(GemmArgs g, int splits, float* workspace, hipStream_t st) {
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    const size_t lds = sizeof(float) * 2 * SLAB;
+    auto kern = gemm_f32_kernel<AL, BL>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const int slabs = (g.K + BK - 1) / BK;
+    if (splits < 1) splits = 1;
+    if (splits > slabs) splits = slabs;
+    g.k_per_split = ((slabs + splits - 1) / splits) * BK;
+    splits = (g.K + g.k_per_split - 1) / g.k_per_split;
+    float* out = g.C;
+    const float* bias = g.bias;
+    const int relu = g.relu, ldc = g.ldc;
+    if (splits > 1) {
+        g.C = workspace;
+        g.ldc = g.N;
+        g.c_split_stride = (long long)g.M * g.N;
+        g.bias = nullptr;
+        g.relu = 0;
+    } else {
+        g.c_split_stride = 0;
+    }
+    hipLaunchKernelGGL(kern, dim3(tn, tm, splits), dim3(NT), lds, st, g);
+    if (splits > 1) {
+        const long long quads = ((long long)g.M * g.N + 3) / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, workspace, out,
+                           bias, g.M, g.N, ldc, splits, g.c_split_stride, relu);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cim_gemm_f32_splits(int M, int N, int K) {
+    // One 512-thread workgroup (128 accumulator VGPRs per lane) is resident per CU, so a launch
+    // runs in rounds of 256 tiles; pick the split-K factor that fills the last round
+    // (e.g. conv wgrad: 288 tiles -> 2 rounds at 56 %; x8 -> 2304 = 9 full rounds).
+    const int CUS = 256;
+    const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int slabs = (K + BK - 1) / BK;
+    if (tiles >= 16 * CUS) return 1;
+    int best = 1;
+    double best_score = -1.0;
+    for (int s = 1; s <= 16; ++s) {
+        if (s > 1 && slabs / s < 16) break;            // keep >= 16 slabs (256 k) per split
+        const long long units = tiles * s;
+        const long long rounds = (units + CUS - 1) / CUS;
+        const double eff = (double)units / (double)(rounds * CUS);
+        const double score = eff - 0.015 * (s - 1);    // split-K costs workspace traffic
+        if (score > best_score + 1e-9) { best_score = score; best = s; }
+    }
+    return best;
+}
+
+extern "C" int cim_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                            int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
+                            void* stream) {
+    CIM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
+    CIM_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N);
+    CIM_CHECK_ARG(a_mcontig ? (M % 4 == 0 && lda % 4 == 0 && lda >= M) : (K % 4 == 0 && lda % 4 == 0 && lda >= K));
+    CIM_CHECK_ARG(b_kcontig ? (K % 4 == 0 && ldb % 4 == 0 && ldb >= K) : (ldb % 4 == 0 && ldb >= N));
+    CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 0, 0};
+    hipStream_t st = cim::as_stream(stream);
+    int rc;
+    if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, splits, workspace, st);
+    else if (!a_mcontig && b_kcontig) rc = launch<A_KCONTIG, B_KCONTIG>(g, splits, workspace, st);
+    else if (a_mcontig && !b_kcontig) rc = launch<A_MCONTIG, B_NCONTIG>(g, splits, workspace, st);
+    else rc = launch<A_MCONTIG, B_KCONTIG>(g, splits, workspace, st);
+    if (rc) { cim::set_error("cim_gemm_f32: launch setup failed (%d)", rc); return rc; }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_conv3x3_f32(const float* X, const float* Whwio, const float* bias, float* Y, int R, int P, int Cin,
+                               int Cout, int relu, void* stream) {
+    CIM_CHECK_ARG(X && Whwio && Y && R > 0 && P > 0 && Cin > 0 && Cout > 0);
+    CIM_CHECK_ARG(Cin % BK == 0 && Cout % 4 == 0);
+    GemmArgs g{X, Whwio, Y, bias, R * P * P, Cout, 9 * Cin, Cin, Cout, Cout, relu, 0, 0, P, Cin};
+    int rc = launch<A_CONV_K, B_NCONTIG>(g, 1, nullptr, cim::as_stream(stream));
+    if (rc) { cim::set_error("cim_conv3x3_f32: launch setup failed (%d)", rc); return rc; }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_conv3x3_wgrad_f32(const float* X, const float* dY, float* dWhwio, int R, int P, int Cin, int Cout,
+                                     int splits, float* workspace, void* stream) {
+    CIM_CHECK_ARG(X && dY && dWhwio && R > 0 && P > 0 && Cin > 0 && Cout > 0);
+    CIM_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0);
+    CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
+    GemmArgs g{X, dY, dWhwio, nullptr, 9 * Cin, Cout, R * P * P, Cin, Cout, Cout, 0, 0, 0, P, Cin};
+    int rc = launch<A_CONV_M, B_NCONTIG>(g, splits, workspace, cim::as_stream(stream));
+    if (rc) { cim::set_error("cim_conv3x3_wgrad_f32: launch setup failed (%d)", rc); return rc; }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..core.config import cfg
-from ..ops import roi_align_maskcat
+from ..ops import conv3x3, linear, roi_align_maskcat
 
 
 class MaskFuse(nn.Module):
@@ -38,7 +38,12 @@ class MaskFuse(nn.Module):
             raise NotImplementedError("MaskFuse: only ROI_XFORM_METHOD=RoIAlign is on the CIM path (got %s)" % method)
         cat = roi_align_maskcat(x, rois, masks, cfg.FAST_RCNN.ROI_XFORM_RESOLUTION, self.spatial_scale,
                                 cfg.FAST_RCNN.ROI_XFORM_SAMPLING_RATIO, aligned=True)
-        y = self.mask_branch(cat)
+        # exact-fp32 MFMA contractions (cim_amd/csrc/gemm_f32.hip); the nn.Conv2d / nn.Linear
+        # modules only hold the parameters (reference names and layouts)
+        conv = self.mask_branch[0]
+        y = conv3x3(cat, conv.weight, conv.bias, relu=True)
         n = y.size(0)
         # (c, h, w) flatten order of the reference's `.view(batch, -1)` on an NCHW tensor
-        return self.seg_fc(y.contiguous(memory_format=torch.contiguous_format).view(n, -1))
+        y = y.contiguous(memory_format=torch.contiguous_format).view(n, -1)
+        fc1, fc2 = self.seg_fc[0], self.seg_fc[2]
+        return linear(linear(y, fc1.weight, fc1.bias, relu=True), fc2.weight, fc2.bias, relu=True)

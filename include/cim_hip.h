@@ -126,6 +126,31 @@ int cim_assign(const uint16_t* iou_f16, int N, const int32_t* gt_idx, const int3
                float* pseudo_labels, uint16_t* pseudo_iou_f16, float* loss_weights, int32_t* max_idx,
                void* stream);
 
+/* ------------------------------------------------------------------ MaskFuse contractions (a-2)
+ * Exact-fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32) replacing the ATen/cuDNN calls behind
+ * MaskFuse, lib/modeling/resnet50.py:104-110,135-136 (Conv2d(2C,C,3,pad=1), Linear(49C,4096),
+ * Linear(4096,4096)) and their autograd backward.
+ *
+ * C[M,N] = A . B (+ bias[N]) (ReLU optional), row-major C with leading dimension ldc.
+ *   a_mcontig = 0: A element (m,k) at A[m*lda + k];  1: at A[k*lda + m]
+ *   b_kcontig = 0: B element (k,n) at B[k*ldb + n];  1: at B[n*ldb + k]   (nn.Linear weight)
+ * splits > 1: split-K through `workspace` (splits*M*N floats), reduced in a fixed order
+ * (deterministic).  cim_gemm_f32_splits() returns the split count the library would choose. */
+int cim_gemm_f32_splits(int M, int N, int K);
+int cim_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                 int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu,
+                 int splits, float* workspace, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution on R independent P x P maps as an implicit GEMM
+ * (no im2col buffer): X [R,P,P,Cin] (NHWC), Whwio [3,3,Cin,Cout], Y [R,P,P,Cout].
+ * The data gradient is the same call on dY with the spatially flipped, in/out-swapped weights. */
+int cim_conv3x3_f32(const float* X, const float* Whwio, const float* bias, float* Y,
+                    int R, int P, int Cin, int Cout, int relu, void* stream);
+
+/* Weight gradient: dWhwio [3,3,Cin,Cout] = im2col(X)^T . dY, dY [R,P,P,Cout]. */
+int cim_conv3x3_wgrad_f32(const float* X, const float* dY, float* dWhwio,
+                          int R, int P, int Cin, int Cout, int splits, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""-m gpu: the exact-fp32 MFMA contractions (cim_amd/csrc/gemm_f32.hip) through the C ABI against
+fp64 references: every operand layout, ragged M/N/K, split-K, the implicit 3x3 conv and its
+data / weight gradients, and the autograd wrappers used by MaskFuse."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from cim_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rel(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 4096, 4096), (300, 260, 1000), (37, 8, 20), (513, 516, 48), (256, 256, 16)])
+@pytest.mark.parametrize("a_m,b_k", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_layouts_vs_fp64(dev, M, N, K, a_m, b_k):
+    from cim_amd.ops import gemm as G
+    if (a_m and M % 4) or (not a_m and K % 4) or (b_k and K % 4):
+        pytest.skip("layout needs 16-byte rows")
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double() + bias.double()
+    a_dev = (A.t().contiguous() if a_m else A).to(dev)
+    b_dev = (B.t().contiguous() if b_k else B).to(dev)
+    c = G.gemm(a_dev, b_dev, M, N, K, M if a_m else K, K if b_k else N, bool(a_m), bool(b_k), bias.to(dev))
+    assert _rel(c.cpu(), ref) < 2e-6        # exact-fp32 class error (K <= 4096)
+    c2 = G.gemm(a_dev, b_dev, M, N, K, M if a_m else K, K if b_k else N, bool(a_m), bool(b_k), bias.to(dev), relu=True)
+    assert _rel(c2.cpu(), ref.clamp(min=0)) < 2e-6
+
+
+def test_gemm_is_asymmetric_and_deterministic(dev):
+    """A = I with an asymmetric B catches a transposed C write; split-K reduces in a fixed order."""
+    from cim_amd.ops import gemm as G
+    n = 320
+    B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 1000.0
+    c = G.gemm(torch.eye(n).to(dev), B.to(dev), n, n, n, n, n)
+    assert torch.equal(c.cpu(), B)
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(200, 50176, generator=g).to(dev)          # fc1-like: few tiles, long K -> split-K
+    W = torch.randn(256, 50176, generator=g).to(dev)
+    y1 = G.gemm(A, W, 200, 256, 50176, 50176, 50176, b_kcontig=True)
+    y2 = G.gemm(A, W, 200, 256, 50176, 50176, 50176, b_kcontig=True)
+    assert torch.equal(y1, y2)
+    assert _rel(y1.cpu(), A.cpu().double() @ W.cpu().double().t()) < 3e-5   # K = 50176: fp32 accumulation error grows with K
+
+
+@pytest.mark.parametrize("R,Cin,Cout", [(11, 32, 48), (40, 64, 272), (6, 16, 16)])
+def test_conv3x3_fwd_bwd_vs_fp64(dev, R, Cin, Cout):
+    from cim_amd.ops import conv3x3
+    g = torch.Generator().manual_seed(R + Cin)
+    x = torch.randn(R, Cin, 7, 7, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    go = torch.randn(R, Cout, 7, 7, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.relu(F.conv2d(xr, wr, br, padding=1))
+    yr.backward(go.double())
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = conv3x3(xd, wd, bd, relu=True)
+    assert y.shape == (R, Cout, 7, 7)
+    y.backward(go.to(dev))
+    assert _rel(y.detach().cpu(), yr.detach()) < 2e-6
+    assert _rel(xd.grad.cpu(), xr.grad) < 2e-6
+    assert _rel(wd.grad.cpu(), wr.grad) < 2e-6
+    assert _rel(bd.grad.cpu(), br.grad) < 2e-6
+
+
+def test_linear_fwd_bwd_vs_fp64(dev):
+    from cim_amd.ops import linear
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(130, 392, generator=g)
+    w = torch.randn(96, 392, generator=g) * 0.05
+    b = torch.randn(96, generator=g)
+    go = torch.randn(130, 96, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.relu(F.linear(xr, wr, br))
+    yr.backward(go.double())
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = linear(xd, wd, bd, relu=True)
+    y.backward(go.to(dev))
+    for got, ref in ((y.detach(), yr.detach()), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        assert _rel(got.cpu(), ref) < 2e-6
+
+
+def test_conv3x3_full_size_linearity(dev):
+    """cfg2 size (1000 x 7 x 7, 2048 -> 1024): conv(a + 2b) == conv(a) + 2 conv(b)."""
+    from cim_amd.ops import conv3x3
+    g = torch.Generator(device=dev).manual_seed(0)
+    w = torch.randn(1024, 2048, 3, 3, device=dev, generator=g) * 0.01
+    a = torch.randn(1000, 7, 7, 2048, device=dev, generator=g).permute(0, 3, 1, 2)
+    b = torch.randn(1000, 7, 7, 2048, device=dev, generator=g).permute(0, 3, 1, 2)
+    ya, yb, yab = conv3x3(a, w), conv3x3(b, w), conv3x3(a + 2 * b, w)
+    torch.testing.assert_close(yab, ya + 2 * yb, rtol=1e-4, atol=1e-4)
+    # spot-check 8 output rows against fp64
+    idx = torch.tensor([0, 17, 48, 49, 500 * 49 + 24, 999 * 49 + 48, 999 * 49, 12345])
+    ref = F.conv2d(a[idx // 49].double().cpu(), w.double().cpu(), padding=1)
+    for j, i in enumerate(idx.tolist()):
+        p = i % 49
+        got = ya[i // 49, :, p // 7, p % 7].cpu().double()
+        assert float((got - ref[j, :, p // 7, p % 7]).abs().max()) < 1e-4
