@@ -25,7 +25,7 @@ from torch import nn
 
 class DataParallel(nn.Module):
     def __init__(self, module, device_ids=None, output_device=None, dim=0, cpu_keywords=(), minibatch=False,
-                 batch_outputs=True, bucket_bytes=256 << 20, process_group=None):
+                 batch_outputs=True, bucket_bytes=64 << 20, process_group=None):
         super().__init__()
         self.module = module
         self.cpu_keywords = list(cpu_keywords)
@@ -39,6 +39,7 @@ class DataParallel(nn.Module):
         self.output_device = self.device
         self._sync = True
         self._pending = []
+        self._next_bucket = 0
         self._build_flat_grads(bucket_bytes)
 
     # ------------------------------------------------------------------ flat gradient storage
@@ -78,14 +79,24 @@ class DataParallel(nn.Module):
             return
         bk = self.buckets[self._bucket_of[p]]
         bk["ready"] += 1
-        if bk["ready"] == len(bk["params"]):
+        if p.grad.data_ptr() < self.flat_grad.data_ptr() or \
+                p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * 4:
+            raise RuntimeError("DataParallel: a .grad was replaced (use zero_grad(set_to_none=False) / "
+                               "DataParallel.zero_grad())")
+        self._launch_ready_buckets()
+
+    def _launch_ready_buckets(self, force=False):
+        """Buckets are reduced STRICTLY in index order, so every rank issues the same sequence of
+        collectives even if a rank's autograd produced gradients in a different order or skipped
+        a parameter (e.g. a refinement head whose CIM layer returned None on that image)."""
+        while self._next_bucket < len(self.buckets):
+            bk = self.buckets[self._next_bucket]
+            if not force and bk["ready"] < len(bk["params"]):
+                break
             bk["ready"] = 0
-            if p.grad.data_ptr() < self.flat_grad.data_ptr() or \
-                    p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * 4:
-                raise RuntimeError("DataParallel: a .grad was replaced (use zero_grad(set_to_none=False) / "
-                                   "DataParallel.zero_grad())")
             self._pending.append(dist.all_reduce(self.flat_grad[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM,
                                                  group=self.process_group, async_op=True))
+            self._next_bucket += 1
 
     def zero_grad(self, set_to_none=False):
         """One memset of the flat buffer (param.grad stay views into it)."""
@@ -101,10 +112,16 @@ class DataParallel(nn.Module):
             self._sync = old
 
     def finish_gradient_sync(self):
-        """Wait for the in-flight bucket all-reduces (call after backward, before optimizer.step)."""
+        """Reduce whatever has not been reduced yet (in bucket order) and wait for the in-flight
+        all-reduces.  Call after backward, before optimizer.step()."""
+        if self.world_size > 1 and self._sync:
+            self._launch_ready_buckets(force=True)
         for w in self._pending:
             w.wait()
         self._pending = []
+        self._next_bucket = 0
+        for bk in self.buckets:
+            bk["ready"] = 0
 
     def loss_scale(self):
         return 1.0 / self.world_size

@@ -18,8 +18,9 @@ class Tiny(nn.Module):
             p.requires_grad = False
         self.b = nn.Linear(16, 3)
 
-    def forward(self, data, scale=None):
-        y = self.b(torch.relu(self.frozen(torch.relu(self.a(data))))).pow(2).sum()
+    def forward(self, data, scale=None, skip_b=False):
+        h = torch.relu(self.frozen(torch.relu(self.a(data))))
+        y = (h if skip_b else self.b(h)).pow(2).sum()
         return {"losses": {"l": (y * scale).unsqueeze(0)}}
 
 
@@ -59,17 +60,24 @@ def _worker(rank, world, port, out):
     (o["losses"]["l"].sum() * dp.loss_scale()).backward()
     dp.finish_gradient_sync()
     g2 = dp.flat_grad.clone()
+    # step 3: rank 1 skips one head entirely (its parameters get no gradient on that rank):
+    # the strict bucket order must still pair up the collectives of both ranks
+    dp.zero_grad()
+    o = dp(data=[_data(rank)], scale=[torch.tensor(1.0)], skip_b=[rank == 1])
+    (o["losses"]["l"].sum() * dp.loss_scale()).backward()
+    dp.finish_gradient_sync()
+    g3 = dp.flat_grad.clone()
     if rank == 0:
-        torch.save({"g1": g1, "g2": g2}, out)
+        torch.save({"g1": g1, "g2": g2, "g3": g3}, out)
     dist.destroy_process_group()
 
 
-def _local_grad(data, scale):
+def _local_grad(data, scale, skip_b=False):
     torch.manual_seed(0)
     m = Tiny()
-    m(data, scale)["losses"]["l"].sum().backward()
+    m(data, scale, skip_b)["losses"]["l"].sum().backward()
     params = [p for p in m.parameters() if p.requires_grad]
-    return torch.cat([p.grad.reshape(-1) for p in reversed(params)])
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in reversed(params)])
 
 
 def test_dp_allreduce_world2(tmp_path):
@@ -82,6 +90,8 @@ def test_dp_allreduce_world2(tmp_path):
     want2 = (_local_grad(_data(0), 0.5) + _local_grad(_data(1), 0.5)
              + _local_grad(_data(10), 2.0) + _local_grad(_data(11), 2.0)) / 2
     torch.testing.assert_close(got["g2"], want2, rtol=1e-5, atol=1e-6)
+    want3 = (_local_grad(_data(0), 1.0) + _local_grad(_data(1), 1.0, skip_b=True)) / 2
+    torch.testing.assert_close(got["g3"], want3, rtol=1e-5, atol=1e-6)
 
 
 def test_dp_single_process_passthrough():
