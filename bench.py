@@ -105,7 +105,7 @@ def make_optimizer(model):
             (bias if "bias" in name else nonbias).append(p)
     lr, wd = 0.0005, 0.0005                                   # configs/resnet50_voc.yaml SOLVER
     return torch.optim.SGD([dict(params=nonbias, lr=lr, weight_decay=wd),
-                            dict(params=bias, lr=2 * lr, weight_decay=0.0)], lr=lr, momentum=0.9, foreach=True)
+                            dict(params=bias, lr=2 * lr, weight_decay=0.0)], lr=lr, momentum=0.9, fused=True)
 
 
 def cpu_baseline(config, budget_n=250):

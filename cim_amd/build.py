@@ -32,7 +32,8 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", LIB + ".tmp"] + sources()
+           "-Wall", "-Wno-unused-function"] + os.environ.get("CIM_HIPCC_FLAGS", "").split() + \
+          ["-o", LIB + ".tmp"] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -25,7 +25,10 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BM = 256, BN = 256, BK = 16;
+#ifndef CIM_GEMM_BK
+#define CIM_GEMM_BK 16
+#endif
+constexpr int BM = 256, BN = 256, BK = CIM_GEMM_BK;
 constexpr int WAVES_M = 2, WAVES_N = 4;
 constexpr int NT = 64 * WAVES_M * WAVES_N;      // 512 threads
 constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // 128 x 64 per wave
@@ -233,7 +236,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const GemmArgs g) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order (speed only): workgroup b runs on XCD b % 8; give each XCD a contiguous
+    // run of tiles (n fastest) so the tiles sharing an A row-panel hit the same 4 MB L2.
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+#ifndef CIM_GEMM_NO_XCD
+    {
+        const int tn = gridDim.x, nt = gridDim.x * gridDim.y;
+        const int b = blockIdx.y * tn + blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;   // bijective for any nt
+        tile_m = t / tn;
+        tile_n = t - tile_m * tn;
+    }
+#endif
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
