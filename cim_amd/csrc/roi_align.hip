@@ -336,159 +336,6 @@ static int launch_bwd_tile(const float* go, const float* rois, const float* mask
     return 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Backward, register-resident formulation (default when the map is small enough: B == 1,
-// H*W <= 256*PPT).  Same separable math as the LDS-tile kernel above, but the gradient tile of
-// the workgroup's 16-channel chunk lives in VGPRs: lane (slot, cg) OWNS pixels slot + 256*j of
-// the map for all ROIs, so there is no read-modify-write hazard between ROIs at all and the
-// per-ROI barrier disappears.  Per batch of RB ROIs the workgroup stages their weight tables and
-// (mask-folded, count-divided) output gradients in LDS (one barrier per batch, double-buffered),
-// then every lane walks its own pixels.  ~45 KB LDS and few VGPRs -> several workgroups per CU.
-// grid = (C/16, RG); block = 1024; blockIdx.x is remapped so that the 8 chunks sharing 512 B of
-// every pixel run on the same XCD (their 64 B segments merge in that XCD's L2).
-constexpr int RB = 4;      // ROIs per barrier
-template <int PPT, bool MASKCAT>
-__global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_reg_kernel(const float* __restrict__ grad_out,
-                                                                         const float* __restrict__ rois,
-                                                                         const float* __restrict__ masks,
-                                                                         float* __restrict__ grad_in, int C, int H,
-                                                                         int W, int K, int P, float scale,
-                                                                         int sampling_ratio, int aligned,
-                                                                         int use_atomic) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int CH = 16, CG = 4, NT = TILE_THREADS, SLOTS = NT / CG;
-    const int HW = H * W;
-    const int tab = P * (H + W);
-    const int per_roi = P * P * CH + tab + 8;            // floats: g | wy | wx | geometry
-    const int tid = threadIdx.x;
-    const int cg = tid & 3, slot = tid >> 2;
-    // XCD-aware chunk mapping (speed only): XCD x = blockIdx.x % 8 owns chunks 8x' .. contiguous
-    const int nchunks = gridDim.x;
-    int chunk = blockIdx.x;
-    if ((nchunks & 7) == 0) chunk = (blockIdx.x & 7) * (nchunks >> 3) + (blockIdx.x >> 3);
-    const int c0 = chunk * CH;
-    const int OC = MASKCAT ? 2 * C : C;
-
-    float4 acc[PPT];
-    int py[PPT], px[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int p = slot + SLOTS * j;
-        py[j] = (p < HW) ? p / W : -1000000;
-        px[j] = (p < HW) ? p % W : -1000000;
-    }
-
-    int buf = 0;
-    for (int k0 = blockIdx.y * RB; k0 < K; k0 += gridDim.y * RB) {
-        float* base = lds + buf * RB * per_roi;
-        const int nr = min(RB, K - k0);
-        // stage tables + gradients of the batch
-        for (int r = 0; r < nr; ++r) {
-            const int k = k0 + r;
-            const RoiGeom g = roi_geom(rois + 5 * (size_t)k, scale, P, sampling_ratio, aligned);
-            float* gb_ = base + r * per_roi;
-            float* wy = gb_ + P * P * CH;
-            float* wx = wy + P * H;
-            for (int e = tid; e < tab; e += NT) {
-                const bool isy = e < P * H;
-                const int e2 = isy ? e : e - P * H;
-                const int size = isy ? H : W;
-                const int pb = e2 / size, pos = e2 % size;
-                const int gn = isy ? g.gh : g.gw;
-                const float start = isy ? g.y1 : g.x1, bin = isy ? g.bh : g.bw;
-                float a = 0.0f;
-                for (int is = 0; is < gn; ++is) {
-                    const float v = start + pb * bin + (is + 0.5f) * bin / (float)gn;
-                    const Tap t = make_tap(v, size);
-                    if (!t.valid) continue;
-                    if (t.lo == pos) a += t.h;
-                    if (t.hi == pos) a += t.l;
-                }
-                (isy ? wy : wx)[e2] = a;
-            }
-            for (int e = tid; e < P * P * CG; e += NT) {
-                const int bin = e / CG, q = e % CG;
-                const float* src = grad_out + ((size_t)k * P * P + bin) * OC + c0 + q * 4;
-                float4 v = *reinterpret_cast<const float4*>(src);
-                if (MASKCAT) {
-                    const float m = masks[(size_t)k * P * P + bin];
-                    const float4 v2 = *reinterpret_cast<const float4*>(src + C);
-                    v = make_float4(v.x + m * v2.x, v.y + m * v2.y, v.z + m * v2.z, v.w + m * v2.w);
-                }
-                reinterpret_cast<float4*>(gb_)[e] = make_float4(v.x / g.count, v.y / g.count, v.z / g.count, v.w / g.count);
-            }
-        }
-        __syncthreads();
-        for (int r = 0; r < nr; ++r) {
-            const RoiGeom g = roi_geom(rois + 5 * (size_t)(k0 + r), scale, P, sampling_ratio, aligned);
-            const float* gb_ = base + r * per_roi;
-            const float* wy = gb_ + P * P * CH;
-            const float* wx = wy + P * H;
-            const float ylast = g.y1 + (float)P * g.bh, xlast = g.x1 + (float)P * g.bw;
-            const int ylo = (int)floorf(fminf(g.y1, ylast)) - 1, yhi = (int)floorf(fmaxf(g.y1, ylast)) + 2;
-            const int xlo = (int)floorf(fminf(g.x1, xlast)) - 1, xhi = (int)floorf(fmaxf(g.x1, xlast)) + 2;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const int y = py[j], x = px[j];
-                if (y < ylo || y > yhi || x < xlo || x > xhi) continue;
-                int phl, phh, pwl, pwh;
-                bin_range(g.y1, g.bh, P, y, phl, phh);
-                bin_range(g.x1, g.bw, P, x, pwl, pwh);
-                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int ph = phl; ph <= phh; ++ph) {
-                    const float a = wy[ph * H + y];
-                    if (a == 0.0f) continue;
-                    float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int pw = pwl; pw <= pwh; ++pw) {
-                        const float b_ = wx[pw * W + x];
-                        if (b_ == 0.0f) continue;
-                        const float4 gv = reinterpret_cast<const float4*>(gb_)[(ph * P + pw) * CG + cg];
-                        row.x += b_ * gv.x; row.y += b_ * gv.y; row.z += b_ * gv.z; row.w += b_ * gv.w;
-                    }
-                    a4.x += a * row.x; a4.y += a * row.y; a4.z += a * row.z; a4.w += a * row.w;
-                }
-                acc[j].x += a4.x; acc[j].y += a4.y; acc[j].z += a4.z; acc[j].w += a4.w;
-            }
-        }
-        buf ^= 1;
-    }
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int p = slot + SLOTS * j;
-        if (p >= HW) continue;
-        float* dst = grad_in + (size_t)p * C + c0 + cg * 4;
-        if (use_atomic) {
-            atomicAdd(dst + 0, acc[j].x); atomicAdd(dst + 1, acc[j].y); atomicAdd(dst + 2, acc[j].z); atomicAdd(dst + 3, acc[j].w);
-        } else {
-            *reinterpret_cast<float4*>(dst) = acc[j];
-        }
-    }
-}
-
-template <int PPT, bool MASKCAT>
-static int launch_bwd_reg(const float* go, const float* rois, const float* masks, float* gin, int C, int H, int W, int K,
-                          int P, float scale, int sr, int aligned, hipStream_t st) {
-    const size_t lds = sizeof(float) * 2 * RB * ((size_t)P * P * 16 + (size_t)P * (H + W) + 8);
-    auto kern = roi_align_bwd_reg_kernel<PPT, MASKCAT>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    const int chunks = C / 16;
-    int rg = (256 + chunks - 1) / chunks;            // one 1024-thread workgroup per CU (124 VGPRs)
-    const int batches = (K + RB - 1) / RB;
-    if (rg > batches) rg = batches;
-    if (rg < 1) rg = 1;
-    if (rg > 1) {
-        hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * (size_t)H * W * C, st);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3(chunks, rg), dim3(TILE_THREADS), lds, st, go, rois, masks, gin, C, H, W, K, P, scale,
-                       sr, aligned, rg > 1 ? 1 : 0);
-    return 0;
-}
-
 template <bool MASKCAT>
 int launch_fwd(const float* feat, const float* rois, const float* masks, float* out, int B, int C, int H, int W, int K,
                int P, float scale, int sr, int aligned, hipStream_t st) {
@@ -507,11 +354,6 @@ template <bool MASKCAT>
 int launch_bwd(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W, int K,
                int P, float scale, int sr, int aligned, hipStream_t st) {
     const size_t budget = 150 * 1024;
-    if (K > 0 && B == 1 && P <= 16 && C % 16 == 0 && (size_t)P * (H + W) * 32 <= 96 * 1024) {
-        const int hw = H * W;
-        if (hw <= 256 * 6) return launch_bwd_reg<6, MASKCAT>(go, rois, masks, gin, C, H, W, K, P, scale, sr, aligned, st);
-        if (hw <= 256 * 12) return launch_bwd_reg<12, MASKCAT>(go, rois, masks, gin, C, H, W, K, P, scale, sr, aligned, st);
-    }
     if (K > 0 && P <= 16 && C % 4 == 0) {
         if (C % 16 == 0 && bwd_tile_lds(16, H, W, P) <= budget)
             return launch_bwd_tile<16, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, st);

@@ -40,7 +40,8 @@ def _roi_case(seed, C, H, W, K, img_scale=16.0):
 
 
 @pytest.mark.parametrize("C,H,W,K,aligned", [(8, 13, 17, 24, True), (3, 9, 11, 16, True), (64, 33, 43, 40, True),
-                                              (8, 13, 17, 24, False)])
+                                              (8, 13, 17, 24, False), (4, 13, 17, 24, True), (4, 13, 17, 24, False),
+                                              (16, 45, 60, 33, True), (16, 45, 60, 33, False)])
 def test_roi_align_fwd_bwd_vs_oracle(dev, C, H, W, K, aligned):
     from cim_amd.ops import roi_align
     from oracle import roi_align as oracle
@@ -49,7 +50,7 @@ def test_roi_align_fwd_bwd_vs_oracle(dev, C, H, W, K, aligned):
     x = _cl(feat, dev).requires_grad_(True)
     out = roi_align(x, torch.from_numpy(rois).to(dev), 7, 1 / 16.0, 0, "avg", aligned)
     assert out.shape == (K, C, 7, 7)
-    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)         # bit-exact forward
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)         # bit-identical forward
     rng = np.random.RandomState(1)
     go = rng.randn(K, C, 7, 7).astype(np.float32)
     out.backward(torch.from_numpy(go).to(dev))

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused ROIAlign+mask-cat kernels at BASELINE cfg2 size (1000 synthetic
+proposals, 1024 x 33 x 43 map): ms per launch and fraction of the 8 TB/s HBM roofline on the
+algorithmic bytes of SURVEY.md 8(d)."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cim_amd import _lib, synthetic  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfgname = sys.argv[1] if len(sys.argv) > 1 else "resnet50_voc"
+inp = synthetic.make_image_inputs(cfgname, seed=3, with_image=False)
+C = {"resnet50_voc": 1024, "resnet50_coco2017": 1024, "vgg16_voc": 512}[cfgname]
+stride = 8 if cfgname.startswith("vgg") else 16
+H, W = -(-inp["image_hw"][0] // stride), -(-inp["image_hw"][1] // stride)
+K = inp["rois"].shape[0]
+rois = torch.from_numpy(inp["rois"]).to(dev)
+masks = torch.from_numpy(inp["masks"]).to(dev)
+feat = torch.randn(1, H, W, C, device=dev)
+cat = torch.empty(K, 7, 7, 2 * C, device=dev)
+gcat = torch.randn(K, 7, 7, 2 * C, device=dev)
+gin = torch.empty(1, H, W, C, device=dev)
+st = _lib.stream_ptr()
+
+
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+fwd = lambda: _lib.call("cim_roi_align_maskcat_fwd", feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, st)
+bwd = lambda: _lib.call("cim_roi_align_maskcat_bwd", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, st)
+nbytes = 4.0 * (C * H * W + 5 * K + 49 * K) + 4.0 * K * 2 * C * 49
+tf, tb = timeit(fwd), timeit(bwd)
+print(json.dumps(dict(config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, fwd_ms=tf, fwd_frac=nbytes / tf / 1e6 / 8000,
+                      bwd_ms=tb, bwd_frac=nbytes / tb / 1e6 / 8000)))
