@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--config", default="resnet50_voc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=250)
+    ap.add_argument("--miopen-find", action="store_true",
+                    help="let MIOpen time its solvers for the backbone convs (default: immediate mode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +160,7 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.backends.cudnn.benchmark = args.miopen_find      # backbone convs (a-11) go through MIOpen
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     _lib.load()                                                # no HIP extension -> fail loudly
