@@ -134,4 +134,4 @@ def step(model, inp, iou, asy, n_sub=None, seed=0, timings=None):
     t0 = time.perf_counter()
     feat_b.backward(feat.grad)
     tick("backbone_bwd", t0)
-    return {k: float(v) for k, v in losses.items()}
+    return {k: float(v.detach()) for k, v in losses.items()}

@@ -49,3 +49,33 @@ def procedural(shape, salt):
     return ((h.astype(np.float64) / float(1 << 20) - 0.5) * 0.2).astype(np.float32).reshape(shape)
 
 
+
+
+# ---- whole-step case: cfg1 vgg16_voc, N = 300, procedural weights and image
+E2E = dict(config="vgg16_voc", n=300, seed=21, np_seed=5)
+
+
+def procedural_init(model):
+    """Platform-independent pseudo-random weights for every parameter (same on the reference model
+    and on cim_amd's): legacy RandomState integers / 2**20 (exact in fp32), He-uniform-sized for
+    weights, +-0.05 for biases.  Keeps activations O(1) and the mining scores separated by
+    >= 1e-4 relative (top-K) so that fp32 noise between CPU and GPU cannot flip an index."""
+    import torch
+    with torch.no_grad():
+        for k, (name, p) in enumerate(model.named_parameters()):
+            rng = np.random.RandomState(1000 + k)
+            u = rng.randint(-(1 << 20), 1 << 20, size=tuple(p.shape)).astype(np.float32) / np.float32(1 << 20)
+            if p.dim() >= 2:
+                fan_in = p.numel() // p.shape[0]
+                p.copy_(torch.from_numpy(u * np.float32((6.0 / fan_in) ** 0.5)))
+            else:
+                p.copy_(torch.from_numpy(u * np.float32(0.05)))
+
+
+def e2e_inputs():
+    inp = synthetic.make_image_inputs(E2E["config"], seed=E2E["seed"], n=E2E["n"], with_image=False)
+    H, W = inp["image_hw"]
+    inp["data"] = (procedural((1, 3, H, W), 777) * 10.0).astype(np.float32)
+    iou, asy = oracle_mask_iou.mask_iou_maps(inp["full_masks"])
+    inp["iou"], inp["asy"] = iou, asy
+    return inp

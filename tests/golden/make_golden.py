@@ -34,7 +34,7 @@ sys.path.insert(0, HERE)
 import _ref_shims  # noqa: E402
 from cim_amd import synthetic  # noqa: E402
 from oracle import mask_iou as oracle_mask_iou  # noqa: E402  (only to build INPUT maps)
-from cases import MINING_CASES, THRESHOLDS, case_inputs, procedural  # noqa: E402
+from cases import E2E, MINING_CASES, THRESHOLDS, case_inputs, e2e_inputs, procedural, procedural_init  # noqa: E402
 
 class FrameTap:
     """sys.settrace tap on heads.py frames: snapshots named locals of CIM_label / MIST_label
@@ -283,6 +283,79 @@ def gen_mask_iou_witness():
     print("mask_iou witness pairs:", len(found))
 
 
+def gen_e2e():
+    """cfg1 (vgg16_voc, 300 proposals) through the REFERENCE's Generalized_RCNN / vgg16.MaskFuse /
+    heads, with oracle/roi_align_ref.c plugged in where the reference imports mmcv.ops.RoIAlign
+    (lib/ops/__init__.py:6).  Captures the 4 losses and every parameter's gradient norm + head."""
+    import pickle
+    import tempfile
+    from oracle import roi_align as ora
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, feat, rois, P, scale, sr):
+            ctx.rois, ctx.shape, ctx.args = rois.detach().numpy(), tuple(feat.shape), (P, scale, sr)
+            return torch.from_numpy(ora.roi_align_fwd(feat.detach().numpy(), ctx.rois, P, scale, sr, True))
+
+        @staticmethod
+        def backward(ctx, go):
+            P, scale, sr = ctx.args
+            g = ora.roi_align_bwd(go.contiguous().numpy(), ctx.rois, ctx.shape, P, scale, sr, True)
+            return torch.from_numpy(g.astype(np.float32)), None, None, None, None
+
+    class RoIAlignStub(torch.nn.Module):          # constructor signature of mmcv.ops.RoIAlign
+        def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode="avg", aligned=True,
+                     use_torchvision=False):
+            super().__init__()
+            self.args = (output_size, spatial_scale, sampling_ratio)
+
+        def forward(self, x, rois):
+            return _Fn.apply(x, rois, *self.args)
+
+    sys.modules["mmcv.ops"].RoIAlign = RoIAlignStub
+    for m in [k for k in sys.modules if k == "ops" or k.startswith("ops.")]:
+        del sys.modules[m]
+    cfgmod = importlib.import_module("core.config")
+    cfg = cfgmod.cfg
+    cfg.MODEL.NUM_CLASSES = 20                                       # tools/train.py:185-190
+    cfgmod.cfg_from_file(_ref_shims.REF_ROOT + "/configs/vgg16_voc.yaml")
+    cfg.MODEL.LOAD_IMAGENET_PRETRAINED_WEIGHTS = False
+    tmp = tempfile.mkdtemp()
+    cfg.iou_dir = cfg.asy_iou_dir = tmp
+    mb = importlib.import_module("modeling.model_builder")
+    model = mb.Generalized_RCNN().train()
+    procedural_init(model)
+    inp = e2e_inputs()
+    with open(os.path.join(tmp, "img.pkl"), "wb") as f:
+        pickle.dump(inp["iou"], f)
+    # both maps live in ONE directory here, so write the containment map under a second stem
+    cfg.asy_iou_dir = tempfile.mkdtemp()
+    with open(os.path.join(cfg.asy_iou_dir, "img.pkl"), "wb") as f:
+        pickle.dump(inp["asy"], f)
+    t = lambda a: torch.from_numpy(a).unsqueeze(0)
+    np.random.seed(E2E["np_seed"])
+    out = model(data=torch.from_numpy(inp["data"]), rois=t(inp["rois"]), masks=t(inp["masks"]), labels=t(inp["labels"]),
+                gtrois=torch.zeros(1, 1, 6), mat=t(inp["mat"]), path="/x/img.jpg", index=t(inp["index"]))
+    probe = np.random.random_sample()
+    total = sum(v.sum() for v in out["losses"].values())
+    total.backward()
+    store = {"loss_" + k: np.array(float(v)) for k, v in out["losses"].items()}
+    store["rng_probe"] = np.array(probe)
+    names, norms, heads_ = [], [], []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(name)
+        norms.append(float(p.grad.double().norm()))
+        heads_.append(p.grad.reshape(-1)[:8].numpy().astype(np.float64) if p.numel() >= 8 else np.zeros(8))
+    store["grad_names"] = np.array(names)
+    store["grad_norms"] = np.array(norms)
+    store["grad_heads"] = np.stack(heads_)
+    store["blob_conv_absmean"] = np.array(float(out["blob_conv"].abs().mean()))
+    np.savez_compressed(os.path.join(HERE, "e2e_vgg16_voc.npz"), **store)
+    print("e2e", {k: float(v) for k, v in store.items() if k.startswith("loss_")}, "params with grad:", len(names))
+
+
 def main():
     _ref_shims.install()
     heads = importlib.import_module("modeling.heads")
@@ -291,6 +364,7 @@ def main():
     gen_heads_small(heads)
     gen_mask_iou()
     gen_mask_iou_witness()
+    gen_e2e()
 
 
 if __name__ == "__main__":

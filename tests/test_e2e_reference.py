@@ -1,0 +1,65 @@
+"""Whole training step against the REFERENCE itself (tests/golden/e2e_vgg16_voc.npz: BASELINE cfg1,
+vgg16_voc, 300 proposals, captured by running /root/reference's Generalized_RCNN + heads with the
+oracle ROIAlign plugged in for mmcv): the CPU oracle step (not gpu) and the HIP model (gpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cases import E2E, e2e_inputs, procedural_init
+
+
+def _model():
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    apply_preset(E2E["config"])
+    m = Generalized_RCNN().train()
+    procedural_init(m)
+    return m
+
+
+def _check(g, losses, named_grads, probe):
+    assert probe == float(g["rng_probe"]), "anti-noise sampling consumed a different NumPy RNG stream"
+    for k in ("bag_loss", "pcl_loss", "cls_loss", "iou_loss"):
+        np.testing.assert_allclose(losses[k], float(g["loss_" + k]), rtol=2e-3, atol=1e-6, err_msg=k)
+    names = [str(n) for n in g["grad_names"]]
+    assert names == [n for n, _ in named_grads], "parameter names / order differ from the reference"
+    for (name, grad), norm, head in zip(named_grads, g["grad_norms"], g["grad_heads"]):
+        n = grad.numel()
+        floor = 1e-7 * n ** 0.5
+        assert abs(float(grad.double().norm()) - norm) <= 2e-2 * norm + floor, name
+        if n >= 8 and norm > 1e-6:      # (detector.bias: softmax over proposals -> exact gradient 0, pure rounding noise)
+            np.testing.assert_allclose(grad.reshape(-1)[:8].double().numpy(), head, rtol=5e-2,
+                                       atol=5e-2 * norm / n ** 0.5 + 1e-9, err_msg=name)
+
+
+def test_cpu_oracle_step_matches_reference(golden_dir):
+    from oracle import cpu_step
+    g = np.load(os.path.join(golden_dir, "e2e_vgg16_voc.npz"))
+    m = _model()
+    inp = e2e_inputs()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    losses = cpu_step.step(m, inp, inp["iou"], inp["asy"], seed=E2E["np_seed"])
+    probe = np.random.random_sample()
+    grads = [(n, p.grad) for n, p in m.named_parameters() if p.grad is not None]
+    _check(g, losses, grads, probe)
+
+
+@pytest.mark.gpu
+def test_hip_step_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "e2e_vgg16_voc.npz"))
+    dev = torch.device("cuda:0")
+    m = _model().to(dev)
+    inp = e2e_inputs()
+    t = lambda a: torch.from_numpy(a).unsqueeze(0).to(dev)
+    np.random.seed(E2E["np_seed"])
+    out = m(data=torch.from_numpy(inp["data"]).to(dev), rois=t(inp["rois"]), masks=t(inp["masks"]),
+            labels=t(inp["labels"]), gtrois=None, mat=t(inp["mat"]), index=t(inp["index"]),
+            iou_map=torch.from_numpy(inp["iou"]).to(dev), asy_iou_map=torch.from_numpy(inp["asy"]).to(dev))
+    probe = np.random.random_sample()
+    sum(v.sum() for v in out["losses"].values()).backward()
+    losses = {k: float(v.detach()) for k, v in out["losses"].items()}
+    grads = [(n, p.grad.cpu()) for n, p in m.named_parameters() if p.grad is not None]
+    np.testing.assert_allclose(float(out["blob_conv"].abs().mean()), float(g["blob_conv_absmean"]), rtol=1e-3)
+    _check(g, losses, grads, probe)
