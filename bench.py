@@ -67,16 +67,21 @@ class KernelTimer:
 def instrument(model, timer):
     orig_call = _lib.call
 
-    state = {"conv": 0}
+    state = {"conv": 0, "bg": 0}
 
     def call(name, *args):
         if name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_bwd"):
-            state["conv"] = 0
+            if name.endswith("fwd"):
+                state["conv"] = state["bg"] = 0
             with timer.span(name):
                 return orig_call(name, *args)
         if name == "cim_conv3x3_f32":       # per step: 1st launch = forward, 2nd = data gradient
             state["conv"] += 1
             with timer.span("maskfuse_conv_fwd" if state["conv"] == 1 else "maskfuse_conv_dgrad"):
+                return orig_call(name, *args)
+        if name == "cim_gemm_f32_batched":  # Winograd-domain GEMMs, per step: forward, data grad, weight grad
+            state["bg"] += 1
+            with timer.span(("wino_gemm_fwd", "wino_gemm_dgrad", "wino_gemm_wgrad")[min(state["bg"], 3) - 1]):
                 return orig_call(name, *args)
         if name == "cim_conv3x3_wgrad_f32":
             with timer.span("maskfuse_conv_wgrad"):
@@ -219,11 +224,18 @@ def main():
         H, W = inp["image_hw"]
         Cf = model.Conv_Body.dim_out
         Hf, Wf = -(-H // 16), -(-W // 16)
-        # dominant kernel: MaskFuse 3x3 conv forward (a-2), 2*49*N*(2Cf*9)*Cf flops
-        conv_ms = timer.mean_ms("maskfuse_conv_fwd")
-        conv_flops = 2.0 * 49 * n * (2 * Cf * 9) * Cf
-        roofline = dict(bound="mfma", kernel="gemm_f32_kernel<A_CONV_K,B_NCONTIG> (MaskFuse conv3x3 fwd)", achieved=conv_flops / (conv_ms * 1e-3) / 1e12,
-                        peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None)
+        # dominant kernel: the exact-fp32 MFMA GEMM of the MaskFuse 3x3 conv forward (a-2).
+        #   Winograd F(2x2,3x3) (default): 16 batched GEMMs [16N x 2Cf] x [2Cf x Cf] = 2*16*16N*2Cf*Cf flops
+        #   direct implicit GEMM (CIM_CONV_ALGO=direct): 2*49N*18Cf*Cf flops        
+        wino_ms = timer.mean_ms("wino_gemm_fwd")
+        if wino_ms:
+            kname = "gemm_f32_kernel<A_KCONTIG,B_NCONTIG> x16 (MaskFuse conv3x3 fwd, Winograd F(2x2,3x3) domain)"
+            conv_ms, conv_flops = wino_ms, 2.0 * 16 * (16 * n) * (2 * Cf) * Cf
+        else:
+            kname = "gemm_f32_kernel<A_CONV_K,B_NCONTIG> (MaskFuse conv3x3 fwd, implicit GEMM)"
+            conv_ms, conv_flops = timer.mean_ms("maskfuse_conv_fwd"), 2.0 * 49 * n * (2 * Cf * 9) * Cf
+        roofline = dict(bound="mfma", kernel=kname, achieved=conv_flops / (conv_ms * 1e-3) / 1e12,
+                        peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None, ms=conv_ms)
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         # HBM-bound hand-written kernels: fused ROIAlign+mask-cat fwd / bwd
         ra_bytes = 4.0 * (Cf * Hf * Wf + 5 * n + 49 * n) + 4.0 * n * 2 * Cf * 49

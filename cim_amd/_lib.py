@@ -3,7 +3,7 @@ library is missing or a call fails, this raises."""
 import ctypes
 import os
 
-from ctypes import c_float, c_int, c_void_p
+from ctypes import c_float, c_int, c_longlong, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcim_hip.so")
@@ -25,6 +25,12 @@ SIGNATURES = {
     "cim_gemm_f32": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P],
     "cim_conv3x3_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "cim_conv3x3_wgrad_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    "cim_gemm_f32_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, _P],
+    "cim_wino_input_transform": [_P, _P, c_int, c_int, c_int, _P],
+    "cim_wino_filter_transform": [_P, _P, c_int, c_int, c_int, _P],
+    "cim_wino_output_transform": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "cim_wino_dy_transform": [_P, _P, c_int, c_int, c_int, _P],
+    "cim_wino_wgrad_output": [_P, _P, c_int, c_int, _P],
     "cim_assign": [_P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P],
 }
 

@@ -51,6 +51,9 @@ struct GemmArgs {
     long long c_split_stride;   // elements between split-K partial outputs
     // implicit 3x3 conv geometry (A_CONV_*): A is X[R, P, P, Cin] (NHWC)
     int P, Cin;
+    // batched mode (batch > 1, no split-K): blockIdx.z selects the problem; strides in elements
+    int batch;
+    long long a_bs, b_bs, c_bs;
 };
 
 // ---- A operand -------------------------------------------------------------------------------
@@ -231,7 +234,7 @@ __device__ __forceinline__ void a_load(const L& l, const GemmArgs& g, int k0, in
 
 // grid = (tiles_n, tiles_m, splits); block = 512
 template <int AL, int BL>
-__global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const GemmArgs g_in) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -250,7 +253,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const GemmArgs g) {
     }
 #endif
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kbeg = blockIdx.z * g.k_per_split;
+    GemmArgs gb = g_in;
+    int zsplit = blockIdx.z;
+    if (gb.batch > 1) {          // batched: one independent GEMM per z (Winograd positions)
+        gb.A += (size_t)blockIdx.z * gb.a_bs;
+        gb.B += (size_t)blockIdx.z * gb.b_bs;
+        gb.C += (size_t)blockIdx.z * gb.c_bs;
+        zsplit = 0;
+    }
+    const GemmArgs& g = gb;
+    const int kbeg = zsplit * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
     typename ASel<AL>::type la;
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const GemmArgs g) {
     }
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    float* C = g.C + (size_t)blockIdx.z * g.c_split_stride;
+    float* C = g.C + (size_t)zsplit * g.c_split_stride;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
@@ -372,7 +384,8 @@ int launch(GemmArgs g, int splits, float* workspace, hipStream_t st) {
     } else {
         g.c_split_stride = 0;
     }
-    hipLaunchKernelGGL(kern, dim3(tn, tm, splits), dim3(NT), lds, st, g);
+    if (g.batch > 1 && splits > 1) return -1;
+    hipLaunchKernelGGL(kern, dim3(tn, tm, g.batch > 1 ? g.batch : splits), dim3(NT), lds, st, g);
     if (splits > 1) {
         const long long quads = ((long long)g.M * g.N + 3) / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, workspace, out,
@@ -412,7 +425,7 @@ extern "C" int cim_gemm_f32(const float* A, const float* B, float* C, const floa
     CIM_CHECK_ARG(a_mcontig ? (M % 4 == 0 && lda % 4 == 0 && lda >= M) : (K % 4 == 0 && lda % 4 == 0 && lda >= K));
     CIM_CHECK_ARG(b_kcontig ? (K % 4 == 0 && ldb % 4 == 0 && ldb >= K) : (ldb % 4 == 0 && ldb >= N));
     CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 0, 0};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 0, 0, 1, 0, 0, 0};
     hipStream_t st = cim::as_stream(stream);
     int rc;
     if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, splits, workspace, st);
@@ -428,7 +441,7 @@ extern "C" int cim_conv3x3_f32(const float* X, const float* Whwio, const float* 
                                int Cout, int relu, void* stream) {
     CIM_CHECK_ARG(X && Whwio && Y && R > 0 && P > 0 && Cin > 0 && Cout > 0);
     CIM_CHECK_ARG(Cin % BK == 0 && Cout % 4 == 0);
-    GemmArgs g{X, Whwio, Y, bias, R * P * P, Cout, 9 * Cin, Cin, Cout, Cout, relu, 0, 0, P, Cin};
+    GemmArgs g{X, Whwio, Y, bias, R * P * P, Cout, 9 * Cin, Cin, Cout, Cout, relu, 0, 0, P, Cin, 1, 0, 0, 0};
     int rc = launch<A_CONV_K, B_NCONTIG>(g, 1, nullptr, cim::as_stream(stream));
     if (rc) { cim::set_error("cim_conv3x3_f32: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
@@ -440,9 +453,28 @@ extern "C" int cim_conv3x3_wgrad_f32(const float* X, const float* dY, float* dWh
     CIM_CHECK_ARG(X && dY && dWhwio && R > 0 && P > 0 && Cin > 0 && Cout > 0);
     CIM_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0);
     CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
-    GemmArgs g{X, dY, dWhwio, nullptr, 9 * Cin, Cout, R * P * P, Cin, Cout, Cout, 0, 0, 0, P, Cin};
+    GemmArgs g{X, dY, dWhwio, nullptr, 9 * Cin, Cout, R * P * P, Cin, Cout, Cout, 0, 0, 0, P, Cin, 1, 0, 0, 0};
     int rc = launch<A_CONV_M, B_NCONTIG>(g, splits, workspace, cim::as_stream(stream));
     if (rc) { cim::set_error("cim_conv3x3_wgrad_f32: launch setup failed (%d)", rc); return rc; }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                                    int ldc, int a_mcontig, int b_kcontig, int batch, long long a_bs, long long b_bs,
+                                    long long c_bs, void* stream) {
+    CIM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535);
+    CIM_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N && a_bs % 4 == 0 && b_bs % 4 == 0 && c_bs % 4 == 0);
+    CIM_CHECK_ARG(a_mcontig ? (M % 4 == 0 && lda % 4 == 0 && lda >= M) : (K % 4 == 0 && lda % 4 == 0 && lda >= K));
+    CIM_CHECK_ARG(b_kcontig ? (K % 4 == 0 && ldb % 4 == 0 && ldb >= K) : (ldb % 4 == 0 && ldb >= N));
+    GemmArgs g{A, B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, 0, batch, a_bs, b_bs, c_bs};
+    hipStream_t st = cim::as_stream(stream);
+    int rc;
+    if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, 1, nullptr, st);
+    else if (!a_mcontig && b_kcontig) rc = launch<A_KCONTIG, B_KCONTIG>(g, 1, nullptr, st);
+    else if (a_mcontig && !b_kcontig) rc = launch<A_MCONTIG, B_NCONTIG>(g, 1, nullptr, st);
+    else rc = launch<A_MCONTIG, B_KCONTIG>(g, 1, nullptr, st);
+    if (rc) { cim::set_error("cim_gemm_f32_batched: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;
 }

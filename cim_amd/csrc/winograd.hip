@@ -1,0 +1,251 @@
+// Winograd F(2x2, 3x3) transforms for the MaskFuse 3x3 convolution on R x P x P ROI maps (P = 7).
+//
+// Replaces (together with the batched fp32 MFMA GEMM of gemm_f32.hip) the direct evaluation of
+// nn.Conv2d(2C, C, 3, padding=1) of /root/reference/lib/modeling/resnet50.py:104 and its two
+// gradients: 16 multiplies per 2x2 output tile instead of 36, i.e. 1.07 instead of 1.85 TFLOP per
+// contraction at cfg2 (7x7 outputs are covered by 4x4 tiles of 2x2; 49/64 of the tile grid is used).
+// All arithmetic is fp32; the transform matrices contain only 0, +-1, +-1/2, so the result differs
+// from the direct fp32 sum by ~2e-6 relative (measured; the direct fp32 sum itself is at 6e-7).
+//
+//   forward / data gradient:  Y = A^T [ (G g G^T) . (B^T d B) ] A          (Lavin & Gray F(2x2,3x3))
+//   weight gradient        :  dW = A3^T [ (B^T d B) . (G2 dy G2^T) ] A3    (F(3x3,2x2), SAME B^T:
+//                              the transformed input V is computed once in forward and reused)
+//
+// Layouts (all fp32): activations NHWC [R,P,P,C]; transformed operands are position-major so that
+// each of the 16 positions is one plain GEMM:  V [16][R*T*T][C],  U [16][Cin][Cout],
+// M [16][R*T*T][Cout]  (T = ceil(P/2) tiles per side).  Memory-bound kernels: one lane = one
+// (tile, 4 channels), every access a 16 B/lane contiguous run along C.
+#include "common.h"
+#include "../../include/cim_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+// V[pos][m][c] = (B^T d B)[pos],  d = 4x4 input patch of tile m (zero outside the map).
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int R, int P,
+                                                         int T, int C) {
+    const int m = blockIdx.x;                  // tile index: (r, ty, tx)
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
+        float4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = 2 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ix = 2 * tx - 1 + j;
+                d[i][j] = ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P)
+                              ? *reinterpret_cast<const float4*>(x + (((size_t)r * P + iy) * P + ix) * C + c)
+                              : f4(0.f);
+            }
+        }
+        float4 u[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // rows: B^T d
+            u[0][j] = d[0][j] - d[2][j];
+            u[1][j] = d[1][j] + d[2][j];
+            u[2][j] = d[2][j] - d[1][j];
+            u[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {          // columns: (.) B
+            const float4 v0 = u[i][0] - u[i][2], v1 = u[i][1] + u[i][2], v2 = u[i][2] - u[i][1], v3 = u[i][1] - u[i][3];
+            float* dst = V + (size_t)(i * 4) * MC + (size_t)m * C + c;
+            *reinterpret_cast<float4*>(dst) = v0;
+            *reinterpret_cast<float4*>(dst + MC) = v1;
+            *reinterpret_cast<float4*>(dst + 2 * MC) = v2;
+            *reinterpret_cast<float4*>(dst + 3 * MC) = v3;
+        }
+    }
+}
+
+// U[pos][k][n] = (G g G^T)[pos].  mode 0 (forward): k = ci, n = co, g = W[co][ci][:, :]
+//                                 mode 1 (data gradient): k = co, n = ci, g = W[co][ci] rotated by 180 degrees
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
+                                                          int Cin, int mode) {
+    const int Kd = mode ? Cout : Cin, Nd = mode ? Cin : Cout;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)Kd * Nd) return;
+    const int k = (int)(idx / Nd), n = (int)(idx % Nd);
+    const int co = mode ? k : n, ci = mode ? n : k;
+    const float* g = W + ((size_t)co * Cin + ci) * 9;
+    float w[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) w[a][b] = mode ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = w[0][b];
+        t[1][b] = 0.5f * (w[0][b] + w[1][b] + w[2][b]);
+        t[2][b] = 0.5f * (w[0][b] - w[1][b] + w[2][b]);
+        t[3][b] = w[2][b];
+    }
+    const size_t KN = (size_t)Kd * Nd;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float* dst = U + (size_t)(a * 4) * KN + idx;
+        dst[0] = t[a][0];
+        dst[KN] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        dst[2 * KN] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        dst[3 * KN] = t[a][2];
+    }
+}
+
+// y[r, 2ty+a, 2tx+b, c] = (A^T M A)[a][b] + bias[c], optional ReLU; rows / columns >= P are dropped.
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int R, int P, int T, int C, int relu) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
+        float4 q[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[i][j] = *reinterpret_cast<const float4*>(M + (size_t)(i * 4 + j) * MC + (size_t)m * C + c);
+        float4 s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = q[0][j] + q[1][j] + q[2][j];
+            s[1][j] = q[1][j] - q[2][j] - q[3][j];
+        }
+        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c) : f4(0.f);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = 2 * ty + a;
+            if (oy >= P) continue;
+            float4 o[2];
+            o[0] = s[a][0] + s[a][1] + s[a][2] + bv;
+            o[1] = s[a][1] - s[a][2] - s[a][3] + bv;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ox = 2 * tx + b;
+                if (ox >= P) continue;
+                float4 v = o[b];
+                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                *reinterpret_cast<float4*>(y + (((size_t)r * P + oy) * P + ox) * C + c) = v;
+            }
+        }
+    }
+}
+
+// D[pos][m][c] = (G2 dy G2^T)[pos], dy = the tile's 2x2 output-gradient patch (zero past the map),
+// G2 = [[1,0],[1/2,1/2],[1/2,-1/2],[0,-1]]   (F(3x3,2x2) with the forward's B^T).
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int P,
+                                                      int T, int C) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
+        float4 d[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int oy = 2 * ty + a, ox = 2 * tx + b;
+                d[a][b] = (oy < P && ox < P) ? *reinterpret_cast<const float4*>(dy + (((size_t)r * P + oy) * P + ox) * C + c) : f4(0.f);
+            }
+        float4 u[4][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            u[0][b] = d[0][b];
+            u[1][b] = 0.5f * (d[0][b] + d[1][b]);
+            u[2][b] = 0.5f * (d[0][b] - d[1][b]);
+            u[3][b] = f4(0.f) - d[1][b];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* dst = D + (size_t)(i * 4) * MC + (size_t)m * C + c;
+            *reinterpret_cast<float4*>(dst) = u[i][0];
+            *reinterpret_cast<float4*>(dst + MC) = 0.5f * (u[i][0] + u[i][1]);
+            *reinterpret_cast<float4*>(dst + 2 * MC) = 0.5f * (u[i][0] - u[i][1]);
+            *reinterpret_cast<float4*>(dst + 3 * MC) = f4(0.f) - u[i][1];
+        }
+    }
+}
+
+// dW[co][ci][3][3] = A3^T dU A3,  dU[pos][ci][co],  A3^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]].
+__global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dW, int Cout,
+                                                             int Cin) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;     // (ci, co), co fastest
+    const size_t KN = (size_t)Cin * Cout;
+    if (idx >= KN) return;
+    const int ci = (int)(idx / Cout), co = (int)(idx % Cout);
+    float q[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[i][j] = dU[(size_t)(i * 4 + j) * KN + idx];
+    float s[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = q[0][j] + q[1][j] + q[2][j];
+        s[1][j] = q[1][j] - q[2][j];
+        s[2][j] = q[1][j] + q[2][j] + q[3][j];
+    }
+    float* dst = dW + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        dst[a * 3 + 0] = s[a][0] + s[a][1] + s[a][2];
+        dst[a * 3 + 1] = s[a][1] - s[a][2];
+        dst[a * 3 + 2] = s[a][1] + s[a][2] + s[a][3];
+    }
+}
+
+}  // namespace
+
+#define WINO_GEOM_OK() CIM_CHECK_ARG(R > 0 && P > 0 && P <= 64 && C > 0 && C % 4 == 0)
+
+extern "C" int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, void* stream) {
+    WINO_GEOM_OK();
+    CIM_CHECK_ARG(x && V);
+    const int T = (P + 1) / 2;
+    hipLaunchKernelGGL(wino_input_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, void* stream) {
+    CIM_CHECK_ARG(W && U && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1));
+    const size_t n = (size_t)Cout * Cin;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U,
+                       Cout, Cin, mode);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_output_transform(const float* M, const float* bias, float* y, int R, int P, int C, int relu,
+                                         void* stream) {
+    WINO_GEOM_OK();
+    CIM_CHECK_ARG(M && y);
+    const int T = (P + 1) / 2;
+    hipLaunchKernelGGL(wino_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C,
+                       relu);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_dy_transform(const float* dy, float* D, int R, int P, int C, void* stream) {
+    WINO_GEOM_OK();
+    CIM_CHECK_ARG(dy && D);
+    const int T = (P + 1) / 2;
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, void* stream) {
+    CIM_CHECK_ARG(dU && dW && Cout > 0 && Cin > 0);
+    const size_t n = (size_t)Cout * Cin;
+    hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU,
+                       dW, Cout, Cin);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}

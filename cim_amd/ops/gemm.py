@@ -6,6 +6,8 @@ N x 7 x 7 ROI maps of /root/reference/lib/modeling/resnet50.py:104-110,135-136; 
 the reference's layouts ([out,in] and [out,in,3,3]) so checkpoints and optimizers are unchanged.
 Forward and both backward contractions run on hand-written HIP; there is no CPU fallback.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -61,49 +63,100 @@ class LinearFunction(Function):
         return dx, dw, db, None
 
 
+def _bgemm(a, b, c, m, n, k, lda, ldb, a_mcontig, batch, a_bs, b_bs, c_bs):
+    _lib.call("cim_gemm_f32_batched", a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, lda, ldb, n,
+              int(a_mcontig), 0, batch, a_bs, b_bs, c_bs, _lib.stream_ptr())
+
+
+CONV_ALGO = os.environ.get("CIM_CONV_ALGO", "winograd")     # "winograd" (F(2x2,3x3), default) | "direct"
+
+
 class Conv3x3Function(Function):
     """y = relu?(conv2d(x, w, b, padding=1)) on channels-last ROI maps.
-    x: logical [R,Cin,P,P] in torch.channels_last (physical [R,P,P,Cin]); w [Cout,Cin,3,3]."""
+    x: logical [R,Cin,P,P] in torch.channels_last (physical [R,P,P,Cin]); w [Cout,Cin,3,3].
+
+    Default algorithm: Winograd F(2x2,3x3) in fp32 - input / filter transforms, 16 batched exact-fp32
+    MFMA GEMMs, output transform (cim_amd/csrc/winograd.hip); the transformed input V is kept for
+    the weight gradient (F(3x3,2x2) shares its B^T).  `CIM_CONV_ALGO=direct` selects the implicit
+    GEMM on the untransformed data (1.72x more multiplies, ~3x closer to the fp64 result)."""
 
     @staticmethod
     def forward(ctx, x, w, b, relu):
         x = x.contiguous(memory_format=torch.channels_last)
         r, cin, p, _ = x.shape
         cout = w.shape[0]
-        whwio = w.permute(2, 3, 1, 0).contiguous()
-        y = torch.empty((r, p, p, cout), dtype=torch.float32, device=x.device)
-        _lib.call("cim_conv3x3_f32", x.data_ptr(), whwio.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cin, cout,
-                  int(relu), _lib.stream_ptr())
-        ctx.save_for_backward(x, w, y if relu else None)
+        w = w.contiguous()
+        dev = x.device
+        st = _lib.stream_ptr()
+        y = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
+        ctx.algo = CONV_ALGO if (cin % 4 == 0 and cout % 4 == 0) else "direct"
+        V = None
+        if ctx.algo == "winograd":
+            t = (p + 1) // 2
+            mt = r * t * t
+            V = torch.empty((16, mt, cin), dtype=torch.float32, device=dev)
+            U = torch.empty((16, cin, cout), dtype=torch.float32, device=dev)
+            M = torch.empty((16, mt, cout), dtype=torch.float32, device=dev)
+            _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), r, p, cin, st)
+            _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), cout, cin, 0, st)
+            _bgemm(V, U, M, mt, cout, cin, cin, cout, False, 16, mt * cin, cin * cout, mt * cout)
+            _lib.call("cim_wino_output_transform", M.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cout, int(relu), st)
+        else:
+            whwio = w.permute(2, 3, 1, 0).contiguous()
+            _lib.call("cim_conv3x3_f32", x.data_ptr(), whwio.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cin, cout,
+                      int(relu), st)
+        ctx.save_for_backward(x, w, y if relu else None, V)
         ctx.relu = relu
         ctx.has_bias = b is not None
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, V = ctx.saved_tensors
         r, cin, p, _ = x.shape
         cout = w.shape[0]
+        dev = x.device
         dy = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)      # physical [R,P,P,Cout]
         if ctx.relu:
             dy = dy * (y > 0)
         dy = dy.contiguous()
         dx = dw = db = None
         st = _lib.stream_ptr()
+        wino = ctx.algo == "winograd"
+        t = (p + 1) // 2
+        mt = r * t * t
         if ctx.needs_input_grad[0]:
-            # data gradient = the same implicit GEMM on dY with flipped, in/out-swapped weights
-            w2 = w.flip(2, 3).permute(2, 3, 0, 1).contiguous()                         # [3,3,Cout,Cin]
-            dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=x.device)
-            _lib.call("cim_conv3x3_f32", dy.data_ptr(), w2.data_ptr(), None, dxp.data_ptr(), r, p, cout, cin, 0, st)
+            dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
+            if wino:
+                # data gradient = the same convolution of dY with the 180-degree rotated, in/out-swapped filter
+                Vd = torch.empty((16, mt, cout), dtype=torch.float32, device=dev)
+                U2 = torch.empty((16, cout, cin), dtype=torch.float32, device=dev)
+                M2 = torch.empty((16, mt, cin), dtype=torch.float32, device=dev)
+                _lib.call("cim_wino_input_transform", dy.data_ptr(), Vd.data_ptr(), r, p, cout, st)
+                _lib.call("cim_wino_filter_transform", w.data_ptr(), U2.data_ptr(), cout, cin, 1, st)
+                _bgemm(Vd, U2, M2, mt, cin, cout, cout, cin, False, 16, mt * cout, cout * cin, mt * cin)
+                _lib.call("cim_wino_output_transform", M2.data_ptr(), None, dxp.data_ptr(), r, p, cin, 0, st)
+            else:
+                w2 = w.flip(2, 3).permute(2, 3, 0, 1).contiguous()                     # [3,3,Cout,Cin]
+                _lib.call("cim_conv3x3_f32", dy.data_ptr(), w2.data_ptr(), None, dxp.data_ptr(), r, p, cout, cin, 0, st)
             dx = dxp.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            m, n, k = 9 * cin, cout, r * p * p
-            splits = _lib.call("cim_gemm_f32_splits", m, n, k)
-            ws = _ws(m, n, splits, x)
-            dwh = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
-            _lib.call("cim_conv3x3_wgrad_f32", x.data_ptr(), dy.data_ptr(), dwh.data_ptr(), r, p, cin, cout, splits,
-                      _lib.ptr(ws), st)
-            dw = dwh.permute(3, 2, 0, 1)
+            if wino:
+                D = torch.empty((16, mt, cout), dtype=torch.float32, device=dev)
+                dU = torch.empty((16, cin, cout), dtype=torch.float32, device=dev)
+                dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+                _lib.call("cim_wino_dy_transform", dy.data_ptr(), D.data_ptr(), r, p, cout, st)
+                # dU[pos] = V[pos]^T . D[pos]:  A = V[pos] read M-contiguously (element (ci, m) at V[m*Cin + ci])
+                _bgemm(V, D, dU, cin, cout, mt, cin, cout, True, 16, mt * cin, mt * cout, cin * cout)
+                _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, st)
+            else:
+                m, n, k = 9 * cin, cout, r * p * p
+                splits = _lib.call("cim_gemm_f32_splits", m, n, k)
+                ws = _ws(m, n, splits, x)
+                dwh = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=dev)
+                _lib.call("cim_conv3x3_wgrad_f32", x.data_ptr(), dy.data_ptr(), dwh.data_ptr(), r, p, cin, cout, splits,
+                          _lib.ptr(ws), st)
+                dw = dwh.permute(3, 2, 0, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1, 2))
         return dx, dw, db, None

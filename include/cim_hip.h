@@ -151,6 +151,27 @@ int cim_conv3x3_f32(const float* X, const float* Whwio, const float* bias, float
 int cim_conv3x3_wgrad_f32(const float* X, const float* dY, float* dWhwio,
                           int R, int P, int Cin, int Cout, int splits, float* workspace, void* stream);
 
+/* `batch` independent GEMMs of identical shape in one launch (strides in elements between
+ * consecutive problems); used for the 16 positions of the Winograd-domain convolution. */
+int cim_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K,
+                         int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
+                         int batch, long long a_bs, long long b_bs, long long c_bs, void* stream);
+
+/* Winograd F(2x2,3x3) evaluation of the same 3x3 / stride 1 / pad 1 convolution (fp32 throughout,
+ * 1.72x fewer multiplies at P = 7): T = ceil(P/2) tiles per side, 16 transform positions.
+ *   cim_wino_input_transform : x [R,P,P,C]            -> V [16][R*T*T][C]       (B^T d B)
+ *   cim_wino_filter_transform: W [Cout,Cin,3,3]       -> U [16][K][N]           (G g G^T)
+ *        mode 0: K = Cin, N = Cout (forward);  mode 1: K = Cout, N = Cin, taps rotated (data gradient)
+ *   (16 GEMMs  M[pos] = V[pos] . U[pos]  through cim_gemm_f32_batched)
+ *   cim_wino_output_transform: M [16][R*T*T][C], bias -> y [R,P,P,C]            (A^T m A, +bias, ReLU)
+ *   weight gradient: cim_wino_dy_transform: dy [R,P,P,C] -> D [16][R*T*T][C]    (G2 dy G2^T)
+ *        16 GEMMs dU[pos] = V[pos]^T . D[pos];  cim_wino_wgrad_output: dU [16][Cin][Cout] -> dW [Cout,Cin,3,3] */
+int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, void* stream);
+int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, void* stream);
+int cim_wino_output_transform(const float* M, const float* bias, float* y, int R, int P, int C, int relu, void* stream);
+int cim_wino_dy_transform(const float* dy, float* D, int R, int P, int C, void* stream);
+int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

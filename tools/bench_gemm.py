@@ -61,6 +61,21 @@ def main():
     ws = torch.empty(max(sp, 1) * 18 * C * C, device=dev)
     t = timeit(lambda: _lib.call("cim_conv3x3_wgrad_f32", xp.data_ptr(), dy.data_ptr(), dwh.data_ptr(), N, 7, 2 * C, C, sp, ws.data_ptr(), st))
     res["conv_wgrad_cim_ms"], res["conv_wgrad_cim_tf"], res["conv_wgrad_splits"] = t, fl / t / 1e9, sp
+    # Winograd F(2x2,3x3) pipeline (autograd wrapper: fwd, and fwd+bwd)
+    from cim_amd.ops import conv3x3
+    import cim_amd.ops.gemm as GG
+    for algo in ("winograd", "direct"):
+        GG.CONV_ALGO = algo
+        xr_ = x.detach().clone().requires_grad_(True)
+        wr_ = w.detach().clone().requires_grad_(True)
+        t = timeit(lambda: conv3x3(xr_, wr_, b, relu=True))
+        res["conv_fwd_%s_ms" % algo] = t
+        go = torch.randn(N, C, 7, 7, device=dev).contiguous(memory_format=torch.channels_last)
+        def fb():
+            xr_.grad = None; wr_.grad = None
+            conv3x3(xr_, wr_, b, relu=True).backward(go)
+        t = timeit(fb)
+        res["conv_fwd_bwd_%s_ms" % algo] = t
     # fc1: [N, 49C] x [4096, 49C]^T
     K1 = 49 * C
     xf = torch.randn(N, K1, device=dev, generator=g)
