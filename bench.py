@@ -102,6 +102,16 @@ def init_for_synthetic(model):
             torch.nn.init.constant_(m.bn3.weight, 0.25)
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs of this script, tools/pmc_traffic.py); None when the file is absent."""
+    path = os.path.join(REPO, "profiles", "r1", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
+
+
 def make_optimizer(model):
     """Param groups of tools/train.py:282-311 (bias: lr x2, no weight decay), SGD momentum 0.9."""
     bias, nonbias = [], []
@@ -113,7 +123,7 @@ def make_optimizer(model):
                             dict(params=bias, lr=2 * lr, weight_decay=0.0)], lr=lr, momentum=0.9, fused=True)
 
 
-def cpu_baseline(config, budget_n=250):
+def cpu_baseline(config, budget_n=0):
     """The oracle's CPU restatement of the same step, timed on this host (bounded sample)."""
     from oracle import cpu_step, mask_iou as omi
     apply_preset(config)
@@ -126,6 +136,7 @@ def cpu_baseline(config, budget_n=250):
     model = Generalized_RCNN().train()
     inp = synthetic.make_image_inputs(config, seed=3)
     n = inp["rois"].shape[0]
+    budget_n = n if budget_n <= 0 else min(budget_n, n)
     iou, asy = omi.mask_iou_maps(inp["full_masks"])
     cpu_step.step(model, inp, iou, asy, n_sub=8, seed=3)          # untimed warm-up (oneDNN primitive creation)
     for p in model.parameters():
@@ -154,7 +165,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="resnet50_voc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=250)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="proposals in the CPU sample (0 = all)")
     ap.add_argument("--miopen-find", action="store_true",
                     help="let MIOpen time its solvers for the backbone convs (default: immediate mode)")
     args = ap.parse_args()
@@ -237,6 +248,10 @@ def main():
         roofline = dict(bound="mfma", kernel=kname, achieved=conv_flops / (conv_ms * 1e-3) / 1e12,
                         peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None, ms=conv_ms)
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
+        pmc = pmc_traffic()
+        g00 = pmc.get("gemm_f32_kernel<0, 0>")
+        if wino_ms and g00:      # first <A_KCONTIG,B_NCONTIG> launch of a step = the Winograd forward GEMM
+            roofline["traffic"] = (g00["fetch_kib_per_dispatch"][0] + g00["write_kib_per_dispatch"][0]) * 1024
         # HBM-bound hand-written kernels: fused ROIAlign+mask-cat fwd / bwd
         ra_bytes = 4.0 * (Cf * Hf * Wf + 5 * n + 49 * n) + 4.0 * n * 2 * Cf * 49
         hbm = []
@@ -244,8 +259,10 @@ def main():
             ms = timer.mean_ms(name)
             if ms:
                 ach = ra_bytes / (ms * 1e-3) / 1e9
+                pk = pmc.get("roi_align_fwd_kernel<4, true>" if name.endswith("fwd") else "roi_align_bwd_tile_kernel<16, true>")
                 hbm.append(dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                                frac=ach / HBM_PEAK_GBS, ms=ms, traffic=None))
+                                frac=ach / HBM_PEAK_GBS, ms=ms, algorithmic_bytes=ra_bytes,
+                                traffic=pk["hbm_bytes_mean"] if pk else None))
         line = dict(metric="images/sec training step (ResNet-50 VOC, ~1k proposals/img)",
                     value=world * args.steps / elapsed, unit="images/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
