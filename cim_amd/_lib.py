@@ -31,6 +31,7 @@ SIGNATURES = {
     "cim_wino_output_transform": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_dy_transform": [_P, _P, c_int, c_int, c_int, _P],
     "cim_wino_wgrad_output": [_P, _P, c_int, c_int, _P],
+    "cim_losses_fwd": [_P, _P],
     "cim_assign": [_P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P],
 }
 

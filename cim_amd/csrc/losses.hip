@@ -1,0 +1,240 @@
+// The four CIM training losses and their gradients w.r.t. the head scores, fused (gfx950).
+//
+// Replaces cls_iou_loss + loss_weight_bag_loss (x REFINE_TIMES), mil_bag_loss and PCL_loss of
+// /root/reference/lib/modeling/heads.py:10-166 (formulas: SURVEY.md App. E) - ~400 tiny ATen
+// launches per step in the reference formulation - by ONE launch of REFINE_TIMES + 2 workgroups
+// ("jobs"): job i < R = refinement layer i, job R = mil_bag_loss, job R+1 = PCL_loss.  The inputs
+// are a few tens of thousand floats, so each job is one 1024-lane workgroup: row passes with lanes
+// over proposals, column passes with one wave per class column (first-index arg-max by shuffles).
+// Alongside each loss the job writes its gradient "components" (d loss_k / d score tensor) for a
+// unit upstream gradient; autograd combines them with the actual upstream scalars.
+//   fp32, log via logf; every score is clamped to [1e-6, 1-1e-6] before a log exactly like the
+//   reference, with the clamp's pass-through gradient (inclusive bounds).
+#include "common.h"
+#include "../../include/cim_hip.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr float LO = 1e-6f, HI = 1.0f - 1e-6f;
+
+__device__ __forceinline__ float clampf(float x) { return fminf(fmaxf(x, LO), HI); }
+__device__ __forceinline__ float inrange(float x) { return (x >= LO && x <= HI) ? 1.0f : 0.0f; }
+
+__device__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.0f;
+    for (int w = 0; w < NT / 64; ++w) s += red[w];
+    return s;
+}
+
+// (value, index) max over the 64 lanes; ties -> lower index (first maximum)
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+__device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot) {
+    const int N = a.N, C1 = a.C1, tid = threadIdx.x;
+    const float* rc = a.rc[li];
+    const float* ri = a.ri[li];
+    const float* Y = a.pseudo_labels[li];
+    const uint16_t* t16 = a.pseudo_iou_f16[li];
+    const float* w = a.loss_weights[li];
+    const float ws = a.weight_scale[li];           // lmda of model_builder.py:172,194
+    float* g_rc_cls = a.grad + (size_t)(3 + 4 * li + 0) * N * C1;
+    float* g_rc_bag = a.grad + (size_t)(3 + 4 * li + 1) * N * C1;
+    float* g_ri_iou = a.grad + (size_t)(3 + 4 * li + 2) * N * C1;
+    float* g_ri_bag = a.grad + (size_t)(3 + 4 * li + 3) * N * C1;
+    for (int i = tid; i < N * C1; i += NT) { g_rc_cls[i] = 0.f; g_rc_bag[i] = 0.f; g_ri_iou[i] = 0.f; g_ri_bag[i] = 0.f; }
+    float* out = a.part + 4 * li;                  // [bag, pcl, cls, iou]
+    if (!a.layer_valid[li]) {                      // CIM_layer returned None: the layer contributes nothing
+        if (tid < 4) out[tid] = 0.0f;
+        return;
+    }
+    // pass 1 over rows: labelled class of each row, cls / iou numerators and counts
+    float s_cls = 0.f, s_iou = 0.f, n_lab = 0.f, n_fg = 0.f;
+    for (int n = tid; n < N; n += NT) {
+        int h = -1;
+        for (int c = 0; c < C1; ++c)
+            if (Y[(size_t)n * C1 + c] != 0.0f) { h = c; break; }
+        hot[n] = h;
+        if (h < 0) continue;
+        const float wn = ws * w[n];
+        s_cls += -logf(clampf(rc[(size_t)n * C1 + h])) * wn;
+        n_lab += 1.0f;
+        if (h >= 1) {
+            const float d = clampf(ri[(size_t)n * C1 + h]) - cim::h2f(t16[n]);
+            const float ad = fabsf(d);
+            s_iou += (ad < 1.0f ? 0.5f * d * d : ad - 0.5f) * wn;
+            n_fg += 1.0f;
+        }
+    }
+    s_cls = block_sum(s_cls, red);
+    s_iou = block_sum(s_iou, red);
+    n_lab = block_sum(n_lab, red);
+    n_fg = block_sum(n_fg, red);
+    const float cls_loss = n_lab > 0.f ? s_cls / n_lab : 0.f;                  // heads.py:104-114
+    const float iou_loss = n_fg > 0.f ? s_iou / n_fg : 0.f;                    // heads.py:116-136
+    // pass 2 over rows: gradient components of cls_loss / iou_loss
+    for (int n = tid; n < N; n += NT) {
+        const int h = hot[n];
+        if (h < 0) continue;
+        const float wn = ws * w[n];
+        const float x = rc[(size_t)n * C1 + h];
+        g_rc_cls[(size_t)n * C1 + h] = -wn / (clampf(x) * n_lab) * inrange(x);
+        if (h >= 1) {
+            const float xi = ri[(size_t)n * C1 + h];
+            const float d = clampf(xi) - cim::h2f(t16[n]);
+            const float dd = fabsf(d) < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f);
+            g_ri_iou[(size_t)n * C1 + h] = dd * wn / n_fg * inrange(xi);
+        }
+    }
+    __syncthreads();
+    // column pass (loss_weight_bag_loss, heads.py:43-74): one wave per class column
+    const int wave = tid >> 6, lane = tid & 63;
+    float bag = 0.0f;
+    for (int c = wave; c < C1; c += NT / 64) {
+        float fv = -INFINITY, uv = -INFINITY;
+        int fi = INT_MAX, ui = INT_MAX;
+        for (int n = lane; n < N; n += 64) {
+            const float u = clampf(rc[(size_t)n * C1 + c]) * clampf(ri[(size_t)n * C1 + c]);
+            const float f = (hot[n] == c) ? u : 0.0f;                            // ind * predict * tmp_pseudo_label
+            if (f > fv) { fv = f; fi = n; }
+            if (u > uv) { uv = u; ui = n; }
+        }
+        wave_argmax(fv, fi);
+        wave_argmax(uv, ui);
+        if (lane == 0) {
+            const float L = (c == 0) ? 1.0f : a.labels[c - 1];
+            const float raw = fv * L + uv * (1.0f - L);
+            const float agg = clampf(raw);
+            const bool seen = (L == 1.0f);
+            const int idx = seen ? fi : ui;
+            const float om = seen ? ws * w[idx] : 1.0f;
+            bag += -(L * logf(agg) + (1.0f - L) * logf(1.0f - agg)) * om / (float)C1;
+            const float dagg = -(L / agg - (1.0f - L) / (1.0f - agg)) * om / (float)C1 * inrange(raw);
+            const float du_f = dagg * L * ((hot[fi] == c) ? 1.0f : 0.0f);
+            const float du_u = dagg * (1.0f - L);
+            if (du_f != 0.0f) {
+                const float xr = rc[(size_t)fi * C1 + c], xi = ri[(size_t)fi * C1 + c];
+                g_rc_bag[(size_t)fi * C1 + c] += du_f * clampf(xi) * inrange(xr);
+                g_ri_bag[(size_t)fi * C1 + c] += du_f * clampf(xr) * inrange(xi);
+            }
+            if (du_u != 0.0f) {
+                const float xr = rc[(size_t)ui * C1 + c], xi = ri[(size_t)ui * C1 + c];
+                g_rc_bag[(size_t)ui * C1 + c] += du_u * clampf(xi) * inrange(xr);
+                g_ri_bag[(size_t)ui * C1 + c] += du_u * clampf(xr) * inrange(xi);
+            }
+        }
+    }
+    bag = block_sum(bag, red);
+    if (tid == 0) { out[0] = bag; out[1] = 0.f; out[2] = cls_loss; out[3] = iou_loss; }
+}
+
+__device__ void mil_job(const cim_loss_args& a, float* red) {
+    const int N = a.N, C1 = a.C1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float* g_pc = a.grad;                                   // component 0: d bag / d predict_cls
+    float* g_pd = a.grad + (size_t)2 * N * C1;              // component 2: d bag / d predict_det
+    float bag = 0.0f;
+    for (int c = wave; c < C1; c += NT / 64) {              // heads.py:149-166
+        float s = 0.0f;
+        for (int n = lane; n < N; n += 64) s += a.pc[(size_t)n * C1 + c] * a.pd[(size_t)n * C1 + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float L = (c == 0) ? 1.0f : a.labels[c - 1];
+        const float p = clampf(s);
+        if (lane == 0) bag += -(L * logf(p) + (1.0f - L) * logf(1.0f - p)) / (float)C1;
+        const float ds = -(L / p - (1.0f - L) / (1.0f - p)) / (float)C1 * inrange(s);
+        for (int n = lane; n < N; n += 64) {
+            g_pc[(size_t)n * C1 + c] = ds * a.pd[(size_t)n * C1 + c];
+            g_pd[(size_t)n * C1 + c] = ds * a.pc[(size_t)n * C1 + c];
+        }
+    }
+    bag = block_sum(bag, red);
+    float* out = a.part + 4 * a.R;
+    if (tid == 0) { out[0] = bag; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f; }
+}
+
+__device__ void pcl_job(const cim_loss_args& a, float* red) {
+    const int N = a.N, C1 = a.C1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float* g = a.grad + (size_t)1 * N * C1;                 // component 1: d pcl / d predict_cls
+    for (int i = tid; i < N * C1; i += NT) g[i] = 0.f;
+    __syncthreads();
+    float den = 1e-6f;                                      // heads.py:22
+    for (int k = 0; k < a.K; ++k) den += (float)a.cluster_size[k];
+    const float scale = 12.0f / den;                        // heads.py:40-41
+    float acc = 0.0f;
+    // (cluster, column) pairs over the 16 waves
+    for (int job = wave; job < a.K * C1; job += NT / 64) {
+        const int k = job / C1, c = job % C1;
+        const float nk = (float)a.cluster_size[k];
+        if (k == a.bg_cluster) {                            // heads.py:33-38: every member row vs its own pattern
+            float s = 0.0f;
+            for (int n = lane; n < N; n += 64) {
+                if (a.row_cluster[n] != k) continue;
+                const float x = a.pc[(size_t)n * C1 + c], p = clampf(x);
+                const float t = (a.row_col[n] == c) ? 1.0f : 0.0f;
+                s += -(t * logf(p) + (1.0f - t) * logf(1.0f - p));
+                g[(size_t)n * C1 + c] = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(x);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) acc += s / (float)C1;            // = n_k * mean over (rows, cols)
+        } else {                                            // heads.py:25-31: mean row vector vs column indicator
+            float s = 0.0f;
+            int any = 0;
+            for (int n = lane; n < N; n += 64) {
+                if (a.row_cluster[n] != k) continue;
+                s += a.pc[(size_t)n * C1 + c];
+                any |= (a.row_col[n] == c);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); any |= __shfl_xor(any, o); }
+            const float v = s / nk, p = clampf(v), t = any ? 1.0f : 0.0f;
+            if (lane == 0) acc += nk * (-(t * logf(p) + (1.0f - t) * logf(1.0f - p))) / (float)C1;
+            const float dv = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(v);   // n_k * (1/n_k)
+            for (int n = lane; n < N; n += 64)
+                if (a.row_cluster[n] == k) g[(size_t)n * C1 + c] = dv;
+        }
+    }
+    acc = block_sum(acc, red);
+    float* out = a.part + 4 * (a.R + 1);
+    if (tid == 0) { out[0] = 0.f; out[1] = scale * acc; out[2] = 0.f; out[3] = 0.f; }
+}
+
+__global__ __launch_bounds__(NT) void losses_kernel(const cim_loss_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);            // [16]
+    int* hot = reinterpret_cast<int*>(smem + 64);           // [N]
+    const int job = blockIdx.x;
+    if (job < a.R) refine_job(a, job, red, hot);
+    else if (job == a.R) mil_job(a, red);
+    else pcl_job(a, red);
+}
+
+}  // namespace
+
+extern "C" int cim_losses_fwd(const cim_loss_args* args, void* stream) {
+    CIM_CHECK_ARG(args != nullptr);
+    const cim_loss_args& a = *args;
+    CIM_CHECK_ARG(a.N > 0 && a.N <= 15000 && a.C1 > 1 && a.R >= 0 && a.R <= 3 && a.K >= 0);
+    CIM_CHECK_ARG(a.pc && a.pd && a.labels && a.part && a.grad);
+    for (int i = 0; i < a.R; ++i)
+        CIM_CHECK_ARG(a.rc[i] && a.ri[i] && (!a.layer_valid[i] || (a.pseudo_labels[i] && a.pseudo_iou_f16[i] && a.loss_weights[i])));
+    CIM_CHECK_ARG(a.K == 0 || (a.row_cluster && a.row_col && a.cluster_size));
+    const size_t lds = 64 + sizeof(int) * (size_t)a.N;
+    hipLaunchKernelGGL(losses_kernel, dim3(a.R + 2), dim3(NT), lds, cim::as_stream(stream), a);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}

@@ -10,6 +10,8 @@ include/cim_hip.h (cim_amd/csrc/mining.hip); only the anti-noise sampling stays 
 because the reference draws it from the process-global legacy NumPy RNG (heads.py:459) and
 bit-identical pseudo labels require the identical stream.  There is no CPU fallback.
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -134,6 +136,116 @@ def PCL_loss(predict_cls, mat, labels):
     bg_term = (rows * bce_rows.unsqueeze(0)).sum(dim=1) / n_k.clamp(min=1)
     term = torch.where(is_bg, bg_term, fg_term) * n_k
     return 12 * (term.sum() / (1e-6 + n_k.sum()))
+
+
+# --------------------------------------------------------------------------- fused losses (HIP)
+class _LossArgs(ctypes.Structure):
+    """Mirror of `cim_loss_args` in include/cim_hip.h."""
+    _fields_ = [("pc", ctypes.c_void_p), ("pd", ctypes.c_void_p),
+                ("rc", ctypes.c_void_p * 3), ("ri", ctypes.c_void_p * 3),
+                ("pseudo_labels", ctypes.c_void_p * 3), ("pseudo_iou_f16", ctypes.c_void_p * 3),
+                ("loss_weights", ctypes.c_void_p * 3), ("weight_scale", ctypes.c_float * 3),
+                ("layer_valid", ctypes.c_int * 3), ("labels", ctypes.c_void_p),
+                ("row_cluster", ctypes.c_void_p), ("row_col", ctypes.c_void_p), ("cluster_size", ctypes.c_void_p),
+                ("K", ctypes.c_int), ("bg_cluster", ctypes.c_int),
+                ("N", ctypes.c_int), ("C1", ctypes.c_int), ("R", ctypes.c_int),
+                ("part", ctypes.c_void_p), ("grad", ctypes.c_void_p)]
+
+
+class PCLPlan:
+    """Cluster structure of the PRM matrix `mat` (reference heads.py:14-36), built once per image
+    on the host: per-row cluster index and column, cluster sizes, background cluster.  `None` is
+    returned by `build` for matrices with more than one non-zero per row (general torch path)."""
+
+    def __init__(self, row_cluster, row_col, sizes, bg, device):
+        self.K = int(len(sizes))
+        self.bg = int(bg)
+        self.row_cluster = torch.from_numpy(row_cluster).to(device)
+        self.row_col = torch.from_numpy(row_col).to(device)
+        self.sizes = torch.from_numpy(sizes).to(device)
+
+    @staticmethod
+    def build(mat, device):
+        m = mat.detach().cpu().numpy() if torch.is_tensor(mat) else np.asarray(mat)
+        nz = m != 0
+        if (nz.sum(1) > 1).any():
+            return None
+        row_col = nz.argmax(1).astype(np.int32)
+        vals = m[np.arange(m.shape[0]), row_col]
+        ids = np.unique(vals[vals != 0])
+        col0 = np.unique(m[:, 0][m[:, 0] != 0])
+        assert len(col0) <= 1                                      # heads.py:20
+        row_cluster = np.full(m.shape[0], -1, dtype=np.int32)
+        sizes = np.zeros(len(ids), dtype=np.int32)
+        for k, v in enumerate(ids):
+            sel = vals == v
+            row_cluster[sel] = k
+            sizes[k] = int(sel.sum())
+        bg = int(np.nonzero(ids == col0[0])[0][0]) if len(col0) == 1 else -1
+        return PCLPlan(row_cluster, row_col, sizes, bg, device)
+
+
+class FusedLossFunction(torch.autograd.Function):
+    """All four losses of the training step in one HIP launch (cim_amd/csrc/losses.hip).
+    Returns a tensor [4] = (bag_loss, pcl_loss, cls_loss, iou_loss) with the per-layer lmda weights
+    applied and iou NOT yet multiplied by 3 (model_builder.py:199 does that)."""
+
+    @staticmethod
+    def forward(ctx, meta, pc, pd, *scores):
+        R = meta["R"]
+        rc, ri = scores[:R], scores[R:2 * R]
+        N, C1 = pc.shape
+        dev = pc.device
+        pc, pd = pc.contiguous(), pd.contiguous()
+        rc = [t.contiguous() for t in rc]
+        ri = [t.contiguous() for t in ri]
+        part = torch.empty((R + 2, 4), dtype=torch.float32, device=dev)
+        grad = torch.empty((3 + 4 * R, N, C1), dtype=torch.float32, device=dev)
+        a = _LossArgs()
+        a.pc, a.pd = pc.data_ptr(), pd.data_ptr()
+        keep = []
+        for i in range(R):
+            a.rc[i], a.ri[i] = rc[i].data_ptr(), ri[i].data_ptr()
+            ps = meta["pseudo"][i]
+            a.layer_valid[i] = 0 if ps is None else 1
+            a.weight_scale[i] = float(meta["scales"][i])
+            if ps is not None:
+                y, t16, w = (ps[0].contiguous(), ps[1].contiguous(), ps[2].contiguous())
+                assert t16.dtype == torch.float16 and y.dtype == torch.float32 and w.dtype == torch.float32
+                keep += [y, t16, w]
+                a.pseudo_labels[i], a.pseudo_iou_f16[i], a.loss_weights[i] = y.data_ptr(), t16.data_ptr(), w.data_ptr()
+        labels = meta["labels"].reshape(-1).to(torch.float32).contiguous()
+        plan = meta["plan"]
+        a.labels = labels.data_ptr()
+        a.K, a.bg_cluster = plan.K, plan.bg
+        if plan.K:
+            a.row_cluster, a.row_col, a.cluster_size = plan.row_cluster.data_ptr(), plan.row_col.data_ptr(), plan.sizes.data_ptr()
+        a.N, a.C1, a.R = N, C1, R
+        a.part, a.grad = part.data_ptr(), grad.data_ptr()
+        _lib.call("cim_losses_fwd", ctypes.byref(a), _lib.stream_ptr())
+        ctx.R = R
+        ctx.save_for_backward(grad)
+        return part.sum(dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (G,) = ctx.saved_tensors
+        R = ctx.R
+        g_bag, g_pcl, g_cls, g_iou = g[0], g[1], g[2], g[3]
+        d_pc = g_bag * G[0] + g_pcl * G[1]
+        d_pd = g_bag * G[2]
+        d_rc = [g_cls * G[3 + 4 * i] + g_bag * G[4 + 4 * i] for i in range(R)]
+        d_ri = [g_iou * G[5 + 4 * i] + g_bag * G[6 + 4 * i] for i in range(R)]
+        return (None, d_pc, d_pd, *d_rc, *d_ri)
+
+
+def fused_losses(predict_cls, predict_det, ref_cls_score, ref_iou_score, labels, pseudo, scales, plan):
+    """pseudo[i] = (pseudo_labels, pseudo_iou_labels, loss_weights) of CIM_layer i, or None;
+    scales[i] = lmda.  Returns (bag_loss, pcl_loss, cls_loss, iou_loss) as 0-dim tensors."""
+    R = len(ref_cls_score)
+    meta = dict(R=R, pseudo=list(pseudo), scales=list(scales), labels=labels, plan=plan)
+    out = FusedLossFunction.apply(meta, predict_cls, predict_det, *ref_cls_score, *ref_iou_score)
+    return out[0], out[1], out[2], out[3]
 
 
 # --------------------------------------------------------------------------- scoring heads

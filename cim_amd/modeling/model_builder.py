@@ -97,10 +97,12 @@ class Generalized_RCNN(nn.Module):
                 iou_map=None, asy_iou_map=None):
         with torch.set_grad_enabled(self.training):
             im_data = data
-            labels_host = None
+            labels_host = mat_host = None
             if self.training:
                 if not labels.is_cuda:
                     labels_host = labels.detach().reshape(-1).numpy().copy()
+                if not mat.is_cuda:
+                    mat_host = mat.detach().squeeze(dim=0).numpy()
                 dev, dt = im_data.device, im_data.dtype
                 rois = rois.squeeze(dim=0).to(device=dev, dtype=dt)
                 masks = masks.squeeze(dim=0).to(device=dev, dtype=dt)
@@ -124,26 +126,44 @@ class Generalized_RCNN(nn.Module):
 
             n = predict_cls.shape[0]
             ctx = heads.MiningContext(labels, n, predict_cls.device, labels_host=labels_host)
-            zero = seg_x.new_zeros(())
-            losses = dict(bag_loss=zero.clone(), pcl_loss=zero.clone(), cls_loss=zero.clone(), iou_loss=zero.clone())
-            for i, (cls_score, iou_score, layer) in enumerate(zip(ref_cls_score, ref_iou_score, self.CIM_layer_list)):
-                lmda = 3 if i == 0 else 1                                   # model_builder.py:172
+            pseudo, scales = [], []
+            for i, layer in enumerate(self.CIM_layer_list):
                 src_cls, src_det = (predict_cls, predict_det) if i == 0 else (ref_cls_score[i - 1], ref_iou_score[i - 1])
-                pseudo_labels, pseudo_iou_labels, loss_weights = layer(src_cls, src_det, rois, labels, iou_map,
-                                                                       asy_iou_map, using_CIM=self.using_CIM[i],
-                                                                       _ctx=ctx)
-                if pseudo_labels is None:
-                    continue
-                loss_weights = lmda * loss_weights
-                cls_loss, iou_loss, bag_loss = heads.cls_iou_loss(cls_score, iou_score, pseudo_labels,
-                                                                  pseudo_iou_labels, loss_weights, labels)
-                losses["cls_loss"] = losses["cls_loss"] + cls_loss
-                losses["iou_loss"] = losses["iou_loss"] + 3 * iou_loss        # model_builder.py:199
-                losses["bag_loss"] = losses["bag_loss"] + bag_loss
-            losses["bag_loss"] = losses["bag_loss"] + heads.mil_bag_loss(predict_cls, predict_det, labels)
-            losses["pcl_loss"] = losses["pcl_loss"] + heads.PCL_loss(predict_cls, mat, labels)
+                out = layer(src_cls, src_det, rois, labels, iou_map, asy_iou_map, using_CIM=self.using_CIM[i], _ctx=ctx)
+                pseudo.append(None if out[0] is None else out)               # model_builder.py:189-190
+                scales.append(3 if i == 0 else 1)                            # lmda, model_builder.py:172
+            plan = self._pcl_plan(mat, mat_host)
+            if plan is not None and cfg.REFINE_TIMES <= 3:
+                # all four losses + their gradient components in one HIP launch (csrc/losses.hip)
+                bag, pcl, cls_l, iou_l = heads.fused_losses(predict_cls, predict_det, ref_cls_score, ref_iou_score,
+                                                            labels, pseudo, scales, plan)
+                losses = dict(bag_loss=bag, pcl_loss=pcl, cls_loss=cls_l, iou_loss=3 * iou_l)   # model_builder.py:199
+            else:   # general `mat` (several non-zeros per row): the reference's formulation in ATen ops
+                zero = seg_x.new_zeros(())
+                losses = dict(bag_loss=zero.clone(), pcl_loss=zero.clone(), cls_loss=zero.clone(), iou_loss=zero.clone())
+                for i, ps in enumerate(pseudo):
+                    if ps is None:
+                        continue
+                    cls_loss, iou_loss, bag_loss = heads.cls_iou_loss(ref_cls_score[i], ref_iou_score[i], ps[0], ps[1],
+                                                                      scales[i] * ps[2], labels)
+                    losses["cls_loss"] = losses["cls_loss"] + cls_loss
+                    losses["iou_loss"] = losses["iou_loss"] + 3 * iou_loss
+                    losses["bag_loss"] = losses["bag_loss"] + bag_loss
+                losses["bag_loss"] = losses["bag_loss"] + heads.mil_bag_loss(predict_cls, predict_det, labels)
+                losses["pcl_loss"] = losses["pcl_loss"] + heads.PCL_loss(predict_cls, mat, labels)
             return_dict["losses"] = {k: v.unsqueeze(0) for k, v in losses.items()}
             return return_dict
+
+    def _pcl_plan(self, mat, mat_host):
+        """PRM cluster plan of this image.  Built from the host copy when the loader handed a CPU
+        tensor; for a device-resident `mat` it is read back once and cached by storage identity."""
+        if mat_host is not None:
+            return heads.PCLPlan.build(mat_host, mat.device)
+        key = (mat.data_ptr(), mat._version, tuple(mat.shape))
+        cache = getattr(self, "_plan_cache", None)
+        if cache is None or cache[0] != key:
+            self._plan_cache = (key, heads.PCLPlan.build(mat, mat.device))
+        return self._plan_cache[1]
 
     def roi_feature_transform(self, blobs_in, rois, method="RoIPoolF", resolution=7, spatial_scale=1.0 / 16.0,
                               sampling_ratio=0):

@@ -172,6 +172,41 @@ int cim_wino_output_transform(const float* M, const float* bias, float* y, int R
 int cim_wino_dy_transform(const float* dy, float* D, int R, int P, int C, void* stream);
 int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, void* stream);
 
+/* ------------------------------------------------------------------ losses (a-8, a-9, a-10)
+ * Replaces cls_iou_loss + loss_weight_bag_loss (per refinement layer), mil_bag_loss and PCL_loss,
+ * lib/modeling/heads.py:10-166, as summed by lib/modeling/model_builder.py:170-204.
+ * One launch: R (= REFINE_TIMES <= 3) + 2 workgroups.  All score tensors are [N, C1] f32.
+ *   part [R+2][4]  per-job partial losses in the order {bag, pcl, cls, iou}: rows 0..R-1 = the
+ *                  refinement layers (iou NOT yet multiplied by 3), row R = mil_bag, row R+1 = PCL
+ *   grad [3 + 4R][N][C1]  gradient components for a unit upstream gradient:
+ *        0: d bag(mil)/d predict_cls   1: d pcl/d predict_cls   2: d bag(mil)/d predict_det
+ *        3+4i: d cls_i/d refine_cls[i]   4+4i: d bag_i/d refine_cls[i]
+ *        5+4i: d iou_i/d refine_iou[i]   6+4i: d bag_i/d refine_iou[i]
+ * PCL cluster plan (host-built from `mat`, heads.py:14-21): row_cluster [N] = index of the row's
+ * cluster (-1: none), row_col [N] = column of its non-zero entry, cluster_size [K], bg_cluster =
+ * index of the background cluster (-1: none). */
+typedef struct cim_loss_args {
+    const float* pc;                 /* predict_cls */
+    const float* pd;                 /* predict_det */
+    const float* rc[3];              /* refine_cls[i] */
+    const float* ri[3];              /* refine_iou[i] */
+    const float* pseudo_labels[3];   /* [N,C1] one-hot / zero rows (CIM_layer output) */
+    const uint16_t* pseudo_iou_f16[3]; /* [N] binary16 {0,1} */
+    const float* loss_weights[3];    /* [N] (unscaled) */
+    float weight_scale[3];           /* lmda: 3 for layer 0, else 1 (model_builder.py:172) */
+    int layer_valid[3];              /* 0: CIM_layer returned None -> layer skipped */
+    const float* labels;             /* [C1-1] image labels */
+    const int32_t* row_cluster;
+    const int32_t* row_col;
+    const int32_t* cluster_size;
+    int K, bg_cluster;
+    int N, C1, R;
+    float* part;
+    float* grad;
+} cim_loss_args;
+
+int cim_losses_fwd(const cim_loss_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,3 +316,54 @@ def test_training_step_matches_cpu_oracle(dev, config):
         assert float((g - g_ref).norm()) < tol, "gradient mismatch at %s" % name
         checked += 1
     assert checked > 20
+
+
+# ------------------------------------------------------------------ fused HIP losses (csrc/losses.hip)
+@pytest.mark.parametrize("name", ["n300_c20_k2", "n1000_c80_k3"])
+def test_fused_losses_match_reference_and_autograd(dev, name, golden_dir):
+    """One-launch HIP losses vs (a) the reference's fp32 values (goldens) and (b) the ATen formulation's
+    autograd gradients, including a skipped refinement layer and non-unit upstream gradients."""
+    from cim_amd.modeling import heads
+    g = np.load(os.path.join(golden_dir, "losses_%s.npz" % name))
+    m = np.load(os.path.join(golden_dir, "mining_%s.npz" % name))
+    inp = case_inputs(MINING_CASES[name])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    labels = t(inp["labels"])
+    plan = heads.PCLPlan.build(inp["mat"], dev)
+    assert plan is not None and plan.K >= 2
+    for valid in ([True, True, True], [True, False, True]):
+        pc = t(inp["layers"][0][0]).requires_grad_(True)
+        pd = t(inp["layers"][0][1]).requires_grad_(True)
+        rc = [t(inp["layers"][i][0]).requires_grad_(True) for i in range(3)]
+        ri = [t(inp["layers"][i][2]).requires_grad_(True) for i in range(3)]
+        pseudo = [(t(m["l%d_pseudo_labels" % i]), t(m["l%d_pseudo_iou_labels" % i]), t(m["l%d_loss_weights" % i]))
+                  if valid[i] else None for i in range(3)]
+        scales = [3, 1, 1]
+        bag, pcl, cls_l, iou_l = heads.fused_losses(pc, pd, rc, ri, labels, pseudo, scales, plan)
+        up = torch.tensor([0.7, 1.3, 2.0, 0.5], device=dev)
+        (up[0] * bag + up[1] * pcl + up[2] * cls_l + up[3] * iou_l).backward()
+        got = [x.grad.clone() for x in [pc, pd] + rc + ri]
+        for x in [pc, pd] + rc + ri:
+            x.grad = None
+        # ATen formulation (cim_amd.modeling.heads functions mirror the reference one to one)
+        rb = rcl = rio = 0
+        for i in range(3):
+            if pseudo[i] is None:
+                continue
+            c, io, b = heads.cls_iou_loss(rc[i], ri[i], pseudo[i][0], pseudo[i][1], scales[i] * pseudo[i][2], labels)
+            rb, rcl, rio = rb + b, rcl + c, rio + io
+        rb = rb + heads.mil_bag_loss(pc, pd, labels)
+        rp = heads.PCL_loss(pc, t(inp["mat"]), labels)
+        (up[0] * rb + up[1] * rp + up[2] * rcl + up[3] * rio).backward()
+        for a, b_ in zip((bag, pcl, cls_l, iou_l), (rb, rp, rcl, rio)):
+            np.testing.assert_allclose(float(a), float(b_), rtol=2e-5, atol=1e-7)
+        for x, gg in zip([pc, pd] + rc + ri, got):
+            ref = x.grad if x.grad is not None else torch.zeros_like(x)
+            scale = float(ref.abs().max()) + 1e-12
+            assert float((gg - ref).abs().max()) <= 2e-5 * scale + 1e-9
+        if all(valid):   # and against the reference's own numbers
+            want = [g["f32_l%d_cls_iou_bag" % i] for i in range(3)]
+            np.testing.assert_allclose(float(cls_l), sum(w[0] for w in want), rtol=2e-5)
+            np.testing.assert_allclose(float(iou_l), sum(w[1] for w in want), rtol=2e-5)
+            np.testing.assert_allclose(float(bag), sum(w[2] for w in want) + float(g["f32_mil_bag"]), rtol=2e-5)
+            np.testing.assert_allclose(float(pcl), float(g["f32_pcl"]), rtol=2e-5)
