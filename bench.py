@@ -98,8 +98,10 @@ def init_for_synthetic(model):
     every bottleneck (as zero-init-residual schemes do) so activations stay O(1) and the
     synthetic training steps stay finite.  Architecture and work per step are unchanged."""
     for m in model.modules():
-        if hasattr(m, "bn3"):
+        if hasattr(m, "bn3"):                                   # bottleneck (ResNet-50, HRNet stem / head)
             torch.nn.init.constant_(m.bn3.weight, 0.25)
+        elif hasattr(m, "bn2") and hasattr(m, "downsample"):    # HRNet basic block
+            torch.nn.init.constant_(m.bn2.weight, 0.25)
 
 
 def pmc_traffic():
@@ -200,9 +202,12 @@ def main():
                  iou_map=[iou], asy_iou_map=[asy])
     np.random.seed(cfg.RNG_SEED + rank)                        # the anti-noise sampling stream
 
+    feat_hw = [0, 0]
+
     def step():
         dp.zero_grad()
         out = dp(**batch)
+        feat_hw[:] = out["blob_conv"].shape[-2:]
         loss = sum(v.sum() for v in out["losses"].values()) * dp.loss_scale()
         loss.backward()
         dp.finish_gradient_sync()
@@ -234,7 +239,7 @@ def main():
     if rank == 0:
         H, W = inp["image_hw"]
         Cf = model.Conv_Body.dim_out
-        Hf, Wf = -(-H // 16), -(-W // 16)
+        Hf, Wf = feat_hw
         # dominant kernel: the exact-fp32 MFMA GEMM of the MaskFuse 3x3 conv forward (a-2).
         #   Winograd F(2x2,3x3) (default): 16 batched GEMMs [16N x 2Cf] x [2Cf x Cf] = 2*16*16N*2Cf*Cf flops
         #   direct implicit GEMM (CIM_CONV_ALGO=direct): 2*49N*18Cf*Cf flops        
@@ -263,7 +268,9 @@ def main():
                 hbm.append(dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=ach / HBM_PEAK_GBS, ms=ms, algorithmic_bytes=ra_bytes,
                                 traffic=pk["hbm_bytes_mean"] if pk else None))
-        line = dict(metric="images/sec training step (ResNet-50 VOC, ~1k proposals/img)",
+        metric = "images/sec training step (ResNet-50 VOC, ~1k proposals/img)" if args.config == "resnet50_voc" \
+            else "images/sec training step (%s)" % args.config
+        line = dict(metric=metric,
                     value=world * args.steps / elapsed, unit="images/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
                     scaling="weak", vs_baseline=None, dtype="fp32", data="synthetic",

@@ -70,7 +70,7 @@ def _to_attr(d):
 
 def _merge(a, b):
     for k, v in a.items():
-        if isinstance(v, dict) and isinstance(b.get(k), dict):
+        if isinstance(v, dict) and isinstance(b.get(k), dict) and (b[k] or k not in ("EXTRA",)):
             _merge(v, b[k])
         else:
             if isinstance(v, str) and isinstance(b.get(k), tuple):

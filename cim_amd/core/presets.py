@@ -16,6 +16,10 @@ PRESETS = {
                       flags=dict(VGG_CLS_FEATURE=True)),
     "resnet50_voc": dict(CONV_BODY="resnet50.torch_resnet50", ROI_BOX_HEAD="resnet50.MaskFuse", NUM_CLASSES=20,
                          flags={}),
+    "hrnet48_voc": dict(CONV_BODY="HRNet.get_HRNet", ROI_BOX_HEAD="HRNet.MaskFuse", NUM_CLASSES=20,
+                        flags=dict(HRNET_CLS_FEATURE=True)),
+    "hrnet48_coco2017": dict(CONV_BODY="HRNet.get_HRNet", ROI_BOX_HEAD="HRNet.MaskFuse", NUM_CLASSES=80,
+                             flags=dict(HRNET_CLS_FEATURE=True)),
     "resnet50_coco2017": dict(CONV_BODY="resnet50.torch_resnet50", ROI_BOX_HEAD="resnet50.MaskFuse", NUM_CLASSES=80,
                               flags={}),
 }

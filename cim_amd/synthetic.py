@@ -16,6 +16,7 @@ CONFIGS = {
     "resnet50_voc": dict(orig_hw=(375, 500), target=688, n=1000, classes=20, n_pos=2, body="resnet50"),
     "resnet50_coco2017": dict(orig_hw=(480, 640), target=688, n=2000, classes=80, n_pos=3, body="resnet50"),
     "hrnet48_coco2017": dict(orig_hw=(480, 640), target=688, n=2000, classes=80, n_pos=3, body="hrnet48"),
+    "hrnet48_voc": dict(orig_hw=(375, 500), target=688, n=1000, classes=20, n_pos=2, body="hrnet48"),
 }
 
 

@@ -356,6 +356,31 @@ def gen_e2e():
     print("e2e", {k: float(v) for k, v in store.items() if k.startswith("loss_")}, "params with grad:", len(names))
 
 
+def gen_hrnet():
+    """The reference's HRNet-W48 trunk (lib/modeling/HRNet.py) on procedural weights: state_dict keys
+    and the fused 2048-channel stride-32 map for an image whose sides are not multiples of 32."""
+    cfgmod = importlib.import_module("core.config")
+    cfg = cfgmod.cfg
+    cfg.MODEL.NUM_CLASSES = 20
+    cfgmod.cfg_from_file(_ref_shims.REF_ROOT + "/configs/hrnet48_voc.yaml")
+    cfg.MODEL.LOAD_IMAGENET_PRETRAINED_WEIGHTS = False
+    hr = importlib.import_module("modeling.HRNet")
+    model = hr.get_HRNet()
+    model.train()                      # (the reference's train() override returns None)
+    procedural_init(model)
+    x = torch.from_numpy(procedural((1, 3, 150, 220), 4242) * 10.0)
+    y = model(x)
+    y.sum().backward()
+    trainable = [n for n, p in model.named_parameters() if p.requires_grad]
+    with_grad = [n for n, p in model.named_parameters() if p.grad is not None]
+    np.savez_compressed(os.path.join(HERE, "hrnet_w48.npz"), out=y.detach().numpy(),
+                        keys=np.array(list(model.state_dict().keys())), trainable=np.array(trainable),
+                        with_grad=np.array(with_grad),
+                        grad_norm_final=np.array(float(model.final_layer[0].weight.grad.norm())),
+                        grad_norm_stage3=np.array(float(model.stage3[0].branches[0][0].conv1.weight.grad.norm())))
+    print("hrnet", tuple(y.shape), len(model.state_dict()), "trainable", len(trainable), "with grad", len(with_grad))
+
+
 def main():
     _ref_shims.install()
     heads = importlib.import_module("modeling.heads")
@@ -365,6 +390,7 @@ def main():
     gen_mask_iou()
     gen_mask_iou_witness()
     gen_e2e()
+    gen_hrnet()
 
 
 if __name__ == "__main__":

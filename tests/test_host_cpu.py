@@ -98,3 +98,24 @@ def test_cls_iou_model_matches_reference(golden_dir):
     np.testing.assert_allclose(torch.stack(rc).numpy(), g["refine_cls"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(torch.stack(ri).numpy(), g["refine_iou"], rtol=1e-5, atol=1e-7)
     assert [n for n, _ in model.named_parameters()][:4] == ["classifier.weight", "classifier.bias", "detector.weight", "detector.bias"]
+
+
+def test_hrnet_w48_matches_reference(golden_dir):
+    """cfg5 body: same state_dict keys, frozen set and output as the reference's HRNet.py on procedural weights."""
+    from cases import procedural_init
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.HRNet import get_HRNet
+    g = np.load(os.path.join(golden_dir, "hrnet_w48.npz"))
+    apply_preset("hrnet48_voc")
+    m = get_HRNet().train()
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    assert [n for n, p in m.named_parameters() if p.requires_grad] == [str(k) for k in g["trainable"]]
+    procedural_init(m)
+    y = m(torch.from_numpy(procedural((1, 3, 150, 220), 4242) * 10.0))
+    assert y.shape == g["out"].shape
+    np.testing.assert_allclose(y.detach().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    y.sum().backward()
+    assert [n for n, p in m.named_parameters() if p.grad is not None] == [str(k) for k in g["with_grad"]]
+    np.testing.assert_allclose(float(m.final_layer[0].weight.grad.norm()), float(g["grad_norm_final"]), rtol=1e-3)
+    np.testing.assert_allclose(float(m.stage3[0].branches[0][0].conv1.weight.grad.norm()), float(g["grad_norm_stage3"]), rtol=1e-3)
+    assert all(not b.training for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))
