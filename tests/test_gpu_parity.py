@@ -370,3 +370,48 @@ def test_fused_losses_match_reference_and_autograd(dev, name, golden_dir):
             np.testing.assert_allclose(float(iou_l), sum(w[1] for w in want), rtol=2e-5)
             np.testing.assert_allclose(float(bag), sum(w[2] for w in want) + float(g["f32_mil_bag"]), rtol=2e-5)
             np.testing.assert_allclose(float(pcl), float(g["f32_pcl"]), rtol=2e-5)
+
+
+# ------------------------------------------------------------------ model boundary (a-12): pickle path, eval branch
+def test_model_pickle_path_and_eval_branch(dev, tmp_path):
+    """forward(path=...) reads <iou_dir>/<stem>.pkl / <asy_iou_dir>/<stem>.pkl like model_builder.py:147-159
+    and gives the same losses as passing the maps; eval mode returns refine_score (model_builder.py:60-68)."""
+    import pickle
+    from cim_amd import synthetic
+    from cim_amd.core.config import cfg
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    from oracle import mask_iou as omi
+    apply_preset("resnet50_voc")
+    torch.manual_seed(1)
+    inp = synthetic.make_image_inputs("resnet50_voc", seed=9, n=40)
+    inp["data"] = inp["data"][:, :, :160, :224].copy()
+    inp["rois"][:, 1:] *= np.float32(0.3)
+    iou, asy = omi.mask_iou_maps(inp["full_masks"])
+    (tmp_path / "iou").mkdir()
+    (tmp_path / "asy").mkdir()
+    pickle.dump(iou, open(tmp_path / "iou" / "2008_000123.pkl", "wb"))
+    pickle.dump(asy, open(tmp_path / "asy" / "2008_000123.pkl", "wb"))
+    cfg.iou_dir, cfg.asy_iou_dir = str(tmp_path / "iou"), str(tmp_path / "asy")
+    model = Generalized_RCNN().to(dev).train()
+    t = lambda a: torch.from_numpy(a).unsqueeze(0)             # CPU tensors, as the loader hands them over
+    kw = dict(data=torch.from_numpy(inp["data"]).to(dev), rois=t(inp["rois"]), masks=t(inp["masks"]), labels=t(inp["labels"]),
+              gtrois=None, mat=t(inp["mat"]), index=t(inp["index"]))
+    np.random.seed(3)
+    a = model(path="/data/VOC2012/JPEGImages/2008_000123.jpg", **kw)
+    np.random.seed(3)
+    b = model(iou_map=torch.from_numpy(iou).to(dev), asy_iou_map=torch.from_numpy(asy).to(dev), **kw)
+    for k in ("bag_loss", "pcl_loss", "cls_loss", "iou_loss"):
+        assert a["losses"][k].shape == (1,)
+        # (not bit-equal: MIOpen may pick a different backbone conv algorithm on the second call)
+        np.testing.assert_allclose(float(a["losses"][k]), float(b["losses"][k]), rtol=1e-5)
+    with pytest.raises(NotImplementedError):                  # missing pickle: model_builder.py:150-152
+        model(path="/x/missing.jpg", **kw)
+    with pytest.raises(ValueError):                           # check_inference: model_builder.py:45-58
+        model.convbody_net(kw["data"])
+    model.eval()
+    out = model(data=kw["data"], rois=torch.from_numpy(inp["rois"]).to(dev), masks=torch.from_numpy(inp["masks"]).to(dev),
+                labels=None, gtrois=None, mat=None)
+    assert set(out) == {"blob_conv", "refine_score"} and len(out["refine_score"]) == 3
+    assert out["refine_score"][0].shape == (40, 20) and not out["refine_score"][0].requires_grad
+    assert model.convbody_net(kw["data"]).shape[1] == 1024
