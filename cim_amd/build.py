@@ -27,7 +27,11 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None):
+    global LIB
+    if out is not None:
+        LIB = out
+        force = True
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -42,5 +46,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    outs = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--out=")]
+    build(force="--force" in sys.argv, verbose=True, out=outs[0] if outs else None)
     print(LIB)

@@ -28,8 +28,18 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #ifndef CIM_GEMM_BK
 #define CIM_GEMM_BK 16
 #endif
-constexpr int BM = 256, BN = 256, BK = CIM_GEMM_BK;
-constexpr int WAVES_M = 2, WAVES_N = 4;
+#ifndef CIM_GEMM_BN
+#define CIM_GEMM_BN 256
+#endif
+#ifndef CIM_GEMM_WAVES_M
+#define CIM_GEMM_WAVES_M 2
+#endif
+#ifndef CIM_GEMM_MINW
+#define CIM_GEMM_MINW 2      // waves per SIMD the register allocator must leave room for (2 = one workgroup per CU)
+#endif
+constexpr int BM = 256, BN = CIM_GEMM_BN, BK = CIM_GEMM_BK;
+constexpr int WAVES_M = CIM_GEMM_WAVES_M, WAVES_N = 8 / CIM_GEMM_WAVES_M;
+constexpr int RESIDENT = CIM_GEMM_MINW / 2;   // co-resident 512-thread workgroups per CU
 constexpr int NT = 64 * WAVES_M * WAVES_N;      // 512 threads
 constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // 128 x 64 per wave
 constexpr int MI = WM / 32, NI = WN / 32;        // 4 x 2 MFMA tiles
@@ -119,14 +129,14 @@ struct ALoaderK {
 // M-contiguous: element (m, k) at A[k*lda + m]; thread owns float4 pieces (k row, 4 consecutive m).
 template <int AL>
 struct ALoaderM {
-    static constexpr int PIECES = BM * BK / 4 / NT;
+    static constexpr int COLS4 = BM / 4, ROWS = NT / COLS4, PIECES = BK / ROWS;
     int mq, krow0;
     const float* base;   // column base (A + m), null when out of range
     int dy, dx;
 
     __device__ __forceinline__ void init(const GemmArgs& g, int m0, int tid) {
-        mq = tid & 63;
-        krow0 = tid >> 6;
+        mq = tid % COLS4;
+        krow0 = tid / COLS4;
         const int m = m0 + mq * 4;
         if (AL == A_CONV_M) {   // m = (tap, ci); 4 consecutive m share the tap (Cin % 4 == 0)
             const int tap = m / g.Cin;
@@ -141,7 +151,7 @@ struct ALoaderM {
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int k = k0 + krow0 + i * (NT / 64);
+            const int k = k0 + krow0 + i * ROWS;
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (base == nullptr || k >= kend) continue;
             if (AL == A_CONV_M) {   // k = output pixel row (roi, oh, ow); gather the tap-shifted input pixel
@@ -158,25 +168,25 @@ struct ALoaderM {
     __device__ __forceinline__ void store(float* as, const float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i)
-            *reinterpret_cast<float4*>(as + (krow0 + i * (NT / 64)) * LDS_A + mq * 4) = v[i];
+            *reinterpret_cast<float4*>(as + (krow0 + i * ROWS) * LDS_A + mq * 4) = v[i];
     }
 };
 
 // ---- B operand -------------------------------------------------------------------------------
 struct BLoaderN {   // element (k, n) at B[k*ldb + n]
-    static constexpr int PIECES = BN * BK / 4 / NT;
+    static constexpr int COLS4 = BN / 4, ROWS = NT / COLS4, PIECES = BK / ROWS;
     int nq, krow0;
     const float* base;
     __device__ __forceinline__ void init(const GemmArgs& g, int n0, int tid) {
-        nq = tid & 63;
-        krow0 = tid >> 6;
+        nq = tid % COLS4;
+        krow0 = tid / COLS4;
         const int n = n0 + nq * 4;
         base = (n < g.N) ? g.B + n : nullptr;
     }
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int k = k0 + krow0 + i * (NT / 64);
+            const int k = k0 + krow0 + i * ROWS;
             v[i] = (base != nullptr && k < kend) ? *reinterpret_cast<const float4*>(base + (size_t)k * g.ldb)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -184,7 +194,7 @@ struct BLoaderN {   // element (k, n) at B[k*ldb + n]
     __device__ __forceinline__ void store(float* bs, const float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i)
-            *reinterpret_cast<float4*>(bs + (krow0 + i * (NT / 64)) * LDS_B + nq * 4) = v[i];
+            *reinterpret_cast<float4*>(bs + (krow0 + i * ROWS) * LDS_B + nq * 4) = v[i];
     }
 };
 
@@ -234,7 +244,7 @@ __device__ __forceinline__ void a_load(const L& l, const GemmArgs& g, int k0, in
 
 // grid = (tiles_n, tiles_m, splits); block = 512
 template <int AL, int BL>
-__global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const GemmArgs g_in) {
+__global__ __launch_bounds__(NT, CIM_GEMM_MINW) void gemm_f32_kernel(const GemmArgs g_in) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -397,22 +407,23 @@ int launch(GemmArgs g, int splits, float* workspace, hipStream_t st) {
 }  // namespace
 
 extern "C" int cim_gemm_f32_splits(int M, int N, int K) {
-    // One 512-thread workgroup (128 accumulator VGPRs per lane) is resident per CU, so a launch
-    // runs in rounds of 256 tiles; pick the split-K factor that fills the last round
-    // (e.g. conv wgrad: 288 tiles -> 2 rounds at 56 %; x8 -> 2304 = 9 full rounds).
-    const int CUS = 256;
-    const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // RESIDENT 512-thread workgroups fit per CU, so a launch runs in rounds of 256*RESIDENT tiles;
+    // split-K fills the last round (e.g. direct conv wgrad: 288 tiles -> 2 rounds at 56 %; x8 -> 9 full
+    // rounds) but costs a workspace round trip of (2s+1)*M*N floats.  Pick the split with the least
+    // estimated time: flops / (125 TF * round efficiency) + workspace bytes / 4 TB/s.
+    const double CUS = 256.0 * RESIDENT;
+    const double tiles = (double)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int slabs = (K + BK - 1) / BK;
-    if (tiles >= 16 * CUS) return 1;
+    const double flops = 2.0 * M * (double)N * K;
     int best = 1;
-    double best_score = -1.0;
+    double best_t = 1e30;
     for (int s = 1; s <= 16; ++s) {
         if (s > 1 && slabs / s < 16) break;            // keep >= 16 slabs (256 k) per split
-        const long long units = tiles * s;
-        const long long rounds = (units + CUS - 1) / CUS;
-        const double eff = (double)units / (double)(rounds * CUS);
-        const double score = eff - 0.015 * (s - 1);    // split-K costs workspace traffic
-        if (score > best_score + 1e-9) { best_score = score; best = s; }
+        const double units = tiles * s;
+        const double rounds = (double)(long long)((units + CUS - 1) / CUS);
+        const double eff = units / (rounds * CUS);
+        const double t = flops / (125e12 * eff) + (s > 1 ? (2.0 * s + 1.0) * M * (double)N * 4.0 / 4e12 : 0.0);
+        if (t < best_t) { best_t = t; best = s; }
     }
     return best;
 }

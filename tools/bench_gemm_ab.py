@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Within-process A/B of two builds of the GEMM kernel (libcim_hip.so vs libcim_hip_alt.so) on the
+step's contraction shapes; interleaved rounds, median ms."""
+import ctypes
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cim_amd import _lib  # noqa: E402
+
+dev = torch.device("cuda:0")
+libs = {"base": _lib.load()}
+alt = ctypes.CDLL(os.path.join(_lib.HERE, "libcim_hip_alt.so"))
+for name, argt in _lib.SIGNATURES.items():
+    getattr(alt, name).argtypes = argt
+    getattr(alt, name).restype = ctypes.c_int
+libs["alt"] = alt
+st = torch.cuda.current_stream().cuda_stream
+N, C = 1000, 1024
+mt = N * 16
+g = torch.Generator(device=dev).manual_seed(0)
+V = torch.randn(16, mt, 2 * C, device=dev, generator=g)
+U = torch.randn(16, 2 * C, C, device=dev, generator=g)
+M = torch.empty(16, mt, C, device=dev)
+D = torch.randn(16, mt, C, device=dev, generator=g)
+dU = torch.empty(16, 2 * C, C, device=dev)
+K1 = 49 * C
+xf = torch.randn(N, K1, device=dev, generator=g)
+w1 = torch.randn(4096, K1, device=dev, generator=g) * 0.01
+dyf = torch.randn(N, 4096, device=dev, generator=g)
+y1 = torch.empty(N, 4096, device=dev)
+dx1 = torch.empty(N, K1, device=dev)
+dw1 = torch.empty(4096, K1, device=dev)
+ws = torch.empty(4 * 4096 * 50176, device=dev)     # 3.3 GB: up to 4 splits of the largest C
+
+
+def cases(lib):
+    sp = lambda m, n, k: min(lib.cim_gemm_f32_splits(m, n, k), (4 * 4096 * 50176) // (m * n))
+    return {
+        "wino_fwd": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), U.data_ptr(), M.data_ptr(), mt, C, 2 * C, 2 * C, C, C, 0, 0, 16, mt * 2 * C, 2 * C * C, mt * C, st), 16 * 2.0 * mt * 2 * C * C),
+        "wino_wgrad": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), D.data_ptr(), dU.data_ptr(), 2 * C, C, mt, 2 * C, C, C, 1, 0, 16, mt * 2 * C, mt * C, 2 * C * C, st), 16 * 2.0 * mt * 2 * C * C),
+        "fc1_fwd": (lambda: lib.cim_gemm_f32(xf.data_ptr(), w1.data_ptr(), y1.data_ptr(), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), ws.data_ptr(), st), 2.0 * N * K1 * 4096),
+        "fc1_dgrad": (lambda: lib.cim_gemm_f32(dyf.data_ptr(), w1.data_ptr(), dx1.data_ptr(), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, sp(N, K1, 4096), ws.data_ptr(), st), 2.0 * N * K1 * 4096),
+        "fc1_wgrad": (lambda: lib.cim_gemm_f32(dyf.data_ptr(), xf.data_ptr(), dw1.data_ptr(), None, 4096, K1, N, 4096, K1, K1, 1, 0, 0, sp(4096, K1, N), ws.data_ptr(), st), 2.0 * N * K1 * 4096),
+    }
+
+
+def timeit(fn, n=3):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        rc = fn()
+        assert rc == 0, rc
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+res = {k: {n: [] for n in cases(libs["base"])} for k in libs}
+for k in libs:
+    for n, (fn, _) in cases(libs[k]).items():
+        timeit(fn, 1)
+for rnd in range(5):
+    for k in libs:
+        for n, (fn, fl) in cases(libs[k]).items():
+            res[k][n].append(timeit(fn))
+fl = {n: f for n, (_, f) in cases(libs["base"]).items()}
+for n in fl:
+    b, a = statistics.median(res["base"][n]), statistics.median(res["alt"][n])
+    print("%-11s base %.3f ms (%.1f TF)   alt %.3f ms (%.1f TF)   alt/base %.3f" % (n, b, fl[n] / b / 1e9, a, fl[n] / a / 1e9, a / b))
+# correctness of alt vs base on one case
+cases(libs["base"])["wino_fwd"][0](); m0 = M.clone(); cases(libs["alt"])["wino_fwd"][0]()
+print("alt == base (wino_fwd):", bool(torch.equal(m0, M)))
