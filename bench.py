@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--config", default="resnet50_voc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="proposals in the CPU sample (0 = all)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
+                                                       "multi-rank check on a box with fewer GPUs than ranks)")
     ap.add_argument("--miopen-find", action="store_true",
                     help="let MIOpen time its solvers for the backbone convs (default: immediate mode)")
     args = ap.parse_args()
@@ -176,11 +178,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if args.backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # functional check: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.backends.cudnn.benchmark = args.miopen_find      # backbone convs (a-11) go through MIOpen
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     _lib.load()                                                # no HIP extension -> fail loudly
 
     apply_preset(args.config)

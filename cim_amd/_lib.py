@@ -32,6 +32,8 @@ SIGNATURES = {
     "cim_wino_dy_transform": [_P, _P, c_int, c_int, c_int, _P],
     "cim_wino_wgrad_output": [_P, _P, c_int, c_int, _P],
     "cim_losses_fwd": [_P, _P],
+    "cim_head_act_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],
+    "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cim_assign": [_P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P],
 }
 

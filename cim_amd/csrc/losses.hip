@@ -238,3 +238,127 @@ extern "C" int cim_losses_fwd(const cim_loss_args* args, void* stream) {
     CIM_CHECK_LAUNCH();
     return 0;
 }
+
+// =============================================================================================
+// Head activations (a-3): the epilogue of cls_iou_model.forward, /root/reference/lib/modeling/heads.py:199-217.
+// Input = the fused linear output  logits [N, (2+2R)*C1]  with column blocks
+//   [ classifier | detector | refine_cls[0..R) | refine_iou[0..R) ],
+// output scores in the same layout: softmax over classes (classifier, refine_cls), softmax over
+// PROPOSALS (detector, dim 0), sigmoid (refine_iou).  Two launches forward (detector column
+// statistics, then one wave per proposal row) and two backward.
+namespace {
+
+__global__ __launch_bounds__(256) void head_colstat_kernel(const float* __restrict__ x, int N, int C1, int ld, int off,
+                                                           float* __restrict__ stat) {
+    // block c: max and sum(exp(x - max)) over rows of column off + c
+    __shared__ float red[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float m = -INFINITY;
+    for (int n = tid; n < N; n += 256) m = fmaxf(m, x[(size_t)n * ld + off + c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.0f;
+    for (int n = tid; n < N; n += 256) s += expf(x[(size_t)n * ld + off + c] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        stat[c] = m;
+        stat[C1 + c] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+// one wave per row; blocks: 0 = classifier, 1 = detector, 2..2+R = refine_cls, then refine_iou
+__global__ __launch_bounds__(256) void head_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C1,
+                                                           int R, const float* __restrict__ stat) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const int ld = (2 + 2 * R) * C1;
+    const float* xr = x + (size_t)row * ld;
+    float* yr = y + (size_t)row * ld;
+    for (int b = 0; b < 2 + 2 * R; ++b) {
+        const int off = b * C1;
+        if (b == 1) {                                   // softmax over proposals (dim 0)
+            for (int c = lane; c < C1; c += 64) yr[off + c] = expf(xr[off + c] - stat[c]) / stat[C1 + c];
+        } else if (b < 2 + R) {                         // softmax over classes
+            float m = -INFINITY;
+            for (int c = lane; c < C1; c += 64) m = fmaxf(m, xr[off + c]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            float s = 0.0f;
+            for (int c = lane; c < C1; c += 64) s += expf(xr[off + c] - m);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            for (int c = lane; c < C1; c += 64) yr[off + c] = expf(xr[off + c] - m) / s;
+        } else {                                        // sigmoid
+            for (int c = lane; c < C1; c += 64) yr[off + c] = 1.0f / (1.0f + expf(-xr[off + c]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_coldot_kernel(const float* __restrict__ y, const float* __restrict__ dy, int N,
+                                                          int C1, int ld, int off, float* __restrict__ dot) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float s = 0.0f;
+    for (int n = tid; n < N; n += 256) s += y[(size_t)n * ld + off + c] * dy[(size_t)n * ld + off + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) dot[c] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void head_act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int N, int C1, int R,
+                                                           const float* __restrict__ dot) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const int ld = (2 + 2 * R) * C1;
+    const float* yr = y + (size_t)row * ld;
+    const float* gr = dy + (size_t)row * ld;
+    float* dr = dx + (size_t)row * ld;
+    for (int b = 0; b < 2 + 2 * R; ++b) {
+        const int off = b * C1;
+        if (b == 1) {
+            for (int c = lane; c < C1; c += 64) dr[off + c] = yr[off + c] * (gr[off + c] - dot[c]);
+        } else if (b < 2 + R) {
+            float s = 0.0f;
+            for (int c = lane; c < C1; c += 64) s += yr[off + c] * gr[off + c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            for (int c = lane; c < C1; c += 64) dr[off + c] = yr[off + c] * (gr[off + c] - s);
+        } else {
+            for (int c = lane; c < C1; c += 64) dr[off + c] = gr[off + c] * yr[off + c] * (1.0f - yr[off + c]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cim_head_act_fwd(const float* logits, float* scores, float* colstat, int N, int C1, int R, void* stream) {
+    CIM_CHECK_ARG(logits && scores && colstat && N > 0 && C1 > 0 && R >= 0 && R <= 8);
+    const int ld = (2 + 2 * R) * C1;
+    hipStream_t st = cim::as_stream(stream);
+    hipLaunchKernelGGL(head_colstat_kernel, dim3(C1), dim3(256), 0, st, logits, N, C1, ld, C1, colstat);
+    hipLaunchKernelGGL(head_act_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, logits, scores, N, C1, R, colstat);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_head_act_bwd(const float* scores, const float* grad_scores, float* grad_logits, float* coldot, int N,
+                                int C1, int R, void* stream) {
+    CIM_CHECK_ARG(scores && grad_scores && grad_logits && coldot && N > 0 && C1 > 0 && R >= 0 && R <= 8);
+    const int ld = (2 + 2 * R) * C1;
+    hipStream_t st = cim::as_stream(stream);
+    hipLaunchKernelGGL(head_coldot_kernel, dim3(C1), dim3(256), 0, st, scores, grad_scores, N, C1, ld, C1, coldot);
+    hipLaunchKernelGGL(head_act_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, scores, grad_scores, grad_logits, N, C1, R,
+                       coldot);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}

@@ -270,13 +270,43 @@ class cls_iou_model(nn.Module):
         layers = [self.classifier, self.detector] + list(self.refine_cls) + list(self.refine_iou)
         w = torch.cat([l.weight for l in layers], dim=0)
         b = torch.cat([l.bias for l in layers], dim=0)
-        logits = F.linear(seg_feature, w, b).split(self.classifier.out_features, dim=1)
+        logits = F.linear(seg_feature, w, b)
         r = len(self.refine_cls)
-        predict_cls = F.softmax(logits[0], dim=-1)
-        predict_det = F.softmax(logits[1], dim=0)
-        refine_cls_score = [F.softmax(l, dim=-1) for l in logits[2:2 + r]]
-        refine_iou_score = [torch.sigmoid(l) for l in logits[2 + r:2 + 2 * r]]
-        return predict_cls, predict_det, refine_cls_score, refine_iou_score
+        c1 = self.classifier.out_features
+        if logits.is_cuda and logits.dtype == torch.float32:
+            scores = HeadActFunction.apply(logits, c1, r).split(c1, dim=1)     # fused HIP epilogue
+        else:   # CPU tensors (host-side tests of the module): the same maths in ATen
+            lg = logits.split(c1, dim=1)
+            scores = ([F.softmax(lg[0], dim=-1), F.softmax(lg[1], dim=0)] + [F.softmax(l, dim=-1) for l in lg[2:2 + r]]
+                      + [torch.sigmoid(l) for l in lg[2 + r:2 + 2 * r]])
+        return scores[0], scores[1], list(scores[2:2 + r]), list(scores[2 + r:2 + 2 * r])
+
+
+class HeadActFunction(torch.autograd.Function):
+    """softmax(classes) / softmax(proposals) / sigmoid epilogue of the 8 heads in two HIP launches
+    (cim_amd/csrc/losses.hip: head_colstat_kernel + head_act_fwd_kernel), analytic backward."""
+
+    @staticmethod
+    def forward(ctx, logits, c1, r):
+        logits = logits.contiguous()
+        n = logits.shape[0]
+        scores = torch.empty_like(logits)
+        stat = torch.empty(2 * c1, dtype=torch.float32, device=logits.device)
+        _lib.call("cim_head_act_fwd", logits.data_ptr(), scores.data_ptr(), stat.data_ptr(), n, c1, r, _lib.stream_ptr())
+        ctx.save_for_backward(scores)
+        ctx.dims = (n, c1, r)
+        return scores
+
+    @staticmethod
+    def backward(ctx, g):
+        (scores,) = ctx.saved_tensors
+        n, c1, r = ctx.dims
+        g = g.contiguous()
+        dx = torch.empty_like(scores)
+        dot = torch.empty(c1, dtype=torch.float32, device=scores.device)
+        _lib.call("cim_head_act_bwd", scores.data_ptr(), g.data_ptr(), dx.data_ptr(), dot.data_ptr(), n, c1, r,
+                  _lib.stream_ptr())
+        return dx, None, None
 
 
 # --------------------------------------------------------------------------- mining

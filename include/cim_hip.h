@@ -207,6 +207,15 @@ typedef struct cim_loss_args {
 
 int cim_losses_fwd(const cim_loss_args* args, void* stream);
 
+/* ------------------------------------------------------------------ head activations (a-3)
+ * Replaces the softmax / sigmoid epilogue of cls_iou_model.forward, lib/modeling/heads.py:199-217.
+ * logits / scores [N, (2+2R)*C1] with column blocks [classifier | detector | refine_cls[R] | refine_iou[R]]:
+ * softmax over classes (classifier, refine_cls), softmax over PROPOSALS (detector), sigmoid (refine_iou).
+ * colstat / coldot: [2*C1] / [C1] f32 scratch for the detector's column reductions. */
+int cim_head_act_fwd(const float* logits, float* scores, float* colstat, int N, int C1, int R, void* stream);
+int cim_head_act_bwd(const float* scores, const float* grad_scores, float* grad_logits, float* coldot,
+                     int N, int C1, int R, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -415,3 +415,38 @@ def test_model_pickle_path_and_eval_branch(dev, tmp_path):
     assert set(out) == {"blob_conv", "refine_score"} and len(out["refine_score"]) == 3
     assert out["refine_score"][0].shape == (40, 20) and not out["refine_score"][0].requires_grad
     assert model.convbody_net(kw["data"]).shape[1] == 1024
+
+
+def test_head_activations_hip_vs_reference_and_autograd(dev, golden_dir):
+    """cls_iou_model on the device (fused HIP epilogue) vs the reference's outputs (heads_small.npz) and vs
+    ATen autograd for the backward."""
+    import torch.nn.functional as F
+    from cases import procedural
+    from cim_amd.modeling import heads
+    g = np.load(os.path.join(golden_dir, "heads_small.npz"))
+    model = heads.cls_iou_model(64, 21, 3)
+    with torch.no_grad():
+        for k, (_, p) in enumerate(model.named_parameters()):
+            p.copy_(torch.from_numpy(procedural(tuple(p.shape), k + 1)))
+    model = model.to(dev)
+    x = torch.from_numpy(procedural((50, 64), 99) * 20).to(dev)
+    pc, pd, rc, ri = model(x)
+    np.testing.assert_allclose(pc.detach().cpu().numpy(), g["predict_cls"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pd.detach().cpu().numpy(), g["predict_det"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(torch.stack(rc).detach().cpu().numpy(), g["refine_cls"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(torch.stack(ri).detach().cpu().numpy(), g["refine_iou"], rtol=1e-5, atol=1e-7)
+    # backward vs ATen on random logits, N and C1 not multiples of 64
+    torch.manual_seed(0)
+    for n, c1, r in ((301, 21, 3), (77, 81, 3), (5, 3, 1)):
+        lg = (torch.randn(n, (2 + 2 * r) * c1, device=dev) * 3).requires_grad_(True)
+        up = torch.randn(n, (2 + 2 * r) * c1, device=dev)
+        s = heads.HeadActFunction.apply(lg, c1, r)
+        (s * up).sum().backward()
+        got = lg.grad.clone()
+        lg.grad = None
+        parts = lg.split(c1, dim=1)
+        ref = torch.cat([F.softmax(parts[0], -1), F.softmax(parts[1], 0)] + [F.softmax(p, -1) for p in parts[2:2 + r]]
+                        + [torch.sigmoid(p) for p in parts[2 + r:]], dim=1)
+        (ref * up).sum().backward()
+        torch.testing.assert_close(s, ref, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(got, lg.grad, rtol=1e-4, atol=1e-6)
