@@ -174,6 +174,9 @@ def main():
                     help="let MIOpen time its solvers for the backbone convs (default: immediate mode)")
     args = ap.parse_args()
 
+    if os.environ.get("CIM_BENCH_WATCHDOG"):        # debugging aid: dump all thread stacks if a phase stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CIM_BENCH_WATCHDOG"]), repeat=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -275,8 +278,8 @@ def main():
                 hbm.append(dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=ach / HBM_PEAK_GBS, ms=ms, algorithmic_bytes=ra_bytes,
                                 traffic=pk["hbm_bytes_mean"] if pk else None))
-        metric = "images/sec training step (ResNet-50 VOC, ~1k proposals/img)" if args.config == "resnet50_voc" \
-            else "images/sec training step (%s)" % args.config
+        metric = "images/sec training step (ResNet-50 VOC, ~1k proposals/img) at 1/2/4/8 GPU" \
+            if args.config == "resnet50_voc" else "images/sec training step (%s)" % args.config      # BASELINE.json
         line = dict(metric=metric,
                     value=world * args.steps / elapsed, unit="images/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
