@@ -13,7 +13,7 @@
 // BK = 16 staged through LDS as [k][m] / [k][n] (row stride +4 floats), so each MFMA operand
 // fetch is one conflict-free ds_read_b32 of 32 consecutive floats per half-wave.  Global->LDS is
 // register-staged and double-buffered: the loads of slab t+1 are issued before the MFMAs of
-// slab t and written to the other LDS buffer afterwards (one barrier per slab).
+// slab t; three LDS slabs rotate so the LDS write + barrier sit in the middle of a slab's MFMAs.
 // Operand layouts are template parameters (no runtime dispatch inside the loop):
 //   A: K-contiguous rows (activations [M,K], optionally gathered as 3x3-conv patches) or
 //      M-contiguous rows ([K,M], e.g. dY^T / im2col^T for weight gradients)
@@ -27,6 +27,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 #ifndef CIM_GEMM_BK
 #define CIM_GEMM_BK 16
+#endif
+#ifndef CIM_GEMM_EXP
+#define CIM_GEMM_EXP 0   // ablation switches (tools/bench_gemm_ab.py); 0 = product
 #endif
 #ifndef CIM_GEMM_BN
 #define CIM_GEMM_BN 256
@@ -288,43 +291,81 @@ __global__ __launch_bounds__(NT, CIM_GEMM_MINW) void gemm_f32_kernel(const GemmA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // Three LDS slabs in rotation.  Per slab t: first half of the k-steps, then the registers holding
+    // slab t+1 (loaded from HBM/L2 during slab t-1) are written to LDS buffer (t+1)%3 and the loads
+    // of slab t+2 are issued, ONE barrier, second half of the k-steps.  The LDS write, the barrier
+    // skew and the next slab's first operand reads are therefore covered by MFMAs still in flight;
+    // a buffer is rewritten only two barriers after its last read.
     float4 ra[ASel<AL>::type::PIECES], rb[BSel<BL>::type::PIECES];
+    const int nslab = (kend - kbeg + BK - 1) / BK;
     a_load<AL>(la, g, kbeg, kend, ra);
     lb.load(g, kbeg, kend, rb);
     la.store(smem, ra);
     lb.store(smem + BK * LDS_A, rb);
+    if (nslab > 1) {
+        a_load<AL>(la, g, kbeg + BK, kend, ra);
+        lb.load(g, kbeg + BK, kend, rb);
+    }
     __syncthreads();
 
-    const int nslab = (kend - kbeg + BK - 1) / BK;
     const int lk = lane >> 5, l31 = lane & 31;
+    const int a_off = wm * WM + l31 + lk * LDS_A;            // this lane's A fragment column, k-parity row
+    const int b_off = BK * LDS_A + wn * WN + l31 + lk * LDS_B;
+    // MFMA operand fragments are double-buffered in registers: the ds_reads of k-step s+1 (for the
+    // last step: of the NEXT slab's first step, whose buffer is complete since the mid-slab barrier)
+    // are issued before the MFMAs of step s, so LDS latency never sits between two MFMA groups.
+    float af[2][MI], bf[2][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[0][i] = smem[a_off + i * 32];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bf[0][j] = smem[b_off + j * 32];
+    int ic = 0;                                   // LDS buffer of the current slab (t % 3)
+    constexpr int STEPS = BK / 2;
+    static_assert(STEPS % 2 == 0, "fragment double-buffer parity assumes an even number of k-steps per slab");
     for (int t = 0; t < nslab; ++t) {
-        float* cur = smem + (t & 1) * SLAB;
-        float* nxt = smem + ((t + 1) & 1) * SLAB;
-        const bool more = (t + 1 < nslab);
-        if (more) {   // issue the next slab's global loads before the MFMAs of this one
-            a_load<AL>(la, g, kbeg + (t + 1) * BK, kend, ra);
-            lb.load(g, kbeg + (t + 1) * BK, kend, rb);
-        }
-        const float* as = cur + wm * WM + l31;
-        const float* bs = cur + BK * LDS_A + wn * WN + l31;
+        const int in_ = (ic == 2) ? 0 : ic + 1;
+        const float* cur = smem + ic * SLAB;
+        float* nxt = smem + in_ * SLAB;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[MI], bf[NI];
+        for (int st = 0; st < STEPS; ++st) {
+            if (st == STEPS / 2) {
+#if CIM_GEMM_EXP != 1 && CIM_GEMM_EXP != 3
+                if (t + 1 < nslab) {
+                    la.store(nxt, ra);
+                    lb.store(nxt + BK * LDS_A, rb);
+                }
+#endif
+#if CIM_GEMM_EXP != 1 && CIM_GEMM_EXP != 2
+                if (t + 2 < nslab) {
+                    a_load<AL>(la, g, kbeg + (t + 2) * BK, kend, ra);
+                    lb.load(g, kbeg + (t + 2) * BK, kend, rb);
+                }
+#endif
+#if CIM_GEMM_EXP != 4
+                __syncthreads();
+#endif
+            }
+            const int pc = st & 1, pn = pc ^ 1;
+            if (st + 1 < STEPS) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = as[(kk + lk) * LDS_A + i * 32];
+                for (int i = 0; i < MI; ++i) af[pn][i] = cur[a_off + (st + 1) * 2 * LDS_A + i * 32];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = bs[(kk + lk) * LDS_B + j * 32];
+                for (int j = 0; j < NI; ++j) bf[pn][j] = cur[b_off + (st + 1) * 2 * LDS_B + j * 32];
+            } else if (t + 1 < nslab) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[pn][i] = nxt[a_off + i * 32];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[pn][j] = nxt[b_off + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE this step's MFMAs (hipcc would sink it)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pc][i], bf[pc][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
-            la.store(nxt, ra);
-            lb.store(nxt + BK * LDS_A, rb);
-        }
-        __syncthreads();
+        ic = in_;
     }
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -373,7 +414,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int AL, int BL>
 int launch(GemmArgs g, int splits, float* workspace, hipStream_t st) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
-    const size_t lds = sizeof(float) * 2 * SLAB;
+    const size_t lds = sizeof(float) * 3 * SLAB;
     auto kern = gemm_f32_kernel<AL, BL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

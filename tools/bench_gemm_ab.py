@@ -13,11 +13,13 @@ from cim_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda:0")
 libs = {"base": _lib.load()}
-alt = ctypes.CDLL(os.path.join(_lib.HERE, "libcim_hip_alt.so"))
-for name, argt in _lib.SIGNATURES.items():
-    getattr(alt, name).argtypes = argt
-    getattr(alt, name).restype = ctypes.c_int
-libs["alt"] = alt
+import glob
+for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):
+    alt = ctypes.CDLL(path)
+    for name, argt in _lib.SIGNATURES.items():
+        getattr(alt, name).argtypes = argt
+        getattr(alt, name).restype = ctypes.c_int
+    libs[os.path.basename(path)[len("libcim_hip_"):-3]] = alt
 st = torch.cuda.current_stream().cuda_stream
 N, C = 1000, 1024
 mt = N * 16
@@ -69,8 +71,4 @@ for rnd in range(5):
             res[k][n].append(timeit(fn))
 fl = {n: f for n, (_, f) in cases(libs["base"]).items()}
 for n in fl:
-    b, a = statistics.median(res["base"][n]), statistics.median(res["alt"][n])
-    print("%-11s base %.3f ms (%.1f TF)   alt %.3f ms (%.1f TF)   alt/base %.3f" % (n, b, fl[n] / b / 1e9, a, fl[n] / a / 1e9, a / b))
-# correctness of alt vs base on one case
-cases(libs["base"])["wino_fwd"][0](); m0 = M.clone(); cases(libs["alt"])["wino_fwd"][0]()
-print("alt == base (wino_fwd):", bool(torch.equal(m0, M)))
+    print("%-11s " % n + "   ".join("%s %.3f ms (%.1f TF)" % (k, statistics.median(res[k][n]), fl[n] / statistics.median(res[k][n]) / 1e9) for k in libs))
