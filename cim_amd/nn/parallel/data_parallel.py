@@ -25,7 +25,7 @@ from torch import nn
 
 class DataParallel(nn.Module):
     def __init__(self, module, device_ids=None, output_device=None, dim=0, cpu_keywords=(), minibatch=False,
-                 batch_outputs=True, bucket_bytes=64 << 20, process_group=None):
+                 batch_outputs=True, bucket_bytes=64 << 20, process_group=None, force_flat_grads=False):
         super().__init__()
         self.module = module
         self.cpu_keywords = list(cpu_keywords)
@@ -40,12 +40,20 @@ class DataParallel(nn.Module):
         self._sync = True
         self._pending = []
         self._next_bucket = 0
+        self._force_flat = force_flat_grads
         self._build_flat_grads(bucket_bytes)
 
     # ------------------------------------------------------------------ flat gradient storage
     def _build_flat_grads(self, bucket_bytes):
         params = [p for p in self.module.parameters() if p.requires_grad]
         self._params = params
+        self.flat_grad = None
+        self.buckets = []
+        if self.world_size == 1 and not self._force_flat:
+            # single process: nothing to reduce -> let autograd hand its gradient tensors over as
+            # they are (no accumulate-into-view add per parameter, no 1 GB memset per step); the
+            # reference's DataParallel is a pass-through on one GPU too (data_parallel.py:107-108)
+            return
         total = sum(p.numel() for p in params)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
         # reverse registration order ~ order in which backward produces gradients
@@ -99,8 +107,13 @@ class DataParallel(nn.Module):
             self._next_bucket += 1
 
     def zero_grad(self, set_to_none=False):
-        """One memset of the flat buffer (param.grad stay views into it)."""
-        self.flat_grad.zero_()
+        """One memset of the flat buffer (param.grad stay views into it); without a flat buffer
+        (single process) the gradients are simply dropped."""
+        if self.flat_grad is None:
+            for p in self._params:
+                p.grad = None
+        else:
+            self.flat_grad.zero_()
 
     @contextlib.contextmanager
     def no_sync(self):

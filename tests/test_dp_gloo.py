@@ -97,10 +97,20 @@ def test_dp_allreduce_world2(tmp_path):
 def test_dp_single_process_passthrough():
     from cim_amd.nn import DataParallel
     torch.manual_seed(0)
-    dp = DataParallel(Tiny(), minibatch=True)
+    dp = DataParallel(Tiny(), minibatch=True, force_flat_grads=True)
     assert dp.world_size == 1 and hasattr(dp, "module")
     o = dp(data=[_data(0)], scale=[torch.tensor(1.0)])
     o["losses"]["l"].sum().backward()
     torch.testing.assert_close(dp.flat_grad, _local_grad(_data(0), 1.0))
     dp.zero_grad()
     assert float(dp.flat_grad.abs().sum()) == 0 and dp.module.a.weight.grad.data_ptr() >= dp.flat_grad.data_ptr()
+    # default single-process mode: no flat buffer, gradients handed over by autograd as they are
+    torch.manual_seed(0)
+    dp2 = DataParallel(Tiny(), minibatch=True)
+    assert dp2.flat_grad is None
+    dp2(data=[_data(0)], scale=[torch.tensor(1.0)])["losses"]["l"].sum().backward()
+    dp2.finish_gradient_sync()
+    got = torch.cat([p.grad.reshape(-1) for p in reversed([q for q in dp2.module.parameters() if q.requires_grad])])
+    torch.testing.assert_close(got, _local_grad(_data(0), 1.0))
+    dp2.zero_grad()
+    assert all(p.grad is None for p in dp2.module.parameters())
