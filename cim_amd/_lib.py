@@ -12,9 +12,10 @@ LIB_PATH = os.path.join(HERE, "libcim_hip.so")
 _P = c_void_p
 SIGNATURES = {
     "cim_roi_align_fwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
-    "cim_roi_align_bwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
+    "cim_roi_align_bwd_workspace": [c_int, c_int, c_int, c_int],
+    "cim_roi_align_bwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
     "cim_roi_align_maskcat_fwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
-    "cim_roi_align_maskcat_bwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
+    "cim_roi_align_maskcat_bwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
     "cim_mask_pack": [_P, _P, c_int, c_int, _P],
     "cim_mask_iou_pair": [_P, c_int, c_int, _P, _P, _P, _P],
     "cim_asy_flag": [_P, c_int, c_float, _P, _P],
@@ -63,12 +64,12 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_longlong if name == "cim_roi_align_bwd_workspace" else c_int
     _lib = lib
     return lib
 
 
-VALUE_RETURNING = {"cim_gemm_f32_splits"}      # return a count, not a status
+VALUE_RETURNING = {"cim_gemm_f32_splits", "cim_roi_align_bwd_workspace"}      # return a count, not a status
 
 
 def call(name, *args):

@@ -199,19 +199,73 @@ __device__ __forceinline__ void bin_range(float start, float bin, int P, int pos
     }
 }
 
-template <int CH, bool MASKCAT>
+// Per-ROI record written once per launch by roi_tables_kernel (when the caller provides a workspace):
+//   wy [P][H] | wx [P][W] | yr [H] | xr [W] | ylo yhi xlo xhi | count | batch      (4-byte words)
+// yr / xr: packed range of bins with a non-zero weight on that row / column: lo | hi << 8 | none << 16.
+__host__ __device__ __forceinline__ int roi_rec_words(int P, int H, int W) { return ((P + 1) * (H + W) + 6 + 3) & ~3; }
+
+__global__ __launch_bounds__(256) void roi_tables_kernel(const float* __restrict__ rois, float* __restrict__ rec_all, int K,
+                                                         int P, int H, int W, float scale, int sampling_ratio, int aligned) {
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const RoiGeom g = roi_geom(rois + 5 * (size_t)k, scale, P, sampling_ratio, aligned);
+    float* rec = rec_all + (size_t)k * roi_rec_words(P, H, W);
+    float* wy = rec;
+    float* wx = wy + P * H;
+    int* yr = reinterpret_cast<int*>(wx + P * W);
+    int* xr = yr + H;
+    int* box = xr + W;
+    for (int e = tid; e < P * (H + W); e += 256) {
+        const bool isy = e < P * H;
+        const int e2 = isy ? e : e - P * H;
+        const int size = isy ? H : W;
+        const int pb = e2 / size, pos = e2 % size;
+        const int gn = isy ? g.gh : g.gw;
+        const float start = isy ? g.y1 : g.x1, bin = isy ? g.bh : g.bw;
+        float acc = 0.0f;
+        for (int is = 0; is < gn; ++is) {
+            const float v = start + pb * bin + (is + 0.5f) * bin / (float)gn;
+            const Tap t = make_tap(v, size);
+            if (!t.valid) continue;
+            if (t.lo == pos) acc += t.h;
+            if (t.hi == pos) acc += t.l;
+        }
+        (isy ? wy : wx)[e2] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < H + W; e += 256) {
+        const bool isy = e < H;
+        const int pos = isy ? e : e - H, size = isy ? H : W;
+        const float* tabp = isy ? wy : wx;
+        int lo = P, hi = -1;
+        for (int pb = 0; pb < P; ++pb)
+            if (tabp[pb * size + pos] != 0.0f) { lo = min(lo, pb); hi = pb; }
+        (isy ? yr : xr)[pos] = (hi < 0) ? 0x10000 : (lo | (hi << 8));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int ylo = H, yhi = -1, xlo = W, xhi = -1;
+        for (int y = 0; y < H; ++y) if (!(yr[y] & 0x10000)) { ylo = min(ylo, y); yhi = y; }
+        for (int x = 0; x < W; ++x) if (!(xr[x] & 0x10000)) { xlo = min(xlo, x); xhi = x; }
+        box[0] = ylo; box[1] = yhi; box[2] = xlo; box[3] = xhi;
+        reinterpret_cast<float*>(box)[4] = g.count;
+        box[5] = g.b;
+    }
+}
+
+template <int CH, bool MASKCAT, bool PRE>
 __global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_tile_kernel(const float* __restrict__ grad_out,
                                                                           const float* __restrict__ rois,
                                                                           const float* __restrict__ masks,
                                                                           float* __restrict__ grad_in, int B, int C,
                                                                           int H, int W, int K, int P, float scale,
                                                                           int sampling_ratio, int aligned,
-                                                                          int use_atomic) {
+                                                                          int use_atomic, const float* __restrict__ pre) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CG = CH / 4;
     constexpr int NT = TILE_THREADS;
     const int HW = H * W;
-    const int tab = P * (H + W);
+    const int tab = PRE ? (P + 1) * (H + W) : P * (H + W);     // PRE: + packed bin ranges per row / column
+    const int recw = roi_rec_words(P, H, W);
     float* tile = lds;                        // [HW][CH]
     float* gbuf = tile + (size_t)HW * CH;     // 2 x [P*P][CH]   (already divided by count), double-buffered
     float* wtab = gbuf + 2 * P * P * CH;      // 2 x ([P][H] + [P][W]), double-buffered
@@ -223,13 +277,24 @@ __global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_tile_kernel(const 
         for (int i = tid; i < HW * CG; i += NT) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         int buf = 0;
         for (int k = blockIdx.y; k < K; k += gridDim.y) {
-            const RoiGeom g = roi_geom(rois + 5 * (size_t)k, scale, P, sampling_ratio, aligned);
+            RoiGeom g;
+            const float* rec = pre + (size_t)k * recw;
+            const int* box = reinterpret_cast<const int*>(rec + (P + 1) * (H + W));
+            if (PRE) {
+                g.count = reinterpret_cast<const float*>(box)[4];
+                g.b = box[5];
+            } else {
+                g = roi_geom(rois + 5 * (size_t)k, scale, P, sampling_ratio, aligned);
+            }
             if (g.b != b) continue;                               // block-uniform
             float* gb_ = gbuf + buf * P * P * CH;
             float* wy = wtab + buf * tab;
             float* wx = wy + P * H;
+            if (PRE) {      // tables + bin ranges of this ROI were computed once for all channel chunks
+                for (int e = tid; e < tab; e += NT) wy[e] = rec[e];
+            }
             // weight tables: one entry per lane, loop over the bin's samples
-            for (int e = tid; e < tab; e += NT) {
+            for (int e = tid; e < (PRE ? 0 : tab); e += NT) {
                 const bool isy = e < P * H;
                 const int e2 = isy ? e : e - P * H;
                 const int size = isy ? H : W;
@@ -262,21 +327,34 @@ __global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_tile_kernel(const 
             // read-modify-writes of ROI k-1 (issued before this barrier by every lane) are complete.
             __syncthreads();
             // conservative bounding box of the pixels the ROI's samples can touch
-            const float ylast = g.y1 + (float)P * g.bh, xlast = g.x1 + (float)P * g.bw;
-            const int ylo = max(0, (int)floorf(fminf(g.y1, ylast)) - 1), yhi = min(H - 1, (int)floorf(fmaxf(g.y1, ylast)) + 2);
-            const int xlo = max(0, (int)floorf(fminf(g.x1, xlast)) - 1), xhi = min(W - 1, (int)floorf(fmaxf(g.x1, xlast)) + 2);
+            int ylo, yhi, xlo, xhi;
+            const int* yr = reinterpret_cast<const int*>(wx + P * W);
+            const int* xr = yr + H;
+            if (PRE) {
+                ylo = box[0]; yhi = box[1]; xlo = box[2]; xhi = box[3];
+            } else {
+                const float ylast = g.y1 + (float)P * g.bh, xlast = g.x1 + (float)P * g.bw;
+                ylo = max(0, (int)floorf(fminf(g.y1, ylast)) - 1); yhi = min(H - 1, (int)floorf(fmaxf(g.y1, ylast)) + 2);
+                xlo = max(0, (int)floorf(fminf(g.x1, xlast)) - 1); xhi = min(W - 1, (int)floorf(fmaxf(g.x1, xlast)) + 2);
+            }
             if (yhi >= ylo && xhi >= xlo) {
                 const int rw = xhi - xlo + 1, items = (yhi - ylo + 1) * rw * CG;
                 for (int it = tid; it < items; it += NT) {
                     const int cg = it % CG, pix = it / CG;
                     const int y = ylo + pix / rw, x = xlo + pix % rw;
                     int phl, phh, pwl, pwh;
-                    bin_range(g.y1, g.bh, P, y, phl, phh);
-                    bin_range(g.x1, g.bw, P, x, pwl, pwh);
+                    if (PRE) {
+                        const int ry = yr[y], rx = xr[x];
+                        if ((ry | rx) & 0x10000) continue;
+                        phl = ry & 0xff; phh = (ry >> 8) & 0xff; pwl = rx & 0xff; pwh = (rx >> 8) & 0xff;
+                    } else {
+                        bin_range(g.y1, g.bh, P, y, phl, phh);
+                        bin_range(g.x1, g.bw, P, x, pwl, pwh);
+                    }
                     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     for (int ph = phl; ph <= phh; ++ph) {
                         const float a = wy[ph * H + y];
-                        if (a == 0.0f) continue;
+                        if (!PRE && a == 0.0f) continue;
                         float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
                         for (int pw = pwl; pw <= pwh; ++pw) {
                             const float bw_ = wx[pw * W + x];
@@ -311,14 +389,15 @@ __global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_tile_kernel(const 
 
 // LDS bytes of the tile kernel for a channel chunk of CH
 static size_t bwd_tile_lds(int CH, int H, int W, int P) {
-    return sizeof(float) * ((size_t)H * W * CH + 2 * (size_t)P * P * CH + 2 * (size_t)P * (H + W));
+    return sizeof(float) * ((size_t)H * W * CH + 2 * (size_t)P * P * CH + 2 * (size_t)(P + 1) * (H + W));
 }
 
 template <int CH, bool MASKCAT>
 static int launch_bwd_tile(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H,
-                           int W, int K, int P, float scale, int sr, int aligned, hipStream_t st) {
+                           int W, int K, int P, float scale, int sr, int aligned, float* ws, hipStream_t st) {
     const size_t lds = bwd_tile_lds(CH, H, W, P);
-    auto kern = roi_align_bwd_tile_kernel<CH, MASKCAT>;
+    auto kern = ws ? roi_align_bwd_tile_kernel<CH, MASKCAT, true> : roi_align_bwd_tile_kernel<CH, MASKCAT, false>;
+    if (ws) hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), 0, st, rois, ws, K, P, H, W, scale, sr, aligned);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -332,7 +411,7 @@ static int launch_bwd_tile(const float* go, const float* rois, const float* mask
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3(chunks, rg), dim3(TILE_THREADS), lds, st, go, rois, masks, gin, B, C, H, W, K, P, scale,
-                       sr, aligned, rg > 1 ? 1 : 0);
+                       sr, aligned, rg > 1 ? 1 : 0, ws);
     return 0;
 }
 
@@ -352,15 +431,15 @@ int launch_fwd(const float* feat, const float* rois, const float* masks, float* 
 
 template <bool MASKCAT>
 int launch_bwd(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W, int K,
-               int P, float scale, int sr, int aligned, hipStream_t st) {
+               int P, float scale, int sr, int aligned, float* ws, hipStream_t st) {
     const size_t budget = 150 * 1024;
     if (K > 0 && P <= 16 && C % 4 == 0) {
         if (C % 16 == 0 && bwd_tile_lds(16, H, W, P) <= budget)
-            return launch_bwd_tile<16, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, st);
+            return launch_bwd_tile<16, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st);
         if (C % 8 == 0 && bwd_tile_lds(8, H, W, P) <= budget)
-            return launch_bwd_tile<8, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, st);
+            return launch_bwd_tile<8, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st);
         if (bwd_tile_lds(4, H, W, P) <= budget)
-            return launch_bwd_tile<4, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, st);
+            return launch_bwd_tile<4, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st);
     }
     // generic fallback (odd channel counts, maps too large for an LDS tile): global atomics
     hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * (size_t)B * H * W * C, st);
@@ -393,12 +472,17 @@ extern "C" int cim_roi_align_fwd(const float* feat, const float* rois, float* ou
     return 0;
 }
 
+extern "C" long long cim_roi_align_bwd_workspace(int K, int P, int H, int W) {
+    return (long long)sizeof(float) * (long long)K * roi_rec_words(P, H, W);
+}
+
 extern "C" int cim_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in, int B, int C, int H, int W,
-                                 int K, int P, float spatial_scale, int sampling_ratio, int aligned, void* stream) {
+                                 int K, int P, float spatial_scale, int sampling_ratio, int aligned, float* workspace,
+                                 void* stream) {
     ROI_ARGS_OK();
     CIM_CHECK_ARG(grad_in && (grad_out || K == 0));
     int rc = launch_bwd<false>(grad_out, rois, nullptr, grad_in, B, C, H, W, K, P, spatial_scale, sampling_ratio,
-                               aligned, cim::as_stream(stream));
+                               aligned, workspace, cim::as_stream(stream));
     if (rc) return rc;
     CIM_CHECK_LAUNCH();
     return 0;
@@ -418,11 +502,11 @@ extern "C" int cim_roi_align_maskcat_fwd(const float* feat, const float* rois, c
 
 extern "C" int cim_roi_align_maskcat_bwd(const float* grad_cat, const float* rois, const float* masks, float* grad_in,
                                          int B, int C, int H, int W, int K, int P, float spatial_scale,
-                                         int sampling_ratio, int aligned, void* stream) {
+                                         int sampling_ratio, int aligned, float* workspace, void* stream) {
     ROI_ARGS_OK();
     CIM_CHECK_ARG(grad_in && ((grad_cat && masks) || K == 0));
     int rc = launch_bwd<true>(grad_cat, rois, masks, grad_in, B, C, H, W, K, P, spatial_scale, sampling_ratio, aligned,
-                              cim::as_stream(stream));
+                              workspace, cim::as_stream(stream));
     if (rc) return rc;
     CIM_CHECK_LAUNCH();
     return 0;

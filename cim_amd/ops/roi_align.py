@@ -27,6 +27,12 @@ def _nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
+def _workspace(k, p, h, w, device):
+    """Scratch for the per-ROI interpolation tables of the backward kernel."""
+    nbytes = _lib.call("cim_roi_align_bwd_workspace", max(k, 1), p, h, w)
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
 def _empty_nhwc(k, c, h, w, like):
     return torch.empty((k, h, w, c), dtype=like.dtype, device=like.device).permute(0, 3, 1, 2)
 
@@ -56,7 +62,7 @@ class RoIAlignFunction(Function):
         grad_out = _nhwc(grad_out)
         grad_in = _empty_nhwc(B, C, H, W, grad_out)
         _lib.call("cim_roi_align_bwd", grad_out.data_ptr(), rois.data_ptr(), grad_in.data_ptr(), B, C, H, W, K, P,
-                  scale, sr, aligned, _lib.stream_ptr())
+                  scale, sr, aligned, _workspace(K, P, H, W, grad_out.device).data_ptr(), _lib.stream_ptr())
         return grad_in, None, None, None, None, None
 
 
@@ -89,7 +95,8 @@ class RoIAlignMaskCatFunction(Function):
         grad_cat = _nhwc(grad_cat)
         grad_in = _empty_nhwc(B, C, H, W, grad_cat)
         _lib.call("cim_roi_align_maskcat_bwd", grad_cat.data_ptr(), rois.data_ptr(), masks.data_ptr(),
-                  grad_in.data_ptr(), B, C, H, W, K, P, scale, sr, aligned, _lib.stream_ptr())
+                  grad_in.data_ptr(), B, C, H, W, K, P, scale, sr, aligned,
+                  _workspace(K, P, H, W, grad_cat.device).data_ptr(), _lib.stream_ptr())
         return grad_in, None, None, None, None, None, None
 
 

@@ -41,10 +41,13 @@ int cim_roi_align_fwd(const float* feat, const float* rois, float* out,
                       int B, int C, int H, int W, int K, int P,
                       float spatial_scale, int sampling_ratio, int aligned, void* stream);
 
-/* grad_in [B,H,W,C] is fully overwritten (zero-filled on `stream`, then accumulated). */
+/* grad_in [B,H,W,C] is fully overwritten (zero-filled on `stream`, then accumulated).
+ * workspace: optional device scratch of cim_roi_align_bwd_workspace(K,P,H,W) bytes; when given, the
+ * per-ROI interpolation tables are built once per launch instead of once per (ROI, channel chunk). */
+long long cim_roi_align_bwd_workspace(int K, int P, int H, int W);
 int cim_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in,
                       int B, int C, int H, int W, int K, int P,
-                      float spatial_scale, int sampling_ratio, int aligned, void* stream);
+                      float spatial_scale, int sampling_ratio, int aligned, float* workspace, void* stream);
 
 /* Fused ROIAlign + mask multiply + channel concat: the input of MaskFuse.mask_branch,
  * lib/modeling/resnet50.py:121-134 (vgg16.py:162-175, HRNet.py:615-628):
@@ -57,7 +60,7 @@ int cim_roi_align_maskcat_fwd(const float* feat, const float* rois, const float*
 
 int cim_roi_align_maskcat_bwd(const float* grad_cat, const float* rois, const float* masks, float* grad_in,
                               int B, int C, int H, int W, int K, int P,
-                              float spatial_scale, int sampling_ratio, int aligned, void* stream);
+                              float spatial_scale, int sampling_ratio, int aligned, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------ mask IoU / containment maps (a-7)
  * Replaces lib/utils/mask_utils.py:6-18 (mask_iou) and :20-32 (mask_asymmetric_iou) as driven

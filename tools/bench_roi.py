@@ -38,7 +38,8 @@ def timeit(fn, n=10):
 
 
 fwd = lambda: _lib.call("cim_roi_align_maskcat_fwd", feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, st)
-bwd = lambda: _lib.call("cim_roi_align_maskcat_bwd", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, st)
+ws = torch.empty(_lib.call("cim_roi_align_bwd_workspace", K, 7, H, W) // 4 + 1, device=dev)
+bwd = lambda: _lib.call("cim_roi_align_maskcat_bwd", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
 nbytes = 4.0 * (C * H * W + 5 * K + 49 * K) + 4.0 * K * 2 * C * 49
 tf, tb = timeit(fwd), timeit(bwd)
 print(json.dumps(dict(config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, fwd_ms=tf, fwd_frac=nbytes / tf / 1e6 / 8000,
