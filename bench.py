@@ -253,10 +253,15 @@ def main():
         # dominant kernel: the exact-fp32 MFMA GEMM of the MaskFuse 3x3 conv forward (a-2).
         #   Winograd F(2x2,3x3) (default): 16 batched GEMMs [16N x 2Cf] x [2Cf x Cf] = 2*16*16N*2Cf*Cf flops
         #   direct implicit GEMM (CIM_CONV_ALGO=direct): 2*49N*18Cf*Cf flops        
+        #   Winograd F(4x4,3x3) (CIM_CONV_ALGO=winograd4): 36 batched GEMMs [4N x 2Cf] x [2Cf x Cf]
         wino_ms = timer.mean_ms("wino_gemm_fwd")
+        from cim_amd.ops import gemm as gemm_mod
+        tile = 4 if gemm_mod.CONV_ALGO == "winograd4" else 2
         if wino_ms:
-            kname = "gemm_f32_kernel<A_KCONTIG,B_NCONTIG> x16 (MaskFuse conv3x3 fwd, Winograd F(2x2,3x3) domain)"
-            conv_ms, conv_flops = wino_ms, 2.0 * 16 * (16 * n) * (2 * Cf) * Cf
+            npos, tiles = (tile + 2) ** 2, ((7 + tile - 1) // tile) ** 2
+            kname = "gemm_f32_kernel<A_KCONTIG,B_NCONTIG> x%d (MaskFuse conv3x3 fwd, Winograd F(%dx%d,3x3) domain)" \
+                % (npos, tile, tile)
+            conv_ms, conv_flops = wino_ms, 2.0 * npos * (tiles * n) * (2 * Cf) * Cf
         else:
             kname = "gemm_f32_kernel<A_CONV_K,B_NCONTIG> (MaskFuse conv3x3 fwd, implicit GEMM)"
             conv_ms, conv_flops = timer.mean_ms("maskfuse_conv_fwd"), 2.0 * 49 * n * (2 * Cf * 9) * Cf
@@ -265,7 +270,7 @@ def main():
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         pmc = pmc_traffic()
         g00 = pmc.get("gemm_f32_kernel<0, 0>")
-        if wino_ms and g00:      # first <A_KCONTIG,B_NCONTIG> launch of a step = the Winograd forward GEMM
+        if wino_ms and g00 and pmc.get("_conv_algo", "winograd") == gemm_mod.CONV_ALGO:      # first <A_KCONTIG,B_NCONTIG> launch of a step = the Winograd forward GEMM
             roofline["traffic"] = (g00["fetch_kib_per_dispatch"][0] + g00["write_kib_per_dispatch"][0]) * 1024
         # HBM-bound hand-written kernels: fused ROIAlign+mask-cat fwd / bwd
         ra_bytes = 4.0 * (Cf * Hf * Wf + 5 * n + 49 * n) + 4.0 * n * 2 * Cf * 49

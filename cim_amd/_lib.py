@@ -27,11 +27,11 @@ SIGNATURES = {
     "cim_conv3x3_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "cim_conv3x3_wgrad_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "cim_gemm_f32_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, _P],
-    "cim_wino_input_transform": [_P, _P, c_int, c_int, c_int, _P],
-    "cim_wino_filter_transform": [_P, _P, c_int, c_int, c_int, _P],
-    "cim_wino_output_transform": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
-    "cim_wino_dy_transform": [_P, _P, c_int, c_int, c_int, _P],
-    "cim_wino_wgrad_output": [_P, _P, c_int, c_int, _P],
+    "cim_wino_input_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "cim_wino_filter_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "cim_wino_output_transform": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "cim_wino_dy_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "cim_wino_wgrad_output": [_P, _P, c_int, c_int, c_int, _P],
     "cim_losses_fwd": [_P, _P],
     "cim_head_act_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],

@@ -199,52 +199,253 @@ __global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __rest
     }
 }
 
+
+// =============================================================================================
+// F(4x4, 3x3) / F(3x3, 4x4) on the point set {0, 1, -1, 2, -1/2, inf} (wino43_mats.h, generated and
+// verified in rational arithmetic by tools/gen_winograd.py): 36 multiplies per 4x4 output tile
+// instead of 144, i.e. 0.60 TFLOP per contraction at cfg2 (P = 7 -> 2x2 tiles, 49/64 used).
+// fp32 throughout; measured error 7e-6 (F(2x2,3x3): 1.2e-6, direct: 6e-7) - selected with
+// CIM_CONV_ALGO=winograd4.  Same kernel structure as above; lanes own 2 channels (float2) so the
+// 6x6 patch fits in registers, and the matrix products are unrolled against the constexpr tables
+// (zero entries vanish at compile time).
+#include "wino43_mats.h"
+
+__device__ __forceinline__ float2 f2(float v) { return make_float2(v, v); }
+__device__ __forceinline__ void fma2(float2& a, float s, float2 v) { a.x += s * v.x; a.y += s * v.y; }
+
+__global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int R, int P,
+                                                           int T, int C) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
+        float2 d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int iy = 4 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ix = 4 * tx - 1 + j;
+                d[i][j] = ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P)
+                              ? *reinterpret_cast<const float2*>(x + (((size_t)r * P + iy) * P + ix) * C + c)
+                              : f2(0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float2 trow[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                trow[j] = f2(0.f);
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (W43_BT[i][k] != 0.0f) fma2(trow[j], W43_BT[i][k], d[k][j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float2 v = f2(0.f);
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (W43_BT[j][k] != 0.0f) fma2(v, W43_BT[j][k], trow[k]);
+                *reinterpret_cast<float2*>(V + (size_t)(i * 6 + j) * MC + (size_t)m * C + c) = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino43_filter_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
+                                                            int Cin, int mode) {
+    const int Kd = mode ? Cout : Cin, Nd = mode ? Cin : Cout;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)Kd * Nd) return;
+    const int k = (int)(idx / Nd), n = (int)(idx % Nd);
+    const int co = mode ? k : n, ci = mode ? n : k;
+    const float* g = W + ((size_t)co * Cin + ci) * 9;
+    float w[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) w[a][b] = mode ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
+    float t[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) t[i][b] = W43_G[i][0] * w[0][b] + W43_G[i][1] * w[1][b] + W43_G[i][2] * w[2][b];
+    const size_t KN = (size_t)Kd * Nd;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            U[(size_t)(i * 6 + j) * KN + idx] = t[i][0] * W43_G[j][0] + t[i][1] * W43_G[j][1] + t[i][2] * W43_G[j][2];
+}
+
+__global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int R, int P, int T, int C, int relu) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
+        float2 s[4][6];                                   // AT . q, accumulated row by row of q
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s[a][j] = f2(0.f);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float2 q = *reinterpret_cast<const float2*>(M + (size_t)(i * 6 + j) * MC + (size_t)m * C + c);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (W43_AT[a][i] != 0.0f) fma2(s[a][j], W43_AT[a][i], q);
+            }
+        const float2 bv = bias ? *reinterpret_cast<const float2*>(bias + c) : f2(0.f);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oy = 4 * ty + a;
+            if (oy >= P) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ox = 4 * tx + b;
+                if (ox >= P) continue;
+                float2 v = bv;
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (W43_AT[b][j] != 0.0f) fma2(v, W43_AT[b][j], s[a][j]);
+                if (relu) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
+                *reinterpret_cast<float2*>(y + (((size_t)r * P + oy) * P + ox) * C + c) = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino43_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int P,
+                                                        int T, int C) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
+        float2 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int oy = 4 * ty + a, ox = 4 * tx + b;
+                d[a][b] = (oy < P && ox < P) ? *reinterpret_cast<const float2*>(dy + (((size_t)r * P + oy) * P + ox) * C + c) : f2(0.f);
+            }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float2 trow[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                trow[b] = f2(0.f);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (W43_G4[i][a] != 0.0f) fma2(trow[b], W43_G4[i][a], d[a][b]);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float2 v = f2(0.f);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (W43_G4[j][b] != 0.0f) fma2(v, W43_G4[j][b], trow[b]);
+                *reinterpret_cast<float2*>(D + (size_t)(i * 6 + j) * MC + (size_t)m * C + c) = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino43_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dW, int Cout,
+                                                               int Cin) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;     // (ci, co), co fastest
+    const size_t KN = (size_t)Cin * Cout;
+    if (idx >= KN) return;
+    const int ci = (int)(idx / Cout), co = (int)(idx % Cout);
+    float s[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s[a][j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float q = dU[(size_t)(i * 6 + j) * KN + idx];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if (W43_A3T[a][i] != 0.0f) s[a][j] += W43_A3T[a][i] * q;
+        }
+    float* dst = dW + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (W43_A3T[b][j] != 0.0f) v += W43_A3T[b][j] * s[a][j];
+            dst[a * 3 + b] = v;
+        }
+}
+
 }  // namespace
 
 #define WINO_GEOM_OK() CIM_CHECK_ARG(R > 0 && P > 0 && P <= 64 && C > 0 && C % 4 == 0)
 
-extern "C" int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, void* stream) {
+#define WINO_TILE_OK() CIM_CHECK_ARG(tile == 2 || tile == 4)
+
+extern "C" int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, int tile, void* stream) {
     WINO_GEOM_OK();
+    WINO_TILE_OK();
     CIM_CHECK_ARG(x && V);
-    const int T = (P + 1) / 2;
-    hipLaunchKernelGGL(wino_input_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C);
+    const int T = (P + tile - 1) / tile;
+    if (tile == 4) hipLaunchKernelGGL(wino43_input_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C);
+    else hipLaunchKernelGGL(wino_input_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C);
     CIM_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, void* stream) {
+extern "C" int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, int tile, void* stream) {
     CIM_CHECK_ARG(W && U && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1));
+    WINO_TILE_OK();
     const size_t n = (size_t)Cout * Cin;
-    hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U,
+    if (tile == 4) hipLaunchKernelGGL(wino43_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U, Cout, Cin, mode);
+    else hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U,
                        Cout, Cin, mode);
     CIM_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int cim_wino_output_transform(const float* M, const float* bias, float* y, int R, int P, int C, int relu,
-                                         void* stream) {
+                                         int tile, void* stream) {
     WINO_GEOM_OK();
+    WINO_TILE_OK();
     CIM_CHECK_ARG(M && y);
-    const int T = (P + 1) / 2;
-    hipLaunchKernelGGL(wino_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C,
+    const int T = (P + tile - 1) / tile;
+    if (tile == 4) hipLaunchKernelGGL(wino43_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C, relu);
+    else hipLaunchKernelGGL(wino_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C,
                        relu);
     CIM_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int cim_wino_dy_transform(const float* dy, float* D, int R, int P, int C, void* stream) {
+extern "C" int cim_wino_dy_transform(const float* dy, float* D, int R, int P, int C, int tile, void* stream) {
     WINO_GEOM_OK();
+    WINO_TILE_OK();
     CIM_CHECK_ARG(dy && D);
-    const int T = (P + 1) / 2;
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
+    const int T = (P + tile - 1) / tile;
+    if (tile == 4) hipLaunchKernelGGL(wino43_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
+    else hipLaunchKernelGGL(wino_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
     CIM_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, void* stream) {
+extern "C" int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, int tile, void* stream) {
     CIM_CHECK_ARG(dU && dW && Cout > 0 && Cin > 0);
+    WINO_TILE_OK();
     const size_t n = (size_t)Cout * Cin;
-    hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU,
+    if (tile == 4) hipLaunchKernelGGL(wino43_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
+    else hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU,
                        dW, Cout, Cin);
     CIM_CHECK_LAUNCH();
     return 0;

@@ -68,7 +68,7 @@ def _bgemm(a, b, c, m, n, k, lda, ldb, a_mcontig, batch, a_bs, b_bs, c_bs):
               int(a_mcontig), 0, batch, a_bs, b_bs, c_bs, _lib.stream_ptr())
 
 
-CONV_ALGO = os.environ.get("CIM_CONV_ALGO", "winograd")     # "winograd" (F(2x2,3x3), default) | "direct"
+CONV_ALGO = os.environ.get("CIM_CONV_ALGO", "winograd4")    # "winograd4" (F(4x4,3x3), default) | "winograd" (F(2x2,3x3)) | "direct"
 
 
 class Conv3x3Function(Function):
@@ -90,17 +90,19 @@ class Conv3x3Function(Function):
         st = _lib.stream_ptr()
         y = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
         ctx.algo = CONV_ALGO if (cin % 4 == 0 and cout % 4 == 0) else "direct"
+        ctx.tile = tile = 4 if ctx.algo == "winograd4" else 2
+        npos = (tile + 2) ** 2
         V = None
-        if ctx.algo == "winograd":
-            t = (p + 1) // 2
+        if ctx.algo.startswith("winograd"):
+            t = (p + tile - 1) // tile
             mt = r * t * t
-            V = torch.empty((16, mt, cin), dtype=torch.float32, device=dev)
-            U = torch.empty((16, cin, cout), dtype=torch.float32, device=dev)
-            M = torch.empty((16, mt, cout), dtype=torch.float32, device=dev)
-            _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), r, p, cin, st)
-            _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), cout, cin, 0, st)
-            _bgemm(V, U, M, mt, cout, cin, cin, cout, False, 16, mt * cin, cin * cout, mt * cout)
-            _lib.call("cim_wino_output_transform", M.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cout, int(relu), st)
+            V = torch.empty((npos, mt, cin), dtype=torch.float32, device=dev)
+            U = torch.empty((npos, cin, cout), dtype=torch.float32, device=dev)
+            M = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
+            _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), r, p, cin, tile, st)
+            _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), cout, cin, 0, tile, st)
+            _bgemm(V, U, M, mt, cout, cin, cin, cout, False, npos, mt * cin, cin * cout, mt * cout)
+            _lib.call("cim_wino_output_transform", M.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cout, int(relu), tile, st)
         else:
             whwio = w.permute(2, 3, 1, 0).contiguous()
             _lib.call("cim_conv3x3_f32", x.data_ptr(), whwio.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cin, cout,
@@ -122,33 +124,35 @@ class Conv3x3Function(Function):
         dy = dy.contiguous()
         dx = dw = db = None
         st = _lib.stream_ptr()
-        wino = ctx.algo == "winograd"
-        t = (p + 1) // 2
+        wino = ctx.algo.startswith("winograd")
+        tile = ctx.tile
+        npos = (tile + 2) ** 2
+        t = (p + tile - 1) // tile
         mt = r * t * t
         if ctx.needs_input_grad[0]:
             dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
             if wino:
                 # data gradient = the same convolution of dY with the 180-degree rotated, in/out-swapped filter
-                Vd = torch.empty((16, mt, cout), dtype=torch.float32, device=dev)
-                U2 = torch.empty((16, cout, cin), dtype=torch.float32, device=dev)
-                M2 = torch.empty((16, mt, cin), dtype=torch.float32, device=dev)
-                _lib.call("cim_wino_input_transform", dy.data_ptr(), Vd.data_ptr(), r, p, cout, st)
-                _lib.call("cim_wino_filter_transform", w.data_ptr(), U2.data_ptr(), cout, cin, 1, st)
-                _bgemm(Vd, U2, M2, mt, cin, cout, cout, cin, False, 16, mt * cout, cout * cin, mt * cin)
-                _lib.call("cim_wino_output_transform", M2.data_ptr(), None, dxp.data_ptr(), r, p, cin, 0, st)
+                Vd = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
+                U2 = torch.empty((npos, cout, cin), dtype=torch.float32, device=dev)
+                M2 = torch.empty((npos, mt, cin), dtype=torch.float32, device=dev)
+                _lib.call("cim_wino_input_transform", dy.data_ptr(), Vd.data_ptr(), r, p, cout, tile, st)
+                _lib.call("cim_wino_filter_transform", w.data_ptr(), U2.data_ptr(), cout, cin, 1, tile, st)
+                _bgemm(Vd, U2, M2, mt, cin, cout, cout, cin, False, npos, mt * cout, cout * cin, mt * cin)
+                _lib.call("cim_wino_output_transform", M2.data_ptr(), None, dxp.data_ptr(), r, p, cin, 0, tile, st)
             else:
                 w2 = w.flip(2, 3).permute(2, 3, 0, 1).contiguous()                     # [3,3,Cout,Cin]
                 _lib.call("cim_conv3x3_f32", dy.data_ptr(), w2.data_ptr(), None, dxp.data_ptr(), r, p, cout, cin, 0, st)
             dx = dxp.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             if wino:
-                D = torch.empty((16, mt, cout), dtype=torch.float32, device=dev)
-                dU = torch.empty((16, cin, cout), dtype=torch.float32, device=dev)
+                D = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
+                dU = torch.empty((npos, cin, cout), dtype=torch.float32, device=dev)
                 dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
-                _lib.call("cim_wino_dy_transform", dy.data_ptr(), D.data_ptr(), r, p, cout, st)
+                _lib.call("cim_wino_dy_transform", dy.data_ptr(), D.data_ptr(), r, p, cout, tile, st)
                 # dU[pos] = V[pos]^T . D[pos]:  A = V[pos] read M-contiguously (element (ci, m) at V[m*Cin + ci])
-                _bgemm(V, D, dU, cin, cout, mt, cin, cout, True, 16, mt * cin, mt * cout, cin * cout)
-                _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, st)
+                _bgemm(V, D, dU, cin, cout, mt, cin, cout, True, npos, mt * cin, mt * cout, cin * cout)
+                _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, tile, st)
             else:
                 m, n, k = 9 * cin, cout, r * p * p
                 splits = _lib.call("cim_gemm_f32_splits", m, n, k)

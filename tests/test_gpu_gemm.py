@@ -56,12 +56,13 @@ def test_gemm_is_asymmetric_and_deterministic(dev):
     assert _rel(y1.cpu(), A.cpu().double() @ W.cpu().double().t()) < 3e-5   # K = 50176: fp32 accumulation error grows with K
 
 
-@pytest.mark.parametrize("algo", ["winograd", "direct"])
+@pytest.mark.parametrize("algo", ["winograd", "winograd4", "direct"])
 @pytest.mark.parametrize("R,Cin,Cout", [(11, 32, 48), (40, 64, 272), (6, 16, 16)])
 def test_conv3x3_fwd_bwd_vs_fp64(dev, R, Cin, Cout, algo, monkeypatch):
     from cim_amd.ops import conv3x3, gemm as G
     monkeypatch.setattr(G, "CONV_ALGO", algo)
-    tol = 2e-6 if algo == "direct" else 6e-6          # F(2x2,3x3) in fp32: ~3x the direct sum's error
+    # fp32 error classes: direct sum ~6e-7, F(2x2,3x3) ~1.5e-6, F(4x4,3x3) on {0,1,-1,2,-1/2,inf} ~7e-6
+    tol = {"direct": 2e-6, "winograd": 6e-6, "winograd4": 3e-5}[algo]
     g = torch.Generator().manual_seed(R + Cin)
     x = torch.randn(R, Cin, 7, 7, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
@@ -105,8 +106,11 @@ def test_conv3x3_full_size_linearity(dev):
     w = torch.randn(1024, 2048, 3, 3, device=dev, generator=g) * 0.01
     a = torch.randn(1000, 7, 7, 2048, device=dev, generator=g).permute(0, 3, 1, 2)
     b = torch.randn(1000, 7, 7, 2048, device=dev, generator=g).permute(0, 3, 1, 2)
+    from cim_amd.ops import gemm as gemm_mod
     ya, yb, yab = conv3x3(a, w), conv3x3(b, w), conv3x3(a + 2 * b, w)
-    torch.testing.assert_close(yab, ya + 2 * yb, rtol=1e-4, atol=2e-4)
+    # outputs are O(3); F(4x4,3x3) carries ~5x the rounding error of F(2x2,3x3)
+    atol = 8e-4 if gemm_mod.CONV_ALGO == "winograd4" else 2e-4
+    torch.testing.assert_close(yab, ya + 2 * yb, rtol=1e-4, atol=atol)
     # spot-check 8 output rows against fp64
     idx = torch.tensor([0, 17, 48, 49, 500 * 49 + 24, 999 * 49 + 48, 999 * 49, 12345])
     ref = F.conv2d(a[idx // 49].double().cpu(), w.double().cpu(), padding=1)

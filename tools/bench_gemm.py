@@ -64,7 +64,7 @@ def main():
     # Winograd F(2x2,3x3) pipeline (autograd wrapper: fwd, and fwd+bwd)
     from cim_amd.ops import conv3x3
     import cim_amd.ops.gemm as GG
-    for algo in ("winograd", "direct"):
+    for algo in ("winograd", "winograd4", "direct"):
         GG.CONV_ALGO = algo
         xr_ = x.detach().clone().requires_grad_(True)
         wr_ = w.detach().clone().requires_grad_(True)

@@ -3,7 +3,7 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_FETCH_SIZE -o r -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_WRITE_SIZE -o r -- python3 bench.py ...
-    python3 tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > profiles/r1/pmc_traffic.json
+    python3 tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE [conv_algo] > profiles/r1/pmc_traffic.json
 
 Counters are in KiB per dispatch.  MI355X_MICROARCH.md (HBM) warns that on gfx950 FETCH_SIZE can
 report half of the bytes of a wide streaming read and asks for a calibration on a known byte
@@ -18,7 +18,7 @@ import json
 import sys
 
 OURS = ("gemm_f32_kernel", "roi_align", "mask_iou", "mask_pack", "mask_area", "splitk", "asy_flag", "seed_select",
-        "contain_argmax", "arbitrate", "assign_kernel", "wino_")
+        "contain_argmax", "arbitrate", "assign_kernel", "wino")
 
 
 def per_kernel(d, counter):
@@ -32,7 +32,8 @@ def per_kernel(d, counter):
 
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {}
+    # which conv algorithm the profiled run used (bench.py only attaches GEMM traffic when it matches)
+    out = {"_conv_algo": sys.argv[3] if len(sys.argv) > 3 else "winograd4"}
     for k in fetch:
         f = [v for _, v in sorted(fetch[k])]
         w = [v for _, v in sorted(write.get(k, []))]
