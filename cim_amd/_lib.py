@@ -22,6 +22,8 @@ SIGNATURES = {
     "cim_seed_select": [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P],
     "cim_contain_argmax": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P],
     "cim_arbitrate": [_P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P],
+    "cim_gemm_set_engine": [c_int],
+    "cim_gemm_get_engine": [],
     "cim_gemm_f32_splits": [c_int, c_int, c_int],
     "cim_gemm_f32": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P],
     "cim_conv3x3_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
@@ -65,11 +67,15 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = c_longlong if name == "cim_roi_align_bwd_workspace" else c_int
+    engine = os.environ.get("CIM_GEMM_ENGINE", "bf16x3")
+    if engine not in ("bf16x3", "fp32"):
+        raise CimHipError("CIM_GEMM_ENGINE must be bf16x3 or fp32, got %r" % engine)
+    lib.cim_gemm_set_engine(1 if engine == "bf16x3" else 0)
     _lib = lib
     return lib
 
 
-VALUE_RETURNING = {"cim_gemm_f32_splits", "cim_roi_align_bwd_workspace"}      # return a count, not a status
+VALUE_RETURNING = {"cim_gemm_f32_splits", "cim_roi_align_bwd_workspace", "cim_gemm_get_engine"}      # return a count, not a status
 
 
 def call(name, *args):

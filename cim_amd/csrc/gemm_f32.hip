@@ -69,6 +69,68 @@ struct GemmArgs {
     long long a_bs, b_bs, c_bs;
 };
 
+
+// ---- bf16x3 engine: LDS layout + operand split -------------------------------------------------
+// Every fp32 operand element x is split EXACTLY into three bf16 terms x = h + m + l
+// (h = rne_bf16(x), m = rne_bf16(x - h), l = rne_bf16(x - h - m): 3 x 8 significant bits), and
+// a*b is evaluated as the six MFMA products hh + hm + mh + mm + hl + lh (every bf16 x bf16 product
+// is exact in the fp32 accumulator; the dropped ml + lm + ll terms are < 2^-23 |a*b|, measured
+// 2e-8 * sqrt(K) against 1.6e-6 * sqrt(K) of an fp32 accumulation chain - tools/gen_winograd.py
+// style check in tests/test_gpu_gemm.py::test_bf16x3_error_class).  The products run on
+// v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense; 6 products -> 419 TFLOP/s fp32-equivalent peak
+// against 157 TFLOP/s of v_mfma_f32_32x32x2_f32).
+//
+// LDS, per operand and 16-k slab: [plane h|m|l][k-group of 8][256 rows][8 bf16 = 16 B], so one
+// ds_read_b128 is a lane's whole MFMA operand (row = lane & 31, k-group = lane >> 5).  Rows are stored
+// at slot(r) = (r & ~3) | ((r + (r >> 4)) & 3): the 16-lane groups of ds_read_b128 and the 32-lane
+// groups of the M-contiguous writers' ds_write_b32 (lanes 4 rows apart) both cover all 16 bank quads.
+constexpr int X3_KG = BM * 16 + 64;        // bytes per (plane, k-group): 256 rows x 16 B (+64: the two k-groups land 16 banks apart)
+constexpr int X3_PLANE = 2 * X3_KG;
+constexpr int X3_OPER = 3 * X3_PLANE;
+constexpr int X3_SLAB = 2 * X3_OPER;       // A + B (BM == BN)
+static_assert(BM == BN && BK == 16, "bf16x3 engine: 256 x 256 x 16 slabs");
+
+__device__ __forceinline__ int x3_slot(int r) { return (r & ~3) | ((r + (r >> 4)) & 3); }
+__device__ __forceinline__ unsigned x3_cvt_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// (a, b) -> packed bf16 pairs of the three terms; a in the low half
+__device__ __forceinline__ void x3_split(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = x3_cvt_pk(a, b);
+    a -= __uint_as_float(h << 16);
+    b -= __uint_as_float(h & 0xffff0000u);
+    m = x3_cvt_pk(a, b);
+    a -= __uint_as_float(m << 16);
+    b -= __uint_as_float(m & 0xffff0000u);
+    l = x3_cvt_pk(a, b);
+}
+// K-contiguous piece: row r, k = 4q .. 4q+3
+__device__ __forceinline__ void x3_store_k(char* op, int r, int q, const float4& v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    x3_split(v.x, v.y, h0, m0, l0);
+    x3_split(v.z, v.w, h1, m1, l1);
+    char* d = op + (q >> 1) * X3_KG + x3_slot(r) * 16 + (q & 1) * 8;
+    *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(d + X3_PLANE) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = make_uint2(l0, l1);
+}
+// M-contiguous pieces: rows 4mq .. 4mq+3 at k = 2kr (v[0]) and 2kr + 1 (v[1])
+__device__ __forceinline__ void x3_store_m(char* op, int mq, int kr, const float4 (&v)[2]) {
+    const float a[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, b[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+    char* d = op + (kr >> 2) * X3_KG + (kr & 3) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned h, m, l;
+        x3_split(a[j], b[j], h, m, l);
+        char* dj = d + x3_slot(mq * 4 + j) * 16;
+        *reinterpret_cast<unsigned*>(dj) = h;
+        *reinterpret_cast<unsigned*>(dj + X3_PLANE) = m;
+        *reinterpret_cast<unsigned*>(dj + 2 * X3_PLANE) = l;
+    }
+}
+
 // ---- A operand -------------------------------------------------------------------------------
 // K-contiguous: each thread owns float4 pieces (row, 4 consecutive k); BM*BK/4/NT = 2 pieces.
 template <int AL>
@@ -127,6 +189,10 @@ struct ALoaderK {
             d[3 * LDS_A] = v[i].w;
         }
     }
+    __device__ __forceinline__ void store3(char* op, const float4 (&v)[PIECES]) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) x3_store_k(op, row[i], q, v[i]);
+    }
 };
 
 // M-contiguous: element (m, k) at A[k*lda + m]; thread owns float4 pieces (k row, 4 consecutive m).
@@ -154,7 +220,7 @@ struct ALoaderM {
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int k = k0 + krow0 + i * ROWS;
+            const int k = k0 + krow0 * PIECES + i;          // a thread owns PIECES consecutive k rows
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (base == nullptr || k >= kend) continue;
             if (AL == A_CONV_M) {   // k = output pixel row (roi, oh, ow); gather the tap-shifted input pixel
@@ -171,8 +237,9 @@ struct ALoaderM {
     __device__ __forceinline__ void store(float* as, const float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i)
-            *reinterpret_cast<float4*>(as + (krow0 + i * ROWS) * LDS_A + mq * 4) = v[i];
+            *reinterpret_cast<float4*>(as + (krow0 * PIECES + i) * LDS_A + mq * 4) = v[i];
     }
+    __device__ __forceinline__ void store3(char* op, const float4 (&v)[PIECES]) const { x3_store_m(op, mq, krow0, v); }
 };
 
 // ---- B operand -------------------------------------------------------------------------------
@@ -189,7 +256,7 @@ struct BLoaderN {   // element (k, n) at B[k*ldb + n]
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int k = k0 + krow0 + i * ROWS;
+            const int k = k0 + krow0 * PIECES + i;
             v[i] = (base != nullptr && k < kend) ? *reinterpret_cast<const float4*>(base + (size_t)k * g.ldb)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -197,8 +264,9 @@ struct BLoaderN {   // element (k, n) at B[k*ldb + n]
     __device__ __forceinline__ void store(float* bs, const float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i)
-            *reinterpret_cast<float4*>(bs + (krow0 + i * ROWS) * LDS_B + nq * 4) = v[i];
+            *reinterpret_cast<float4*>(bs + (krow0 * PIECES + i) * LDS_B + nq * 4) = v[i];
     }
+    __device__ __forceinline__ void store3(char* op, const float4 (&v)[PIECES]) const { x3_store_m(op, nq, krow0, v); }
 };
 
 struct BLoaderK {   // element (k, n) at B[n*ldb + k]  (nn.Linear weight [N, K])
@@ -230,6 +298,10 @@ struct BLoaderK {   // element (k, n) at B[n*ldb + k]  (nn.Linear weight [N, K])
             d[2 * LDS_B] = v[i].z;
             d[3 * LDS_B] = v[i].w;
         }
+    }
+    __device__ __forceinline__ void store3(char* op, const float4 (&v)[PIECES]) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) x3_store_k(op, row[i], q, v[i]);
     }
 };
 
@@ -389,6 +461,135 @@ __global__ __launch_bounds__(NT, CIM_GEMM_MINW) void gemm_f32_kernel(const GemmA
     }
 }
 
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// bf16x3 engine.  Same tiling, loaders, split-K / batched modes and epilogue as gemm_f32_kernel; a slab is
+// one 16-k MFMA step (8 output tiles x 6 products = 48 MFMAs per wave).  Two LDS buffers: slab t+1 is
+// split and written (and slab t+2's global loads issued) between the small-term and the large-term
+// products of slab t, one barrier per slab.
+template <int AL, int BL>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16x3_kernel(const GemmArgs g_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    {
+        const int tn = gridDim.x, nt = gridDim.x * gridDim.y;
+        const int b = blockIdx.y * tn + blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        tile_m = t / tn;
+        tile_n = t - tile_m * tn;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    GemmArgs gb = g_in;
+    int zsplit = blockIdx.z;
+    if (gb.batch > 1) {
+        gb.A += (size_t)blockIdx.z * gb.a_bs;
+        gb.B += (size_t)blockIdx.z * gb.b_bs;
+        gb.C += (size_t)blockIdx.z * gb.c_bs;
+        zsplit = 0;
+    }
+    const GemmArgs& g = gb;
+    const int kbeg = zsplit * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    typename ASel<AL>::type la;
+    typename BSel<BL>::type lb;
+    la.init(g, m0, tid);
+    lb.init(g, n0, tid);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[ASel<AL>::type::PIECES], rb[BSel<BL>::type::PIECES];
+    const int nslab = (kend - kbeg + BK - 1) / BK;
+    a_load<AL>(la, g, kbeg, kend, ra);
+    lb.load(g, kbeg, kend, rb);
+    la.store3(smem3, ra);
+    lb.store3(smem3 + X3_OPER, rb);
+    if (nslab > 1) {
+        a_load<AL>(la, g, kbeg + BK, kend, ra);
+        lb.load(g, kbeg + BK, kend, rb);
+    }
+    __syncthreads();
+
+    const int lk = lane >> 5, l31 = lane & 31;
+    int a_off[MI], b_off[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a_off[i] = lk * X3_KG + x3_slot(wm * WM + i * 32 + l31) * 16;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) b_off[j] = X3_OPER + lk * X3_KG + x3_slot(wn * WN + j * 32 + l31) * 16;
+
+#define X3_FRAG(base, off, plane) (*reinterpret_cast<const bf16x8*>((base) + (off) + (plane) * X3_PLANE))
+#define X3_MMA(AF, BF)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i], BF[j], acc[i][j], 0, 0, 0)
+
+    for (int t = 0; t < nslab; ++t) {
+        const char* cur = smem3 + (t & 1) * X3_SLAB;
+        char* nxt = smem3 + ((t + 1) & 1) * X3_SLAB;
+        bf16x8 ah[MI], ax[MI], bh[NI], bx[NI];
+        // small terms first: l*h, h*l, m*m
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bh[j] = X3_FRAG(cur, b_off[j], 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) ax[i] = X3_FRAG(cur, a_off[i], 2);
+        X3_MMA(ax, bh);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) ah[i] = X3_FRAG(cur, a_off[i], 0);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bx[j] = X3_FRAG(cur, b_off[j], 2);
+        X3_MMA(ah, bx);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) ax[i] = X3_FRAG(cur, a_off[i], 1);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bx[j] = X3_FRAG(cur, b_off[j], 1);
+        X3_MMA(ax, bx);
+        // every fragment of slab t is in registers: the other buffer can be refilled
+        if (t + 1 < nslab) {
+            la.store3(nxt, ra);
+            lb.store3(nxt + X3_OPER, rb);
+        }
+        if (t + 2 < nslab) {
+            a_load<AL>(la, g, kbeg + (t + 2) * BK, kend, ra);
+            lb.load(g, kbeg + (t + 2) * BK, kend, rb);
+        }
+        X3_MMA(ah, bx);     // h*m
+        X3_MMA(ax, bh);     // m*h
+        X3_MMA(ah, bh);     // h*h
+        __syncthreads();
+    }
+#undef X3_FRAG
+#undef X3_MMA
+
+    float* C = g.C + (size_t)zsplit * g.c_split_stride;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n >= g.N) continue;
+        const float bv = (g.bias != nullptr) ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (g.relu) v = fmaxf(v, 0.0f);
+                C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
 // sum split-K partials (fixed order: deterministic), add bias, optional ReLU.  One float4 per lane.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
                                                             const float* __restrict__ bias, int M, int N, int ldc,
@@ -411,11 +612,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = s;
 }
 
+int g_engine = 1;      // 0: v_mfma_f32_32x32x2_f32;  1: bf16x3 split on v_mfma_f32_32x32x16_bf16 (default)
+
 template <int AL, int BL>
 int launch(GemmArgs g, int splits, float* workspace, hipStream_t st) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
-    const size_t lds = sizeof(float) * 3 * SLAB;
-    auto kern = gemm_f32_kernel<AL, BL>;
+    const bool x3 = g_engine == 1;
+    const size_t lds = x3 ? (size_t)2 * X3_SLAB : sizeof(float) * 3 * SLAB;
+    auto kern = x3 ? gemm_bf16x3_kernel<AL, BL> : gemm_f32_kernel<AL, BL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int slabs = (g.K + BK - 1) / BK;
@@ -447,6 +651,14 @@ int launch(GemmArgs g, int splits, float* workspace, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int cim_gemm_set_engine(int engine) {
+    CIM_CHECK_ARG(engine == 0 || engine == 1);
+    g_engine = engine;
+    return 0;
+}
+
+extern "C" int cim_gemm_get_engine(void) { return g_engine; }
+
 extern "C" int cim_gemm_f32_splits(int M, int N, int K) {
     // RESIDENT 512-thread workgroups fit per CU, so a launch runs in rounds of 256*RESIDENT tiles;
     // split-K fills the last round (e.g. direct conv wgrad: 288 tiles -> 2 rounds at 56 %; x8 -> 9 full
@@ -463,7 +675,7 @@ extern "C" int cim_gemm_f32_splits(int M, int N, int K) {
         const double units = tiles * s;
         const double rounds = (double)(long long)((units + CUS - 1) / CUS);
         const double eff = units / (rounds * CUS);
-        const double t = flops / (125e12 * eff) + (s > 1 ? (2.0 * s + 1.0) * M * (double)N * 4.0 / 4e12 : 0.0);
+        const double t = flops / ((g_engine == 1 ? 250e12 : 125e12) * eff) + (s > 1 ? (2.0 * s + 1.0) * M * (double)N * 4.0 / 4e12 : 0.0);
         if (t < best_t) { best_t = t; best = s; }
     }
     return best;

@@ -130,15 +130,22 @@ int cim_assign(const uint16_t* iou_f16, int N, const int32_t* gt_idx, const int3
                void* stream);
 
 /* ------------------------------------------------------------------ MaskFuse contractions (a-2)
- * Exact-fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32) replacing the ATen/cuDNN calls behind
- * MaskFuse, lib/modeling/resnet50.py:104-110,135-136 (Conv2d(2C,C,3,pad=1), Linear(49C,4096),
- * Linear(4096,4096)) and their autograd backward.
+ * fp32-in / fp32-out MFMA GEMMs replacing the ATen/cuDNN calls behind MaskFuse,
+ * lib/modeling/resnet50.py:104-110,135-136 (Conv2d(2C,C,3,pad=1), Linear(49C,4096),
+ * Linear(4096,4096)) and their autograd backward.  Two arithmetic engines, same results class:
+ *   engine 1 (default): every fp32 operand is split exactly into three bf16 terms in the kernel and the
+ *     product evaluated as six v_mfma_f32_32x32x16_bf16 products with fp32 accumulation
+ *     (dropped terms < 2^-23 |a*b|: two orders below the fp32 accumulation rounding itself);
+ *   engine 0: v_mfma_f32_32x32x2_f32 (f32 multiplies).
+ * cim_gemm_set_engine() selects process-wide (host code sets it from CIM_GEMM_ENGINE = bf16x3 | fp32).
  *
  * C[M,N] = A . B (+ bias[N]) (ReLU optional), row-major C with leading dimension ldc.
  *   a_mcontig = 0: A element (m,k) at A[m*lda + k];  1: at A[k*lda + m]
  *   b_kcontig = 0: B element (k,n) at B[k*ldb + n];  1: at B[n*ldb + k]   (nn.Linear weight)
  * splits > 1: split-K through `workspace` (splits*M*N floats), reduced in a fixed order
  * (deterministic).  cim_gemm_f32_splits() returns the split count the library would choose. */
+int cim_gemm_set_engine(int engine);
+int cim_gemm_get_engine(void);
 int cim_gemm_f32_splits(int M, int N, int K);
 int cim_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                  int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu,

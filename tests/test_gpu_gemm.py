@@ -56,6 +56,49 @@ def test_gemm_is_asymmetric_and_deterministic(dev):
     assert _rel(y1.cpu(), A.cpu().double() @ W.cpu().double().t()) < 3e-5   # K = 50176: fp32 accumulation error grows with K
 
 
+@pytest.mark.parametrize("K", [2048, 50176])
+def test_bf16x3_error_class(dev, K):
+    """The default engine (fp32 operands split exactly into 3 bf16 terms, 6 MFMA products, fp32
+    accumulate) must sit in the same error class as the f32-multiply MFMA engine against fp64, on
+    unit-variance data and on data with a large dynamic range (exponents spread over 2^+-20)."""
+    from cim_amd import _lib
+    from cim_amd.ops import gemm as G
+    g = torch.Generator().manual_seed(K)
+    M = N = 256
+    for spread in (0.0, 20.0):
+        A = torch.randn(M, K, generator=g) * torch.exp2(spread * (torch.rand(M, K, generator=g) - 0.5))
+        B = torch.randn(K, N, generator=g) * torch.exp2(spread * (torch.rand(K, N, generator=g) - 0.5))
+        ref = A.double() @ B.double()
+        scale = (A.double().abs() @ B.double().abs())            # condition-aware error scale
+        err = {}
+        try:
+            for engine in (0, 1):
+                _lib.call("cim_gemm_set_engine", engine)
+                c = G.gemm(A.to(dev), B.to(dev), M, N, K, K, N)
+                err[engine] = float(((c.cpu().double() - ref).abs() / scale).max())
+        finally:
+            _lib.call("cim_gemm_set_engine", 1)
+        assert err[0] < 2e-6 and err[1] < 2e-6, err               # both far below fp32 eps * sqrt(K)
+        assert err[1] < 2.0 * err[0] + 1e-8, err
+
+
+def test_bf16x3_exact_on_bf16_representable(dev):
+    """Operands that are sums of three bf16 terms with small-integer products are reproduced exactly:
+    checks the split (h, m, l planes), the swizzled LDS layout and the k-pair packing of every loader."""
+    from cim_amd.ops import gemm as G
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 264, 176
+    A = torch.randint(-8, 9, (M, K), generator=g).float() + torch.randint(-8, 9, (M, K), generator=g).float() / 4096.0
+    B = torch.randint(-8, 9, (K, N), generator=g).float()
+    ref = (A.double() @ B.double())
+    for a_m in (0, 1):
+        for b_k in (0, 1):
+            a_dev = (A.t().contiguous() if a_m else A).to(dev)
+            b_dev = (B.t().contiguous() if b_k else B).to(dev)
+            c = G.gemm(a_dev, b_dev, M, N, K, M if a_m else K, K if b_k else N, bool(a_m), bool(b_k))
+            assert torch.equal(c.cpu().double(), ref), (a_m, b_k)
+
+
 @pytest.mark.parametrize("algo", ["winograd", "winograd4", "direct"])
 @pytest.mark.parametrize("R,Cin,Cout", [(11, 32, 48), (40, 64, 272), (6, 16, 16)])
 def test_conv3x3_fwd_bwd_vs_fp64(dev, R, Cin, Cout, algo, monkeypatch):
