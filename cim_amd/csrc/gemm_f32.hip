@@ -97,7 +97,14 @@ __device__ __forceinline__ unsigned x3_cvt_pk(float lo, float hi) {
     return r;
 }
 // (a, b) -> packed bf16 pairs of the three terms; a in the low half
+#ifndef CIM_X3_EXP
+#define CIM_X3_EXP 0     // ablation switches for tools/bench_gemm_ab.py; 0 = product
+#endif
 __device__ __forceinline__ void x3_split(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+#if CIM_X3_EXP == 1
+    h = m = l = __float_as_uint(a) ^ __float_as_uint(b);
+    return;
+#endif
     h = x3_cvt_pk(a, b);
     a -= __uint_as_float(h << 16);
     b -= __uint_as_float(h & 0xffff0000u);
@@ -154,11 +161,23 @@ struct ALoaderK {
                 ow[i] = p % g.P;
                 ptr[i] = (m < g.M) ? g.A + (size_t)m * g.Cin + q * 4 : nullptr;
             } else {
-                ptr[i] = (m < g.M) ? g.A + (size_t)m * g.lda + q * 4 : nullptr;
+                // branch-free: rows >= M re-read row M-1 (their C rows are never stored)
+                ptr[i] = g.A + (size_t)min(m, g.M - 1) * g.lda;
             }
         }
     }
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, float4 (&v)[PIECES]) const {
+        if constexpr (AL != A_CONV_K) {
+            const int k = k0 + q * 4;
+            const int kc = min(k, g.K - 4);
+            const bool in = k < g.K;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(ptr[i] + kc);
+                v[i] = make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f);
+            }
+            return;
+        }
         int dy = 0, dx = 0, ci0 = k0;
         if (AL == A_CONV_K) {   // slab = 16 channels of one tap (Cin % BK == 0)
             const int tap = k0 / g.Cin;
@@ -214,10 +233,20 @@ struct ALoaderM {
             base = (m < g.M) ? g.A + (m - tap * g.Cin) : nullptr;
         } else {
             dy = dx = 0;
-            base = (m < g.M) ? g.A + m : nullptr;
+            base = g.A + min(m, g.M - 4);       // branch-free: columns >= M re-read the last quad
         }
     }
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
+        if constexpr (AL != A_CONV_M) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int k = k0 + krow0 * PIECES + i;
+                const float4 t = *reinterpret_cast<const float4*>(base + (size_t)min(k, g.K - 1) * g.lda);
+                const bool in = k < kend;
+                v[i] = make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int k = k0 + krow0 * PIECES + i;          // a thread owns PIECES consecutive k rows
@@ -251,14 +280,15 @@ struct BLoaderN {   // element (k, n) at B[k*ldb + n]
         nq = tid % COLS4;
         krow0 = tid / COLS4;
         const int n = n0 + nq * 4;
-        base = (n < g.N) ? g.B + n : nullptr;
+        base = g.B + min(n, g.N - 4);           // branch-free: columns >= N re-read the last quad (never stored)
     }
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int k = k0 + krow0 * PIECES + i;
-            v[i] = (base != nullptr && k < kend) ? *reinterpret_cast<const float4*>(base + (size_t)k * g.ldb)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 t = *reinterpret_cast<const float4*>(base + (size_t)min(k, g.K - 1) * g.ldb);
+            const bool in = k < kend;
+            v[i] = make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f);
         }
     }
     __device__ __forceinline__ void store(float* bs, const float4 (&v)[PIECES]) const {
@@ -280,14 +310,18 @@ struct BLoaderK {   // element (k, n) at B[n*ldb + k]  (nn.Linear weight [N, K])
         for (int i = 0; i < PIECES; ++i) {
             row[i] = (tid >> 2) + i * (NT / 4);
             const int n = n0 + row[i];
-            ptr[i] = (n < g.N) ? g.B + (size_t)n * g.ldb + q * 4 : nullptr;
+            ptr[i] = g.B + (size_t)min(n, g.N - 1) * g.ldb;     // branch-free: rows >= N re-read row N-1
         }
     }
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
+        const int k = k0 + q * 4;
+        const int kc = min(k, g.K - 4);
+        const bool in = k < kend;
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i)
-            v[i] = (ptr[i] != nullptr && k0 + q * 4 < kend) ? *reinterpret_cast<const float4*>(ptr[i] + k0)
-                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < PIECES; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(ptr[i] + kc);
+            v[i] = make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f);
+        }
     }
     __device__ __forceinline__ void store(float* bs, const float4 (&v)[PIECES]) const {
 #pragma unroll
@@ -515,9 +549,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x3_kernel(const GemmArgs g_in)
     lb.load(g, kbeg, kend, rb);
     la.store3(smem3, ra);
     lb.store3(smem3 + X3_OPER, rb);
-    if (nslab > 1) {
-        a_load<AL>(la, g, kbeg + BK, kend, ra);
-        lb.load(g, kbeg + BK, kend, rb);
+#pragma unroll 1
+    for (int pre = 1; pre <= 2; ++pre) {     // slab 1 -> LDS buffer 1, slab 2 -> registers
+        const int kn = kbeg + min(pre, nslab - 1) * BK;
+        a_load<AL>(la, g, kn, kend, ra);
+        lb.load(g, kn, kend, rb);
+        if (pre == 1) {
+            la.store3(smem3 + X3_SLAB, ra);
+            lb.store3(smem3 + X3_SLAB + X3_OPER, rb);
+        }
     }
     __syncthreads();
 
@@ -533,39 +573,64 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x3_kernel(const GemmArgs g_in)
     _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)        \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i], BF[j], acc[i][j], 0, 0, 0)
 
+    // Three LDS buffers, one barrier per slab.  During slab t a wave (1) multiplies the fragments of slab t,
+    // (2) splits + writes slab t+2 (its fp32 values were loaded from HBM/L2 during slab t-1) and issues the
+    // global loads of slab t+3, (3) prefetches the first fragments of slab t+1 (complete since the barrier
+    // that ended slab t-1) - so neither the barrier nor LDS latency sits in front of the next slab's MFMAs.
+    // Buffer (t+2)%3 was last read in slab t-1.  sched_barrier fences keep each third of the MFMAs with
+    // its share of the VALU / LDS work (hipcc otherwise bunches the conversions).
+    bf16x8 ah[MI], ax[MI], bh[NI], bx[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bh[j] = X3_FRAG(smem3, b_off[j], 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) ax[i] = X3_FRAG(smem3, a_off[i], 2);
+    int ic = 0;
     for (int t = 0; t < nslab; ++t) {
-        const char* cur = smem3 + (t & 1) * X3_SLAB;
-        char* nxt = smem3 + ((t + 1) & 1) * X3_SLAB;
-        bf16x8 ah[MI], ax[MI], bh[NI], bx[NI];
-        // small terms first: l*h, h*l, m*m
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bh[j] = X3_FRAG(cur, b_off[j], 0);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) ax[i] = X3_FRAG(cur, a_off[i], 2);
-        X3_MMA(ax, bh);
+        const int i1 = (ic == 2) ? 0 : ic + 1, i2 = (i1 == 2) ? 0 : i1 + 1;
+        const char* cur = smem3 + ic * X3_SLAB;
+        const char* nx1 = smem3 + i1 * X3_SLAB;
+        char* nx2 = smem3 + i2 * X3_SLAB;
+        // ---- third 1: l*h, h*l; fetch the remaining fragments of this slab
 #pragma unroll
         for (int i = 0; i < MI; ++i) ah[i] = X3_FRAG(cur, a_off[i], 0);
 #pragma unroll
         for (int j = 0; j < NI; ++j) bx[j] = X3_FRAG(cur, b_off[j], 2);
-        X3_MMA(ah, bx);
+        X3_MMA(ax, bh);
 #pragma unroll
         for (int i = 0; i < MI; ++i) ax[i] = X3_FRAG(cur, a_off[i], 1);
+        X3_MMA(ah, bx);
 #pragma unroll
         for (int j = 0; j < NI; ++j) bx[j] = X3_FRAG(cur, b_off[j], 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- third 2: m*m, h*m; A of slab t+2 -> LDS, A of slab t+3 <- global
         X3_MMA(ax, bx);
-        // every fragment of slab t is in registers: the other buffer can be refilled
-        if (t + 1 < nslab) {
-            la.store3(nxt, ra);
-            lb.store3(nxt + X3_OPER, rb);
-        }
-        if (t + 2 < nslab) {
-            a_load<AL>(la, g, kbeg + (t + 2) * BK, kend, ra);
-            lb.load(g, kbeg + (t + 2) * BK, kend, rb);
-        }
-        X3_MMA(ah, bx);     // h*m
-        X3_MMA(ax, bh);     // m*h
-        X3_MMA(ah, bh);     // h*h
+#if CIM_X3_EXP != 2 && CIM_X3_EXP != 5
+        la.store3(nx2, ra);
+#endif
+        const int kn = kbeg + min(t + 3, nslab - 1) * BK;
+#if CIM_X3_EXP != 3 && CIM_X3_EXP != 5
+        a_load<AL>(la, g, kn, kend, ra);
+#endif
+        X3_MMA(ah, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- third 3: m*h, h*h; B likewise; prefetch l(A), h(B) of slab t+1
+        X3_MMA(ax, bh);
+#if CIM_X3_EXP != 2 && CIM_X3_EXP != 5
+        lb.store3(nx2 + X3_OPER, rb);
+#endif
+#if CIM_X3_EXP != 3 && CIM_X3_EXP != 5
+        lb.load(g, kn, kend, rb);
+#endif
+#pragma unroll
+        for (int i = 0; i < MI; ++i) ax[i] = X3_FRAG(nx1, a_off[i], 2);
+        X3_MMA(ah, bh);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bh[j] = X3_FRAG(nx1, b_off[j], 0);
+        __builtin_amdgcn_sched_barrier(0);
+#if CIM_X3_EXP != 4 && CIM_X3_EXP != 5
         __syncthreads();
+#endif
+        ic = i1;
     }
 #undef X3_FRAG
 #undef X3_MMA
@@ -618,7 +683,7 @@ template <int AL, int BL>
 int launch(GemmArgs g, int splits, float* workspace, hipStream_t st) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     const bool x3 = g_engine == 1;
-    const size_t lds = x3 ? (size_t)2 * X3_SLAB : sizeof(float) * 3 * SLAB;
+    const size_t lds = x3 ? (size_t)3 * X3_SLAB : sizeof(float) * 3 * SLAB;
     auto kern = x3 ? gemm_bf16x3_kernel<AL, BL> : gemm_f32_kernel<AL, BL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

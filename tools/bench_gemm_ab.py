@@ -22,13 +22,14 @@ for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):
     libs[os.path.basename(path)[len("libcim_hip_"):-3]] = alt
 st = torch.cuda.current_stream().cuda_stream
 N, C = 1000, 1024
-mt = N * 16
+NPOS = 36
+mt = N * 4
 g = torch.Generator(device=dev).manual_seed(0)
-V = torch.randn(16, mt, 2 * C, device=dev, generator=g)
-U = torch.randn(16, 2 * C, C, device=dev, generator=g)
-M = torch.empty(16, mt, C, device=dev)
-D = torch.randn(16, mt, C, device=dev, generator=g)
-dU = torch.empty(16, 2 * C, C, device=dev)
+V = torch.randn(NPOS, mt, 2 * C, device=dev, generator=g)
+U = torch.randn(NPOS, 2 * C, C, device=dev, generator=g)
+M = torch.empty(NPOS, mt, C, device=dev)
+D = torch.randn(NPOS, mt, C, device=dev, generator=g)
+dU = torch.empty(NPOS, 2 * C, C, device=dev)
 K1 = 49 * C
 xf = torch.randn(N, K1, device=dev, generator=g)
 w1 = torch.randn(4096, K1, device=dev, generator=g) * 0.01
@@ -42,8 +43,8 @@ ws = torch.empty(4 * 4096 * 50176, device=dev)     # 3.3 GB: up to 4 splits of t
 def cases(lib):
     sp = lambda m, n, k: min(lib.cim_gemm_f32_splits(m, n, k), (4 * 4096 * 50176) // (m * n))
     return {
-        "wino_fwd": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), U.data_ptr(), M.data_ptr(), mt, C, 2 * C, 2 * C, C, C, 0, 0, 16, mt * 2 * C, 2 * C * C, mt * C, st), 16 * 2.0 * mt * 2 * C * C),
-        "wino_wgrad": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), D.data_ptr(), dU.data_ptr(), 2 * C, C, mt, 2 * C, C, C, 1, 0, 16, mt * 2 * C, mt * C, 2 * C * C, st), 16 * 2.0 * mt * 2 * C * C),
+        "wino_fwd": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), U.data_ptr(), M.data_ptr(), mt, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, mt * 2 * C, 2 * C * C, mt * C, st), NPOS * 2.0 * mt * 2 * C * C),
+        "wino_wgrad": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), D.data_ptr(), dU.data_ptr(), 2 * C, C, mt, 2 * C, C, C, 1, 0, NPOS, mt * 2 * C, mt * C, 2 * C * C, st), NPOS * 2.0 * mt * 2 * C * C),
         "fc1_fwd": (lambda: lib.cim_gemm_f32(xf.data_ptr(), w1.data_ptr(), y1.data_ptr(), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), ws.data_ptr(), st), 2.0 * N * K1 * 4096),
         "fc1_dgrad": (lambda: lib.cim_gemm_f32(dyf.data_ptr(), w1.data_ptr(), dx1.data_ptr(), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, sp(N, K1, 4096), ws.data_ptr(), st), 2.0 * N * K1 * 4096),
         "fc1_wgrad": (lambda: lib.cim_gemm_f32(dyf.data_ptr(), xf.data_ptr(), dw1.data_ptr(), None, 4096, K1, N, 4096, K1, K1, 1, 0, 0, sp(4096, K1, N), ws.data_ptr(), st), 2.0 * N * K1 * 4096),
