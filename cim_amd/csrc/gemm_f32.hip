@@ -532,8 +532,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x3_kernel(const GemmArgs g_in)
 
     typename ASel<AL>::type la;
     typename BSel<BL>::type lb;
+#if CIM_X3_EXP == 8
+    la.init(g, 0, tid);      // ablation: every tile streams the same (cache-resident) operand panels
+    lb.init(g, 0, tid);
+#else
     la.init(g, m0, tid);
     lb.init(g, n0, tid);
+#endif
 
     f32x16 acc[MI][NI];
 #pragma unroll

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-kernel statistics of the TIMED steps only, from a rocprofv3 --kernel-trace CSV of bench.py.
+
+    rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o r -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline
+    python3 tools/trace_steps.py /tmp/kt/r_kernel_trace.csv 4 > profiles/r1/bench_kernel_stats.csv
+
+A step is delimited by its (single) ROIAlign forward dispatch; everything before the first of the last
+`steps` ROIAlign forwards (warm-up, MIOpen's one-off solver search on a box with a cold database, the
+one-off mask-IoU maps) is dropped.  Columns mirror rocprofv3 --stats, plus per-step figures."""
+import collections
+import csv
+import sys
+
+
+def main():
+    path, steps = sys.argv[1], int(sys.argv[2])
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if "roi_align_fwd_kernel" in r["Kernel_Name"]]
+    assert len(marks) >= steps, "fewer ROIAlign forwards than steps in the trace"
+    # the backbone forward precedes ROIAlign inside a step: start at the end of the previous step's last kernel,
+    # i.e. right after the optimizer's last dispatch before the first timed ROIAlign -> use the previous ROIAlign
+    # forward's step end; simplest robust cut: begin at the first dispatch after the (steps+1)-th last mark's step.
+    first = marks[-steps]
+    # walk back to the start of that step: the backbone's first kernel follows the previous step's optimizer
+    # (multi_tensor_apply) - find the last optimizer dispatch before `first`
+    start = 0
+    for i in range(first, -1, -1):
+        if "multi_tensor_apply" in rows[i]["Kernel_Name"] or "FusedSgd" in rows[i]["Kernel_Name"]:
+            start = i + 1
+            break
+    sel = rows[start:]
+    stat = collections.OrderedDict()
+    for r in sel:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        s = stat.setdefault(r["Kernel_Name"], [0, 0, 1 << 62, 0])
+        s[0] += 1
+        s[1] += d
+        s[2] = min(s[2], d)
+        s[3] = max(s[3], d)
+    total = sum(s[1] for s in stat.values())
+    w = csv.writer(sys.stdout)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "CallsPerStep", "MsPerStep"])
+    for name, s in sorted(stat.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([name, s[0], s[1], "%.1f" % (s[1] / s[0]), "%.3f" % (100.0 * s[1] / total), s[2], s[3],
+                    "%.2f" % (s[0] / steps), "%.4f" % (s[1] / steps / 1e6)])
+    w.writerow(["TOTAL (%d timed steps)" % steps, sum(s[0] for s in stat.values()), total, "", "100", "", "", "",
+                "%.4f" % (total / steps / 1e6)])
+
+
+if __name__ == "__main__":
+    main()
