@@ -91,10 +91,11 @@ constexpr int X3_SLAB = 2 * X3_OPER;       // A + B (BM == BN)
 static_assert(BM == BN && BK == 16, "bf16x3 engine: 256 x 256 x 16 slabs");
 
 __device__ __forceinline__ int x3_slot(int r) { return (r & ~3) | ((r + (r >> 4)) & 3); }
-__device__ __forceinline__ unsigned x3_cvt_pk(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+typedef __bf16 x3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned x3_cvt_pk(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even)
+    const x3_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, x3_bf16x2));
 }
 // (a, b) -> packed bf16 pairs of the three terms; a in the low half
 #ifndef CIM_X3_EXP
