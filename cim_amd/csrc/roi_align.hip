@@ -9,6 +9,7 @@
 // Layout: feat [B,H,W,C], out [K,P,P,C] (or cat [K,P,P,2C]).  A workgroup owns one
 // (roi, bin-row); its lanes run along C, so every global access is a contiguous
 // 16 B/lane x 64-lane (1 KiB per wave) segment of one feature pixel's channel vector.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/cim_hip.h"
 
@@ -387,6 +388,192 @@ __global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_tile_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward, pixel-owner form (default when the per-launch tables exist and the tile fits).
+// Same ownership idea as above - a workgroup owns 16 channels of the whole map as an LDS tile - but
+//   * a LANE owns one pixel of the ROI's bounding box with all 16 channels (16 accumulators), so the
+//     index arithmetic, range unpacking and weight fetches are paid once per 16 channels, not per 4;
+//   * the tile uses a 20-dword pixel stride: the read-modify-write ds_read/write_b128 of 16
+//     neighbouring pixels hit 16 distinct bank quads; the gradient reads are wave-wide broadcasts;
+//   * PX_DEPTH ROIs' gradient blocks and tables are in flight in registers (fetched while earlier ROIs
+//     are accumulated): at 64 B granularity one ROI in flight per CU reads only ~1.1 TB/s;
+//   * when at most 2 x 2 bins touch every pixel of the wave (bins >= ~2 px, the common case) all
+//     weights and then all four gradient blocks are fetched back-to-back: 3 LDS round trips per pixel.
+// grid = (C/16, RG); block = 512.
+#ifndef CIM_ROI_EXP
+#define CIM_ROI_EXP 0      // ablation switches for tools/bench_roi.py
+#endif
+constexpr int PX_THREADS = 512;
+constexpr int PX_STRIDE = 20;      // dwords per tile pixel: 16 channels + 4 pad
+constexpr int PX_DEPTH = 3;        // ROIs in flight (registers) per workgroup
+constexpr int PX_MAXTAB = 2;       // staged table words per lane (ceil(((P+1)(H+W)+6)/512) must not exceed this)
+
+static size_t bwd_px_lds(int H, int W, int P) {
+    return sizeof(float) * ((size_t)H * W * PX_STRIDE + 2 * PX_DEPTH * ((size_t)P * P * 16 + (size_t)((P + 1) * (H + W) + 8)));
+}
+
+template <bool MASKCAT>
+__global__ __launch_bounds__(PX_THREADS) void roi_align_bwd_px16_kernel(const float* __restrict__ grad_out,
+                                                                        const float* __restrict__ masks,
+                                                                        float* __restrict__ grad_in, int B, int C, int H,
+                                                                        int W, int K, int P, int use_atomic,
+                                                                        const float* __restrict__ pre) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int HW = H * W, PP = P * P;
+    const int tabw = (P + 1) * (H + W);            // wy | wx | yr | xr
+    const int stw = tabw + 6;                      // + box[4], count, batch
+    const int recw = roi_rec_words(P, H, W);
+    float* tile = lds;                             // [HW][PX_STRIDE]
+    float* gbuf = tile + (size_t)HW * PX_STRIDE;   // 2 sets x PX_DEPTH slots x [PP][16]
+    float* tbuf = gbuf + 2 * PX_DEPTH * PP * 16;   // 2 sets x PX_DEPTH slots x (tabw + 8)
+    const int tstride = tabw + 8;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * 16;
+    const int OC = MASKCAT ? 2 * C : C;
+    const int gbin = tid >> 2, gcg = tid & 3;      // staging role: gradient float4 (bin, channel quad)
+
+    for (int b = 0; b < B; ++b) {
+        for (int i = tid; i < HW * (PX_STRIDE / 4); i += PX_THREADS)
+            reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int D = PX_DEPTH;
+        float4 sg[D], sg2[D];
+        float sm[D], scount[D], stab[D][PX_MAXTAB];
+        // branch-free (clamped indices, every lane loads): the D fetches must be ONE basic block, or hipcc
+        // puts an s_waitcnt vmcnt(0) in front of each and serialises them ahead of the barrier
+        const int gbin_c = min(gbin, PP - 1);
+        auto fetch = [&](int k, int d) {
+            k = min(k, K - 1);
+            const float* rec = pre + (size_t)k * recw;
+            scount[d] = rec[tabw + 4];
+            const float* src = grad_out + ((size_t)k * PP + gbin_c) * OC + c0 + gcg * 4;
+            sg[d] = *reinterpret_cast<const float4*>(src);
+            if (MASKCAT) {
+                sg2[d] = *reinterpret_cast<const float4*>(src + C);
+                sm[d] = masks[(size_t)k * PP + gbin_c];
+            }
+#pragma unroll
+            for (int j = 0; j < PX_MAXTAB; ++j) stab[d][j] = rec[min(tid + j * PX_THREADS, stw - 1)];
+        };
+        auto stage = [&](int slot, int d) {
+            if (gbin < PP) {
+                float4 v = sg[d];
+                if (MASKCAT)
+                    v = make_float4(v.x + sm[d] * sg2[d].x, v.y + sm[d] * sg2[d].y, v.z + sm[d] * sg2[d].z,
+                                    v.w + sm[d] * sg2[d].w);
+                const float c = scount[d];
+                reinterpret_cast<float4*>(gbuf + slot * PP * 16)[tid] = make_float4(v.x / c, v.y / c, v.z / c, v.w / c);
+            }
+#pragma unroll
+            for (int j = 0; j < PX_MAXTAB; ++j) {
+                const int e = tid + j * PX_THREADS;
+                if (e < stw) tbuf[slot * tstride + e] = stab[d][j];
+            }
+        };
+        // Batches of D ROIs: stage the batch (fetched during the previous batch) into one of two slot sets,
+        // issue the next batch's fetches, ONE barrier, accumulate the D ROIs.  Inside a batch the waves never
+        // synchronise: wave w owns the tile rows y = w (mod 8), so no two waves touch the same pixel.
+        const int kstep = gridDim.y;
+        const int wave = tid >> 6, lane = tid & 63;
+        int set = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) fetch(blockIdx.y + d * kstep, d);
+        for (int k0 = blockIdx.y; k0 < ((CIM_ROI_EXP == 5 || CIM_ROI_EXP == 6) ? 0 : K); k0 += D * kstep) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (k0 + d * kstep < K) stage(set * D + d, d);
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (CIM_ROI_EXP != 3) fetch(k0 + (D + d) * kstep, d);
+            __syncthreads();
+            for (int d = 0; d < D; ++d) {
+                if (k0 + d * kstep >= K) break;
+                const int slot = set * D + d;
+                const float* wy = tbuf + slot * tstride;
+                const float* wx = wy + P * H;
+                const int* yr = reinterpret_cast<const int*>(wx + P * W);
+                const int* xr = yr + H;
+                const int* box = xr + W;
+                const float* gb_ = gbuf + slot * PP * 16;
+                if (box[5] != b) continue;             // block-uniform
+                const int ylo = box[0], yhi = box[1], xlo = box[2], xhi = box[3];
+                if (yhi < ylo || xhi < xlo) continue;
+                const int ys = ylo + ((wave - ylo) & 7);                 // first row of this wave inside the box
+                if (ys > yhi) continue;                                  // wave-uniform
+                const int rw = xhi - xlo + 1, items = ((yhi - ys) / 8 + 1) * rw;
+                const float inv_rw = 1.0f / (float)rw;
+                for (int it0 = 0; it0 < (CIM_ROI_EXP == 1 ? 0 : items); it0 += 64) {
+                    const int it = it0 + lane;
+                    const bool live = it < items;
+                    const int itc = live ? it : 0;
+                    const int yy = (int)(((float)itc + 0.5f) * inv_rw);   // exact: the fraction is >= 0.5/rw off an integer
+                    const int y = ys + 8 * yy, x = xlo + (itc - yy * rw);
+                    const int ry = yr[y], rx = xr[x];
+                    const bool on = live && !((ry | rx) & 0x10000);
+                    const int phl = ry & 0xff, phh = (ry >> 8) & 0xff, pwl = rx & 0xff, pwh = (rx >> 8) & 0xff;
+                    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+                    const bool small = !on || (phh - phl <= 1 && pwh - pwl <= 1);
+                    if (__all(small)) {
+                        const int p0 = on ? phl : 0, p1 = on ? phh : 0, q0 = on ? pwl : 0, q1 = on ? pwh : 0;
+                        const float wy0 = on ? wy[p0 * H + y] : 0.0f, wy1 = (on && p1 != p0) ? wy[p1 * H + y] : 0.0f;
+                        const float wx0 = wx[q0 * W + x], wx1 = (q1 != q0) ? wx[q1 * W + x] : 0.0f;
+                        const float4* g00 = reinterpret_cast<const float4*>(gb_ + (p0 * P + q0) * 16);
+                        const float4* g01 = reinterpret_cast<const float4*>(gb_ + (p0 * P + q1) * 16);
+                        const float4* g10 = reinterpret_cast<const float4*>(gb_ + (p1 * P + q0) * 16);
+                        const float4* g11 = reinterpret_cast<const float4*>(gb_ + (p1 * P + q1) * 16);
+                        const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+#define PX_ACC(A, J)                                                                                          \
+    {                                                                                                         \
+        const float4 u = g00[J], v = g01[J], s_ = g10[J], t_ = g11[J];                                        \
+        A.x = w00 * u.x + w01 * v.x + w10 * s_.x + w11 * t_.x;                                                \
+        A.y = w00 * u.y + w01 * v.y + w10 * s_.y + w11 * t_.y;                                                \
+        A.z = w00 * u.z + w01 * v.z + w10 * s_.z + w11 * t_.z;                                                \
+        A.w = w00 * u.w + w01 * v.w + w10 * s_.w + w11 * t_.w;                                                \
+    }
+                        PX_ACC(a0, 0) PX_ACC(a1, 1) PX_ACC(a2, 2) PX_ACC(a3, 3)
+#undef PX_ACC
+                    } else if (on && CIM_ROI_EXP != 4) {
+                        for (int ph = phl; ph <= phh; ++ph) {
+                            const float a = wy[ph * H + y];
+                            for (int pw = pwl; pw <= pwh; ++pw) {
+                                const float w = a * wx[pw * W + x];
+                                const float4* gv = reinterpret_cast<const float4*>(gb_ + (ph * P + pw) * 16);
+                                const float4 g0 = gv[0], g1 = gv[1], g2 = gv[2], g3 = gv[3];
+                                a0.x += w * g0.x; a0.y += w * g0.y; a0.z += w * g0.z; a0.w += w * g0.w;
+                                a1.x += w * g1.x; a1.y += w * g1.y; a1.z += w * g1.z; a1.w += w * g1.w;
+                                a2.x += w * g2.x; a2.y += w * g2.y; a2.z += w * g2.z; a2.w += w * g2.w;
+                                a3.x += w * g3.x; a3.y += w * g3.y; a3.z += w * g3.z; a3.w += w * g3.w;
+                            }
+                        }
+                    }
+                    if (on) {
+                        float4* t4 = reinterpret_cast<float4*>(tile + (size_t)(y * W + x) * PX_STRIDE);
+                        float4 c0_ = t4[0], c1_ = t4[1], c2_ = t4[2], c3_ = t4[3];
+                        c0_.x += a0.x; c0_.y += a0.y; c0_.z += a0.z; c0_.w += a0.w;
+                        c1_.x += a1.x; c1_.y += a1.y; c1_.z += a1.z; c1_.w += a1.w;
+                        c2_.x += a2.x; c2_.y += a2.y; c2_.z += a2.z; c2_.w += a2.w;
+                        c3_.x += a3.x; c3_.y += a3.y; c3_.z += a3.z; c3_.w += a3.w;
+                        t4[0] = c0_; t4[1] = c1_; t4[2] = c2_; t4[3] = c3_;
+                    }
+                }
+            }
+            set ^= 1;
+        }
+        __syncthreads();
+        float* gb = grad_in + (size_t)b * HW * C;
+        for (int i = tid; i < ((CIM_ROI_EXP == 2 || CIM_ROI_EXP == 6) ? 0 : HW * 4); i += PX_THREADS) {
+            const int pix = i >> 2, cg = i & 3;
+            const float4 v = *reinterpret_cast<const float4*>(tile + (size_t)pix * PX_STRIDE + cg * 4);
+            float* dst = gb + (size_t)pix * C + c0 + cg * 4;
+            if (use_atomic) {
+                atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+            } else {
+                *reinterpret_cast<float4*>(dst) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // LDS bytes of the tile kernel for a channel chunk of CH
 static size_t bwd_tile_lds(int CH, int H, int W, int P) {
     return sizeof(float) * ((size_t)H * W * CH + 2 * (size_t)P * P * CH + 2 * (size_t)(P + 1) * (H + W));
@@ -430,9 +617,34 @@ int launch_fwd(const float* feat, const float* rois, const float* masks, float* 
 }
 
 template <bool MASKCAT>
+static int launch_bwd_px16(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W,
+                           int K, int P, float scale, int sr, int aligned, float* ws, hipStream_t st) {
+    const size_t lds = bwd_px_lds(H, W, P);
+    auto kern = roi_align_bwd_px16_kernel<MASKCAT>;
+    hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), 0, st, rois, ws, K, P, H, W, scale, sr, aligned);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const int chunks = C / 16;
+    int rg = (256 + chunks - 1) / chunks;
+    if (rg > K) rg = K;
+    if (rg < 1) rg = 1;
+    if (rg > 1) {
+        e = hipMemsetAsync(gin, 0, sizeof(float) * (size_t)B * H * W * C, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(chunks, rg), dim3(PX_THREADS), lds, st, go, masks, gin, B, C, H, W, K, P, rg > 1 ? 1 : 0,
+                       ws);
+    return 0;
+}
+
+template <bool MASKCAT>
 int launch_bwd(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W, int K,
                int P, float scale, int sr, int aligned, float* ws, hipStream_t st) {
     const size_t budget = 150 * 1024;
+    if (K > 0 && ws != nullptr && C % 16 == 0 && P * P * 4 <= PX_THREADS && H < 256 && W < 256 &&
+        (P + 1) * (H + W) + 6 <= PX_MAXTAB * PX_THREADS && bwd_px_lds(H, W, P) <= 160 * 1024 - 512 &&
+        getenv("CIM_ROI_BWD_TILE") == nullptr)
+        return launch_bwd_px16<MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st);
     if (K > 0 && P <= 16 && C % 4 == 0) {
         if (C % 16 == 0 && bwd_tile_lds(16, H, W, P) <= budget)
             return launch_bwd_tile<16, MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st);

@@ -42,5 +42,13 @@ ws = torch.empty(_lib.call("cim_roi_align_bwd_workspace", K, 7, H, W) // 4 + 1, 
 bwd = lambda: _lib.call("cim_roi_align_maskcat_bwd", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
 nbytes = 4.0 * (C * H * W + 5 * K + 49 * K) + 4.0 * K * 2 * C * 49
 tf, tb = timeit(fwd), timeit(bwd)
+import ctypes, glob
+for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):     # ALT builds (ablations)
+    alt = ctypes.CDLL(path)
+    for name, argt in _lib.SIGNATURES.items():
+        getattr(alt, name).argtypes = argt
+    f = lambda: alt.cim_roi_align_maskcat_fwd(feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, st)
+    bw = lambda: alt.cim_roi_align_maskcat_bwd(gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
+    print(os.path.basename(path), "fwd_ms %.4f bwd_ms %.4f" % (timeit(f), timeit(bw)))
 print(json.dumps(dict(config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, fwd_ms=tf, fwd_frac=nbytes / tf / 1e6 / 8000,
                       bwd_ms=tb, bwd_frac=nbytes / tb / 1e6 / 8000)))
