@@ -122,6 +122,124 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restr
     }
 }
 
+// Forward, tap-table form (default for C % 4 == 0, P <= FW_MAXP and sampling grids <= FW_MAXG):
+// the sample positions of a block's bin row are wave-uniform, so their bilinear taps (pixel offsets
+// and weights - ~40 instructions incl. an IEEE division per sample in the kernel above) are computed
+// ONCE per block into LDS and read back as broadcasts, and the loads of two x-samples (8 x 16 B per
+// lane) are issued before either is consumed.  Same operations in the same order as the direct
+// kernel and the oracle: results are bit-identical.
+constexpr int FW_MAXG = 32, FW_MAXP = 8;
+
+template <bool MASKCAT>
+__global__ __launch_bounds__(256) void roi_align_fwd_tab_kernel(const float* __restrict__ feat,
+                                                                const float* __restrict__ rois,
+                                                                const float* __restrict__ masks,
+                                                                float* __restrict__ out, int C, int H, int W, int P,
+                                                                float scale, int sampling_ratio, int aligned) {
+    __shared__ int4 ytab[FW_MAXG];
+    __shared__ int4 xtab[FW_MAXP * FW_MAXG];
+    const int k = blockIdx.x, ph = blockIdx.y, tid = threadIdx.x;
+    const RoiGeom g = roi_geom(rois + 5 * (size_t)k, scale, P, sampling_ratio, aligned);
+    const float* __restrict__ fb = feat + (size_t)g.b * H * W * C;
+    const int OC = MASKCAT ? 2 * C : C;
+    if (g.gh > FW_MAXG || g.gw > FW_MAXG) {      // block-uniform: oversized sampling grid -> direct evaluation
+        for (int c = tid * 4; c < C; c += 256 * 4) {
+            for (int pw = 0; pw < P; ++pw) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int iy = 0; iy < g.gh; ++iy) {
+                    const float y = g.y1 + ph * g.bh + (iy + 0.5f) * g.bh / (float)g.gh;
+                    const Tap ty = make_tap(y, H);
+                    for (int ix = 0; ix < g.gw; ++ix) {
+                        const float x = g.x1 + pw * g.bw + (ix + 0.5f) * g.bw / (float)g.gw;
+                        const Tap tx = make_tap(x, W);
+                        if (!(ty.valid && tx.valid)) continue;
+                        const float4 v1 = *reinterpret_cast<const float4*>(fb + ((size_t)ty.lo * W + tx.lo) * C + c);
+                        const float4 v2 = *reinterpret_cast<const float4*>(fb + ((size_t)ty.lo * W + tx.hi) * C + c);
+                        const float4 v3 = *reinterpret_cast<const float4*>(fb + ((size_t)ty.hi * W + tx.lo) * C + c);
+                        const float4 v4 = *reinterpret_cast<const float4*>(fb + ((size_t)ty.hi * W + tx.hi) * C + c);
+                        const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+                        acc = vadd(acc, vadd(vadd(vadd(vmul(w1, v1), vmul(w2, v2)), vmul(w3, v3)), vmul(w4, v4)));
+                    }
+                }
+                const float4 o = vdiv(acc, g.count);
+                float* dst = out + (((size_t)k * P + ph) * P + pw) * OC + c;
+                *reinterpret_cast<float4*>(dst) = o;
+                if (MASKCAT) *reinterpret_cast<float4*>(dst + C) = vmul(masks[((size_t)k * P + ph) * P + pw], o);
+            }
+        }
+        return;
+    }
+    // taps: {element offset of the low pixel (-1: sample out of range), of the high pixel, l, h}
+    if (tid < g.gh) {
+        const float y = g.y1 + ph * g.bh + (tid + 0.5f) * g.bh / (float)g.gh;
+        const Tap t = make_tap(y, H);
+        ytab[tid] = make_int4(t.valid ? t.lo * W * C : -1, t.hi * W * C, __float_as_int(t.l), __float_as_int(t.h));
+    }
+    for (int e = tid; e < P * g.gw; e += 256) {
+        const int pw = e / g.gw, ix = e - pw * g.gw;
+        const float x = g.x1 + pw * g.bw + (ix + 0.5f) * g.bw / (float)g.gw;
+        const Tap t = make_tap(x, W);
+        xtab[pw * FW_MAXG + ix] = make_int4(t.valid ? t.lo * C : -1, t.hi * C, __float_as_int(t.l), __float_as_int(t.h));
+    }
+    __syncthreads();
+#define FW_SAMPLE(TX, V1, V2, V3, V4)                                                                         \
+    {                                                                                                         \
+        const float xl = __int_as_float(TX.z), xh = __int_as_float(TX.w);                                     \
+        const float w1 = yh * xh, w2 = yh * xl, w3 = yl * xh, w4 = yl * xl;                                   \
+        acc = vadd(acc, vadd(vadd(vadd(vmul(w1, V1), vmul(w2, V2)), vmul(w3, V3)), vmul(w4, V4)));            \
+    }
+    for (int c = tid * 4; c < C; c += 256 * 4) {
+        const float* __restrict__ fc = fb + c;
+        for (int pw = 0; pw < P; ++pw) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int4* xt = xtab + pw * FW_MAXG;
+            for (int iy = 0; iy < g.gh; ++iy) {
+                const int4 ty = ytab[iy];
+                if (ty.x < 0) continue;                                   // wave-uniform
+                const float yl = __int_as_float(ty.z), yh = __int_as_float(ty.w);
+                const float* __restrict__ r0 = fc + ty.x;
+                const float* __restrict__ r1 = fc + ty.y;
+                int ix = 0;
+                for (; ix + 1 < g.gw; ix += 2) {
+                    const int4 ta = xt[ix], tb = xt[ix + 1];
+                    if (ta.x >= 0 && tb.x >= 0) {                         // both loads sets in flight together
+                        const float4 a1 = *reinterpret_cast<const float4*>(r0 + ta.x), a2 = *reinterpret_cast<const float4*>(r0 + ta.y);
+                        const float4 a3 = *reinterpret_cast<const float4*>(r1 + ta.x), a4 = *reinterpret_cast<const float4*>(r1 + ta.y);
+                        const float4 b1 = *reinterpret_cast<const float4*>(r0 + tb.x), b2 = *reinterpret_cast<const float4*>(r0 + tb.y);
+                        const float4 b3 = *reinterpret_cast<const float4*>(r1 + tb.x), b4 = *reinterpret_cast<const float4*>(r1 + tb.y);
+                        FW_SAMPLE(ta, a1, a2, a3, a4)
+                        FW_SAMPLE(tb, b1, b2, b3, b4)
+                    } else {
+                        if (ta.x >= 0) {
+                            const float4 a1 = *reinterpret_cast<const float4*>(r0 + ta.x), a2 = *reinterpret_cast<const float4*>(r0 + ta.y);
+                            const float4 a3 = *reinterpret_cast<const float4*>(r1 + ta.x), a4 = *reinterpret_cast<const float4*>(r1 + ta.y);
+                            FW_SAMPLE(ta, a1, a2, a3, a4)
+                        }
+                        if (tb.x >= 0) {
+                            const float4 b1 = *reinterpret_cast<const float4*>(r0 + tb.x), b2 = *reinterpret_cast<const float4*>(r0 + tb.y);
+                            const float4 b3 = *reinterpret_cast<const float4*>(r1 + tb.x), b4 = *reinterpret_cast<const float4*>(r1 + tb.y);
+                            FW_SAMPLE(tb, b1, b2, b3, b4)
+                        }
+                    }
+                }
+                if (ix < g.gw) {
+                    const int4 ta = xt[ix];
+                    if (ta.x >= 0) {
+                        const float4 a1 = *reinterpret_cast<const float4*>(r0 + ta.x), a2 = *reinterpret_cast<const float4*>(r0 + ta.y);
+                        const float4 a3 = *reinterpret_cast<const float4*>(r1 + ta.x), a4 = *reinterpret_cast<const float4*>(r1 + ta.y);
+                        FW_SAMPLE(ta, a1, a2, a3, a4)
+                    }
+                }
+            }
+            const float4 o = vdiv(acc, g.count);
+            float* dst = out + (((size_t)k * P + ph) * P + pw) * OC + c;
+            *reinterpret_cast<float4*>(dst) = o;
+            if (MASKCAT) *reinterpret_cast<float4*>(dst + C) = vmul(masks[((size_t)k * P + ph) * P + pw], o);
+        }
+    }
+#undef FW_SAMPLE
+}
+
 __device__ __forceinline__ void atomic_add_vec(float* p, float v) { atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_vec(float* p, float4 v) {
     atomicAdd(p + 0, v.x);
@@ -607,7 +725,10 @@ int launch_fwd(const float* feat, const float* rois, const float* masks, float* 
                int P, float scale, int sr, int aligned, hipStream_t st) {
     if (K == 0) return 0;
     dim3 grid(K, P), block(256);
-    if (C % 4 == 0)
+    if (C % 4 == 0 && P <= FW_MAXP && (long long)H * W * C < (1ll << 30) && getenv("CIM_ROI_FWD_DIRECT") == nullptr)
+        hipLaunchKernelGGL((roi_align_fwd_tab_kernel<MASKCAT>), grid, block, 0, st, feat, rois, masks, out, C, H, W, P,
+                           scale, sr, aligned);
+    else if (C % 4 == 0)
         hipLaunchKernelGGL((roi_align_fwd_kernel<4, MASKCAT>), grid, block, 0, st, feat, rois, masks, out, C, H, W, P,
                            scale, sr, aligned);
     else
