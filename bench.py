@@ -291,7 +291,10 @@ def main():
             ms = timer.mean_ms(name)
             if ms:
                 ach = ra_bytes / (ms * 1e-3) / 1e9
-                pk = pmc.get("roi_align_fwd_kernel<4, true>" if name.endswith("fwd") else "roi_align_bwd_tile_kernel<16, true, true>")
+                pk = None
+                for kn, kv in pmc.items():        # whichever forward / backward kernel variant the profiled run used
+                    if kn.startswith("roi_align_fwd" if name.endswith("fwd") else "roi_align_bwd"):
+                        pk = kv
                 hbm.append(dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=ach / HBM_PEAK_GBS, ms=ms, algorithmic_bytes=ra_bytes,
                                 traffic=pk["hbm_bytes_mean"] if pk else None))

@@ -16,7 +16,7 @@ def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "roi_align_fwd_kernel" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "roi_align_fwd" in r["Kernel_Name"]]
     assert len(marks) >= steps, "fewer ROIAlign forwards than steps in the trace"
     # the backbone forward precedes ROIAlign inside a step: start at the end of the previous step's last kernel,
     # i.e. right after the optimizer's last dispatch before the first timed ROIAlign -> use the previous ROIAlign
