@@ -80,7 +80,7 @@ def instrument(model, timer):
             state["conv"] += 1
             with timer.span("maskfuse_conv_fwd" if state["conv"] == 1 else "maskfuse_conv_dgrad"):
                 return orig_call(name, *args)
-        if name == "cim_gemm_f32_batched":  # Winograd-domain GEMMs, per step: forward, data grad, weight grad
+        if name in ("cim_gemm_f32_batched", "cim_gemm_f16x2_batched"):  # Winograd-domain GEMMs, per step: forward, data grad, weight grad
             state["bg"] += 1
             with timer.span(("wino_gemm_fwd", "wino_gemm_dgrad", "wino_gemm_wgrad")[min(state["bg"], 3) - 1]):
                 return orig_call(name, *args)
@@ -266,22 +266,25 @@ def main():
         else:
             kname = "gemm_f32_kernel<A_CONV_K,B_NCONTIG> (MaskFuse conv3x3 fwd, implicit GEMM)"
             conv_ms, conv_flops = timer.mean_ms("maskfuse_conv_fwd"), 2.0 * 49 * n * (2 * Cf * 9) * Cf
-        # engine bf16x3 (default): every algorithmic fp32 multiply-add is executed as SIX bf16 MFMA products
-        # (exact 3-way operand split, fp32 accumulate), so the kernel is priced against the bf16 MFMA peak
-        # with achieved = 6 x algorithmic flops / time; engine fp32: v_mfma_f32_32x32x2_f32 against its own peak.
-        from cim_amd import _lib as _l
-        x3 = _l.call("cim_gemm_get_engine") == 1
+        # split engines: every algorithmic fp32 multiply-add is executed as several half-precision MFMA products with
+        # fp32 accumulation, so the kernel is priced against the bf16/f16 MFMA peak with
+        # achieved = products x algorithmic flops / time.  f16x2 (default): 3 products (scaled two-term fp16 split);
+        # bf16x3: 6 products (exact three-term bf16 split); fp32: v_mfma_f32_32x32x2_f32 against its own peak.
+        engine = gemm_mod.ENGINE
+        products = {"f16x2": 3.0, "bf16x3": 6.0, "fp32": 1.0}[engine]
+        kern = {"f16x2": "gemm_f16x2_kernel", "bf16x3": "gemm_bf16x3_kernel", "fp32": "gemm_f32_kernel"}[engine]
         alg_tf = conv_flops / (conv_ms * 1e-3) / 1e12
-        if x3:
-            kname = kname.replace("gemm_f32_kernel", "gemm_bf16x3_kernel")
-        roofline = dict(bound="mfma", kernel=kname, achieved=(6.0 if x3 else 1.0) * alg_tf,
-                        peak=BF16_MFMA_PEAK_TF if x3 else FP32_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None, ms=conv_ms,
-                        engine="bf16x3: 6 bf16 MFMA products per fp32 multiply-add, fp32 accumulate" if x3
-                        else "fp32: v_mfma_f32_32x32x2_f32",
+        kname = kname.replace("gemm_f32_kernel", kern)
+        roofline = dict(bound="mfma", kernel=kname, achieved=products * alg_tf,
+                        peak=FP32_MFMA_PEAK_TF if engine == "fp32" else BF16_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None,
+                        ms=conv_ms,
+                        engine={"f16x2": "f16x2: 3 f16 MFMA products per fp32 multiply-add (scaled two-term split), fp32 accumulate",
+                                "bf16x3": "bf16x3: 6 bf16 MFMA products per fp32 multiply-add, fp32 accumulate",
+                                "fp32": "fp32: v_mfma_f32_32x32x2_f32"}[engine],
                         algorithmic_tflops=alg_tf, fp32_mfma_peak=FP32_MFMA_PEAK_TF)
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         pmc = pmc_traffic()
-        g00 = pmc.get("gemm_bf16x3_kernel<0, 0>" if x3 else "gemm_f32_kernel<0, 0>")
+        g00 = pmc.get(kern + "<0, 0>")
         if wino_ms and g00 and pmc.get("_conv_algo", "winograd") == gemm_mod.CONV_ALGO:      # first <A_KCONTIG,B_NCONTIG> launch of a step = the Winograd forward GEMM
             roofline["traffic"] = (g00["fetch_kib_per_dispatch"][0] + g00["write_kib_per_dispatch"][0]) * 1024
         # HBM-bound hand-written kernels: fused ROIAlign+mask-cat fwd / bwd
@@ -304,9 +307,13 @@ def main():
                     value=world * args.steps / elapsed, unit="images/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
                     scaling="weak", vs_baseline=None, dtype="fp32", data="synthetic",
-                    dtype_note=("fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated as an exact "
-                                "3 x bf16 operand split (6 MFMA products, dropped terms < 2^-23) - measured error vs fp64 "
-                                "below the f32-multiply engine's (CIM_GEMM_ENGINE=fp32)") if x3 else "fp32 multiplies and accumulation",
+                    dtype_note={"f16x2": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
+                                         "two-term fp16 operand split (3 MFMA products, dropped term <= 2^-22, rms 2^-25.6) - "
+                                         "measured error vs fp64 in the class of the f32-multiply engine (CIM_GEMM_ENGINE=fp32)",
+                                "bf16x3": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated as an exact "
+                                          "3 x bf16 operand split (6 MFMA products, dropped terms < 2^-23) - measured error vs fp64 "
+                                          "below the f32-multiply engine's (CIM_GEMM_ENGINE=fp32)",
+                                "fp32": "fp32 multiplies and accumulation"}[engine],
                     config=dict(workload="%s bs=1/GPU, %d proposals, image 3x%dx%d, feature %dx%dx%d, iter_size=1"
                                          % (args.config, n, H, W, Cf, Hf, Wf), parallelism="dp%d" % world),
                     roofline=roofline, roofline_hbm=hbm)

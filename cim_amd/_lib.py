@@ -29,6 +29,11 @@ SIGNATURES = {
     "cim_conv3x3_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "cim_conv3x3_wgrad_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "cim_gemm_f32_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, _P],
+    "cim_gemm_f16x2_splits": [c_int, c_int, c_int],
+    "cim_amax_rowcol": [_P, c_int, c_int, c_int, c_int, c_longlong, _P, _P, _P],
+    "cim_gemm_f16x2": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P],
+    "cim_gemm_f16x2_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
+                               _P, _P, _P],
     "cim_wino_input_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_filter_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_output_transform": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
@@ -67,15 +72,14 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = c_longlong if name == "cim_roi_align_bwd_workspace" else c_int
-    engine = os.environ.get("CIM_GEMM_ENGINE", "bf16x3")
-    if engine not in ("bf16x3", "fp32"):
-        raise CimHipError("CIM_GEMM_ENGINE must be bf16x3 or fp32, got %r" % engine)
-    lib.cim_gemm_set_engine(1 if engine == "bf16x3" else 0)
+    # CIM_GEMM_ENGINE = f16x2 (default; own entry points, chosen in cim_amd/ops/gemm.py) | bf16x3 | fp32.
+    # cim_gemm_f32 / cim_conv3x3_f32 (operands without scales) run bf16x3 unless fp32 is asked for.
+    lib.cim_gemm_set_engine(0 if os.environ.get("CIM_GEMM_ENGINE", "f16x2") == "fp32" else 1)
     _lib = lib
     return lib
 
 
-VALUE_RETURNING = {"cim_gemm_f32_splits", "cim_roi_align_bwd_workspace", "cim_gemm_get_engine"}      # return a count, not a status
+VALUE_RETURNING = {"cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_gemm_get_engine"}      # return a count, not a status
 
 
 def call(name, *args):

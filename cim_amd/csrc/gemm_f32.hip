@@ -67,6 +67,9 @@ struct GemmArgs {
     // batched mode (batch > 1, no split-K): blockIdx.z selects the problem; strides in elements
     int batch;
     long long a_bs, b_bs, c_bs;
+    // f16x2 engine: |max| bit patterns per A row [batch][M] and per B column [batch][N] (cim_amax_rowcol)
+    const unsigned* a_amax;
+    const unsigned* b_amax;
 };
 
 
@@ -139,6 +142,80 @@ __device__ __forceinline__ void x3_store_m(char* op, int mq, int kr, const float
     }
 }
 
+
+// ---- f16x2 engine: scaled two-term fp16 split ---------------------------------------------------
+// Each fp32 operand element x is scaled by a power of two per A row / per B column (s = 2^(14-e),
+// e = exponent of the row's / column's largest magnitude over K, so |x*s| < 2^15: exact, no overflow)
+// and split into two fp16 terms  x*s = h + l + d,  h = rne_f16(x*s), l = rne_f16(x*s - h):
+// 11 + 11 significant bits + the sign of l = 23 bits, |d| <= 2^-23 |x*s| (zero for 3 operands in 4).
+// a*b is evaluated as the three MFMA products  hl + lh + hh  on v_mfma_f32_32x32x16_f16 (each fp16 x
+// fp16 product is exact in the fp32 accumulator); the dropped l*l term is <= 2^-22 |a*b| (rms 2^-25.6).
+// The accumulator is rescaled by 2^-(ea+eb) in the epilogue (exact).  Elements more than 2^16 below
+// their row / column maximum fall into fp16's subnormal range and keep an ABSOLUTE accuracy of
+// 2^-40 of that maximum - so the result carries the error bound of an fp32 GEMM relative to
+// |a_row| * |b_col| (tests/test_gpu_gemm.py::test_f16x2_error_class).  Half the MFMA work of bf16x3.
+//
+// LDS per operand and 16-k slab: [plane h|l][k-group of 8][256 rows][8 f16 = 16 B], rows swizzled by
+// x3_slot() exactly as in the bf16x3 engine.
+#ifndef CIM_X2_EXP
+#define CIM_X2_EXP 0     // ablation switches for tools/bench_gemm_ab.py; 0 = product
+#endif
+constexpr int X2_KG = BM * 16 + 64;
+constexpr int X2_PLANE = 2 * X2_KG;
+constexpr int X2_OPER = 2 * X2_PLANE;
+constexpr int X2_SLAB = 2 * X2_OPER;       // 33280 B; three buffers = 99840 B
+typedef _Float16 x2_f16x2 __attribute__((ext_vector_type(2)));
+
+// amax bit pattern -> power-of-two scale (biased exponent clamped to [14, 253] so the inverse is normal)
+__device__ __forceinline__ float x2_scale(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);
+    int b = min(268 - e, 253);
+    if (e == 0 || e == 255) b = 127;        // all-zero (or non-finite) row: scale 1
+    return __uint_as_float((unsigned)b << 23);
+}
+__device__ __forceinline__ float x2_inv(float s) { return __uint_as_float((254u << 23) - __float_as_uint(s)); }
+
+// (a, b) already scaled -> packed f16 pairs (a in the low half) of the two terms
+__device__ __forceinline__ void x2_split(float a, float b, unsigned& h, unsigned& l) {
+#if CIM_X2_EXP == 6
+    h = l = __float_as_uint(a) ^ __float_as_uint(b);
+    return;
+#endif
+    const x3_f32x2 v = {a, b};
+    const x2_f16x2 hv = __builtin_convertvector(v, x2_f16x2);          // v_cvt_pk_f16_f32 (RNE)
+    const x3_f32x2 r = {a - (float)hv.x, b - (float)hv.y};               // exact
+    h = __builtin_bit_cast(unsigned, hv);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x2_f16x2));
+}
+// K-contiguous piece: row r, k = 4q .. 4q+3, one scale for the row
+__device__ __forceinline__ void x2_store_k(char* op, int r, int q, const float4& v, float s) {
+    unsigned h0, l0, h1, l1;
+    x2_split(v.x * s, v.y * s, h0, l0);
+    x2_split(v.z * s, v.w * s, h1, l1);
+    char* d = op + (q >> 1) * X2_KG + x3_slot(r) * 16 + (q & 1) * 8;
+    *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(d + X2_PLANE) = make_uint2(l0, l1);
+}
+// M-contiguous pieces: rows 4mq .. 4mq+3 (scales s.x .. s.w) at k = 2kr (v[0]) and 2kr + 1 (v[1])
+__device__ __forceinline__ void x2_store_m(char* op, int mq, int kr, const float4 (&v)[2], const float4& s, float m0, float m1) {
+    // m0 / m1 = 1 (k row inside the problem) or 0 (K tail: the loader re-read a valid row; its product with 0 is 0)
+    const float a[4] = {v[0].x * (s.x * m0), v[0].y * (s.y * m0), v[0].z * (s.z * m0), v[0].w * (s.w * m0)};
+    const float b[4] = {v[1].x * (s.x * m1), v[1].y * (s.y * m1), v[1].z * (s.z * m1), v[1].w * (s.w * m1)};
+    char* d = op + (kr >> 2) * X2_KG + (kr & 3) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned h, l;
+        x2_split(a[j], b[j], h, l);
+        char* dj = d + x3_slot(mq * 4 + j) * 16;
+        *reinterpret_cast<unsigned*>(dj) = h;
+        *reinterpret_cast<unsigned*>(dj + X2_PLANE) = l;
+    }
+}
+__device__ __forceinline__ float4 x2_scale4(const unsigned* amax, int i0, int limit) {
+    return make_float4(x2_scale(amax[min(i0, limit - 1)]), x2_scale(amax[min(i0 + 1, limit - 1)]),
+                       x2_scale(amax[min(i0 + 2, limit - 1)]), x2_scale(amax[min(i0 + 3, limit - 1)]));
+}
+
 // ---- A operand -------------------------------------------------------------------------------
 // K-contiguous: each thread owns float4 pieces (row, 4 consecutive k); BM*BK/4/NT = 2 pieces.
 template <int AL>
@@ -148,7 +225,19 @@ struct ALoaderK {
     int row[PIECES];
     int oh[PIECES], ow[PIECES];
     int q;
+    float sc[PIECES];      // f16x2 engine: row scales
 
+    __device__ __forceinline__ void init_scale(const GemmArgs& g, int m0) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) sc[i] = x2_scale(g.a_amax[min(m0 + row[i], g.M - 1)]);
+    }
+    // raw loads (load<true>) carry no K-tail select, so nothing waits on them until this store: the tail
+    // is zeroed here through the scale (k0 = first k of the slab held in v)
+    __device__ __forceinline__ void store2(char* op, const float4 (&v)[PIECES], int k0, int kend) const {
+        const float m = (k0 + q * 4 < kend) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) x2_store_k(op, row[i], q, v[i], sc[i] * m);
+    }
     __device__ __forceinline__ void init(const GemmArgs& g, int m0, int tid) {
         q = tid & 3;
 #pragma unroll
@@ -167,11 +256,12 @@ struct ALoaderK {
             }
         }
     }
+    template <bool RAW = false>
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, float4 (&v)[PIECES]) const {
         if constexpr (AL != A_CONV_K) {
             const int k = k0 + q * 4;
             const int kc = min(k, g.K - 4);
-            const bool in = k < g.K;
+            const bool in = RAW || k < g.K;
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
                 const float4 t = *reinterpret_cast<const float4*>(ptr[i] + kc);
@@ -222,7 +312,13 @@ struct ALoaderM {
     int mq, krow0;
     const float* base;   // column base (A + m), null when out of range
     int dy, dx;
+    float4 sc;             // f16x2 engine: scales of the 4 owned rows
 
+    __device__ __forceinline__ void init_scale(const GemmArgs& g, int m0) { sc = x2_scale4(g.a_amax, m0 + mq * 4, g.M); }
+    __device__ __forceinline__ void store2(char* op, const float4 (&v)[PIECES], int k0, int kend) const {
+        const int k = k0 + krow0 * PIECES;
+        x2_store_m(op, mq, krow0, v, sc, k < kend ? 1.0f : 0.0f, k + 1 < kend ? 1.0f : 0.0f);
+    }
     __device__ __forceinline__ void init(const GemmArgs& g, int m0, int tid) {
         mq = tid % COLS4;
         krow0 = tid / COLS4;
@@ -237,13 +333,14 @@ struct ALoaderM {
             base = g.A + min(m, g.M - 4);       // branch-free: columns >= M re-read the last quad
         }
     }
+    template <bool RAW = false>
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
         if constexpr (AL != A_CONV_M) {
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
                 const int k = k0 + krow0 * PIECES + i;
                 const float4 t = *reinterpret_cast<const float4*>(base + (size_t)min(k, g.K - 1) * g.lda);
-                const bool in = k < kend;
+                const bool in = RAW || k < kend;
                 v[i] = make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f);
             }
             return;
@@ -277,18 +374,25 @@ struct BLoaderN {   // element (k, n) at B[k*ldb + n]
     static constexpr int COLS4 = BN / 4, ROWS = NT / COLS4, PIECES = BK / ROWS;
     int nq, krow0;
     const float* base;
+    float4 sc;
+    __device__ __forceinline__ void init_scale(const GemmArgs& g, int n0) { sc = x2_scale4(g.b_amax, n0 + nq * 4, g.N); }
+    __device__ __forceinline__ void store2(char* op, const float4 (&v)[PIECES], int k0, int kend) const {
+        const int k = k0 + krow0 * PIECES;
+        x2_store_m(op, nq, krow0, v, sc, k < kend ? 1.0f : 0.0f, k + 1 < kend ? 1.0f : 0.0f);
+    }
     __device__ __forceinline__ void init(const GemmArgs& g, int n0, int tid) {
         nq = tid % COLS4;
         krow0 = tid / COLS4;
         const int n = n0 + nq * 4;
         base = g.B + min(n, g.N - 4);           // branch-free: columns >= N re-read the last quad (never stored)
     }
+    template <bool RAW = false>
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int k = k0 + krow0 * PIECES + i;
             const float4 t = *reinterpret_cast<const float4*>(base + (size_t)min(k, g.K - 1) * g.ldb);
-            const bool in = k < kend;
+            const bool in = RAW || k < kend;
             v[i] = make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f);
         }
     }
@@ -305,6 +409,16 @@ struct BLoaderK {   // element (k, n) at B[n*ldb + k]  (nn.Linear weight [N, K])
     const float* ptr[PIECES];
     int row[PIECES];
     int q;
+    float sc[PIECES];
+    __device__ __forceinline__ void init_scale(const GemmArgs& g, int n0) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) sc[i] = x2_scale(g.b_amax[min(n0 + row[i], g.N - 1)]);
+    }
+    __device__ __forceinline__ void store2(char* op, const float4 (&v)[PIECES], int k0, int kend) const {
+        const float m = (k0 + q * 4 < kend) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) x2_store_k(op, row[i], q, v[i], sc[i] * m);
+    }
     __device__ __forceinline__ void init(const GemmArgs& g, int n0, int tid) {
         q = tid & 3;
 #pragma unroll
@@ -314,10 +428,11 @@ struct BLoaderK {   // element (k, n) at B[n*ldb + k]  (nn.Linear weight [N, K])
             ptr[i] = g.B + (size_t)min(n, g.N - 1) * g.ldb;     // branch-free: rows >= N re-read row N-1
         }
     }
+    template <bool RAW = false>
     __device__ __forceinline__ void load(const GemmArgs& g, int k0, int kend, float4 (&v)[PIECES]) const {
         const int k = k0 + q * 4;
         const int kc = min(k, g.K - 4);
-        const bool in = k < kend;
+        const bool in = RAW || k < kend;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const float4 t = *reinterpret_cast<const float4*>(ptr[i] + kc);
@@ -346,10 +461,10 @@ template <> struct ASel<A_CONV_M> { using type = ALoaderM<A_CONV_M>; };
 template <int BL> struct BSel { using type = BLoaderN; };
 template <> struct BSel<B_KCONTIG> { using type = BLoaderK; };
 
-template <int AL, class L>
+template <int AL, bool RAW = false, class L>
 __device__ __forceinline__ void a_load(const L& l, const GemmArgs& g, int k0, int kend, float4 (&v)[L::PIECES]) {
-    if constexpr (AL == A_KCONTIG || AL == A_CONV_K) l.load(g, k0, v);
-    else l.load(g, k0, kend, v);
+    if constexpr (AL == A_KCONTIG || AL == A_CONV_K) l.template load<RAW>(g, k0, v);
+    else l.template load<RAW>(g, k0, kend, v);
 }
 
 // grid = (tiles_n, tiles_m, splits); block = 512
@@ -661,6 +776,220 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x3_kernel(const GemmArgs g_in)
     }
 }
 
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+// f16x2 engine.  Same tiling, loaders, split-K / batched modes as gemm_bf16x3_kernel; a slab is one 16-k
+// MFMA step (8 output tiles x 3 products = 24 MFMAs per wave), three LDS buffers, one barrier per slab.
+template <int AL, int BL>
+__global__ __launch_bounds__(NT, 2) void gemm_f16x2_kernel(const GemmArgs g_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    {
+        const int tn = gridDim.x, nt = gridDim.x * gridDim.y;
+        const int b = blockIdx.y * tn + blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        tile_m = t / tn;
+        tile_n = t - tile_m * tn;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    GemmArgs gb = g_in;
+    int zsplit = blockIdx.z;
+    if (gb.batch > 1) {
+        gb.A += (size_t)blockIdx.z * gb.a_bs;
+        gb.B += (size_t)blockIdx.z * gb.b_bs;
+        gb.C += (size_t)blockIdx.z * gb.c_bs;
+        gb.a_amax += (size_t)blockIdx.z * gb.M;
+        gb.b_amax += (size_t)blockIdx.z * gb.N;
+        zsplit = 0;
+    }
+    const GemmArgs& g = gb;
+    const int kbeg = zsplit * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    typename ASel<AL>::type la;
+    typename BSel<BL>::type lb;
+    la.init(g, m0, tid);
+    lb.init(g, n0, tid);
+    la.init_scale(g, m0);
+    lb.init_scale(g, n0);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // Global loads run TWO slabs ahead of their LDS store (two register sets, the slab loop is unrolled by
+    // two): a slab lasts ~2 us and the L2/HBM latency under load is of that order - with one set the split +
+    // store of slab t+2 waited on loads issued only one slab earlier (measured: 282 -> 392 TF with the loads
+    // removed, 422 with the stores removed, i.e. a latency chain, not a throughput limit).
+    float4 ra0[ASel<AL>::type::PIECES], rb0[BSel<BL>::type::PIECES];
+    float4 ra1[ASel<AL>::type::PIECES], rb1[BSel<BL>::type::PIECES];
+    const int nslab = (kend - kbeg + BK - 1) / BK;
+    a_load<AL, true>(la, g, kbeg, kend, ra0);
+    lb.template load<true>(g, kbeg, kend, rb0);
+    a_load<AL, true>(la, g, kbeg + min(1, nslab - 1) * BK, kend, ra1);
+    lb.template load<true>(g, kbeg + min(1, nslab - 1) * BK, kend, rb1);
+    la.store2(smem2, ra0, kbeg, kend);
+    lb.store2(smem2 + X2_OPER, rb0, kbeg, kend);
+    a_load<AL, true>(la, g, kbeg + min(2, nslab - 1) * BK, kend, ra0);       // slab 2 -> set 0
+    lb.template load<true>(g, kbeg + min(2, nslab - 1) * BK, kend, rb0);
+    la.store2(smem2 + X2_SLAB, ra1, kbeg + BK, kend);
+    lb.store2(smem2 + X2_SLAB + X2_OPER, rb1, kbeg + BK, kend);
+    a_load<AL, true>(la, g, kbeg + min(3, nslab - 1) * BK, kend, ra1);       // slab 3 -> set 1
+    lb.template load<true>(g, kbeg + min(3, nslab - 1) * BK, kend, rb1);
+    __syncthreads();
+
+    const int lk = lane >> 5, l31 = lane & 31;
+    int a_off[MI], b_off[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a_off[i] = lk * X2_KG + x3_slot(wm * WM + i * 32 + l31) * 16;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) b_off[j] = X2_OPER + lk * X2_KG + x3_slot(wn * WN + j * 32 + l31) * 16;
+
+#if CIM_X2_EXP == 7    /* ablation: MFMA only (fragments stay in registers) */
+#define X2_FRAG(base, off, plane) (al[0])
+#else
+#define X2_FRAG(base, off, plane) (*reinterpret_cast<const f16x8*>((base) + (off) + (plane) * X2_PLANE))
+#endif
+#define X2_MMA(AF, BF)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i], BF[j], acc[i][j], 0, 0, 0)
+
+    // During slab t a wave (1) multiplies slab t (the two cross terms first, then h*h), (2) splits + writes
+    // slab t+2 (register set t%2, loaded during slab t-2) and issues the global loads of slab t+4 into the
+    // same set, (3) prefetches l(A) and h(B) of slab t+1 (complete since the barrier that ended slab t-1).
+    // LDS buffer (t+2)%3 was last read in slab t-1.
+    f16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#if CIM_X2_EXP == 7
+    al[0] = *reinterpret_cast<const f16x8*>(smem2 + a_off[0]);
+#endif
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bh[j] = X2_FRAG(smem2, b_off[j], 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) al[i] = X2_FRAG(smem2, a_off[i], 1);
+    int ic = 0;
+#if CIM_X2_EXP == 2 || CIM_X2_EXP == 5 || CIM_X2_EXP == 7
+#define X2_STORE_A(RA)
+#define X2_STORE_B(RB)
+#else
+#define X2_STORE_A(RA) la.store2(nx2, RA, ks, kend)
+#define X2_STORE_B(RB) lb.store2(nx2 + X2_OPER, RB, ks, kend)
+#endif
+#if CIM_X2_EXP == 3 || CIM_X2_EXP == 5 || CIM_X2_EXP == 7
+#define X2_LOAD_A(RA)
+#define X2_LOAD_B(RB)
+#else
+#define X2_LOAD_A(RA) a_load<AL, true>(la, g, kn, kend, RA)
+#define X2_LOAD_B(RB) lb.template load<true>(g, kn, kend, RB)
+#endif
+#if CIM_X2_EXP == 4 || CIM_X2_EXP == 5 || CIM_X2_EXP == 7
+#define X2_SYNC()
+#else
+#define X2_SYNC() __syncthreads()
+#endif
+#define X2_SLAB_BODY(T, RA, RB)                                                                          \
+    {                                                                                                    \
+        const int i1 = (ic == 2) ? 0 : ic + 1, i2 = (i1 == 2) ? 0 : i1 + 1;                              \
+        const char* cur = smem2 + ic * X2_SLAB;                                                          \
+        const char* nx1 = smem2 + i1 * X2_SLAB;                                                          \
+        char* nx2 = smem2 + i2 * X2_SLAB;                                                                \
+        /* third 1: l*h; fetch h(A), l(B) of this slab */                                                \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) ah[i] = X2_FRAG(cur, a_off[i], 0);                \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) bl[j] = X2_FRAG(cur, b_off[j], 1);                \
+        X2_MMA(al, bh);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        /* third 2: h*l; A of slab t+2 -> LDS, A of slab t+4 <- global */                                \
+        const int kn = kbeg + min((T) + 4, nslab - 1) * BK;                                              \
+        const int ks = kbeg + ((T) + 2) * BK;      /* first k of the slab held in RA / RB */             \
+        X2_STORE_A(RA);                                                                                  \
+        X2_LOAD_A(RA);                                                                                   \
+        X2_MMA(ah, bl);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        /* third 3: h*h; B likewise; prefetch l(A), h(B) of slab t+1 */                                  \
+        X2_STORE_B(RB);                                                                                  \
+        X2_LOAD_B(RB);                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) al[i] = X2_FRAG(nx1, a_off[i], 1);                \
+        X2_MMA(ah, bh);                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) bh[j] = X2_FRAG(nx1, b_off[j], 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        X2_SYNC();                                                                                       \
+        ic = i1;                                                                                         \
+    }
+    int t = 0;
+    for (; t + 1 < nslab; t += 2) {
+        X2_SLAB_BODY(t, ra0, rb0)
+        X2_SLAB_BODY(t + 1, ra1, rb1)
+    }
+    if (t < nslab) X2_SLAB_BODY(t, ra0, rb0)
+#undef X2_SLAB_BODY
+#undef X2_STORE_A
+#undef X2_STORE_B
+#undef X2_LOAD_A
+#undef X2_LOAD_B
+#undef X2_SYNC
+#undef X2_FRAG
+#undef X2_MMA
+
+    // epilogue: undo the operand scales (powers of two: exact), bias, ReLU
+    float* C = g.C + (size_t)zsplit * g.c_split_stride;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n >= g.N) continue;
+        const float bv = (g.bias != nullptr) ? g.bias[n] : 0.0f;
+        const float isb = x2_inv(x2_scale(g.b_amax[n]));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= g.M) continue;
+                const float isa = x2_inv(x2_scale(g.a_amax[m]));
+                float v = acc[i][j][r] * isa * isb + bv;
+                if (g.relu) v = fmaxf(v, 0.0f);
+                C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// |max| bit patterns per row and per column of X [batch][rows][ld] (cols used), accumulated with atomicMax
+// into caller-zeroed arrays; either output may be null.  Workgroup = 128 rows x 1024 columns, a lane owns
+// 4 consecutive columns: column maxima stay in registers, row maxima are wave-reduced per row.
+constexpr int AMAX_ROWS = 128;
+__global__ __launch_bounds__(256) void amax_rowcol_kernel(const float* __restrict__ X, int rows, int cols, int ld,
+                                                          long long bs, unsigned* __restrict__ row_amax,
+                                                          unsigned* __restrict__ col_amax) {
+    X += (size_t)blockIdx.z * bs;
+    const int c = blockIdx.x * 1024 + threadIdx.x * 4;
+    const int r0 = blockIdx.y * AMAX_ROWS, r1 = min(rows, r0 + AMAX_ROWS);
+    const bool cin = c < cols;
+    const float* p = X + (size_t)r0 * ld + (cin ? c : 0);
+    unsigned cx = 0, cy = 0, cz = 0, cw = 0;
+    for (int r = r0; r < r1; ++r, p += ld) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        v.x &= 0x7fffffffu; v.y &= 0x7fffffffu; v.z &= 0x7fffffffu; v.w &= 0x7fffffffu;
+        cx = max(cx, v.x); cy = max(cy, v.y); cz = max(cz, v.z); cw = max(cw, v.w);
+        if (row_amax != nullptr) {
+            unsigned m = cin ? max(max(v.x, v.y), max(v.z, v.w)) : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+            if ((threadIdx.x & 63) == 0) atomicMax(row_amax + (size_t)blockIdx.z * rows + r, m);
+        }
+    }
+    if (col_amax != nullptr && cin) {
+        unsigned* d = col_amax + (size_t)blockIdx.z * cols + c;
+        atomicMax(d, cx); atomicMax(d + 1, cy); atomicMax(d + 2, cz); atomicMax(d + 3, cw);
+    }
+}
+
 // sum split-K partials (fixed order: deterministic), add bias, optional ReLU.  One float4 per lane.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
                                                             const float* __restrict__ bias, int M, int N, int ldc,
@@ -686,11 +1015,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 int g_engine = 1;      // 0: v_mfma_f32_32x32x2_f32;  1: bf16x3 split on v_mfma_f32_32x32x16_bf16 (default)
 
 template <int AL, int BL>
-int launch(GemmArgs g, int splits, float* workspace, hipStream_t st) {
+int launch(GemmArgs g, int splits, float* workspace, hipStream_t st, int engine = -1) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
-    const bool x3 = g_engine == 1;
-    const size_t lds = x3 ? (size_t)3 * X3_SLAB : sizeof(float) * 3 * SLAB;
-    auto kern = x3 ? gemm_bf16x3_kernel<AL, BL> : gemm_f32_kernel<AL, BL>;
+    if (engine < 0) engine = g_engine;
+    const size_t lds = engine == 2 ? (size_t)3 * X2_SLAB : engine == 1 ? (size_t)3 * X3_SLAB : sizeof(float) * 3 * SLAB;
+    auto kern = engine == 1 ? gemm_bf16x3_kernel<AL, BL> : gemm_f32_kernel<AL, BL>;
+    if constexpr (AL == A_KCONTIG || AL == A_MCONTIG) {
+        if (engine == 2) kern = gemm_f16x2_kernel<AL, BL>;
+    } else if (engine == 2) {
+        return -1;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int slabs = (g.K + BK - 1) / BK;
@@ -730,7 +1064,7 @@ extern "C" int cim_gemm_set_engine(int engine) {
 
 extern "C" int cim_gemm_get_engine(void) { return g_engine; }
 
-extern "C" int cim_gemm_f32_splits(int M, int N, int K) {
+static int pick_splits(int M, int N, int K, int engine) {
     // RESIDENT 512-thread workgroups fit per CU, so a launch runs in rounds of 256*RESIDENT tiles;
     // split-K fills the last round (e.g. direct conv wgrad: 288 tiles -> 2 rounds at 56 %; x8 -> 9 full
     // rounds) but costs a workspace round trip of (2s+1)*M*N floats.  Pick the split with the least
@@ -739,6 +1073,7 @@ extern "C" int cim_gemm_f32_splits(int M, int N, int K) {
     const double tiles = (double)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int slabs = (K + BK - 1) / BK;
     const double flops = 2.0 * M * (double)N * K;
+    const double rate = engine == 2 ? 400e12 : engine == 1 ? 250e12 : 125e12;
     int best = 1;
     double best_t = 1e30;
     for (int s = 1; s <= 16; ++s) {
@@ -746,11 +1081,14 @@ extern "C" int cim_gemm_f32_splits(int M, int N, int K) {
         const double units = tiles * s;
         const double rounds = (double)(long long)((units + CUS - 1) / CUS);
         const double eff = units / (rounds * CUS);
-        const double t = flops / ((g_engine == 1 ? 250e12 : 125e12) * eff) + (s > 1 ? (2.0 * s + 1.0) * M * (double)N * 4.0 / 4e12 : 0.0);
+        const double t = flops / (rate * eff) + (s > 1 ? (2.0 * s + 1.0) * M * (double)N * 4.0 / 4e12 : 0.0);
         if (t < best_t) { best_t = t; best = s; }
     }
     return best;
 }
+
+extern "C" int cim_gemm_f32_splits(int M, int N, int K) { return pick_splits(M, N, K, g_engine); }
+extern "C" int cim_gemm_f16x2_splits(int M, int N, int K) { return pick_splits(M, N, K, 2); }
 
 extern "C" int cim_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                             int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
@@ -760,7 +1098,7 @@ extern "C" int cim_gemm_f32(const float* A, const float* B, float* C, const floa
     CIM_CHECK_ARG(a_mcontig ? (M % 4 == 0 && lda % 4 == 0 && lda >= M) : (K % 4 == 0 && lda % 4 == 0 && lda >= K));
     CIM_CHECK_ARG(b_kcontig ? (K % 4 == 0 && ldb % 4 == 0 && ldb >= K) : (ldb % 4 == 0 && ldb >= N));
     CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 0, 0, 1, 0, 0, 0};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 0, 0, 1, 0, 0, 0, nullptr, nullptr};
     hipStream_t st = cim::as_stream(stream);
     int rc;
     if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, splits, workspace, st);
@@ -776,7 +1114,7 @@ extern "C" int cim_conv3x3_f32(const float* X, const float* Whwio, const float* 
                                int Cout, int relu, void* stream) {
     CIM_CHECK_ARG(X && Whwio && Y && R > 0 && P > 0 && Cin > 0 && Cout > 0);
     CIM_CHECK_ARG(Cin % BK == 0 && Cout % 4 == 0);
-    GemmArgs g{X, Whwio, Y, bias, R * P * P, Cout, 9 * Cin, Cin, Cout, Cout, relu, 0, 0, P, Cin, 1, 0, 0, 0};
+    GemmArgs g{X, Whwio, Y, bias, R * P * P, Cout, 9 * Cin, Cin, Cout, Cout, relu, 0, 0, P, Cin, 1, 0, 0, 0, nullptr, nullptr};
     int rc = launch<A_CONV_K, B_NCONTIG>(g, 1, nullptr, cim::as_stream(stream));
     if (rc) { cim::set_error("cim_conv3x3_f32: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
@@ -788,7 +1126,7 @@ extern "C" int cim_conv3x3_wgrad_f32(const float* X, const float* dY, float* dWh
     CIM_CHECK_ARG(X && dY && dWhwio && R > 0 && P > 0 && Cin > 0 && Cout > 0);
     CIM_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0);
     CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
-    GemmArgs g{X, dY, dWhwio, nullptr, 9 * Cin, Cout, R * P * P, Cin, Cout, Cout, 0, 0, 0, P, Cin, 1, 0, 0, 0};
+    GemmArgs g{X, dY, dWhwio, nullptr, 9 * Cin, Cout, R * P * P, Cin, Cout, Cout, 0, 0, 0, P, Cin, 1, 0, 0, 0, nullptr, nullptr};
     int rc = launch<A_CONV_M, B_NCONTIG>(g, splits, workspace, cim::as_stream(stream));
     if (rc) { cim::set_error("cim_conv3x3_wgrad_f32: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
@@ -802,7 +1140,7 @@ extern "C" int cim_gemm_f32_batched(const float* A, const float* B, float* C, in
     CIM_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N && a_bs % 4 == 0 && b_bs % 4 == 0 && c_bs % 4 == 0);
     CIM_CHECK_ARG(a_mcontig ? (M % 4 == 0 && lda % 4 == 0 && lda >= M) : (K % 4 == 0 && lda % 4 == 0 && lda >= K));
     CIM_CHECK_ARG(b_kcontig ? (K % 4 == 0 && ldb % 4 == 0 && ldb >= K) : (ldb % 4 == 0 && ldb >= N));
-    GemmArgs g{A, B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, 0, batch, a_bs, b_bs, c_bs};
+    GemmArgs g{A, B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, 0, batch, a_bs, b_bs, c_bs, nullptr, nullptr};
     hipStream_t st = cim::as_stream(stream);
     int rc;
     if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, 1, nullptr, st);
@@ -810,6 +1148,58 @@ extern "C" int cim_gemm_f32_batched(const float* A, const float* B, float* C, in
     else if (a_mcontig && !b_kcontig) rc = launch<A_MCONTIG, B_NCONTIG>(g, 1, nullptr, st);
     else rc = launch<A_MCONTIG, B_KCONTIG>(g, 1, nullptr, st);
     if (rc) { cim::set_error("cim_gemm_f32_batched: launch setup failed (%d)", rc); return rc; }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_amax_rowcol(const float* X, int rows, int cols, int ld, int batch, long long bs,
+                               uint32_t* row_amax, uint32_t* col_amax, void* stream) {
+    CIM_CHECK_ARG(X && rows > 0 && cols > 0 && batch > 0 && batch <= 65535);
+    CIM_CHECK_ARG(cols % 4 == 0 && ld % 4 == 0 && ld >= cols && bs % 4 == 0);
+    CIM_CHECK_ARG(row_amax != nullptr || col_amax != nullptr);
+    const dim3 grid((cols + 1023) / 1024, (rows + AMAX_ROWS - 1) / AMAX_ROWS, batch);
+    CIM_CHECK_ARG(grid.y <= 65535);
+    hipLaunchKernelGGL(amax_rowcol_kernel, grid, dim3(256), 0, cim::as_stream(stream), X, rows, cols, ld, bs, row_amax,
+                       col_amax);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_gemm_f16x2(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                              int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
+                              const uint32_t* a_amax, const uint32_t* b_amax, void* stream) {
+    CIM_CHECK_ARG(A && B && C && a_amax && b_amax && M > 0 && N > 0 && K > 0);
+    CIM_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N);
+    CIM_CHECK_ARG(a_mcontig ? (M % 4 == 0 && lda % 4 == 0 && lda >= M) : (K % 4 == 0 && lda % 4 == 0 && lda >= K));
+    CIM_CHECK_ARG(b_kcontig ? (K % 4 == 0 && ldb % 4 == 0 && ldb >= K) : (ldb % 4 == 0 && ldb >= N));
+    CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 0, 0, 1, 0, 0, 0, a_amax, b_amax};
+    hipStream_t st = cim::as_stream(stream);
+    int rc;
+    if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, splits, workspace, st, 2);
+    else if (!a_mcontig && b_kcontig) rc = launch<A_KCONTIG, B_KCONTIG>(g, splits, workspace, st, 2);
+    else if (a_mcontig && !b_kcontig) rc = launch<A_MCONTIG, B_NCONTIG>(g, splits, workspace, st, 2);
+    else rc = launch<A_MCONTIG, B_KCONTIG>(g, splits, workspace, st, 2);
+    if (rc) { cim::set_error("cim_gemm_f16x2: launch setup failed (%d)", rc); return rc; }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                                      int ldc, int a_mcontig, int b_kcontig, int batch, long long a_bs, long long b_bs,
+                                      long long c_bs, const uint32_t* a_amax, const uint32_t* b_amax, void* stream) {
+    CIM_CHECK_ARG(A && B && C && a_amax && b_amax && M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535);
+    CIM_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N && a_bs % 4 == 0 && b_bs % 4 == 0 && c_bs % 4 == 0);
+    CIM_CHECK_ARG(a_mcontig ? (M % 4 == 0 && lda % 4 == 0 && lda >= M) : (K % 4 == 0 && lda % 4 == 0 && lda >= K));
+    CIM_CHECK_ARG(b_kcontig ? (K % 4 == 0 && ldb % 4 == 0 && ldb >= K) : (ldb % 4 == 0 && ldb >= N));
+    GemmArgs g{A, B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, 0, batch, a_bs, b_bs, c_bs, a_amax, b_amax};
+    hipStream_t st = cim::as_stream(stream);
+    int rc;
+    if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, 1, nullptr, st, 2);
+    else if (!a_mcontig && b_kcontig) rc = launch<A_KCONTIG, B_KCONTIG>(g, 1, nullptr, st, 2);
+    else if (a_mcontig && !b_kcontig) rc = launch<A_MCONTIG, B_NCONTIG>(g, 1, nullptr, st, 2);
+    else rc = launch<A_MCONTIG, B_KCONTIG>(g, 1, nullptr, st, 2);
+    if (rc) { cim::set_error("cim_gemm_f16x2_batched: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;
 }

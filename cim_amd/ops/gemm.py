@@ -18,15 +18,45 @@ def _ws(m, n, splits, like):
     return torch.empty(splits * m * n, dtype=torch.float32, device=like.device) if splits > 1 else None
 
 
-def gemm(a, b, m, n, k, lda, ldb, a_mcontig=False, b_kcontig=False, bias=None, relu=False, out=None):
-    """C[m,n] = A.B (+bias)(ReLU).  a/b are dense device tensors interpreted by the layout flags."""
+# Arithmetic engine of the contractions: "f16x2" (default: scaled two-term fp16 split,
+# 3 MFMA products), "bf16x3" (exact three-term bf16 split, 6 products), "fp32" (f32 MFMA multiplies).
+ENGINE = os.environ.get("CIM_GEMM_ENGINE", "f16x2")
+if ENGINE not in ("f16x2", "bf16x3", "fp32"):
+    raise _lib.CimHipError("CIM_GEMM_ENGINE must be f16x2, bf16x3 or fp32, got %r" % ENGINE)
+
+
+def amax(x, rows, cols, ld, want_rows=False, want_cols=False, batch=1, bs=0):
+    """|max| bit patterns of a stored [batch][rows][ld] fp32 matrix: per row (over its columns) and / or per
+    column (over its rows), ONE pass over x.  These are the operand scales of the f16x2 engine: an operand
+    read K-contiguously takes the per-row array, one read M/N-contiguously the per-column array."""
+    ra = torch.zeros(batch * rows, dtype=torch.int32, device=x.device) if want_rows else None
+    ca = torch.zeros(batch * cols, dtype=torch.int32, device=x.device) if want_cols else None
+    _lib.call("cim_amax_rowcol", x.data_ptr(), rows, cols, ld, batch, bs, _lib.ptr(ra), _lib.ptr(ca), _lib.stream_ptr())
+    return ra, ca
+
+
+def gemm(a, b, m, n, k, lda, ldb, a_mcontig=False, b_kcontig=False, bias=None, relu=False, out=None,
+         a_amax=None, b_amax=None):
+    """C[m,n] = A.B (+bias)(ReLU).  a/b are dense device tensors interpreted by the layout flags.
+    a_amax / b_amax: operand scales from amax() when the caller already has them (f16x2 engine)."""
     if not a.is_cuda:
         raise _lib.CimHipError("cim_amd.ops.gemm: CUDA/HIP tensors required (no CPU fallback)")
     c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=a.device)
-    splits = _lib.call("cim_gemm_f32_splits", m, n, k)
+    if ENGINE != "f16x2":
+        splits = _lib.call("cim_gemm_f32_splits", m, n, k)
+        ws = _ws(m, n, splits, a)
+        _lib.call("cim_gemm_f32", a.data_ptr(), b.data_ptr(), c.data_ptr(), _lib.ptr(bias), m, n, k, lda, ldb, n,
+                  int(a_mcontig), int(b_kcontig), int(relu), splits, _lib.ptr(ws), _lib.stream_ptr())
+        return c
+    if a_amax is None:
+        a_amax = amax(a, k, m, lda, want_cols=True)[1] if a_mcontig else amax(a, m, k, lda, want_rows=True)[0]
+    if b_amax is None:
+        b_amax = amax(b, n, k, ldb, want_rows=True)[0] if b_kcontig else amax(b, k, n, ldb, want_cols=True)[1]
+    splits = _lib.call("cim_gemm_f16x2_splits", m, n, k)
     ws = _ws(m, n, splits, a)
-    _lib.call("cim_gemm_f32", a.data_ptr(), b.data_ptr(), c.data_ptr(), _lib.ptr(bias), m, n, k, lda, ldb, n,
-              int(a_mcontig), int(b_kcontig), int(relu), splits, _lib.ptr(ws), _lib.stream_ptr())
+    _lib.call("cim_gemm_f16x2", a.data_ptr(), b.data_ptr(), c.data_ptr(), _lib.ptr(bias), m, n, k, lda, ldb, n,
+              int(a_mcontig), int(b_kcontig), int(relu), splits, _lib.ptr(ws), a_amax.data_ptr(), b_amax.data_ptr(),
+              _lib.stream_ptr())
     return c
 
 
@@ -39,8 +69,13 @@ class LinearFunction(Function):
         w = w.contiguous()
         m, k = x.shape
         n = w.shape[0]
-        y = gemm(x, w, m, n, k, k, k, b_kcontig=True, bias=b, relu=relu)
+        xr = xc = wr = wc = None
+        if ENGINE == "f16x2":        # one pass per operand: the row scales serve this product, the column scales the backward
+            xr, xc = amax(x, m, k, k, True, ctx.needs_input_grad[1])
+            wr, wc = amax(w, n, k, k, True, ctx.needs_input_grad[0])
+        y = gemm(x, w, m, n, k, k, k, b_kcontig=True, bias=b, relu=relu, a_amax=xr, b_amax=wr)
         ctx.save_for_backward(x, w, y if relu else None)
+        ctx.scales = (xc, wc)
         ctx.relu = relu
         ctx.has_bias = b is not None
         return y
@@ -54,18 +89,33 @@ class LinearFunction(Function):
         if ctx.relu:
             dy = dy * (y > 0)
         dx = dw = db = None
+        xc, wc = ctx.scales
+        dr = dc = None
+        if ENGINE == "f16x2":
+            dr, dc = amax(dy, m, n, n, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if ctx.needs_input_grad[0]:
-            dx = gemm(dy, w, m, k, n, n, k)                                    # dY[M,N] . W[N,K]
+            dx = gemm(dy, w, m, k, n, n, k, a_amax=dr, b_amax=wc)              # dY[M,N] . W[N,K]
         if ctx.needs_input_grad[1]:
-            dw = gemm(dy, x, n, k, m, n, k, a_mcontig=True)                    # dY^T[N,M] . X[M,K]
+            dw = gemm(dy, x, n, k, m, n, k, a_mcontig=True, a_amax=dc, b_amax=xc)   # dY^T[N,M] . X[M,K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=0)
         return dx, dw, db, None
 
 
-def _bgemm(a, b, c, m, n, k, lda, ldb, a_mcontig, batch, a_bs, b_bs, c_bs):
-    _lib.call("cim_gemm_f32_batched", a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, lda, ldb, n,
-              int(a_mcontig), 0, batch, a_bs, b_bs, c_bs, _lib.stream_ptr())
+def _bgemm(a, b, c, m, n, k, lda, ldb, a_mcontig, batch, a_bs, b_bs, c_bs, a_amax=None, b_amax=None):
+    """`batch` GEMMs C[i] = A[i] . B[i] (B N-contiguous).  a_amax: per-row scales of A ([batch, m]: rows of a
+    K-contiguous A, columns of the stored matrix for an M-contiguous one); b_amax: per-column scales [batch, n]."""
+    if ENGINE != "f16x2":
+        _lib.call("cim_gemm_f32_batched", a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, lda, ldb, n,
+                  int(a_mcontig), 0, batch, a_bs, b_bs, c_bs, _lib.stream_ptr())
+        return
+    if a_amax is None:
+        a_amax = (amax(a, k, m, lda, want_cols=True, batch=batch, bs=a_bs)[1] if a_mcontig
+                  else amax(a, m, k, lda, want_rows=True, batch=batch, bs=a_bs)[0])
+    if b_amax is None:
+        b_amax = amax(b, k, n, ldb, want_cols=True, batch=batch, bs=b_bs)[1]
+    _lib.call("cim_gemm_f16x2_batched", a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, lda, ldb, n,
+              int(a_mcontig), 0, batch, a_bs, b_bs, c_bs, a_amax.data_ptr(), b_amax.data_ptr(), _lib.stream_ptr())
 
 
 CONV_ALGO = os.environ.get("CIM_CONV_ALGO", "winograd4")    # "winograd4" (F(4x4,3x3), default) | "winograd" (F(2x2,3x3)) | "direct"
@@ -101,7 +151,10 @@ class Conv3x3Function(Function):
             M = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
             _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), r, p, cin, tile, st)
             _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), cout, cin, 0, tile, st)
-            _bgemm(V, U, M, mt, cout, cin, cin, cout, False, npos, mt * cin, cin * cout, mt * cout)
+            vr = None
+            if ENGINE == "f16x2":    # one pass over V: row scales for this product, column scales for the weight gradient
+                vr, ctx.v_cols = amax(V, mt, cin, cin, True, ctx.needs_input_grad[1], batch=npos, bs=mt * cin)
+            _bgemm(V, U, M, mt, cout, cin, cin, cout, False, npos, mt * cin, cin * cout, mt * cout, a_amax=vr)
             _lib.call("cim_wino_output_transform", M.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cout, int(relu), tile, st)
         else:
             whwio = w.permute(2, 3, 1, 0).contiguous()
@@ -151,7 +204,8 @@ class Conv3x3Function(Function):
                 dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
                 _lib.call("cim_wino_dy_transform", dy.data_ptr(), D.data_ptr(), r, p, cout, tile, st)
                 # dU[pos] = V[pos]^T . D[pos]:  A = V[pos] read M-contiguously (element (ci, m) at V[m*Cin + ci])
-                _bgemm(V, D, dU, cin, cout, mt, cin, cout, True, npos, mt * cin, mt * cout, cin * cout)
+                _bgemm(V, D, dU, cin, cout, mt, cin, cout, True, npos, mt * cin, mt * cout, cin * cout,
+                       a_amax=getattr(ctx, "v_cols", None))
                 _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, tile, st)
             else:
                 m, n, k = 9 * cin, cout, r * p * p

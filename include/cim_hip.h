@@ -167,6 +167,29 @@ int cim_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N,
                          int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
                          int batch, long long a_bs, long long b_bs, long long c_bs, void* stream);
 
+/* f16x2 engine (the host's default, CIM_GEMM_ENGINE=f16x2): the same contractions as cim_gemm_f32 /
+ * cim_gemm_f32_batched with every fp32 operand scaled by a power of two per A row / per B column and split
+ * into TWO fp16 terms (x*s = h + l, 23 significant bits), evaluated as the three products hl + lh + hh on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation and rescaled exactly in the epilogue.  Error bound of an
+ * fp32 GEMM relative to |a_row|*|b_col| (dropped l*l term <= 2^-22, rms 2^-25.6, per product); half the MFMA
+ * work of the bf16x3 engine.
+ *
+ * cim_amax_rowcol: X is a stored [batch][rows][ld] fp32 matrix (cols used).  row_amax [batch*rows] /
+ * col_amax [batch*cols] (either may be NULL) receive max |x| as IEEE bit patterns through atomicMax, so the
+ * CALLER ZEROES them first.  One pass over X serves both orientations of the operand.
+ * a_amax [batch][M]: the row array of a K-contiguous A, the column array of the stored matrix of an
+ * M-contiguous A;  b_amax [batch][N]: the column array of an N-contiguous B, the row array of a K-contiguous B. */
+int cim_amax_rowcol(const float* X, int rows, int cols, int ld, int batch, long long bs,
+                    uint32_t* row_amax, uint32_t* col_amax, void* stream);
+int cim_gemm_f16x2_splits(int M, int N, int K);
+int cim_gemm_f16x2(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                   int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu,
+                   int splits, float* workspace, const uint32_t* a_amax, const uint32_t* b_amax, void* stream);
+int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int N, int K,
+                           int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
+                           int batch, long long a_bs, long long b_bs, long long c_bs,
+                           const uint32_t* a_amax, const uint32_t* b_amax, void* stream);
+
 /* Winograd F(2x2,3x3) evaluation of the same 3x3 / stride 1 / pad 1 convolution (fp32 throughout,
  * 1.72x fewer multiplies at P = 7): T = ceil(P/2) tiles per side, 16 transform positions.
  *   cim_wino_input_transform : x [R,P,P,C]            -> V [16][R*T*T][C]       (B^T d B)

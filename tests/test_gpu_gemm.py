@@ -21,6 +21,24 @@ def _rel(a, ref):
     return float((a.double() - ref).abs().max() / ref.abs().max())
 
 
+class _engine:
+    """Run the wrapped block on one arithmetic engine of the contraction library."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        from cim_amd import _lib
+        from cim_amd.ops import gemm as G
+        self.G, self.lib, self.saved = G, _lib, (G.ENGINE, _lib.call("cim_gemm_get_engine"))
+        G.ENGINE = self.name
+        _lib.call("cim_gemm_set_engine", 0 if self.name == "fp32" else 1)
+
+    def __exit__(self, *exc):
+        self.G.ENGINE = self.saved[0]
+        self.lib.call("cim_gemm_set_engine", self.saved[1])
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 4096, 4096), (300, 260, 1000), (37, 8, 20), (513, 516, 48), (256, 256, 16)])
 @pytest.mark.parametrize("a_m,b_k", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_layouts_vs_fp64(dev, M, N, K, a_m, b_k):
@@ -46,6 +64,10 @@ def test_gemm_is_asymmetric_and_deterministic(dev):
     n = 320
     B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 1000.0
     c = G.gemm(torch.eye(n).to(dev), B.to(dev), n, n, n, n, n)
+    if G.ENGINE == "f16x2":      # the two-term split carries 23 of fp32's 24 significant bits: I.B is within 1 ulp of B
+        assert float(((c.cpu() - B).abs() / B.clamp(min=1e-30)).max()) <= 2.0 ** -23
+        with _engine("bf16x3"):
+            c = G.gemm(torch.eye(n).to(dev), B.to(dev), n, n, n, n, n)
     assert torch.equal(c.cpu(), B)
     g = torch.Generator().manual_seed(1)
     A = torch.randn(200, 50176, generator=g).to(dev)          # fc1-like: few tiles, long K -> split-K
@@ -56,47 +78,89 @@ def test_gemm_is_asymmetric_and_deterministic(dev):
     assert _rel(y1.cpu(), A.cpu().double() @ W.cpu().double().t()) < 3e-5   # K = 50176: fp32 accumulation error grows with K
 
 
+def test_default_engine_is_f16x2():
+    from cim_amd.ops import gemm as G
+    import os
+    assert G.ENGINE == os.environ.get("CIM_GEMM_ENGINE", "f16x2")
+
+
 @pytest.mark.parametrize("K", [2048, 50176])
-def test_bf16x3_error_class(dev, K):
-    """The default engine (fp32 operands split exactly into 3 bf16 terms, 6 MFMA products, fp32
-    accumulate) must sit in the same error class as the f32-multiply MFMA engine against fp64, on
-    unit-variance data and on data with a large dynamic range (exponents spread over 2^+-20)."""
-    from cim_amd import _lib
+def test_split_engines_error_class(dev, K):
+    """The split engines (f16x2: scaled two-term fp16 split, 3 MFMA products; bf16x3: exact three-term bf16
+    split, 6 products; both fp32 accumulate) must sit in the same error class as the f32-multiply MFMA engine
+    against fp64, on unit-variance data, on data with a large dynamic range (exponents spread over 2^+-20)
+    and on operands whose rows / columns differ in magnitude by 2^+-30 (the per-row / per-column scales)."""
     from cim_amd.ops import gemm as G
     g = torch.Generator().manual_seed(K)
     M = N = 256
-    for spread in (0.0, 20.0):
-        A = torch.randn(M, K, generator=g) * torch.exp2(spread * (torch.rand(M, K, generator=g) - 0.5))
-        B = torch.randn(K, N, generator=g) * torch.exp2(spread * (torch.rand(K, N, generator=g) - 0.5))
+    for case in ("unit", "spread", "rowscale"):
+        A = torch.randn(M, K, generator=g)
+        B = torch.randn(K, N, generator=g)
+        if case == "spread":
+            A = A * torch.exp2(20.0 * (torch.rand(M, K, generator=g) - 0.5))
+            B = B * torch.exp2(20.0 * (torch.rand(K, N, generator=g) - 0.5))
+        if case == "rowscale":
+            A = A * torch.exp2(torch.randint(-30, 31, (M, 1), generator=g).float())
+            B = B * torch.exp2(torch.randint(-30, 31, (1, N), generator=g).float())
         ref = A.double() @ B.double()
-        scale = (A.double().abs() @ B.double().abs())            # condition-aware error scale
+        scale = (A.double().abs() @ B.double().abs())            # condition-aware (componentwise) error scale
         err = {}
-        try:
-            for engine in (0, 1):
-                _lib.call("cim_gemm_set_engine", engine)
+        for engine in ("fp32", "bf16x3", "f16x2"):
+            with _engine(engine):
                 c = G.gemm(A.to(dev), B.to(dev), M, N, K, K, N)
-                err[engine] = float(((c.cpu().double() - ref).abs() / scale).max())
-        finally:
-            _lib.call("cim_gemm_set_engine", 1)
-        assert err[0] < 2e-6 and err[1] < 2e-6, err               # both far below fp32 eps * sqrt(K)
-        assert err[1] < 2.0 * err[0] + 1e-8, err
+            err[engine] = float(((c.cpu().double() - ref).abs() / scale).max())
+        assert max(err.values()) < 2e-6, (case, err)             # all far below fp32 eps * sqrt(K)
+        assert err["bf16x3"] < 2.0 * err["fp32"] + 1e-8, (case, err)
+        assert err["f16x2"] < 2.0 * err["fp32"] + 1e-7, (case, err)
 
 
-def test_bf16x3_exact_on_bf16_representable(dev):
-    """Operands that are sums of three bf16 terms with small-integer products are reproduced exactly:
-    checks the split (h, m, l planes), the swizzled LDS layout and the k-pair packing of every loader."""
+def test_f16x2_small_elements_below_row_max(dev):
+    """Elements 2^-17 .. 2^-30 below their row / column maximum land in fp16's subnormal range after scaling:
+    they keep an absolute accuracy of ~2^-40 of that maximum (nothing is flushed to zero)."""
+    from cim_amd.ops import gemm as G
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 256, 256, 512
+    A = torch.randn(M, K, generator=g) * torch.exp2(-torch.randint(17, 31, (M, K), generator=g).float())
+    B = torch.randn(K, N, generator=g)
+    A[:, 0] = 1.0                                                # the row maximum
+    B[0, :] = 0.0                                                # ... multiplies zero: only the small elements contribute
+    ref = A.double() @ B.double()
+    with _engine("f16x2"):
+        c = G.gemm(A.to(dev), B.to(dev), M, N, K, K, N)
+    # error budget: K elements x 2^-25 (half a subnormal step at scale 2^14) / 2^14 x |b| ~ K * 2^-39 * 4
+    assert float((c.cpu().double() - ref).abs().max()) < K * 2.0 ** -39 * 6
+    assert float((c.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-3      # and they are NOT flushed
+
+
+@pytest.mark.parametrize("engine", ["bf16x3", "f16x2"])
+def test_split_engines_exact_on_representable(dev, engine):
+    """Operands whose split terms have small-integer products are reproduced exactly:
+    checks the split planes, the swizzled LDS layout, the scales and the k-pair packing of every loader."""
     from cim_amd.ops import gemm as G
     g = torch.Generator().manual_seed(5)
     M, N, K = 300, 264, 176
     A = torch.randint(-8, 9, (M, K), generator=g).float() + torch.randint(-8, 9, (M, K), generator=g).float() / 4096.0
     B = torch.randint(-8, 9, (K, N), generator=g).float()
     ref = (A.double() @ B.double())
-    for a_m in (0, 1):
-        for b_k in (0, 1):
-            a_dev = (A.t().contiguous() if a_m else A).to(dev)
-            b_dev = (B.t().contiguous() if b_k else B).to(dev)
-            c = G.gemm(a_dev, b_dev, M, N, K, M if a_m else K, K if b_k else N, bool(a_m), bool(b_k))
-            assert torch.equal(c.cpu().double(), ref), (a_m, b_k)
+    with _engine(engine):
+        for a_m in (0, 1):
+            for b_k in (0, 1):
+                a_dev = (A.t().contiguous() if a_m else A).to(dev)
+                b_dev = (B.t().contiguous() if b_k else B).to(dev)
+                c = G.gemm(a_dev, b_dev, M, N, K, M if a_m else K, K if b_k else N, bool(a_m), bool(b_k))
+                assert torch.equal(c.cpu().double(), ref), (a_m, b_k)
+
+
+def test_amax_rowcol(dev):
+    from cim_amd.ops import gemm as G
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 301, 1100, generator=g)
+    x[1, 7, :] = 0.0
+    xd = x.to(dev)[:, :, :1028].contiguous()
+    x = x[:, :, :1028]
+    ra, ca = G.amax(xd, 301, 1028, 1028, True, True, batch=3, bs=301 * 1028)
+    assert torch.equal(ra.view(torch.float32).cpu().view(3, 301), x.abs().amax(dim=2))
+    assert torch.equal(ca.view(torch.float32).cpu().view(3, 1028), x.abs().amax(dim=1))
 
 
 @pytest.mark.parametrize("algo", ["winograd", "winograd4", "direct"])
