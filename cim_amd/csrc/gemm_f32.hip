@@ -961,9 +961,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_f16x2_kernel(const GemmArgs g_in) 
 }
 
 // |max| bit patterns per row and per column of X [batch][rows][ld] (cols used), accumulated with atomicMax
-// into caller-zeroed arrays; either output may be null.  Workgroup = 128 rows x 1024 columns, a lane owns
-// 4 consecutive columns: column maxima stay in registers, row maxima are wave-reduced per row.
-constexpr int AMAX_ROWS = 128;
+// into caller-zeroed arrays; either output may be null.  Workgroup = AMAX_ROWS rows x 1024 columns, a lane owns
+// 4 consecutive columns: column maxima stay in registers, row maxima are wave-reduced per row.  Four rows are
+// in flight per lane (4 x 16 B loads issued together) - the kernel is a pure HBM stream.
+constexpr int AMAX_ROWS = 64;
+__device__ __forceinline__ unsigned amax_wave(unsigned m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    return m;
+}
 __global__ __launch_bounds__(256) void amax_rowcol_kernel(const float* __restrict__ X, int rows, int cols, int ld,
                                                           long long bs, unsigned* __restrict__ row_amax,
                                                           unsigned* __restrict__ col_amax) {
@@ -972,21 +978,39 @@ __global__ __launch_bounds__(256) void amax_rowcol_kernel(const float* __restric
     const int r0 = blockIdx.y * AMAX_ROWS, r1 = min(rows, r0 + AMAX_ROWS);
     const bool cin = c < cols;
     const float* p = X + (size_t)r0 * ld + (cin ? c : 0);
-    unsigned cx = 0, cy = 0, cz = 0, cw = 0;
-    for (int r = r0; r < r1; ++r, p += ld) {
+    unsigned* ra = row_amax ? row_amax + (size_t)blockIdx.z * rows : nullptr;
+    const bool lead = (threadIdx.x & 63) == 0;
+    uint4 cm = make_uint4(0, 0, 0, 0);
+    int r = r0;
+    for (; r + 4 <= r1; r += 4, p += 4 * (size_t)ld) {
+        uint4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const uint4*>(p + (size_t)i * ld);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i].x &= 0x7fffffffu; v[i].y &= 0x7fffffffu; v[i].z &= 0x7fffffffu; v[i].w &= 0x7fffffffu;
+            cm.x = max(cm.x, v[i].x); cm.y = max(cm.y, v[i].y); cm.z = max(cm.z, v[i].z); cm.w = max(cm.w, v[i].w);
+        }
+        if (ra != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned m = amax_wave(cin ? max(max(v[i].x, v[i].y), max(v[i].z, v[i].w)) : 0u);
+                if (lead) atomicMax(ra + r + i, m);
+            }
+        }
+    }
+    for (; r < r1; ++r, p += ld) {
         uint4 v = *reinterpret_cast<const uint4*>(p);
         v.x &= 0x7fffffffu; v.y &= 0x7fffffffu; v.z &= 0x7fffffffu; v.w &= 0x7fffffffu;
-        cx = max(cx, v.x); cy = max(cy, v.y); cz = max(cz, v.z); cw = max(cw, v.w);
-        if (row_amax != nullptr) {
-            unsigned m = cin ? max(max(v.x, v.y), max(v.z, v.w)) : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-            if ((threadIdx.x & 63) == 0) atomicMax(row_amax + (size_t)blockIdx.z * rows + r, m);
+        cm.x = max(cm.x, v.x); cm.y = max(cm.y, v.y); cm.z = max(cm.z, v.z); cm.w = max(cm.w, v.w);
+        if (ra != nullptr) {
+            const unsigned m = amax_wave(cin ? max(max(v.x, v.y), max(v.z, v.w)) : 0u);
+            if (lead) atomicMax(ra + r, m);
         }
     }
     if (col_amax != nullptr && cin) {
         unsigned* d = col_amax + (size_t)blockIdx.z * cols + c;
-        atomicMax(d, cx); atomicMax(d + 1, cy); atomicMax(d + 2, cz); atomicMax(d + 3, cw);
+        atomicMax(d, cm.x); atomicMax(d + 1, cm.y); atomicMax(d + 2, cm.z); atomicMax(d + 3, cm.w);
     }
 }
 

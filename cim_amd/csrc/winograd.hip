@@ -211,13 +211,22 @@ __global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __rest
 #include "wino43_mats.h"
 
 __device__ __forceinline__ float2 f2(float v) { return make_float2(v, v); }
-__device__ __forceinline__ void fma2(float2& a, float s, float2 v) { a.x += s * v.x; a.y += s * v.y; }
+__device__ __forceinline__ void fma2(float2& a, float s, float2 v) { a.x = fmaf(s, v.x, a.x); a.y = fmaf(s, v.y, a.y); }
 
+// AMAX: also emit row_amax[pos][m] = max |V[pos][m][:]| as IEEE bit patterns (the f16x2 GEMM engine's per-row
+// operand scales, cim_hip.h): a workgroup owns the whole row m of all 36 positions, so the maxima are plain
+// stores (no atomics, no zero-fill) after one transposing reduction through LDS.
+template <bool AMAX>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int R, int P,
-                                                           int T, int C) {
+                                                           int T, int C, unsigned* __restrict__ row_amax) {
     const int m = blockIdx.x;
     const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
     const size_t MC = (size_t)R * T * T * C;
+    unsigned rm[AMAX ? 36 : 1];
+    if constexpr (AMAX) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) rm[i] = 0u;
+    }
     for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
         float2 d[6][6];
 #pragma unroll
@@ -248,9 +257,54 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
                 for (int k = 0; k < 6; ++k)
                     if (W43_BT[j][k] != 0.0f) fma2(v, W43_BT[j][k], trow[k]);
                 *reinterpret_cast<float2*>(V + (size_t)(i * 6 + j) * MC + (size_t)m * C + c) = v;
+                if constexpr (AMAX)
+                    rm[i * 6 + j] = max(rm[i * 6 + j], max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu));
             }
         }
     }
+    if constexpr (AMAX) {
+        __shared__ unsigned red[36][257];
+        __shared__ unsigned red2[36][8];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) red[i][threadIdx.x] = rm[i];
+        __syncthreads();
+        if (threadIdx.x < 36 * 7) {                       // 7 lanes per position, 37 candidates each
+            const int pos = threadIdx.x / 7, seg = threadIdx.x % 7;
+            unsigned v = 0u;
+            for (int k = seg * 37; k < min(256, seg * 37 + 37); ++k) v = max(v, red[pos][k]);
+            red2[pos][seg] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 36) {
+            unsigned v = 0u;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) v = max(v, red2[threadIdx.x][k]);
+            row_amax[(size_t)threadIdx.x * ((size_t)R * T * T) + m] = v;
+        }
+    }
+}
+
+// Column-scale bounds of a Winograd-domain operand from the |max| of the untransformed tensor:
+//   |(L d L^T)[i][j]| <= (sum_k |L[i][k]|) (sum_k |L[j][k]|) max|d|      (L = B^T, G or G4)
+// out[pos][n] = bits(f_pos * max_{t < group} float(in[n * group + t])).  The bound exceeds the true column
+// maximum by a small factor only (<= 49, typically ~5): the f16x2 engine needs an UPPER bound within a few bits.
+__global__ __launch_bounds__(256) void wino43_bound_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n,
+                                                           int group, int kind) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.0f;
+    for (int t = 0; t < group; ++t) a = fmaxf(a, __uint_as_float(in[(size_t)i * group + t]));
+    float f[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        float sum = 0.0f;
+        if (kind == 0) { for (int k = 0; k < 6; ++k) sum += fabsf(W43_BT[p][k]); }
+        else if (kind == 1) { for (int k = 0; k < 3; ++k) sum += fabsf(W43_G[p][k]); }
+        else { for (int k = 0; k < 4; ++k) sum += fabsf(W43_G4[p][k]); }
+        f[p] = sum;
+    }
+#pragma unroll
+    for (int p = 0; p < 36; ++p) out[(size_t)p * n + i] = __float_as_uint(f[p / 6] * f[p % 6] * a * 1.0001f);
 }
 
 __global__ __launch_bounds__(256) void wino43_filter_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
@@ -399,8 +453,27 @@ extern "C" int cim_wino_input_transform(const float* x, float* V, int R, int P, 
     WINO_TILE_OK();
     CIM_CHECK_ARG(x && V);
     const int T = (P + tile - 1) / tile;
-    if (tile == 4) hipLaunchKernelGGL(wino43_input_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C);
+    if (tile == 4) hipLaunchKernelGGL(wino43_input_kernel<false>, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C, (unsigned*)nullptr);
     else hipLaunchKernelGGL(wino_input_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_input_transform_amax(const float* x, float* V, uint32_t* row_amax, int R, int P, int C, int tile,
+                                             void* stream) {
+    WINO_GEOM_OK();
+    CIM_CHECK_ARG(x && V && row_amax && tile == 4);
+    const int T = (P + 3) / 4;
+    hipLaunchKernelGGL(wino43_input_kernel<true>, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C, row_amax);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_scale_bounds(const uint32_t* amax_in, uint32_t* bounds, int n, int group, int kind, int tile,
+                                     void* stream) {
+    CIM_CHECK_ARG(amax_in && bounds && n > 0 && group > 0 && kind >= 0 && kind <= 2 && tile == 4);
+    hipLaunchKernelGGL(wino43_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax_in, bounds, n,
+                       group, kind);
     CIM_CHECK_LAUNCH();
     return 0;
 }

@@ -118,6 +118,13 @@ def _bgemm(a, b, c, m, n, k, lda, ldb, a_mcontig, batch, a_bs, b_bs, c_bs, a_ama
               int(a_mcontig), 0, batch, a_bs, b_bs, c_bs, a_amax.data_ptr(), b_amax.data_ptr(), _lib.stream_ptr())
 
 
+def _bounds(amax_in, n, group, kind, npos, dev):
+    """[npos, n] column-scale bounds of a Winograd-domain operand from the |max| of the untransformed tensor."""
+    out = torch.empty(npos * n, dtype=torch.int32, device=dev)
+    _lib.call("cim_wino_scale_bounds", amax_in.data_ptr(), out.data_ptr(), n, group, kind, 4, _lib.stream_ptr())
+    return out
+
+
 CONV_ALGO = os.environ.get("CIM_CONV_ALGO", "winograd4")    # "winograd4" (F(4x4,3x3), default) | "winograd" (F(2x2,3x3)) | "direct"
 
 
@@ -149,12 +156,25 @@ class Conv3x3Function(Function):
             V = torch.empty((npos, mt, cin), dtype=torch.float32, device=dev)
             U = torch.empty((npos, cin, cout), dtype=torch.float32, device=dev)
             M = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
-            _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), r, p, cin, tile, st)
+            vr = uc = None
+            ctx.fused_scales = ENGINE == "f16x2" and tile == 4
+            if ctx.fused_scales:
+                # operand scales of the f16x2 engine without a pass over the 1.2 GB transformed tensors: row maxima of
+                # V come out of the transform kernel itself; column scales are BOUNDS from the |max| of the
+                # untransformed tensors (x per channel, w per filter) times the transform's absolute row sums
+                vr = torch.empty(npos * mt, dtype=torch.int32, device=dev)
+                _lib.call("cim_wino_input_transform_amax", x.data_ptr(), V.data_ptr(), vr.data_ptr(), r, p, cin, tile, st)
+                w_rows, w_cols = amax(w, cout, cin * 9, cin * 9, True, ctx.needs_input_grad[0])
+                uc = _bounds(w_rows, cout, 1, 1, npos, dev)
+                ctx.w_cols = w_cols
+                if ctx.needs_input_grad[1]:
+                    ctx.v_cols = _bounds(amax(x, r * p * p, cin, cin, want_cols=True)[1], cin, 1, 0, npos, dev)
+            else:
+                _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), r, p, cin, tile, st)
+                if ENGINE == "f16x2":    # one pass over V: row scales for this product, column scales for the weight gradient
+                    vr, ctx.v_cols = amax(V, mt, cin, cin, True, ctx.needs_input_grad[1], batch=npos, bs=mt * cin)
             _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), cout, cin, 0, tile, st)
-            vr = None
-            if ENGINE == "f16x2":    # one pass over V: row scales for this product, column scales for the weight gradient
-                vr, ctx.v_cols = amax(V, mt, cin, cin, True, ctx.needs_input_grad[1], batch=npos, bs=mt * cin)
-            _bgemm(V, U, M, mt, cout, cin, cin, cout, False, npos, mt * cin, cin * cout, mt * cout, a_amax=vr)
+            _bgemm(V, U, M, mt, cout, cin, cin, cout, False, npos, mt * cin, cin * cout, mt * cout, a_amax=vr, b_amax=uc)
             _lib.call("cim_wino_output_transform", M.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cout, int(relu), tile, st)
         else:
             whwio = w.permute(2, 3, 1, 0).contiguous()
@@ -182,6 +202,7 @@ class Conv3x3Function(Function):
         npos = (tile + 2) ** 2
         t = (p + tile - 1) // tile
         mt = r * t * t
+        fused = wino and getattr(ctx, "fused_scales", False)
         if ctx.needs_input_grad[0]:
             dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
             if wino:
@@ -189,9 +210,16 @@ class Conv3x3Function(Function):
                 Vd = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
                 U2 = torch.empty((npos, cout, cin), dtype=torch.float32, device=dev)
                 M2 = torch.empty((npos, mt, cin), dtype=torch.float32, device=dev)
-                _lib.call("cim_wino_input_transform", dy.data_ptr(), Vd.data_ptr(), r, p, cout, tile, st)
+                dr = u2c = None
+                if fused:
+                    dr = torch.empty(npos * mt, dtype=torch.int32, device=dev)
+                    _lib.call("cim_wino_input_transform_amax", dy.data_ptr(), Vd.data_ptr(), dr.data_ptr(), r, p, cout, tile, st)
+                    u2c = _bounds(ctx.w_cols, cin, 9, 1, npos, dev)       # per input channel: max over (co, taps)
+                else:
+                    _lib.call("cim_wino_input_transform", dy.data_ptr(), Vd.data_ptr(), r, p, cout, tile, st)
                 _lib.call("cim_wino_filter_transform", w.data_ptr(), U2.data_ptr(), cout, cin, 1, tile, st)
-                _bgemm(Vd, U2, M2, mt, cin, cout, cout, cin, False, npos, mt * cout, cout * cin, mt * cin)
+                _bgemm(Vd, U2, M2, mt, cin, cout, cout, cin, False, npos, mt * cout, cout * cin, mt * cin,
+                       a_amax=dr, b_amax=u2c)
                 _lib.call("cim_wino_output_transform", M2.data_ptr(), None, dxp.data_ptr(), r, p, cin, 0, tile, st)
             else:
                 w2 = w.flip(2, 3).permute(2, 3, 0, 1).contiguous()                     # [3,3,Cout,Cin]
@@ -203,9 +231,10 @@ class Conv3x3Function(Function):
                 dU = torch.empty((npos, cin, cout), dtype=torch.float32, device=dev)
                 dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
                 _lib.call("cim_wino_dy_transform", dy.data_ptr(), D.data_ptr(), r, p, cout, tile, st)
+                dc = _bounds(amax(dy, r * p * p, cout, cout, want_cols=True)[1], cout, 1, 2, npos, dev) if fused else None
                 # dU[pos] = V[pos]^T . D[pos]:  A = V[pos] read M-contiguously (element (ci, m) at V[m*Cin + ci])
                 _bgemm(V, D, dU, cin, cout, mt, cin, cout, True, npos, mt * cin, mt * cout, cin * cout,
-                       a_amax=getattr(ctx, "v_cols", None))
+                       a_amax=getattr(ctx, "v_cols", None), b_amax=dc)
                 _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, tile, st)
             else:
                 m, n, k = 9 * cin, cout, r * p * p

@@ -202,6 +202,14 @@ int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int 
  * `tile` = 2: F(2x2,3x3), 16 positions (default);  `tile` = 4: F(4x4,3x3) on the points {0,1,-1,2,-1/2,inf},
  * 36 positions, T = ceil(P/4), 3.1x fewer multiplies than direct at P = 7, fp32 error ~7e-6. */
 int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, int tile, void* stream);
+/* f16x2 engine helpers (tile = 4 only):
+ * cim_wino_input_transform_amax: the input transform that also stores row_amax [36][R*T*T] = max |V[pos][m][:]| (bit
+ *   patterns; plain stores, nothing to zero) - the per-row operand scales of the forward / data-gradient GEMMs.
+ * cim_wino_scale_bounds: per-column scale BOUNDS of a transformed operand from the |max| of the untransformed
+ *   tensor, bounds [36][n] = f_pos * max_{t<group} amax_in[n*group + t], f_pos = product of the absolute row sums
+ *   of the transform matrix (kind 0: B^T (input), 1: G (filter), 2: G4 (output gradient)). */
+int cim_wino_input_transform_amax(const float* x, float* V, uint32_t* row_amax, int R, int P, int C, int tile, void* stream);
+int cim_wino_scale_bounds(const uint32_t* amax_in, uint32_t* bounds, int n, int group, int kind, int tile, void* stream);
 int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, int tile, void* stream);
 int cim_wino_output_transform(const float* M, const float* bias, float* y, int R, int P, int C, int relu, int tile, void* stream);
 int cim_wino_dy_transform(const float* dy, float* D, int R, int P, int C, int tile, void* stream);
