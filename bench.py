@@ -71,10 +71,11 @@ def instrument(model, timer):
     state = {"conv": 0, "bg": 0}
 
     def call(name, *args):
-        if name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_bwd"):
-            if name.endswith("fwd"):
+        if name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_fwd_ws", "cim_roi_align_maskcat_bwd",
+                    "cim_roi_align_maskcat_bwd_ws"):
+            if "bwd" not in name:
                 state["conv"] = state["bg"] = 0
-            with timer.span(name):
+            with timer.span("cim_roi_align_maskcat_bwd" if "bwd" in name else "cim_roi_align_maskcat_fwd"):
                 return orig_call(name, *args)
         if name == "cim_conv3x3_f32":       # per step: 1st launch = forward, 2nd = data gradient
             state["conv"] += 1

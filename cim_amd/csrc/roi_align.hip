@@ -371,6 +371,130 @@ __global__ __launch_bounds__(256) void roi_tables_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward, aggregated-weight form (default when the caller provides the table workspace).
+//
+// out[ph,pw,c] = (1/count) sum_y sum_x WY[ph][y] WX[pw][x] feat[y,x,c]   with the per-ROI tables of
+// roi_tables_kernel (the same ones the backward uses).  A bin touches (rows of bin ph) x (columns of bin pw)
+// pixels ONCE each - (gh+1)(gw+1) 16 B loads per lane instead of the 4*gh*gw of the sample-by-sample kernels
+// (2.5-3x fewer at the benchmark's ROI sizes: the tap kernels move 16x the algorithmic bytes through L1).
+// The sum is reassociated, so the result differs from the oracle's sample order by a few ulp (tests state
+// 1e-6 relative); the sample-order kernels above stay behind cim_roi_align_fwd / CIM_ROI_FWD_EXACT=1.
+// The weight tables are built with FP contraction off (same values as the backward's).
+// A workgroup owns one (roi, bin row): it flattens the bin row's (pixel offset, weight) pairs into LDS once,
+// then every lane runs a flat, 4-way unrolled loop over them for its 4 channels.
+constexpr int AG_MAXE = 64;     // entries per (ph, pw) list kept in LDS; larger bins take the sample-order kernel
+
+template <bool MASKCAT>
+__global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __restrict__ feat,
+                                                                const float* __restrict__ masks,
+                                                                float* __restrict__ out, int C, int H, int W, int P,
+                                                                const float* __restrict__ rec_all,
+                                                                const float* __restrict__ rois, float scale,
+                                                                int sampling_ratio, int aligned) {
+    __shared__ int2 ent[FW_MAXP * AG_MAXE];      // {element offset of the pixel, weight bits}
+    __shared__ int s_over;
+    __shared__ int s_n[FW_MAXP], s_xlo[FW_MAXP], s_nx[FW_MAXP];
+    __shared__ int s_rows[64];                   // rows with a non-zero weight in this bin row
+    __shared__ int s_nrows;
+    const int k = blockIdx.x, ph = blockIdx.y, tid = threadIdx.x;
+    const float* rec = rec_all + (size_t)k * roi_rec_words(P, H, W);
+    const float* wy = rec + ph * H;
+    const float* wx = rec + P * H;
+    const int* box = reinterpret_cast<const int*>(rec + (P + 1) * (H + W));
+    const int ylo = box[0], yhi = box[1], xlo = box[2], xhi = box[3];
+    const float inv_count = 1.0f / reinterpret_cast<const float*>(box)[4];
+    const float* __restrict__ fb = feat + (size_t)box[5] * H * W * C;
+    if (tid == 0) {
+        int n = 0;
+        for (int y = ylo; y <= yhi; ++y)
+            if (wy[y] != 0.0f && n < 64) s_rows[n++] = y;
+        s_nrows = n;
+        s_over = 0;
+    } else if (tid >= 64 && tid < 64 + P) {
+        const int pw = tid - 64;
+        int lo = xhi + 1, hi = xlo - 1;
+        for (int x = xlo; x <= xhi; ++x)
+            if (wx[pw * W + x] != 0.0f) { lo = min(lo, x); hi = x; }
+        s_xlo[pw] = lo;
+        s_nx[pw] = max(hi - lo + 1, 0);
+    }
+    __syncthreads();
+    const int nrows = s_nrows;
+    if (tid < P && nrows * s_nx[tid] > AG_MAXE) s_over = 1;      // benign race: every writer stores 1
+    __syncthreads();
+    const int OC = MASKCAT ? 2 * C : C;
+    if (s_over) {      // block-uniform: a bin larger than the LDS list (ROI far larger than the map) -> sample by sample
+        const RoiGeom g = roi_geom(rois + 5 * (size_t)k, scale, P, sampling_ratio, aligned);
+        for (int c = tid * 4; c < C; c += 256 * 4) {
+            for (int pw = 0; pw < P; ++pw) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int iy = 0; iy < g.gh; ++iy) {
+                    const float y = g.y1 + ph * g.bh + (iy + 0.5f) * g.bh / (float)g.gh;
+                    const Tap ty = make_tap(y, H);
+                    for (int ix = 0; ix < g.gw; ++ix) {
+                        const float x = g.x1 + pw * g.bw + (ix + 0.5f) * g.bw / (float)g.gw;
+                        const Tap tx = make_tap(x, W);
+                        if (!(ty.valid && tx.valid)) continue;
+                        const float4 v1 = *reinterpret_cast<const float4*>(fb + ((size_t)ty.lo * W + tx.lo) * C + c);
+                        const float4 v2 = *reinterpret_cast<const float4*>(fb + ((size_t)ty.lo * W + tx.hi) * C + c);
+                        const float4 v3 = *reinterpret_cast<const float4*>(fb + ((size_t)ty.hi * W + tx.lo) * C + c);
+                        const float4 v4 = *reinterpret_cast<const float4*>(fb + ((size_t)ty.hi * W + tx.hi) * C + c);
+                        const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+                        acc = vadd(acc, vadd(vadd(vadd(vmul(w1, v1), vmul(w2, v2)), vmul(w3, v3)), vmul(w4, v4)));
+                    }
+                }
+                const float4 o = vdiv(acc, g.count);
+                float* dst = out + (((size_t)k * P + ph) * P + pw) * OC + c;
+                *reinterpret_cast<float4*>(dst) = o;
+                if (MASKCAT) *reinterpret_cast<float4*>(dst + C) = vmul(masks[((size_t)k * P + ph) * P + pw], o);
+            }
+        }
+        return;
+    }
+    for (int e = tid; e < P * AG_MAXE; e += 256) {
+        const int pw = e / AG_MAXE, i = e % AG_MAXE;
+        const int nx = s_nx[pw];
+        const int n = nrows * nx;
+        if (i == 0) s_n[pw] = n;
+        if (i < n) {
+            const int r = i / nx, x = s_xlo[pw] + (i - r * nx), y = s_rows[r];
+            ent[e] = make_int2((y * W + x) * C, __float_as_int(wy[y] * inv_count * wx[pw * W + x]));
+        }
+    }
+    __syncthreads();
+    for (int c = tid * 4; c < C; c += 256 * 4) {
+        const float* __restrict__ fc = fb + c;
+        for (int pw = 0; pw < P; ++pw) {
+            const int2* el = ent + pw * AG_MAXE;
+            const int n = s_n[pw];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int i = 0;
+            for (; i + 4 <= n; i += 4) {
+                const int2 e0 = el[i], e1 = el[i + 1], e2 = el[i + 2], e3 = el[i + 3];
+                const float4 v0 = *reinterpret_cast<const float4*>(fc + e0.x);
+                const float4 v1 = *reinterpret_cast<const float4*>(fc + e1.x);
+                const float4 v2 = *reinterpret_cast<const float4*>(fc + e2.x);
+                const float4 v3 = *reinterpret_cast<const float4*>(fc + e3.x);
+                const float w0 = __int_as_float(e0.y), w1 = __int_as_float(e1.y), w2 = __int_as_float(e2.y), w3 = __int_as_float(e3.y);
+                acc.x = fmaf(w0, v0.x, acc.x); acc.y = fmaf(w0, v0.y, acc.y); acc.z = fmaf(w0, v0.z, acc.z); acc.w = fmaf(w0, v0.w, acc.w);
+                acc.x = fmaf(w1, v1.x, acc.x); acc.y = fmaf(w1, v1.y, acc.y); acc.z = fmaf(w1, v1.z, acc.z); acc.w = fmaf(w1, v1.w, acc.w);
+                acc.x = fmaf(w2, v2.x, acc.x); acc.y = fmaf(w2, v2.y, acc.y); acc.z = fmaf(w2, v2.z, acc.z); acc.w = fmaf(w2, v2.w, acc.w);
+                acc.x = fmaf(w3, v3.x, acc.x); acc.y = fmaf(w3, v3.y, acc.y); acc.z = fmaf(w3, v3.z, acc.z); acc.w = fmaf(w3, v3.w, acc.w);
+            }
+            for (; i < n; ++i) {
+                const int2 e0 = el[i];
+                const float4 v0 = *reinterpret_cast<const float4*>(fc + e0.x);
+                const float w0 = __int_as_float(e0.y);
+                acc.x = fmaf(w0, v0.x, acc.x); acc.y = fmaf(w0, v0.y, acc.y); acc.z = fmaf(w0, v0.z, acc.z); acc.w = fmaf(w0, v0.w, acc.w);
+            }
+            float* dst = out + (((size_t)k * P + ph) * P + pw) * OC + c;
+            *reinterpret_cast<float4*>(dst) = acc;
+            if (MASKCAT) *reinterpret_cast<float4*>(dst + C) = vmul(masks[((size_t)k * P + ph) * P + pw], acc);
+        }
+    }
+}
+
 template <int CH, bool MASKCAT, bool PRE>
 __global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_tile_kernel(const float* __restrict__ grad_out,
                                                                           const float* __restrict__ rois,
@@ -503,6 +627,216 @@ __global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_tile_kernel(const 
             }
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, gather form (default when the tables exist): the adjoint of roi_align_fwd_agg_kernel.
+//
+//   grad_in[y,x,c] = sum over ROIs k and bins (ph,pw) of  WY_k[ph][y] WX_k[pw][x] / count_k * g_k[ph,pw,c]
+// A workgroup owns a GH x GW block of feature pixels x 1024 channels (lanes along C, 16 B per lane, GH*GW float4
+// accumulators in registers) for one group of 256 ROIs: no LDS tile, no atomics inside the ROI loop; the groups'
+// partial sums meet in grad_in through one atomicAdd per element (ceil(K/256) per element in total; plain stores
+// when K <= 256).  Each lane inspects ONE ROI's bin ranges for the block's rows / columns (one packed table word
+// per row / column); the (gradient offset, mask, GH*GW weights) entries of the bins that touch the block are laid
+// out in LDS by a block-wide prefix sum (deterministic order); then all lanes stream the entry list, 4 entries
+// (8 x 16 B loads with the mask-cat prologue fused) in flight per lane - one gradient load feeds GH*GW FMAs, so
+// neighbouring pixels share the loads of the bins they share (a bin spans ~3.6 x 4.1 pixels at the benchmark's
+// ROI sizes: a 2 x 2 block reads each gradient vector ~5.5 times instead of ~15).
+constexpr int GA_MAXE = 1024;      // entries per LDS window
+#ifndef CIM_ROI_GS
+#define CIM_ROI_GS 256             // ROIs per workgroup (<= 256: one per lane in the inspection phase)
+#endif
+#ifndef CIM_ROI_GU
+#define CIM_ROI_GU 4               // entries in flight per lane in the streaming phase (4 or 8)
+#endif
+constexpr int GA_GS = CIM_ROI_GS;
+#ifndef CIM_ROI_GEXP
+#define CIM_ROI_GEXP 0          // ablations: 1 = no streaming phase, 2 = no flush
+#endif
+
+template <int GH, int GW, bool MASKCAT>
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ grad_out,
+                                                                   const float* __restrict__ masks,
+                                                                   float* __restrict__ grad_in, int C, int H, int W,
+                                                                   int K, int P, int B, int use_atomic,
+                                                                   const float* __restrict__ rec_all) {
+    constexpr int NPX = GH * GW;
+    __shared__ int e_off[GA_MAXE];
+    __shared__ float e_m[GA_MAXE];
+    __shared__ __attribute__((aligned(16))) float e_w[GA_MAXE * NPX];
+    __shared__ int s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (W + GW - 1) / GW;
+    // XCD-aware tile order (speed only): workgroup i runs on XCD i % 8; give each XCD a contiguous run of pixel
+    // tiles so neighbouring tiles - which share most of their bins' gradient vectors - re-read them from ONE L2
+    int tile = blockIdx.x;
+#ifndef CIM_ROI_NO_XCD
+    {
+        const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = tile & 7, i = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+#endif
+    const int y0 = (tile / tiles_x) * GH, x0 = (tile % tiles_x) * GW;
+    const int b = blockIdx.y % B, kgroup = blockIdx.y / B;
+    const int recw = roi_rec_words(P, H, W);
+    const int OC = MASKCAT ? 2 * C : C, PP = P * P;
+
+    float4 acc[NPX];
+#pragma unroll
+    for (int p = 0; p < NPX; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- this lane's ROI: bins touching the block's rows / columns
+    const int k = kgroup * GA_GS + tid;
+    int phl = 0, phh = -1, pwl = 0, pwh = -1;
+    const float* rec = rec_all + (size_t)min(k, K - 1) * recw;
+    const int* yr = reinterpret_cast<const int*>(rec + P * (H + W));
+    const int* xr = yr + H;
+    float inv_count = 0.0f;
+    if (tid < GA_GS && k < K && yr[H + W + 5] == b) {
+        int lo = P, hi = -1;
+#pragma unroll
+        for (int i = 0; i < GH; ++i) {
+            const int r = yr[min(y0 + i, H - 1)];
+            if (y0 + i < H && !(r & 0x10000)) { lo = min(lo, r & 0xff); hi = max(hi, (r >> 8) & 0xff); }
+        }
+        phl = lo; phh = hi;
+        lo = P; hi = -1;
+#pragma unroll
+        for (int j = 0; j < GW; ++j) {
+            const int r = xr[min(x0 + j, W - 1)];
+            if (x0 + j < W && !(r & 0x10000)) { lo = min(lo, r & 0xff); hi = max(hi, (r >> 8) & 0xff); }
+        }
+        pwl = lo; pwh = hi;
+        inv_count = 1.0f / reinterpret_cast<const float*>(yr)[H + W + 4];
+    }
+    const int nph = max(phh - phl + 1, 0), npw = max(pwh - pwl + 1, 0);
+    const int n_mine = (nph > 0 && npw > 0) ? nph * npw : 0;
+    // ---- block-wide exclusive prefix sum of n_mine (deterministic entry order): wave scan + 4 wave totals
+    int incl = n_mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int t = s_wave[w];
+        if (w < wave) wbase += t;
+        total += t;
+    }
+    const int base = wbase + incl - n_mine;
+    const int c = min(blockIdx.z * 1024 + tid * 4, C - 4);      // lanes past C redo the last quad (never stored)
+    const float* __restrict__ gc = grad_out + c;
+
+#define GA_LOAD(G, I)                                                                                  \
+    float4 G = *reinterpret_cast<const float4*>(gc + e_off[I]);                                        \
+    float4 G##h;                                                                                       \
+    if (MASKCAT) G##h = *reinterpret_cast<const float4*>(gc + e_off[I] + C);
+#define GA_ACC(G, I)                                                                                   \
+    {                                                                                                  \
+        if (MASKCAT) {                                                                                 \
+            const float m_ = e_m[I];                                                                   \
+            G.x = fmaf(m_, G##h.x, G.x); G.y = fmaf(m_, G##h.y, G.y);                                  \
+            G.z = fmaf(m_, G##h.z, G.z); G.w = fmaf(m_, G##h.w, G.w);                                  \
+        }                                                                                              \
+        _Pragma("unroll") for (int p = 0; p < NPX; ++p) {                                              \
+            const float w_ = e_w[(I) * NPX + p];                                                       \
+            acc[p].x = fmaf(w_, G.x, acc[p].x); acc[p].y = fmaf(w_, G.y, acc[p].y);                    \
+            acc[p].z = fmaf(w_, G.z, acc[p].z); acc[p].w = fmaf(w_, G.w, acc[p].w);                    \
+        }                                                                                              \
+    }
+    for (int w0 = 0; w0 < total; w0 += GA_MAXE) {
+        // ---- lay out the entries whose index falls in [w0, w0 + GA_MAXE)
+        if (n_mine > 0 && base < w0 + GA_MAXE && base + n_mine > w0) {
+            const float* wy = rec;
+            const float* wx = rec + P * H;
+            int idx = base - w0;
+            for (int ph = phl; ph <= phh; ++ph) {
+                float wyv[GH];
+#pragma unroll
+                for (int i = 0; i < GH; ++i) wyv[i] = (y0 + i < H) ? wy[ph * H + y0 + i] * inv_count : 0.0f;
+                for (int pw = pwl; pw <= pwh; ++pw, ++idx) {
+                    if (idx < 0 || idx >= GA_MAXE) continue;
+                    e_off[idx] = (((k * P) + ph) * P + pw) * OC;      // < 2^31: checked by the launcher
+                    if (MASKCAT) e_m[idx] = masks[(size_t)k * PP + ph * P + pw];
+#pragma unroll
+                    for (int j = 0; j < GW; ++j) {
+                        const float wxv = (x0 + j < W) ? wx[pw * W + x0 + j] : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < GH; ++i) e_w[idx * NPX + i * GW + j] = wyv[i] * wxv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- stream the window: lanes along C, 4 entries in flight
+#if CIM_ROI_GEXP == 1
+        const int n = 0;
+#else
+        const int n = min(GA_MAXE, total - w0);
+#endif
+        int i = 0;
+#if CIM_ROI_GU == 8
+        for (; i + 8 <= n; i += 8) {
+            GA_LOAD(g0, i)
+            GA_LOAD(g1, i + 1)
+            GA_LOAD(g2, i + 2)
+            GA_LOAD(g3, i + 3)
+            GA_LOAD(g4, i + 4)
+            GA_LOAD(g5, i + 5)
+            GA_LOAD(g6, i + 6)
+            GA_LOAD(g7, i + 7)
+            GA_ACC(g0, i)
+            GA_ACC(g1, i + 1)
+            GA_ACC(g2, i + 2)
+            GA_ACC(g3, i + 3)
+            GA_ACC(g4, i + 4)
+            GA_ACC(g5, i + 5)
+            GA_ACC(g6, i + 6)
+            GA_ACC(g7, i + 7)
+        }
+#endif
+        for (; i + 4 <= n; i += 4) {
+            GA_LOAD(g0, i)
+            GA_LOAD(g1, i + 1)
+            GA_LOAD(g2, i + 2)
+            GA_LOAD(g3, i + 3)
+            GA_ACC(g0, i)
+            GA_ACC(g1, i + 1)
+            GA_ACC(g2, i + 2)
+            GA_ACC(g3, i + 3)
+        }
+        for (; i < n; ++i) {
+            GA_LOAD(g0, i)
+            GA_ACC(g0, i)
+        }
+        __syncthreads();
+    }
+#undef GA_LOAD
+#undef GA_ACC
+    const int cs = blockIdx.z * 1024 + tid * 4;
+#if CIM_ROI_GEXP == 2
+    if (cs < C && acc[0].x == 123.456f) {
+#else
+    if (cs < C && (total > 0 || !use_atomic)) {
+#endif
+#pragma unroll
+        for (int i = 0; i < GH; ++i)
+#pragma unroll
+            for (int j = 0; j < GW; ++j)
+                if (y0 + i < H && x0 + j < W) {
+                    float* dst = grad_in + (((size_t)b * H + y0 + i) * W + x0 + j) * C + cs;
+                    const float4 v = acc[i * GW + j];
+                    if (use_atomic) {
+                        atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+                    } else {
+                        *reinterpret_cast<float4*>(dst) = v;
+                    }
+                }
     }
 }
 
@@ -722,9 +1056,18 @@ static int launch_bwd_tile(const float* go, const float* rois, const float* mask
 
 template <bool MASKCAT>
 int launch_fwd(const float* feat, const float* rois, const float* masks, float* out, int B, int C, int H, int W, int K,
-               int P, float scale, int sr, int aligned, hipStream_t st) {
+               int P, float scale, int sr, int aligned, hipStream_t st, float* ws = nullptr) {
     if (K == 0) return 0;
     dim3 grid(K, P), block(256);
+    // aggregated-weight kernel: needs the table workspace, 16-byte channel rows and bins of <= AG_MAXE pixels
+    // (rows, columns per bin <= size/P + 3; maps up to ~35 x 49 at P = 7)
+    if (ws != nullptr && C % 4 == 0 && P <= FW_MAXP && (long long)H * W * C < (1ll << 30) && H <= 64 &&
+        getenv("CIM_ROI_FWD_EXACT") == nullptr) {
+        hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), 0, st, rois, ws, K, P, H, W, scale, sr, aligned);
+        hipLaunchKernelGGL((roi_align_fwd_agg_kernel<MASKCAT>), grid, block, 0, st, feat, masks, out, C, H, W, P, ws, rois,
+                           scale, sr, aligned);
+        return 0;
+    }
     if (C % 4 == 0 && P <= FW_MAXP && (long long)H * W * C < (1ll << 30) && getenv("CIM_ROI_FWD_DIRECT") == nullptr)
         hipLaunchKernelGGL((roi_align_fwd_tab_kernel<MASKCAT>), grid, block, 0, st, feat, rois, masks, out, C, H, W, P,
                            scale, sr, aligned);
@@ -758,10 +1101,39 @@ static int launch_bwd_px16(const float* go, const float* rois, const float* mask
     return 0;
 }
 
+#ifndef CIM_ROI_GH
+#define CIM_ROI_GH 2
+#endif
+#ifndef CIM_ROI_GW
+#define CIM_ROI_GW 4
+#endif
+template <bool MASKCAT>
+static int launch_bwd_gather(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W,
+                             int K, int P, float scale, int sr, int aligned, float* ws, hipStream_t st, int tables_ready) {
+    constexpr int GH = CIM_ROI_GH, GW = CIM_ROI_GW;
+    if (!tables_ready)
+        hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), 0, st, rois, ws, K, P, H, W, scale, sr, aligned);
+    const int tiles = ((H + GH - 1) / GH) * ((W + GW - 1) / GW);
+    const int groups = (K + GA_GS - 1) / GA_GS;
+    if (groups > 1) {
+        hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * (size_t)B * H * W * C, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((roi_align_bwd_gather_kernel<GH, GW, MASKCAT>), dim3(tiles, B * groups, (C + 1023) / 1024), dim3(256), 0,
+                       st, go, masks, gin, C, H, W, K, P, B, groups > 1 ? 1 : 0, ws);
+    return 0;
+}
+
 template <bool MASKCAT>
 int launch_bwd(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W, int K,
-               int P, float scale, int sr, int aligned, float* ws, hipStream_t st) {
+               int P, float scale, int sr, int aligned, float* ws, hipStream_t st, int tables_ready = 0) {
     const size_t budget = 150 * 1024;
+    // gather form: 256 lanes x 4 channels per workgroup (grid.z chunks of 1024 channels), 8-bit bin indices in the
+    // packed ranges, 32-bit element offsets
+    if (K > 0 && ws != nullptr && C % 4 == 0 && P <= 16 && H < 256 && W < 256 && (long long)B * ((K + GA_GS - 1) / GA_GS) <= 65535 &&
+        (long long)K * P * P * (MASKCAT ? 2 : 1) * C < (1ll << 31) && getenv("CIM_ROI_BWD_TILE") == nullptr &&
+        getenv("CIM_ROI_BWD_PX16") == nullptr)
+        return launch_bwd_gather<MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st, tables_ready);
     if (K > 0 && ws != nullptr && C % 16 == 0 && P * P * 4 <= PX_THREADS && H < 256 && W < 256 &&
         (P + 1) * (H + W) + 6 <= PX_MAXTAB * PX_THREADS && bwd_px_lds(H, W, P) <= 160 * 1024 - 512 &&
         getenv("CIM_ROI_BWD_TILE") == nullptr)
@@ -805,6 +1177,30 @@ extern "C" int cim_roi_align_fwd(const float* feat, const float* rois, float* ou
     return 0;
 }
 
+extern "C" int cim_roi_align_fwd_ws(const float* feat, const float* rois, float* out, int B, int C, int H, int W, int K,
+                                    int P, float spatial_scale, int sampling_ratio, int aligned, float* workspace,
+                                    void* stream) {
+    ROI_ARGS_OK();
+    CIM_CHECK_ARG(feat && (out || K == 0));
+    int rc = launch_fwd<false>(feat, rois, nullptr, out, B, C, H, W, K, P, spatial_scale, sampling_ratio, aligned,
+                               cim::as_stream(stream), workspace);
+    if (rc) return rc;
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_roi_align_maskcat_fwd_ws(const float* feat, const float* rois, const float* masks, float* cat, int B,
+                                            int C, int H, int W, int K, int P, float spatial_scale, int sampling_ratio,
+                                            int aligned, float* workspace, void* stream) {
+    ROI_ARGS_OK();
+    CIM_CHECK_ARG(feat && ((cat && masks) || K == 0));
+    int rc = launch_fwd<true>(feat, rois, masks, cat, B, C, H, W, K, P, spatial_scale, sampling_ratio, aligned,
+                              cim::as_stream(stream), workspace);
+    if (rc) return rc;
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" long long cim_roi_align_bwd_workspace(int K, int P, int H, int W) {
     return (long long)sizeof(float) * (long long)K * roi_rec_words(P, H, W);
 }
@@ -816,6 +1212,31 @@ extern "C" int cim_roi_align_bwd(const float* grad_out, const float* rois, float
     CIM_CHECK_ARG(grad_in && (grad_out || K == 0));
     int rc = launch_bwd<false>(grad_out, rois, nullptr, grad_in, B, C, H, W, K, P, spatial_scale, sampling_ratio,
                                aligned, workspace, cim::as_stream(stream));
+    if (rc) return rc;
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_roi_align_bwd_ws(const float* grad_out, const float* rois, float* grad_in, int B, int C, int H, int W,
+                                    int K, int P, float spatial_scale, int sampling_ratio, int aligned, float* workspace,
+                                    int tables_ready, void* stream) {
+    ROI_ARGS_OK();
+    CIM_CHECK_ARG(grad_in && (grad_out || K == 0) && (workspace || !tables_ready));
+    int rc = launch_bwd<false>(grad_out, rois, nullptr, grad_in, B, C, H, W, K, P, spatial_scale, sampling_ratio,
+                               aligned, workspace, cim::as_stream(stream), tables_ready);
+    if (rc) return rc;
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_roi_align_maskcat_bwd_ws(const float* grad_cat, const float* rois, const float* masks, float* grad_in,
+                                            int B, int C, int H, int W, int K, int P, float spatial_scale,
+                                            int sampling_ratio, int aligned, float* workspace, int tables_ready,
+                                            void* stream) {
+    ROI_ARGS_OK();
+    CIM_CHECK_ARG(grad_in && ((grad_cat && masks) || K == 0) && (workspace || !tables_ready));
+    int rc = launch_bwd<true>(grad_cat, rois, masks, grad_in, B, C, H, W, K, P, spatial_scale, sampling_ratio, aligned,
+                              workspace, cim::as_stream(stream), tables_ready);
     if (rc) return rc;
     CIM_CHECK_LAUNCH();
     return 0;

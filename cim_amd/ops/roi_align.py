@@ -6,12 +6,19 @@ arguments, same NCHW tensor semantics, autograd-enabled).  Tensors are kept in
 torch.channels_last memory format internally: the HIP kernels (cim_amd/csrc/roi_align.hip)
 run with lanes along C.  No CPU path: CPU tensors raise.
 """
+import os
+
 import torch
 from torch import nn
 from torch.autograd import Function
 from torch.nn.modules.utils import _pair
 
 from .. import _lib
+
+
+# Forward kernel: the aggregated-weight form by default (each bin reads every pixel it touches once; a few ulp from
+# the sample-order sum); EXACT (CIM_ROI_FWD_EXACT=1) keeps the reference's sample order, bit-identical to the oracle.
+EXACT = os.environ.get("CIM_ROI_FWD_EXACT", "0") == "1"
 
 
 def _check(feat, rois):
@@ -28,7 +35,7 @@ def _nhwc(x):
 
 
 def _workspace(k, p, h, w, device):
-    """Scratch for the per-ROI interpolation tables of the backward kernel."""
+    """Scratch for the per-ROI interpolation tables (aggregated-weight forward, pixel-owner backward)."""
     nbytes = _lib.call("cim_roi_align_bwd_workspace", max(k, 1), p, h, w)
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
@@ -49,8 +56,9 @@ class RoIAlignFunction(Function):
         B, C, H, W = feat.shape
         K = rois.size(0)
         out = _empty_nhwc(K, C, P, P, feat)
-        _lib.call("cim_roi_align_fwd", feat.data_ptr(), rois.data_ptr(), out.data_ptr(), B, C, H, W, K, P,
-                  float(spatial_scale), int(sampling_ratio), int(bool(aligned)), _lib.stream_ptr())
+        ctx.tables = None if EXACT else _workspace(K, P, H, W, feat.device)      # built by the forward, reused by the backward
+        _lib.call("cim_roi_align_fwd_ws", feat.data_ptr(), rois.data_ptr(), out.data_ptr(), B, C, H, W, K, P,
+                  float(spatial_scale), int(sampling_ratio), int(bool(aligned)), _lib.ptr(ctx.tables), _lib.stream_ptr())
         ctx.save_for_backward(rois)
         ctx.geom = (B, C, H, W, K, P, float(spatial_scale), int(sampling_ratio), int(bool(aligned)))
         return out
@@ -61,8 +69,9 @@ class RoIAlignFunction(Function):
         B, C, H, W, K, P, scale, sr, aligned = ctx.geom
         grad_out = _nhwc(grad_out)
         grad_in = _empty_nhwc(B, C, H, W, grad_out)
-        _lib.call("cim_roi_align_bwd", grad_out.data_ptr(), rois.data_ptr(), grad_in.data_ptr(), B, C, H, W, K, P,
-                  scale, sr, aligned, _workspace(K, P, H, W, grad_out.device).data_ptr(), _lib.stream_ptr())
+        ws = ctx.tables if ctx.tables is not None else _workspace(K, P, H, W, grad_out.device)
+        _lib.call("cim_roi_align_bwd_ws", grad_out.data_ptr(), rois.data_ptr(), grad_in.data_ptr(), B, C, H, W, K, P,
+                  scale, sr, aligned, ws.data_ptr(), int(ctx.tables is not None), _lib.stream_ptr())
         return grad_in, None, None, None, None, None
 
 
@@ -82,8 +91,10 @@ class RoIAlignMaskCatFunction(Function):
         if tuple(masks.shape) != (K, P, P):
             raise ValueError("roi_align_maskcat: masks must be [K,P,P]")
         cat = _empty_nhwc(K, 2 * C, P, P, feat)
-        _lib.call("cim_roi_align_maskcat_fwd", feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(),
-                  B, C, H, W, K, P, float(spatial_scale), int(sampling_ratio), int(bool(aligned)), _lib.stream_ptr())
+        ctx.tables = None if EXACT else _workspace(K, P, H, W, feat.device)
+        _lib.call("cim_roi_align_maskcat_fwd_ws", feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(),
+                  B, C, H, W, K, P, float(spatial_scale), int(sampling_ratio), int(bool(aligned)), _lib.ptr(ctx.tables),
+                  _lib.stream_ptr())
         ctx.save_for_backward(rois, masks)
         ctx.geom = (B, C, H, W, K, P, float(spatial_scale), int(sampling_ratio), int(bool(aligned)))
         return cat
@@ -94,9 +105,10 @@ class RoIAlignMaskCatFunction(Function):
         B, C, H, W, K, P, scale, sr, aligned = ctx.geom
         grad_cat = _nhwc(grad_cat)
         grad_in = _empty_nhwc(B, C, H, W, grad_cat)
-        _lib.call("cim_roi_align_maskcat_bwd", grad_cat.data_ptr(), rois.data_ptr(), masks.data_ptr(),
-                  grad_in.data_ptr(), B, C, H, W, K, P, scale, sr, aligned,
-                  _workspace(K, P, H, W, grad_cat.device).data_ptr(), _lib.stream_ptr())
+        ws = ctx.tables if ctx.tables is not None else _workspace(K, P, H, W, grad_cat.device)
+        _lib.call("cim_roi_align_maskcat_bwd_ws", grad_cat.data_ptr(), rois.data_ptr(), masks.data_ptr(),
+                  grad_in.data_ptr(), B, C, H, W, K, P, scale, sr, aligned, ws.data_ptr(), int(ctx.tables is not None),
+                  _lib.stream_ptr())
         return grad_in, None, None, None, None, None, None
 
 

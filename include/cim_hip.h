@@ -49,6 +49,27 @@ int cim_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in,
                       int B, int C, int H, int W, int K, int P,
                       float spatial_scale, int sampling_ratio, int aligned, float* workspace, void* stream);
 
+/* Forward with the backward's table workspace (cim_roi_align_bwd_workspace bytes): the per-ROI separable weight
+ * tables are built once and every bin reads each pixel it touches ONCE with the aggregated weight
+ * WY[ph][y]*WX[pw][x]/count - (gh+1)(gw+1) instead of 4*gh*gw loads per bin.  Same result up to the
+ * reassociation of the sum (a few ulp; cim_roi_align_fwd keeps the reference's sample order bit for bit).
+ * workspace == NULL behaves like cim_roi_align_fwd / cim_roi_align_maskcat_fwd. */
+int cim_roi_align_fwd_ws(const float* feat, const float* rois, float* out,
+                         int B, int C, int H, int W, int K, int P,
+                         float spatial_scale, int sampling_ratio, int aligned, float* workspace, void* stream);
+int cim_roi_align_maskcat_fwd_ws(const float* feat, const float* rois, const float* masks, float* cat,
+                                 int B, int C, int H, int W, int K, int P,
+                                 float spatial_scale, int sampling_ratio, int aligned, float* workspace, void* stream);
+
+/* Backward with tables_ready != 0: `workspace` still holds the tables a *_fwd_ws call on the SAME rois / geometry
+ * built (the aggregated-weight forward and the gather backward share them); 0 rebuilds them. */
+int cim_roi_align_bwd_ws(const float* grad_out, const float* rois, float* grad_in,
+                         int B, int C, int H, int W, int K, int P,
+                         float spatial_scale, int sampling_ratio, int aligned, float* workspace, int tables_ready, void* stream);
+int cim_roi_align_maskcat_bwd_ws(const float* grad_cat, const float* rois, const float* masks, float* grad_in,
+                                 int B, int C, int H, int W, int K, int P,
+                                 float spatial_scale, int sampling_ratio, int aligned, float* workspace, int tables_ready, void* stream);
+
 /* Fused ROIAlign + mask multiply + channel concat: the input of MaskFuse.mask_branch,
  * lib/modeling/resnet50.py:121-134 (vgg16.py:162-175, HRNet.py:615-628):
  *   cat[k,ph,pw,0:C]  = roi_align(feat)[k,ph,pw,:]

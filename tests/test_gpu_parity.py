@@ -42,15 +42,21 @@ def _roi_case(seed, C, H, W, K, img_scale=16.0):
 @pytest.mark.parametrize("C,H,W,K,aligned", [(8, 13, 17, 24, True), (3, 9, 11, 16, True), (64, 33, 43, 40, True),
                                               (8, 13, 17, 24, False), (4, 13, 17, 24, True), (4, 13, 17, 24, False),
                                               (16, 45, 60, 33, True), (16, 45, 60, 33, False)])
-def test_roi_align_fwd_bwd_vs_oracle(dev, C, H, W, K, aligned):
+def test_roi_align_fwd_bwd_vs_oracle(dev, C, H, W, K, aligned, monkeypatch):
     from cim_amd.ops import roi_align
+    import sys
+    ra_mod = sys.modules["cim_amd.ops.roi_align"]        # (the package attribute of that name is the function)
     from oracle import roi_align as oracle
     feat, rois = _roi_case(C * 7 + K, C, H, W, K)
     ref = oracle.roi_align_fwd(feat, rois, P=7, scale=1 / 16.0, aligned=aligned)
     x = _cl(feat, dev).requires_grad_(True)
+    monkeypatch.setattr(ra_mod, "EXACT", True)                             # the reference's sample order
     out = roi_align(x, torch.from_numpy(rois).to(dev), 7, 1 / 16.0, 0, "avg", aligned)
     assert out.shape == (K, C, 7, 7)
     np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)         # bit-identical forward
+    monkeypatch.setattr(ra_mod, "EXACT", False)                            # default: aggregated weights (reassociated sum)
+    out = roi_align(x, torch.from_numpy(rois).to(dev), 7, 1 / 16.0, 0, "avg", aligned)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=0, atol=1e-6 * float(np.abs(feat).max()))
     rng = np.random.RandomState(1)
     go = rng.randn(K, C, 7, 7).astype(np.float32)
     out.backward(torch.from_numpy(go).to(dev))
@@ -64,14 +70,17 @@ def test_roi_align_module_matches_reference_call_convention(dev):
     from cim_amd.ops import RoIAlign
     from oracle import roi_align as oracle
     feat, rois = _roi_case(5, 16, 12, 15, 10)
+    tol = dict(rtol=0, atol=1e-6 * float(np.abs(feat).max()))
     out = RoIAlign(7, 1.0 / 16.0, 0)(torch.from_numpy(feat).to(dev).contiguous(), torch.from_numpy(rois).to(dev).contiguous())
-    np.testing.assert_array_equal(out.cpu().numpy(), oracle.roi_align_fwd(feat, rois))
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.roi_align_fwd(feat, rois), **tol)
     out2 = RoIAlign(7, 1.0 / 16.0, 2)(torch.from_numpy(feat).to(dev), torch.from_numpy(rois).to(dev))
-    np.testing.assert_array_equal(out2.cpu().numpy(), oracle.roi_align_fwd(feat, rois, sampling_ratio=2))
+    np.testing.assert_allclose(out2.cpu().numpy(), oracle.roi_align_fwd(feat, rois, sampling_ratio=2), **tol)
 
 
-def test_roi_align_maskcat_fused_vs_oracle(dev):
+def test_roi_align_maskcat_fused_vs_oracle(dev, monkeypatch):
     from cim_amd.ops import roi_align_maskcat
+    import sys
+    ra_mod = sys.modules["cim_amd.ops.roi_align"]        # (the package attribute of that name is the function)
     from oracle import roi_align as oracle
     C, H, W, K = 32, 20, 25, 30
     feat, rois = _roi_case(77, C, H, W, K)
@@ -80,9 +89,13 @@ def test_roi_align_maskcat_fused_vs_oracle(dev):
     box = oracle.roi_align_fwd(feat, rois)
     ref = np.concatenate([box, box * masks[:, None]], axis=1)
     x = _cl(feat, dev).requires_grad_(True)
+    monkeypatch.setattr(ra_mod, "EXACT", True)
     cat = roi_align_maskcat(x, torch.from_numpy(rois).to(dev), torch.from_numpy(masks).to(dev), 7, 1 / 16.0, 0, True)
     assert cat.shape == (K, 2 * C, 7, 7)
     np.testing.assert_array_equal(cat.detach().cpu().numpy(), ref)
+    monkeypatch.setattr(ra_mod, "EXACT", False)
+    cat = roi_align_maskcat(x, torch.from_numpy(rois).to(dev), torch.from_numpy(masks).to(dev), 7, 1 / 16.0, 0, True)
+    np.testing.assert_allclose(cat.detach().cpu().numpy(), ref, rtol=0, atol=1e-6 * float(np.abs(feat).max()))
     g = rng.randn(K, 2 * C, 7, 7).astype(np.float32)
     cat.backward(torch.from_numpy(g).to(dev))
     g_box = g[:, :C] + g[:, C:] * masks[:, None]

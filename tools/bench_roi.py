@@ -37,8 +37,8 @@ def timeit(fn, n=10):
     return a.elapsed_time(b) / n
 
 
-fwd = lambda: _lib.call("cim_roi_align_maskcat_fwd", feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, st)
 ws = torch.empty(_lib.call("cim_roi_align_bwd_workspace", K, 7, H, W) // 4 + 1, device=dev)
+fwd = lambda: _lib.call("cim_roi_align_maskcat_fwd_ws", feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
 bwd = lambda: _lib.call("cim_roi_align_maskcat_bwd", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
 nbytes = 4.0 * (C * H * W + 5 * K + 49 * K) + 4.0 * K * 2 * C * 49
 tf, tb = timeit(fwd), timeit(bwd)
@@ -47,7 +47,7 @@ for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):   
     alt = ctypes.CDLL(path)
     for name, argt in _lib.SIGNATURES.items():
         getattr(alt, name).argtypes = argt
-    f = lambda: alt.cim_roi_align_maskcat_fwd(feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, st)
+    f = lambda: alt.cim_roi_align_maskcat_fwd_ws(feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
     bw = lambda: alt.cim_roi_align_maskcat_bwd(gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
     print(os.path.basename(path), "fwd_ms %.4f bwd_ms %.4f" % (timeit(f), timeit(bw)))
 print(json.dumps(dict(config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, fwd_ms=tf, fwd_frac=nbytes / tf / 1e6 / 8000,
