@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..core.config import cfg
-from ..ops import conv3x3, linear, roi_align_maskcat
+from ..ops import conv3x3, gemm, linear, roi_align_maskcat
 
 
 class MaskFuse(nn.Module):
@@ -41,7 +41,16 @@ class MaskFuse(nn.Module):
         # exact-fp32 MFMA contractions (cim_amd/csrc/gemm_f32.hip); the nn.Conv2d / nn.Linear
         # modules only hold the parameters (reference names and layouts)
         conv = self.mask_branch[0]
-        y = conv3x3(cat, conv.weight, conv.bias, relu=True)
+        # ROIAlign averages feature pixels, so per channel max |box_x| <= max |x| over the map and
+        # max |box_x * mask| <= that times max |mask| ({0,1} masks: 1): a 6 MB pass instead of one over the
+        # 400 MB cat tensor for the conv's weight-gradient operand scales (f16x2 engine)
+        xc = None
+        if gemm.ENGINE == "f16x2" and gemm.CONV_ALGO == "winograd4":
+            xn = x.detach().contiguous(memory_format=torch.channels_last)
+            fa = gemm.amax(xn, xn.size(0) * xn.size(2) * xn.size(3), xn.size(1), xn.size(1), want_cols=True)[1]
+            fm = (fa.view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
+            xc = torch.cat([fa, fm])
+        y = conv3x3(cat, conv.weight, conv.bias, relu=True, x_col_amax=xc)
         n = y.size(0)
         # (c, h, w) flatten order of the reference's `.view(batch, -1)` on an NCHW tensor
         y = y.contiguous(memory_format=torch.contiguous_format).view(n, -1)

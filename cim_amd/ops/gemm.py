@@ -25,12 +25,25 @@ if ENGINE not in ("f16x2", "bf16x3", "fp32"):
     raise _lib.CimHipError("CIM_GEMM_ENGINE must be f16x2, bf16x3 or fp32, got %r" % ENGINE)
 
 
-def amax(x, rows, cols, ld, want_rows=False, want_cols=False, batch=1, bs=0):
+def _zeros_i32(dev, *sizes):
+    """Zeroed int32 arrays of the given sizes carved out of ONE allocation / fill (0 -> None)."""
+    pad = [(n + 3) & ~3 for n in sizes]
+    buf = torch.zeros(max(sum(pad), 1), dtype=torch.int32, device=dev)
+    out, o = [], 0
+    for n, p in zip(sizes, pad):
+        out.append(buf[o:o + n] if n else None)
+        o += p
+    return out
+
+
+def amax(x, rows, cols, ld, want_rows=False, want_cols=False, batch=1, bs=0, out=None):
     """|max| bit patterns of a stored [batch][rows][ld] fp32 matrix: per row (over its columns) and / or per
     column (over its rows), ONE pass over x.  These are the operand scales of the f16x2 engine: an operand
-    read K-contiguously takes the per-row array, one read M/N-contiguously the per-column array."""
-    ra = torch.zeros(batch * rows, dtype=torch.int32, device=x.device) if want_rows else None
-    ca = torch.zeros(batch * cols, dtype=torch.int32, device=x.device) if want_cols else None
+    read K-contiguously takes the per-row array, one read M/N-contiguously the per-column array.
+    out: (row array, col array) of pre-zeroed int32 storage (see _zeros_i32), else allocated here."""
+    if out is None:
+        out = _zeros_i32(x.device, batch * rows if want_rows else 0, batch * cols if want_cols else 0)
+    ra, ca = out
     _lib.call("cim_amax_rowcol", x.data_ptr(), rows, cols, ld, batch, bs, _lib.ptr(ra), _lib.ptr(ca), _lib.stream_ptr())
     return ra, ca
 
@@ -71,8 +84,9 @@ class LinearFunction(Function):
         n = w.shape[0]
         xr = xc = wr = wc = None
         if ENGINE == "f16x2":        # one pass per operand: the row scales serve this product, the column scales the backward
-            xr, xc = amax(x, m, k, k, True, ctx.needs_input_grad[1])
-            wr, wc = amax(w, n, k, k, True, ctx.needs_input_grad[0])
+            z = _zeros_i32(x.device, m, k if ctx.needs_input_grad[1] else 0, n, k if ctx.needs_input_grad[0] else 0)
+            xr, xc = amax(x, m, k, k, True, ctx.needs_input_grad[1], out=z[0:2])
+            wr, wc = amax(w, n, k, k, True, ctx.needs_input_grad[0], out=z[2:4])
         y = gemm(x, w, m, n, k, k, k, b_kcontig=True, bias=b, relu=relu, a_amax=xr, b_amax=wr)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.scales = (xc, wc)
@@ -138,7 +152,7 @@ class Conv3x3Function(Function):
     GEMM on the untransformed data (1.72x more multiplies, ~3x closer to the fp64 result)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, x_col_amax=None):
         x = x.contiguous(memory_format=torch.channels_last)
         r, cin, p, _ = x.shape
         cout = w.shape[0]
@@ -164,11 +178,15 @@ class Conv3x3Function(Function):
                 # untransformed tensors (x per channel, w per filter) times the transform's absolute row sums
                 vr = torch.empty(npos * mt, dtype=torch.int32, device=dev)
                 _lib.call("cim_wino_input_transform_amax", x.data_ptr(), V.data_ptr(), vr.data_ptr(), r, p, cin, tile, st)
-                w_rows, w_cols = amax(w, cout, cin * 9, cin * 9, True, ctx.needs_input_grad[0])
+                need_xc = ctx.needs_input_grad[1] and x_col_amax is None
+                z = _zeros_i32(dev, cout, cin * 9 if ctx.needs_input_grad[0] else 0, cin if need_xc else 0)
+                w_rows, w_cols = amax(w, cout, cin * 9, cin * 9, True, ctx.needs_input_grad[0], out=z[0:2])
                 uc = _bounds(w_rows, cout, 1, 1, npos, dev)
                 ctx.w_cols = w_cols
                 if ctx.needs_input_grad[1]:
-                    ctx.v_cols = _bounds(amax(x, r * p * p, cin, cin, want_cols=True)[1], cin, 1, 0, npos, dev)
+                    # per-channel |max| of x: computed here, or an upper bound handed in by the producer of x
+                    xc = x_col_amax if x_col_amax is not None else amax(x, r * p * p, cin, cin, want_cols=True, out=(None, z[2]))[1]
+                    ctx.v_cols = _bounds(xc, cin, 1, 0, npos, dev)
             else:
                 _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), r, p, cin, tile, st)
                 if ENGINE == "f16x2":    # one pass over V: row scales for this product, column scales for the weight gradient
@@ -246,12 +264,14 @@ class Conv3x3Function(Function):
                 dw = dwh.permute(3, 2, 0, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def linear(x, weight, bias=None, relu=False):
     return LinearFunction.apply(x, weight, bias, relu)
 
 
-def conv3x3(x, weight, bias=None, relu=False):
-    return Conv3x3Function.apply(x, weight, bias, relu)
+def conv3x3(x, weight, bias=None, relu=False, x_col_amax=None):
+    """x_col_amax: optional int32 [Cin] bit patterns of an UPPER BOUND of max |x[:, c, :, :]| (f16x2 engine: saves the
+    pass over x that derives the weight-gradient operand scales)."""
+    return Conv3x3Function.apply(x, weight, bias, relu, x_col_amax)
