@@ -328,6 +328,7 @@ class MiningContext:
         self.classes_dev = torch.from_numpy(self.classes_host).to(device)
         self.flags = {}
         self._pinned = {}
+        self.slots = 0          # CIM_layer calls enqueued on this context (one pinned staging pair each)
 
     def asy_flag(self, asy_iou_map, con_thr):
         key = (asy_iou_map.data_ptr(), float(con_thr))
@@ -339,9 +340,8 @@ class MiningContext:
         return f
 
     def pinned(self, which, nwords):
-        """Page-locked staging buffers: 'down' (D2H pseudo-GT list) and 'up' (H2D survivors).
-        'up' is rewritten only after the next layer's D2H + stream sync, i.e. after the
-        previous H2D copy on the same stream has completed."""
+        """Page-locked staging buffers, one pair per CIM_layer call of the step: 'down<i>' (D2H pseudo-GT list)
+        and 'up<i>' (H2D survivors).  Served by PyTorch's caching host allocator."""
         buf = self._pinned.get(which)
         if buf is None or buf.numel() < nwords:
             buf = torch.empty(nwords, dtype=torch.int32).pin_memory()
@@ -378,6 +378,15 @@ class CIM_layer(nn.Module):
     @torch.no_grad()
     def forward(self, predict_cls, predict_det, rois, labels, iou_map=None, asy_iou_map=None, using_CIM=True,
                 _ctx=None):
+        return self.finish(self.enqueue(predict_cls, predict_det, rois, labels, iou_map, asy_iou_map, using_CIM, _ctx))
+
+    @torch.no_grad()
+    def enqueue(self, predict_cls, predict_det, rois, labels, iou_map=None, asy_iou_map=None, using_CIM=True,
+                _ctx=None):
+        """Device half of forward(): seed selection, containment mining, arbitration and the asynchronous D2H copy
+        of the pseudo-GT list.  The layers of one step read only the heads' outputs, so the model enqueues all of
+        them before it waits for the first (`finish`, in layer order: the NumPy RNG stream is consumed exactly as
+        by the reference's sequential calls) - one host stall per step instead of one per layer."""
         if not predict_cls.is_cuda:
             raise _lib.CimHipError("CIM_layer: the HIP path needs CUDA/HIP tensors (no CPU fallback)")
         dev = predict_cls.device
@@ -440,10 +449,26 @@ class CIM_layer(nn.Module):
                   gt_class.data_ptr(), gt_weight.data_ptr(), gt_pack.data_ptr(), st)
 
         # ---- the one host round trip of the layer: pseudo-GT list for the NumPy sampling
-        host = ctx.pinned("down", 1 + 3 * N)
+        slot = ctx.slots
+        ctx.slots += 1
+        host = ctx.pinned("down%d" % slot, 1 + 3 * N)
         host[:1 + 3 * N].copy_(gt_pack, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        hp = host.numpy()
+        done = torch.cuda.Event()
+        done.record()
+        return dict(ctx=ctx, slot=slot, host=host, done=done, N=N, C1=C1, n_cls=n_cls, K=K, topk=topk, seeds=seeds,
+                    n_seeds=n_seeds, res=res, gt_class=gt_class, gt_weight=gt_weight, iou_map=iou_map,
+                    asy_iou_map=asy_iou_map, using_CIM=using_CIM, dev=dev, keep_alive=(gt_pack, ws, cls))
+
+    @torch.no_grad()
+    def finish(self, s):
+        """Host half of forward(): wait for this layer's D2H copy, anti-noise sampling on the global NumPy RNG,
+        H2D of the survivors, IoU assignment."""
+        ctx, N, C1, n_cls, K, dev = s["ctx"], s["N"], s["C1"], s["n_cls"], s["K"], s["dev"]
+        topk, seeds, n_seeds, res, gt_class, gt_weight = (s[k] for k in ("topk", "seeds", "n_seeds", "res", "gt_class", "gt_weight"))
+        iou_map, asy_iou_map, using_CIM = s["iou_map"], s["asy_iou_map"], s["using_CIM"]
+        st = _lib.stream_ptr()
+        s["done"].synchronize()
+        hp = s["host"].numpy()
         G = int(hp[0])
         self.last = dict(topk=topk.view(n_cls, K) if n_cls else topk, seeds=seeds.view(n_cls, K) if n_cls else seeds,
                          n_seeds=n_seeds[:n_cls], res=res.view(n_cls, K) if n_cls else res,
@@ -469,7 +494,7 @@ class CIM_layer(nn.Module):
             gt_idx, gt_cls, gt_w = gt_idx[keep], gt_cls[keep], gt_w[keep]
         Gk = int(gt_idx.shape[0])
 
-        up = ctx.pinned("up", 3 * N)
+        up = ctx.pinned("up%d" % s["slot"], 3 * N)      # per layer: the previous layer's H2D may still be in flight
         upn = up.numpy()
         upn[0:Gk] = gt_idx
         upn[Gk:2 * Gk] = gt_cls

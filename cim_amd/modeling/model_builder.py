@@ -126,10 +126,13 @@ class Generalized_RCNN(nn.Module):
 
             n = predict_cls.shape[0]
             ctx = heads.MiningContext(labels, n, predict_cls.device, labels_host=labels_host)
-            pseudo, scales = [], []
-            for i, layer in enumerate(self.CIM_layer_list):
+            pseudo, scales, pending = [], [], []
+            for i, layer in enumerate(self.CIM_layer_list):                  # device halves of all layers first ...
                 src_cls, src_det = (predict_cls, predict_det) if i == 0 else (ref_cls_score[i - 1], ref_iou_score[i - 1])
-                out = layer(src_cls, src_det, rois, labels, iou_map, asy_iou_map, using_CIM=self.using_CIM[i], _ctx=ctx)
+                pending.append(layer.enqueue(src_cls, src_det, rois, labels, iou_map, asy_iou_map,
+                                             using_CIM=self.using_CIM[i], _ctx=ctx))
+            for i, layer in enumerate(self.CIM_layer_list):                  # ... then the host halves, in layer order
+                out = layer.finish(pending[i])
                 pseudo.append(None if out[0] is None else out)               # model_builder.py:189-190
                 scales.append(3 if i == 0 else 1)                            # lmda, model_builder.py:172
             plan = self._pcl_plan(mat, mat_host)
