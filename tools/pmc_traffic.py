@@ -17,7 +17,7 @@ import csv
 import json
 import sys
 
-OURS = ("gemm_f32_kernel", "gemm_bf16x3_kernel", "roi_align", "mask_iou", "mask_pack", "mask_area", "splitk", "asy_flag", "seed_select",
+OURS = ("gemm_f32_kernel", "gemm_bf16x3_kernel", "gemm_f16x2_kernel", "amax_rowcol", "roi_align", "mask_iou", "mask_pack", "mask_area", "splitk", "asy_flag", "seed_select",
         "contain_argmax", "arbitrate", "assign_kernel", "wino")
 
 
