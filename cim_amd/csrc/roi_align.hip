@@ -383,6 +383,10 @@ __global__ __launch_bounds__(256) void roi_tables_kernel(const float* __restrict
 // The weight tables are built with FP contraction off (same values as the backward's).
 // A workgroup owns one (roi, bin row): it flattens the bin row's (pixel offset, weight) pairs into LDS once,
 // then every lane runs a flat, 4-way unrolled loop over them for its 4 channels.
+typedef float ga_f2 __attribute__((ext_vector_type(2)));       // v_pk_fma_f32: two fp32 FMAs per instruction
+__device__ __forceinline__ ga_f2 ga_lo(const float4& v) { return ga_f2{v.x, v.y}; }
+__device__ __forceinline__ ga_f2 ga_hi(const float4& v) { return ga_f2{v.z, v.w}; }
+__device__ __forceinline__ ga_f2 ga_fma(float w, ga_f2 v, ga_f2 a) { return __builtin_elementwise_fma(ga_f2{w, w}, v, a); }
 constexpr int AG_MAXE = 64;     // entries per (ph, pw) list kept in LDS; larger bins take the sample-order kernel
 
 template <bool MASKCAT>
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
         for (int pw = 0; pw < P; ++pw) {
             const int2* el = ent + pw * AG_MAXE;
             const int n = s_n[pw];
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            ga_f2 al = {0.f, 0.f}, ah = {0.f, 0.f};
             int i = 0;
             for (; i + 4 <= n; i += 4) {
                 const int2 e0 = el[i], e1 = el[i + 1], e2 = el[i + 2], e3 = el[i + 3];
@@ -477,17 +481,18 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
                 const float4 v2 = *reinterpret_cast<const float4*>(fc + e2.x);
                 const float4 v3 = *reinterpret_cast<const float4*>(fc + e3.x);
                 const float w0 = __int_as_float(e0.y), w1 = __int_as_float(e1.y), w2 = __int_as_float(e2.y), w3 = __int_as_float(e3.y);
-                acc.x = fmaf(w0, v0.x, acc.x); acc.y = fmaf(w0, v0.y, acc.y); acc.z = fmaf(w0, v0.z, acc.z); acc.w = fmaf(w0, v0.w, acc.w);
-                acc.x = fmaf(w1, v1.x, acc.x); acc.y = fmaf(w1, v1.y, acc.y); acc.z = fmaf(w1, v1.z, acc.z); acc.w = fmaf(w1, v1.w, acc.w);
-                acc.x = fmaf(w2, v2.x, acc.x); acc.y = fmaf(w2, v2.y, acc.y); acc.z = fmaf(w2, v2.z, acc.z); acc.w = fmaf(w2, v2.w, acc.w);
-                acc.x = fmaf(w3, v3.x, acc.x); acc.y = fmaf(w3, v3.y, acc.y); acc.z = fmaf(w3, v3.z, acc.z); acc.w = fmaf(w3, v3.w, acc.w);
+                al = ga_fma(w0, ga_lo(v0), al); ah = ga_fma(w0, ga_hi(v0), ah);
+                al = ga_fma(w1, ga_lo(v1), al); ah = ga_fma(w1, ga_hi(v1), ah);
+                al = ga_fma(w2, ga_lo(v2), al); ah = ga_fma(w2, ga_hi(v2), ah);
+                al = ga_fma(w3, ga_lo(v3), al); ah = ga_fma(w3, ga_hi(v3), ah);
             }
             for (; i < n; ++i) {
                 const int2 e0 = el[i];
                 const float4 v0 = *reinterpret_cast<const float4*>(fc + e0.x);
                 const float w0 = __int_as_float(e0.y);
-                acc.x = fmaf(w0, v0.x, acc.x); acc.y = fmaf(w0, v0.y, acc.y); acc.z = fmaf(w0, v0.z, acc.z); acc.w = fmaf(w0, v0.w, acc.w);
+                al = ga_fma(w0, ga_lo(v0), al); ah = ga_fma(w0, ga_hi(v0), ah);
             }
+            const float4 acc = make_float4(al.x, al.y, ah.x, ah.y);
             float* dst = out + (((size_t)k * P + ph) * P + pw) * OC + c;
             *reinterpret_cast<float4*>(dst) = acc;
             if (MASKCAT) *reinterpret_cast<float4*>(dst + C) = vmul(masks[((size_t)k * P + ph) * P + pw], acc);
@@ -682,9 +687,9 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     const int recw = roi_rec_words(P, H, W);
     const int OC = MASKCAT ? 2 * C : C, PP = P * P;
 
-    float4 acc[NPX];
+    ga_f2 accl[NPX], acch[NPX];
 #pragma unroll
-    for (int p = 0; p < NPX; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < NPX; ++p) accl[p] = acch[p] = ga_f2{0.f, 0.f};
 
     // ---- this lane's ROI: bins touching the block's rows / columns
     const int k = kgroup * GA_GS + tid;
@@ -738,15 +743,16 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     if (MASKCAT) G##h = *reinterpret_cast<const float4*>(gc + e_off[I] + C);
 #define GA_ACC(G, I)                                                                                   \
     {                                                                                                  \
+        ga_f2 gl_ = ga_lo(G), gh_ = ga_hi(G);                                                          \
         if (MASKCAT) {                                                                                 \
             const float m_ = e_m[I];                                                                   \
-            G.x = fmaf(m_, G##h.x, G.x); G.y = fmaf(m_, G##h.y, G.y);                                  \
-            G.z = fmaf(m_, G##h.z, G.z); G.w = fmaf(m_, G##h.w, G.w);                                  \
+            gl_ = ga_fma(m_, ga_lo(G##h), gl_);                                                        \
+            gh_ = ga_fma(m_, ga_hi(G##h), gh_);                                                        \
         }                                                                                              \
         _Pragma("unroll") for (int p = 0; p < NPX; ++p) {                                              \
             const float w_ = e_w[(I) * NPX + p];                                                       \
-            acc[p].x = fmaf(w_, G.x, acc[p].x); acc[p].y = fmaf(w_, G.y, acc[p].y);                    \
-            acc[p].z = fmaf(w_, G.z, acc[p].z); acc[p].w = fmaf(w_, G.w, acc[p].w);                    \
+            accl[p] = ga_fma(w_, gl_, accl[p]);                                                        \
+            acch[p] = ga_fma(w_, gh_, acch[p]);                                                        \
         }                                                                                              \
     }
     for (int w0 = 0; w0 < total; w0 += GA_MAXE) {
@@ -830,7 +836,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
             for (int j = 0; j < GW; ++j)
                 if (y0 + i < H && x0 + j < W) {
                     float* dst = grad_in + (((size_t)b * H + y0 + i) * W + x0 + j) * C + cs;
-                    const float4 v = acc[i * GW + j];
+                    const float4 v = make_float4(accl[i * GW + j].x, accl[i * GW + j].y, acch[i * GW + j].x, acch[i * GW + j].y);
                     if (use_atomic) {
                         atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
                     } else {

@@ -103,6 +103,26 @@ def test_roi_align_maskcat_fused_vs_oracle(dev, monkeypatch):
     np.testing.assert_allclose(x.grad.cpu().numpy(), gref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,C,H,W,K", [(2, 8, 13, 17, 300), (3, 1028, 9, 11, 40), (1, 2048, 17, 22, 70)])
+def test_roi_align_batches_groups_and_channel_chunks(dev, B, C, H, W, K):
+    """Aggregated-weight forward / gather backward beyond the benchmark shape: several images per call, more than
+    256 ROIs (K-groups meeting through atomics), channel counts past one 1024-lane chunk and not a multiple of it."""
+    from cim_amd.ops import roi_align
+    from oracle import roi_align as oracle
+    feat0, rois = _roi_case(B * 31 + K, C, H, W, K)
+    rng = np.random.RandomState(K)
+    feat = rng.randn(B, C, H, W).astype(np.float32)
+    rois[:, 0] = rng.randint(0, B, K)
+    ref = oracle.roi_align_fwd(feat, rois)
+    x = _cl(feat, dev).requires_grad_(True)
+    out = roi_align(x, torch.from_numpy(rois).to(dev), 7, 1 / 16.0)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=0, atol=1e-6 * float(np.abs(feat).max()))
+    go = rng.randn(K, C, 7, 7).astype(np.float32)
+    out.backward(torch.from_numpy(go).to(dev))
+    gref = oracle.roi_align_bwd(go, rois, feat.shape)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gref, rtol=1e-4, atol=2e-4)
+
+
 def test_roi_align_empty_and_bad_args(dev):
     from cim_amd import _lib
     from cim_amd.ops import roi_align
