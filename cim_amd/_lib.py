@@ -39,6 +39,7 @@ SIGNATURES = {
     "cim_gemm_f16x2_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
                                _P, _P, _P],
     "cim_wino_input_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "cim_flatten_chw": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_input_transform_amax": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_scale_bounds": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_filter_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],

@@ -442,6 +442,46 @@ __global__ __launch_bounds__(256) void wino43_wgrad_out_kernel(const float* __re
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// (c, h, w) flatten of the conv output and its adjoint, fused with the ReLU mask.
+// The reference flattens MaskFuse's NCHW conv output with .view(N, -1) (resnet50.py:135): seg_fc.0's weight columns
+// are in (c, h, w) order.  The kernels here keep activations channels-last, so the flatten is a per-ROI [PP][C] ->
+// [C][PP] transpose (forward) and, in the backward, the transpose back fused with the conv's ReLU mask
+// (dy = dflat^T * (y > 0)): one pass each instead of a strided copy + compare + multiply.
+// Workgroup = (ROI, 64-channel chunk), staged through a [PP][65] LDS tile: both global sides are contiguous runs
+// (256 B along C, 64 * PP floats along (c, p)).
+template <bool FWD>
+__global__ __launch_bounds__(256) void flatten_chw_kernel(const float* __restrict__ src, const float* __restrict__ y,
+                                                          float* __restrict__ dst, int PP, int C) {
+    __shared__ float t[64][65];
+    const int r = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    const size_t base = (size_t)r * PP * C;
+    if (FWD) {
+        for (int e = tid; e < PP * 64; e += 256) {
+            const int p = e >> 6, c = e & 63;
+            t[p][c] = src[base + (size_t)p * C + c0 + c];
+        }
+        __syncthreads();
+        for (int e = tid; e < PP * 64; e += 256) {
+            const int c = e / PP, p = e - c * PP;
+            dst[base + (size_t)c0 * PP + e] = t[p][c];
+        }
+    } else {
+        for (int e = tid; e < PP * 64; e += 256) {
+            const int c = e / PP, p = e - c * PP;
+            t[p][c] = src[base + (size_t)c0 * PP + e];
+        }
+        __syncthreads();
+        for (int e = tid; e < PP * 64; e += 256) {
+            const int p = e >> 6, c = e & 63;
+            const size_t o = base + (size_t)p * C + c0 + c;
+            const float v = t[p][c];
+            dst[o] = (y == nullptr || y[o] > 0.0f) ? v : 0.0f;
+        }
+    }
+}
+
 }  // namespace
 
 #define WINO_GEOM_OK() CIM_CHECK_ARG(R > 0 && P > 0 && P <= 64 && C > 0 && C % 4 == 0)
@@ -520,6 +560,16 @@ extern "C" int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int C
     if (tile == 4) hipLaunchKernelGGL(wino43_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
     else hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU,
                        dW, Cout, Cin);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_flatten_chw(const float* src, const float* relu_y, float* dst, int R, int PP, int C, int backward,
+                               void* stream) {
+    CIM_CHECK_ARG(src && dst && R > 0 && PP > 0 && PP <= 64 && C > 0 && C % 64 == 0 && R <= 2147483647 / 1 && C / 64 <= 65535);
+    CIM_CHECK_ARG(backward || relu_y == nullptr);
+    if (backward) hipLaunchKernelGGL(flatten_chw_kernel<false>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C);
+    else hipLaunchKernelGGL(flatten_chw_kernel<true>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C);
     CIM_CHECK_LAUNCH();
     return 0;
 }

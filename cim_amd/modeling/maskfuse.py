@@ -50,9 +50,7 @@ class MaskFuse(nn.Module):
             fa = gemm.amax(xn, xn.size(0) * xn.size(2) * xn.size(3), xn.size(1), xn.size(1), want_cols=True)[1]
             fm = (fa.view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
             xc = torch.cat([fa, fm])
-        y = conv3x3(cat, conv.weight, conv.bias, relu=True, x_col_amax=xc)
-        n = y.size(0)
-        # (c, h, w) flatten order of the reference's `.view(batch, -1)` on an NCHW tensor
-        y = y.contiguous(memory_format=torch.contiguous_format).view(n, -1)
+        # (c, h, w) flatten order of the reference's `.view(batch, -1)` on an NCHW tensor, fused into the conv op
+        y = conv3x3(cat, conv.weight, conv.bias, relu=True, x_col_amax=xc, flatten_chw=True)
         fc1, fc2 = self.seg_fc[0], self.seg_fc[2]
         return linear(linear(y, fc1.weight, fc1.bias, relu=True), fc2.weight, fc2.bias, relu=True)

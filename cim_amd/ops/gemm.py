@@ -176,7 +176,7 @@ class Conv3x3Function(Function):
     GEMM on the untransformed data (1.72x more multiplies, ~3x closer to the fp64 result)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, x_col_amax=None):
+    def forward(ctx, x, w, b, relu, x_col_amax=None, flatten_chw=False):
         x = x.contiguous(memory_format=torch.channels_last)
         r, cin, p, _ = x.shape
         cout = w.shape[0]
@@ -225,6 +225,11 @@ class Conv3x3Function(Function):
         ctx.save_for_backward(x, w, y if relu else None, V)
         ctx.relu = relu
         ctx.has_bias = b is not None
+        ctx.flatten = bool(flatten_chw)
+        if ctx.flatten:      # the reference's `.view(N, -1)` of the NCHW output: (c, h, w) order, one transposing pass
+            flat = torch.empty((r, cout * p * p), dtype=torch.float32, device=dev)
+            _lib.call("cim_flatten_chw", y.data_ptr(), None, flat.data_ptr(), r, p * p, cout, 0, st)
+            return flat
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -233,12 +238,17 @@ class Conv3x3Function(Function):
         r, cin, p, _ = x.shape
         cout = w.shape[0]
         dev = x.device
-        dy = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)      # physical [R,P,P,Cout]
-        if ctx.relu:
-            dy = dy * (y > 0)
-        dy = dy.contiguous()
-        dx = dw = db = None
         st = _lib.stream_ptr()
+        if ctx.flatten:      # transpose back to channels-last fused with the ReLU mask
+            dflat = dy.contiguous()
+            dy = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
+            _lib.call("cim_flatten_chw", dflat.data_ptr(), _lib.ptr(y) if ctx.relu else None, dy.data_ptr(), r, p * p, cout, 1, st)
+        else:
+            dy = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)      # physical [R,P,P,Cout]
+            if ctx.relu:
+                dy = dy * (y > 0)
+            dy = dy.contiguous()
+        dx = dw = db = None
         wino = ctx.algo.startswith("winograd")
         tile = ctx.tile
         npos = (tile + 2) ** 2
@@ -288,14 +298,19 @@ class Conv3x3Function(Function):
                 dw = dwh.permute(3, 2, 0, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def linear(x, weight, bias=None, relu=False):
     return LinearFunction.apply(x, weight, bias, relu)
 
 
-def conv3x3(x, weight, bias=None, relu=False, x_col_amax=None):
+def conv3x3(x, weight, bias=None, relu=False, x_col_amax=None, flatten_chw=False):
     """x_col_amax: optional int32 [Cin] bit patterns of an UPPER BOUND of max |x[:, c, :, :]| (f16x2 engine: saves the
-    pass over x that derives the weight-gradient operand scales)."""
-    return Conv3x3Function.apply(x, weight, bias, relu, x_col_amax)
+    pass over x that derives the weight-gradient operand scales).
+    flatten_chw: return the output flattened as [R, Cout*P*P] in (c, h, w) order - what `.view(R, -1)` gives on the
+    reference's NCHW tensor - through one transposing kernel each way (needs Cout % 64 == 0, P*P <= 64)."""
+    if flatten_chw and not (weight.shape[0] % 64 == 0 and x.shape[-1] * x.shape[-2] <= 64):
+        y = Conv3x3Function.apply(x, weight, bias, relu, x_col_amax, False)
+        return y.contiguous(memory_format=torch.contiguous_format).view(y.size(0), -1)
+    return Conv3x3Function.apply(x, weight, bias, relu, x_col_amax, flatten_chw)

@@ -223,6 +223,11 @@ int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int 
  * `tile` = 2: F(2x2,3x3), 16 positions (default);  `tile` = 4: F(4x4,3x3) on the points {0,1,-1,2,-1/2,inf},
  * 36 positions, T = ceil(P/4), 3.1x fewer multiplies than direct at P = 7, fp32 error ~7e-6. */
 int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, int tile, void* stream);
+/* (c, h, w) flatten between the conv and seg_fc.0 (resnet50.py:135, `.view(N, -1)` of an NCHW tensor) on channels-last
+ * data.  backward = 0: src [R][PP][C] -> dst [R][C][PP].  backward = 1: src [R][C][PP] -> dst [R][PP][C], zeroed where
+ * relu_y [R][PP][C] <= 0 (the conv's ReLU mask; NULL = no mask).  PP <= 64, C % 64 == 0. */
+int cim_flatten_chw(const float* src, const float* relu_y, float* dst, int R, int PP, int C, int backward, void* stream);
+
 /* f16x2 engine helpers (tile = 4 only):
  * cim_wino_input_transform_amax: the input transform that also stores row_amax [36][R*T*T] = max |V[pos][m][:]| (bit
  *   patterns; plain stores, nothing to zero) - the per-row operand scales of the forward / data-gradient GEMMs.

@@ -260,3 +260,26 @@ def test_wino_fused_scales(dev):
     _lib.call("cim_wino_dy_transform", dy.data_ptr(), D.data_ptr(), R, P, Cout, 4, st)
     db = G._bounds(G.amax(dy, R * P * P, Cout, Cout, want_cols=True)[1], Cout, 1, 2, npos, dev)
     assert bool((db.view(torch.float32).view(npos, Cout) >= D.abs().amax(dim=1)).all())
+
+
+@pytest.mark.parametrize("Cout", [64, 192, 48])
+def test_conv3x3_flatten_chw(dev, Cout):
+    """conv3x3(..., flatten_chw=True) == F.relu(F.conv2d(...)).view(R, -1) of the reference's NCHW tensor, forward and
+    backward (transposing kernel fused with the ReLU mask; Cout % 64 != 0 takes the strided-copy path)."""
+    from cim_amd.ops import conv3x3
+    g = torch.Generator().manual_seed(Cout)
+    R, Cin = 9, 32
+    x = torch.randn(R, Cin, 7, 7, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    go = torch.randn(R, Cout * 49, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.relu(F.conv2d(xr, wr, br, padding=1)).view(R, -1)
+    yr.backward(go.double())
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = conv3x3(xd, wd, bd, relu=True, flatten_chw=True)
+    assert y.shape == (R, Cout * 49) and y.is_contiguous()
+    y.backward(go.to(dev))
+    for got, ref in ((y.detach(), yr.detach()), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        assert _rel(got.cpu(), ref) < 3e-5
