@@ -387,6 +387,9 @@ typedef float ga_f2 __attribute__((ext_vector_type(2)));       // v_pk_fma_f32: 
 __device__ __forceinline__ ga_f2 ga_lo(const float4& v) { return ga_f2{v.x, v.y}; }
 __device__ __forceinline__ ga_f2 ga_hi(const float4& v) { return ga_f2{v.z, v.w}; }
 __device__ __forceinline__ ga_f2 ga_fma(float w, ga_f2 v, ga_f2 a) { return __builtin_elementwise_fma(ga_f2{w, w}, v, a); }
+#ifndef CIM_ROI_FU
+#define CIM_ROI_FU 8             // loads in flight per lane in the aggregated forward (4 or 8)
+#endif
 constexpr int AG_MAXE = 64;     // entries per (ph, pw) list kept in LDS; larger bins take the sample-order kernel
 
 template <bool MASKCAT>
@@ -474,6 +477,22 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
             const int n = s_n[pw];
             ga_f2 al = {0.f, 0.f}, ah = {0.f, 0.f};
             int i = 0;
+#if CIM_ROI_FU == 8
+            for (; i + 8 <= n; i += 8) {
+                int2 e[8];
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = el[i + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(fc + e[j].x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = __int_as_float(e[j].y);
+                    al = ga_fma(w, ga_lo(v[j]), al);
+                    ah = ga_fma(w, ga_hi(v[j]), ah);
+                }
+            }
+#endif
             for (; i + 4 <= n; i += 4) {
                 const int2 e0 = el[i], e1 = el[i + 1], e2 = el[i + 2], e3 = el[i + 3];
                 const float4 v0 = *reinterpret_cast<const float4*>(fc + e0.x);
