@@ -72,6 +72,23 @@ def _load_map(directory, stem, what, device, index):
         raise NotImplementedError("Please generate or download " + what)
 
 
+GRAPH_BACKBONE = os.environ.get("CIM_GRAPH_BACKBONE", "0") == "1"     # opt-in: measured SLOWER on ROCm 7.2 (see _conv_body)
+GRAPH_AFTER = 3         # graph a shape from its 3rd occurrence
+GRAPH_SHAPES = 4        # distinct image shapes kept as graphs
+
+
+class _BodyWrapper(nn.Module):
+    """make_graphed_callables patches the forward of the module it is given; one wrapper per image shape shares the
+    body's parameters without touching the body (or the model's state_dict: wrappers live outside the module tree)."""
+
+    def __init__(self, body):
+        super().__init__()
+        self.body = body
+
+    def forward(self, x):
+        return self.body(x)
+
+
 class Generalized_RCNN(nn.Module):
     def __init__(self):
         super().__init__()
@@ -111,7 +128,7 @@ class Generalized_RCNN(nn.Module):
                 if index is not None:
                     index = index.squeeze(dim=0).to(device=dev).long()
             return_dict = {}
-            blob_conv = self.Conv_Body(im_data)
+            blob_conv = self._conv_body(im_data)
             return_dict["blob_conv"] = blob_conv
             seg_x = self.Box_Head(blob_conv, rois, masks.detach())
             predict_cls, predict_det, ref_cls_score, ref_iou_score = self.cls_iou_model(seg_x)
@@ -156,6 +173,37 @@ class Generalized_RCNN(nn.Module):
                 losses["pcl_loss"] = losses["pcl_loss"] + heads.PCL_loss(predict_cls, mat, labels)
             return_dict["losses"] = {k: v.unsqueeze(0) for k, v in losses.items()}
             return return_dict
+
+    def _conv_body(self, im_data):
+        """Backbone forward.  The body is ~200 small library kernels forward and ~250 backward - launched one by one
+        the host cannot keep the GPU fed (the kernels take ~5 us, a PyTorch launch ~8 us).  For an image shape that
+        keeps coming back (training scales are a small set: SURVEY App. C) the body's forward AND backward are
+        captured as HIP graphs (torch.cuda.make_graphed_callables) and replayed: one launch each way.  Shapes are
+        graphed from their GRAPH_AFTER-th occurrence, at most GRAPH_SHAPES of them (each capture pins its
+        activations).  OPT-IN (CIM_GRAPH_BACKBONE=1): measured on MI355X / ROCm 7.2 the replayed step is SLOWER
+        (22.0 vs 20.5 ms at cfg2) - hipGraph kernel nodes cost about as much as eager launches and MIOpen picks
+        workspace-free solvers under capture - so the default stays eager."""
+        state = self.__dict__.setdefault("_graphed_bodies", {"seen": {}, "graphs": {}})
+        if not (GRAPH_BACKBONE and self.training and im_data.is_cuda and torch.is_grad_enabled()
+                and any(p.requires_grad for p in self.Conv_Body.parameters())):
+            return self.Conv_Body(im_data)
+        key = (tuple(im_data.shape), im_data.dtype, im_data.device)
+        g = state["graphs"].get(key)
+        if g is None:
+            n = state["seen"][key] = state["seen"].get(key, 0) + 1
+            if n < GRAPH_AFTER or len(state["graphs"]) >= GRAPH_SHAPES:
+                return self.Conv_Body(im_data)
+            wrapper = _BodyWrapper(self.Conv_Body)
+            try:
+                g = torch.cuda.make_graphed_callables(wrapper, (im_data.detach().clone(),))
+            except Exception as e:      # capture not possible (e.g. a library kernel that allocates): stay eager
+                print("cim_amd: backbone graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e))
+                state["graphs"][key] = False
+                return self.Conv_Body(im_data)
+            state["graphs"][key] = g
+        if g is False:
+            return self.Conv_Body(im_data)
+        return g(im_data)
 
     def _pcl_plan(self, mat, mat_host):
         """PRM cluster plan of this image.  Built from the host copy when the loader handed a CPU

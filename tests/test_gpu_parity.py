@@ -354,6 +354,54 @@ def test_training_step_matches_cpu_oracle(dev, config):
     assert checked > 20
 
 
+@pytest.mark.parametrize("config", ["resnet50_voc", "vgg16_voc"])
+def test_backbone_hip_graph_replay_matches_eager(dev, config, monkeypatch):
+    """From the 3rd step on a recurring image shape the backbone runs as captured HIP graphs (forward and backward):
+    same kernels, so the losses and every parameter gradient must equal the eager steps'; a different shape in
+    between stays eager and does not disturb the cached graph."""
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    from cim_amd import mask_iou, synthetic
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling import model_builder
+    apply_preset(config)
+    monkeypatch.setattr(model_builder, "GRAPH_BACKBONE", True)      # opt-in feature (CIM_GRAPH_BACKBONE=1)
+    torch.manual_seed(0)
+    inp = synthetic.make_image_inputs(config, seed=5, n=32)
+    inp["data"] = inp["data"][:, :, :160, :224].copy()
+    inp["rois"][:, 1:] *= np.float32(0.3)
+    model = model_builder.Generalized_RCNN().to(dev).train()
+    t = lambda a: torch.from_numpy(a).unsqueeze(0).to(dev)
+    diou, dasy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
+    data = torch.from_numpy(inp["data"]).to(dev)
+
+    def step(d):
+        model.zero_grad(set_to_none=True)
+        np.random.seed(11)
+        out = model(data=d, rois=t(inp["rois"]), masks=t(inp["masks"]), labels=t(inp["labels"]), gtrois=None,
+                    mat=t(inp["mat"]), index=t(inp["index"]), iou_map=diou, asy_iou_map=dasy)
+        sum(v.sum() for v in out["losses"].values()).backward()
+        torch.cuda.synchronize()
+        return ({k: float(v) for k, v in out["losses"].items()}, out["blob_conv"].detach().clone(),
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    eager = step(data)
+    step(data)
+    step(data[:, :, :128, :192].contiguous())                       # another shape in between: eager
+    graphed = step(data)                                             # 3rd occurrence of the shape: captured + replayed
+    replay = step(data)
+    st = model.__dict__["_graphed_bodies"]
+    assert any(g not in (None, False) for g in st["graphs"].values()), "backbone was not captured"
+    for got in (graphed, replay):
+        # MIOpen may pick another solver for a conv under capture (no lazily grown workspace): fp32 summation-order noise
+        torch.testing.assert_close(got[1], eager[1], rtol=1e-4, atol=1e-4)
+        for k in eager[0]:
+            np.testing.assert_allclose(got[0][k], eager[0][k], rtol=1e-4, atol=1e-6)
+        assert got[2].keys() == eager[2].keys()
+        for n in eager[2]:
+            d, ref = (got[2][n] - eager[2][n]).norm(), eager[2][n].norm()
+            assert float(d) <= 2e-3 * float(ref) + 1e-7 * eager[2][n].numel() ** 0.5, n
+
+
 # ------------------------------------------------------------------ fused HIP losses (csrc/losses.hip)
 @pytest.mark.parametrize("name", ["n300_c20_k2", "n1000_c80_k3"])
 def test_fused_losses_match_reference_and_autograd(dev, name, golden_dir):
