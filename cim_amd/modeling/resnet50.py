@@ -10,6 +10,7 @@ as resnet50.py:53-77 does.
 import torch.nn as nn
 
 from ..core.config import cfg
+from ..ops import bn_act
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "resnet50.MaskFuse" by get_func)
 
 
@@ -28,13 +29,14 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        # BatchNorm (eval statistics) + residual + ReLU chains as one HIP launch each way (cim_amd/csrc/bn_act.hip);
+        # bn_act falls back to the ATen ops for a BN in training mode or CPU tensors
         identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = bn_act(self.conv1(x), self.bn1)
+        out = bn_act(self.conv2(out), self.bn2)
         if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu(out + identity)
+            identity = bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+        return bn_act(self.conv3(out), self.bn3, residual=identity)
 
 
 def _make_layer(inplanes, planes, blocks, stride):

@@ -150,6 +150,19 @@ int cim_assign(const uint16_t* iou_f16, int N, const int32_t* gt_idx, const int3
                float* pseudo_labels, uint16_t* pseudo_iou_f16, float* loss_weights, int32_t* max_idx,
                void* stream);
 
+/* ------------------------------------------------------------------ backbone BatchNorm chains (a-11)
+ * Frozen-statistics BatchNorm (+ residual) (+ ReLU) of the ResNet / HRNet bodies, lib/modeling/resnet50.py:17-44,53-77
+ * (every BN in eval(): running statistics, trainable affine), one launch each way instead of 2-3 / 3-4 ATen passes.
+ * NCHW fp32; x, res, y, dy, dx, dres are [N,C,HW]; gamma, beta, mean, var, dgamma, dbeta are [C].
+ *   fwd: y = relu?(x*a + b (+ res)),  a = gamma*rsqrt(var+eps),  b = beta - mean*a        (res may be NULL)
+ *   bwd: dz = dy*(y>0 if relu); dx = dz*a; dres = dz; dgamma = sum dz*(x-mean)*rstd; dbeta = sum dz
+ *        (dx, dres, and the dgamma/dbeta pair may be NULL when not needed; y may be NULL without relu) */
+int cim_bn_act_fwd(const float* x, const float* res, const float* gamma, const float* beta, const float* mean,
+                   const float* var, float eps, float* y, int N, int C, int HW, int relu, void* stream);
+int cim_bn_act_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
+                   const float* var, float eps, float* dx, float* dres, float* dgamma, float* dbeta,
+                   int N, int C, int HW, int relu, void* stream);
+
 /* ------------------------------------------------------------------ MaskFuse contractions (a-2)
  * fp32-in / fp32-out MFMA GEMMs replacing the ATen/cuDNN calls behind MaskFuse,
  * lib/modeling/resnet50.py:104-110,135-136 (Conv2d(2C,C,3,pad=1), Linear(49C,4096),

@@ -531,3 +531,50 @@ def test_head_activations_hip_vs_reference_and_autograd(dev, golden_dir):
         (ref * up).sum().backward()
         torch.testing.assert_close(s, ref, rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(got, lg.grad, rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------ backbone BN chains (csrc/bn_act.hip)
+@pytest.mark.parametrize("relu,with_res,affine_grad", [(True, False, True), (True, True, True), (False, False, True),
+                                                        (True, True, False)])
+def test_bn_act_matches_aten(dev, relu, with_res, affine_grad):
+    """relu?(bn_eval(x) + residual) fused, forward and backward, against the ATen formulation in fp64."""
+    import torch.nn.functional as F
+    from cim_amd.ops import bn_act
+    g = torch.Generator().manual_seed(7)
+    N, C, H, W = 2, 24, 13, 17                                       # odd plane size: no 16-byte alignment
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g)); bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g)); bn.running_var.copy_(torch.rand(C, generator=g) + 0.3)
+    if not affine_grad:
+        for p in bn.parameters():
+            p.requires_grad = False
+    x = torch.randn(N, C, H, W, generator=g)
+    r = torch.randn(N, C, H, W, generator=g) if with_res else None
+    go = torch.randn(N, C, H, W, generator=g)
+    import copy
+    bn64 = copy.deepcopy(bn).double()
+    x64 = x.double().requires_grad_(True)
+    r64 = r.double().requires_grad_(True) if with_res else None
+    out = bn64(x64) + (r64 if with_res else 0)
+    out = F.relu(out) if relu else out
+    out.backward(go.double())
+    bnd = copy.deepcopy(bn).to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    rd = r.to(dev).requires_grad_(True) if with_res else None
+    y = bn_act(xd, bnd, residual=rd, relu=relu)
+    y.backward(go.to(dev))
+    tol = dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(y.detach().cpu().double(), out.detach(), **tol)
+    torch.testing.assert_close(xd.grad.cpu().double(), x64.grad, **tol)
+    if with_res:
+        torch.testing.assert_close(rd.grad.cpu().double(), r64.grad, **tol)
+    if affine_grad:
+        torch.testing.assert_close(bnd.weight.grad.cpu().double(), bn64.weight.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(bnd.bias.grad.cpu().double(), bn64.bias.grad, rtol=1e-4, atol=1e-4)
+    else:
+        assert bnd.weight.grad is None and bnd.bias.grad is None
+    bnd.train()                                                      # training-mode BN: ATen path, batch statistics
+    y2 = bn_act(x.to(dev), bnd, relu=relu)
+    ref2 = copy.deepcopy(bn).train()(x)
+    torch.testing.assert_close(y2.detach().cpu(), (F.relu(ref2) if relu else ref2).detach(), rtol=1e-4, atol=1e-4)
