@@ -27,6 +27,7 @@ SIGNATURES = {
     "cim_contain_argmax": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P],
     "cim_arbitrate": [_P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P],
     "cim_bn_act_fwd": [_P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, _P],
+    "cim_bn_act_bwd_chunks": [c_int, c_int, c_int],
     "cim_bn_act_bwd": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_gemm_set_engine": [c_int],
     "cim_gemm_get_engine": [],
@@ -88,7 +89,7 @@ def load():
     return lib
 
 
-VALUE_RETURNING = {"cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_gemm_get_engine"}      # return a count, not a status
+VALUE_RETURNING = {"cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_gemm_get_engine"}      # return a count, not a status
 
 
 def call(name, *args):

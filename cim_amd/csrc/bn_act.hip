@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     }
 }
 
-// grid = C; block = 512.  dx / dres may alias dy (in-place is not used by the host, but nothing forbids it).
+// grid = (C, chunks); block = 512.  A channel's N x HW elements are cut into `chunks` contiguous ranges so that narrow,
+// high-resolution layers (HRNet: 48 channels x 24k pixels) still fill the chip; with chunks > 1 the per-channel sums
+// meet through atomicAdd into caller-zeroed dgamma / dbeta.
 __global__ __launch_bounds__(512) void bn_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                          const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
@@ -42,17 +44,19 @@ __global__ __launch_bounds__(512) void bn_act_bwd_kernel(const float* __restrict
     const int c = blockIdx.x, tid = threadIdx.x;
     const float rstd = rsqrtf(var[c] + eps), mu = mean[c];
     const float a = gamma[c] * rstd;
+    const long long total = (long long)N * HW;
+    const long long per = (total + gridDim.y - 1) / gridDim.y;
+    const long long e0 = (long long)blockIdx.y * per, e1 = min(total, e0 + per);
     float sum_dz = 0.0f, sum_dzx = 0.0f;
-    for (int n = 0; n < N; ++n) {
-        const size_t base = ((size_t)n * C + c) * HW;
-        for (int i = tid; i < HW; i += 512) {
-            float dz = dy[base + i];
-            if (relu && !(y[base + i] > 0.0f)) dz = 0.0f;
-            if (dx != nullptr) dx[base + i] = dz * a;
-            if (dres != nullptr) dres[base + i] = dz;
-            sum_dz += dz;
-            sum_dzx = fmaf(dz, x[base + i] - mu, sum_dzx);
-        }
+    for (long long e = e0 + tid; e < e1; e += 512) {
+        const int n = (int)(e / HW);
+        const size_t i = ((size_t)n * C + c) * HW + (size_t)(e - (long long)n * HW);
+        float dz = dy[i];
+        if (relu && !(y[i] > 0.0f)) dz = 0.0f;
+        if (dx != nullptr) dx[i] = dz * a;
+        if (dres != nullptr) dres[i] = dz;
+        sum_dz += dz;
+        sum_dzx = fmaf(dz, x[i] - mu, sum_dzx);
     }
     if (dgamma == nullptr) return;                // frozen affine: block-uniform
 #pragma unroll
@@ -65,8 +69,13 @@ __global__ __launch_bounds__(512) void bn_act_bwd_kernel(const float* __restrict
     if (tid == 0) {
         float t1 = 0.0f, t2 = 0.0f;
         for (int w = 0; w < 8; ++w) { t1 += s1[w]; t2 += s2[w]; }
-        dbeta[c] = t1;
-        dgamma[c] = t2 * rstd;
+        if (gridDim.y > 1) {
+            atomicAdd(dbeta + c, t1);
+            atomicAdd(dgamma + c, t2 * rstd);
+        } else {
+            dbeta[c] = t1;
+            dgamma[c] = t2 * rstd;
+        }
     }
 }
 
@@ -84,13 +93,25 @@ extern "C" int cim_bn_act_fwd(const float* x, const float* res, const float* gam
     return 0;
 }
 
+// > 1: the launch accumulates dgamma / dbeta with atomicAdd and the caller must zero them first
+extern "C" int cim_bn_act_bwd_chunks(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 1;
+    const long long total = (long long)N * HW;
+    if (C >= 128) return 1;                                    // enough workgroups: plain stores, no zero-fill launch
+    long long want = (1024 + C - 1) / C;                       // ~1024 workgroups
+    const long long cap = (total + 4095) / 4096;               // >= 8 elements per lane
+    if (want > cap) want = cap;
+    return (int)(want < 1 ? 1 : want);
+}
+
 extern "C" int cim_bn_act_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
                               const float* var, float eps, float* dx, float* dres, float* dgamma, float* dbeta, int N, int C,
                               int HW, int relu, void* stream) {
     CIM_CHECK_ARG(dy && x && gamma && mean && var && N > 0 && C > 0 && HW > 0);
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)));
-    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(C), dim3(512), 0, cim::as_stream(stream), dy, y, x, gamma, mean, var, eps, dx,
-                       dres, dgamma, dbeta, N, C, HW, relu);
+    const int chunks = cim_bn_act_bwd_chunks(N, C, HW);
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(C, chunks), dim3(512), 0, cim::as_stream(stream), dy, y, x, gamma, mean, var,
+                       eps, dx, dres, dgamma, dbeta, N, C, HW, relu);
     CIM_CHECK_LAUNCH();
     return 0;
 }

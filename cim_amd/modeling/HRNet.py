@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..core.config import cfg
+from ..ops import bn_act
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "HRNet.MaskFuse" by get_func)
 
 BN_MOMENTUM = 0.1
@@ -36,6 +37,13 @@ def _conv_bn(cin, cout, k, stride, relu, bias=False):
     return nn.Sequential(*layers)
 
 
+def _downsample(ds, x):
+    """conv -> BN projection shortcut (nn.Sequential of exactly those two)."""
+    if len(ds) == 2 and isinstance(ds[1], nn.BatchNorm2d):
+        return bn_act(ds[0](x), ds[1], relu=False)
+    return ds(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -49,10 +57,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
-        res = x if self.downsample is None else self.downsample(x)
-        return self.relu(out + res)
+    def forward(self, x):       # BN (+ residual) + ReLU chains fused (cim_amd/csrc/bn_act.hip) when the BN is in eval()
+        out = bn_act(self.conv1(x), self.bn1)
+        res = x if self.downsample is None else _downsample(self.downsample, x)
+        return bn_act(self.conv2(out), self.bn2, residual=res)
 
 
 class Bottleneck(nn.Module):
@@ -71,11 +79,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        res = x if self.downsample is None else self.downsample(x)
-        return self.relu(out + res)
+        out = bn_act(self.conv1(x), self.bn1)
+        out = bn_act(self.conv2(out), self.bn2)
+        res = x if self.downsample is None else _downsample(self.downsample, x)
+        return bn_act(self.conv3(out), self.bn3, residual=res)
 
 
 BLOCKS = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
@@ -217,8 +224,8 @@ class HighResolutionNet(nn.Module):
         return {name: name for name, _ in self.named_parameters()}, []
 
     def _stem(self, x):
-        x = self.relu(self.bn1(self.conv1(x)))
-        x = self.relu(self.bn2(self.conv2(x)))
+        x = bn_act(self.conv1(x), self.bn1)
+        x = bn_act(self.conv2(x), self.bn2)
         return self.layer1(x)
 
     def _stage(self, idx, ys):

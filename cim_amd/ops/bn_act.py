@@ -35,8 +35,10 @@ class BnActFunction(Function):
         need_affine = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         dx = torch.empty_like(x) if need_x else None
         dres = torch.empty_like(x) if need_res else None
-        dgamma = torch.empty_like(gamma) if need_affine else None
-        dbeta = torch.empty_like(gamma) if need_affine else None
+        dgamma = dbeta = None
+        if need_affine:      # accumulated with atomics when the launch splits a channel over several workgroups
+            alloc = torch.zeros if _lib.call("cim_bn_act_bwd_chunks", n, c, hw) > 1 else torch.empty
+            dgamma, dbeta = alloc(2, c, dtype=torch.float32, device=x.device).unbind(0)
         _lib.call("cim_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                   var.data_ptr(), eps, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), n, c, hw,
                   int(relu), _lib.stream_ptr())

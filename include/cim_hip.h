@@ -156,9 +156,12 @@ int cim_assign(const uint16_t* iou_f16, int N, const int32_t* gt_idx, const int3
  * NCHW fp32; x, res, y, dy, dx, dres are [N,C,HW]; gamma, beta, mean, var, dgamma, dbeta are [C].
  *   fwd: y = relu?(x*a + b (+ res)),  a = gamma*rsqrt(var+eps),  b = beta - mean*a        (res may be NULL)
  *   bwd: dz = dy*(y>0 if relu); dx = dz*a; dres = dz; dgamma = sum dz*(x-mean)*rstd; dbeta = sum dz
- *        (dx, dres, and the dgamma/dbeta pair may be NULL when not needed; y may be NULL without relu) */
+ *        (dx, dres, and the dgamma/dbeta pair may be NULL when not needed; y may be NULL without relu).
+ *        When cim_bn_act_bwd_chunks(N,C,HW) > 1 the per-channel sums are accumulated with atomicAdd: the caller
+ *        zeroes dgamma / dbeta first. */
 int cim_bn_act_fwd(const float* x, const float* res, const float* gamma, const float* beta, const float* mean,
                    const float* var, float eps, float* y, int N, int C, int HW, int relu, void* stream);
+int cim_bn_act_bwd_chunks(int N, int C, int HW);
 int cim_bn_act_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
                    const float* var, float eps, float* dx, float* dres, float* dgamma, float* dbeta,
                    int N, int C, int HW, int relu, void* stream);
