@@ -197,9 +197,9 @@ class Conv3x3Function(Function):
             vr = uc = None
             ctx.fused_scales = ENGINE == "f16x2" and tile == 4
             if ctx.fused_scales:
-                # operand scales of the f16x2 engine without a pass over the 1.2 GB transformed tensors: row maxima of
-                # V come out of the transform kernel itself; column scales are BOUNDS from the |max| of the
-                # untransformed tensors (x per channel, w per filter) times the transform's absolute row sums
+                # operand scales of the f16x2 engine without a pass over the 1.2 GB transformed tensors: all of them are
+                # upper BOUNDS from the |max| of the untransformed tensors (x per tile for the rows of V - inside the
+                # transform kernel -, x per channel, w per filter) times the transform's absolute row sums
                 vr = torch.empty(npos * mt, dtype=torch.int32, device=dev)
                 _lib.call("cim_wino_input_transform_amax", x.data_ptr(), V.data_ptr(), vr.data_ptr(), r, p, cin, tile, st)
                 need_xc = ctx.needs_input_grad[1] and x_col_amax is None

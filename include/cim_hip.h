@@ -245,8 +245,9 @@ int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, int 
 int cim_flatten_chw(const float* src, const float* relu_y, float* dst, int R, int PP, int C, int backward, void* stream);
 
 /* f16x2 engine helpers (tile = 4 only):
- * cim_wino_input_transform_amax: the input transform that also stores row_amax [36][R*T*T] = max |V[pos][m][:]| (bit
- *   patterns; plain stores, nothing to zero) - the per-row operand scales of the forward / data-gradient GEMMs.
+ * cim_wino_input_transform_amax: the input transform that also stores row_amax [36][R*T*T], an upper bound of
+ *   max |V[pos][m][:]| (bit patterns; f_pos * max |x| over the tile's patch and all channels; plain stores, nothing
+ *   to zero) - the per-row operand scales of the forward / data-gradient GEMMs.
  * cim_wino_scale_bounds: per-column scale BOUNDS of a transformed operand from the |max| of the untransformed
  *   tensor, bounds [36][n] = f_pos * max_{t<group} amax_in[n*group + t], f_pos = product of the absolute row sums
  *   of the transform matrix (kind 0: B^T (input), 1: G (filter), 2: G4 (output gradient)). */

@@ -228,9 +228,9 @@ def test_conv3x3_full_size_linearity(dev):
 
 
 def test_wino_fused_scales(dev):
-    """The f16x2 engine's Winograd operand scales: row maxima stored by the input transform equal the maxima of
-    the V it wrote; the column bounds derived from the untransformed tensors dominate the true column maxima
-    (never below - that would overflow fp16 - and within the transform's gain above)."""
+    """The f16x2 engine's Winograd operand scales: the row bounds stored by the input transform and the column bounds
+    derived from the untransformed tensors dominate the true maxima of the transformed operands (never below - that
+    would overflow fp16 - and within the transform's gain above)."""
     from cim_amd import _lib
     from cim_amd.ops import gemm as G
     g = torch.Generator().manual_seed(9)
@@ -244,7 +244,8 @@ def test_wino_fused_scales(dev):
     V0 = torch.empty_like(V)
     _lib.call("cim_wino_input_transform", x.data_ptr(), V0.data_ptr(), R, P, C, 4, st)
     assert torch.equal(V, V0)
-    assert torch.equal(vr.view(torch.float32).view(npos, mt), V.abs().amax(dim=2))
+    rb, true_rows = vr.view(torch.float32).view(npos, mt), V.abs().amax(dim=2)
+    assert bool((rb >= true_rows).all()) and bool((rb <= 49.01 * x.abs().max()).all())
     xc = G.amax(x, R * P * P, C, C, want_cols=True)[1]
     vb = G._bounds(xc, C, 1, 0, npos, dev).view(torch.float32).view(npos, C)
     true = V.abs().amax(dim=1)
