@@ -937,7 +937,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_f16x2_kernel(const GemmArgs g_in) 
 #undef X2_FRAG
 #undef X2_MMA
 
-    // epilogue: undo the operand scales (powers of two: exact), bias, ReLU
+    // epilogue: undo the operand scales (powers of two: exact), bias, ReLU.  The 256 row factors are staged through
+    // LDS (free after the last slab): fetched per accumulator register they were 128 dependent global loads per lane.
+    float* s_isa = reinterpret_cast<float*>(smem2);
+    __syncthreads();
+    if (tid < BM) s_isa[tid] = x2_inv(x2_scale(g.a_amax[min(m0 + tid, g.M - 1)]));
+    __syncthreads();
     float* C = g.C + (size_t)zsplit * g.c_split_stride;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -949,10 +954,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_f16x2_kernel(const GemmArgs g_in) 
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int m = m0 + ml;
                 if (m >= g.M) continue;
-                const float isa = x2_inv(x2_scale(g.a_amax[m]));
-                float v = acc[i][j][r] * isa * isb + bv;
+                float v = acc[i][j][r] * s_isa[ml] * isb + bv;
                 if (g.relu) v = fmaxf(v, 0.0f);
                 C[(size_t)m * g.ldc + n] = v;
             }

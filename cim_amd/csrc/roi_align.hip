@@ -675,12 +675,15 @@ constexpr int GA_MAXE = 1024;      // entries per LDS window
 #define CIM_ROI_GU 4               // entries in flight per lane in the streaming phase (4 or 8)
 #endif
 constexpr int GA_GS = CIM_ROI_GS;
+#ifndef CIM_ROI_GOCC
+#define CIM_ROI_GOCC 4          // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
+#endif
 #ifndef CIM_ROI_GEXP
 #define CIM_ROI_GEXP 0          // ablations: 1 = no streaming phase, 2 = no flush
 #endif
 
 template <int GH, int GW, bool MASKCAT>
-__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ grad_out,
+__global__ __launch_bounds__(256, CIM_ROI_GOCC) void roi_align_bwd_gather_kernel(const float* __restrict__ grad_out,
                                                                    const float* __restrict__ masks,
                                                                    float* __restrict__ grad_in, int C, int H, int W,
                                                                    int K, int P, int B, int use_atomic,

@@ -118,6 +118,12 @@ class Generalized_RCNN(nn.Module):
             if self.training:
                 if not labels.is_cuda:
                     labels_host = labels.detach().reshape(-1).numpy().copy()
+                else:       # device-resident labels: one read-back per tensor version, not a device sync every step
+                    key = (labels.data_ptr(), labels._version, tuple(labels.shape))
+                    cache = self.__dict__.get("_labels_cache")
+                    if cache is None or cache[0] != key:
+                        cache = self.__dict__["_labels_cache"] = (key, labels.detach().reshape(-1).cpu().numpy().copy())
+                    labels_host = cache[1]
                 if not mat.is_cuda:
                     mat_host = mat.detach().squeeze(dim=0).numpy()
                 dev, dt = im_data.device, im_data.dtype
