@@ -966,39 +966,45 @@ __global__ __launch_bounds__(NT, 2) void gemm_f16x2_kernel(const GemmArgs g_in) 
 }
 
 // |max| bit patterns per row and per column of X [batch][rows][ld] (cols used), accumulated with atomicMax
-// into caller-zeroed arrays; either output may be null.  Workgroup = AMAX_ROWS rows x 1024 columns, a lane owns
-// 4 consecutive columns: column maxima stay in registers, row maxima are wave-reduced per row.  Four rows are
-// in flight per lane (4 x 16 B loads issued together) - the kernel is a pure HBM stream.
-constexpr int AMAX_ROWS = 64;
-__device__ __forceinline__ unsigned amax_wave(unsigned m) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    return m;
+// into caller-zeroed arrays; either output may be null.  A lane owns 4 consecutive columns: column maxima stay in
+// registers, row maxima are wave-reduced per row.  The kernel is a pure HBM stream.
+// wave-wide maximum on the VALU (v_max_u32_dpp: row_shr 1,2,4,8 leave each 16-lane row's maximum in its lane 15, then
+// row_bcast:15 / row_bcast:31 carry it up): valid in LANE 63.
+__device__ __forceinline__ unsigned amax_wave(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));
+    return v;
 }
+// rows_per_wg rows (a multiple of AMAX_UNROLL) x 1024 columns per workgroup; AMAX_UNROLL rows (16 B loads) in flight per lane
+constexpr int AMAX_UNROLL = 4;
 __global__ __launch_bounds__(256) void amax_rowcol_kernel(const float* __restrict__ X, int rows, int cols, int ld,
                                                           long long bs, unsigned* __restrict__ row_amax,
-                                                          unsigned* __restrict__ col_amax) {
+                                                          unsigned* __restrict__ col_amax, int rows_per_wg) {
     X += (size_t)blockIdx.z * bs;
     const int c = blockIdx.x * 1024 + threadIdx.x * 4;
-    const int r0 = blockIdx.y * AMAX_ROWS, r1 = min(rows, r0 + AMAX_ROWS);
+    const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
     const bool cin = c < cols;
     const float* p = X + (size_t)r0 * ld + (cin ? c : 0);
     unsigned* ra = row_amax ? row_amax + (size_t)blockIdx.z * rows : nullptr;
-    const bool lead = (threadIdx.x & 63) == 0;
+    const bool lead = (threadIdx.x & 63) == 63;
     uint4 cm = make_uint4(0, 0, 0, 0);
     int r = r0;
-    for (; r + 4 <= r1; r += 4, p += 4 * (size_t)ld) {
-        uint4 v[4];
+    for (; r + AMAX_UNROLL <= r1; r += AMAX_UNROLL, p += AMAX_UNROLL * (size_t)ld) {
+        uint4 v[AMAX_UNROLL];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const uint4*>(p + (size_t)i * ld);
+        for (int i = 0; i < AMAX_UNROLL; ++i) v[i] = *reinterpret_cast<const uint4*>(p + (size_t)i * ld);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AMAX_UNROLL; ++i) {
             v[i].x &= 0x7fffffffu; v[i].y &= 0x7fffffffu; v[i].z &= 0x7fffffffu; v[i].w &= 0x7fffffffu;
             cm.x = max(cm.x, v[i].x); cm.y = max(cm.y, v[i].y); cm.z = max(cm.z, v[i].z); cm.w = max(cm.w, v[i].w);
         }
         if (ra != nullptr) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < AMAX_UNROLL; ++i) {
                 const unsigned m = amax_wave(cin ? max(max(v[i].x, v[i].y), max(v[i].z, v[i].w)) : 0u);
                 if (lead) atomicMax(ra + r + i, m);
             }
@@ -1186,10 +1192,14 @@ extern "C" int cim_amax_rowcol(const float* X, int rows, int cols, int ld, int b
     CIM_CHECK_ARG(X && rows > 0 && cols > 0 && batch > 0 && batch <= 65535);
     CIM_CHECK_ARG(cols % 4 == 0 && ld % 4 == 0 && ld >= cols && bs % 4 == 0);
     CIM_CHECK_ARG(row_amax != nullptr || col_amax != nullptr);
-    const dim3 grid((cols + 1023) / 1024, (rows + AMAX_ROWS - 1) / AMAX_ROWS, batch);
+    // 64 rows x 1024 columns per workgroup (measured: smaller row blocks lose more to the column atomics than they
+    // gain in parallelism, 8 rows in flight per lane no better than 4)
+    const long long strips = (cols + 1023) / 1024;
+    const int rpw = 64;
+    const dim3 grid((unsigned)strips, (rows + rpw - 1) / rpw, batch);
     CIM_CHECK_ARG(grid.y <= 65535);
     hipLaunchKernelGGL(amax_rowcol_kernel, grid, dim3(256), 0, cim::as_stream(stream), X, rows, cols, ld, bs, row_amax,
-                       col_amax);
+                       col_amax, rpw);
     CIM_CHECK_LAUNCH();
     return 0;
 }
