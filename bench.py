@@ -123,8 +123,11 @@ def make_optimizer(model):
         if p.requires_grad:
             (bias if "bias" in name else nonbias).append(p)
     lr, wd = 0.0005, 0.0005                                   # configs/resnet50_voc.yaml SOLVER
-    return torch.optim.SGD([dict(params=nonbias, lr=lr, weight_decay=wd),
-                            dict(params=bias, lr=2 * lr, weight_decay=0.0)], lr=lr, momentum=0.9, fused=True)
+    groups = [dict(params=nonbias, lr=lr, weight_decay=wd), dict(params=bias, lr=2 * lr, weight_decay=0.0)]
+    if os.environ.get("CIM_OPTIM", "hip") == "aten":
+        return torch.optim.SGD(groups, lr=lr, momentum=0.9, fused=True)
+    from cim_amd.optim import SGD          # fused multi-tensor SGD, one HIP launch per step (cim_amd/csrc/sgd.hip)
+    return SGD(groups, lr=lr, momentum=0.9)
 
 
 def cpu_baseline(config, budget_n=0):

@@ -302,6 +302,22 @@ int cim_head_act_fwd(const float* logits, float* scores, float* colstat, int N, 
 int cim_head_act_bwd(const float* scores, const float* grad_scores, float* grad_logits, float* coldot,
                      int N, int C1, int R, void* stream);
 
+/* ------------------------------------------------------------------ optimizer step
+ * Fused multi-tensor SGD with momentum and weight decay: torch.optim.SGD's update (dampening 0, no Nesterov) as
+ * constructed at tools/train.py:282-311 and stepped at :438, ONE launch for all tensors:
+ *     g' = g + wd*p ;  buf = momentum*buf + g' ;  p = p - lr*buf        (buf zero-initialised by the caller)
+ * `table` is a DEVICE array of n_chunks records; a workgroup streams one record.  Chunks of one tensor are consecutive
+ * element ranges (the host uses 16384 elements); `aligned` != 0 promises 16-byte alignment of the three pointers. */
+typedef struct cim_sgd_chunk {
+    uint64_t p;        /* float* parameter chunk (device address) */
+    uint64_t g;        /* const float* gradient chunk */
+    uint64_t buf;      /* float* momentum buffer chunk */
+    int32_t n;         /* elements */
+    int32_t aligned;
+    float lr, wd;
+} cim_sgd_chunk;
+int cim_sgd_multi(const cim_sgd_chunk* table, int n_chunks, float momentum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

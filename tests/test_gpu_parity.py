@@ -578,3 +578,38 @@ def test_bn_act_matches_aten(dev, relu, with_res, affine_grad):
     y2 = bn_act(x.to(dev), bnd, relu=relu)
     ref2 = copy.deepcopy(bn).train()(x)
     torch.testing.assert_close(y2.detach().cpu(), (F.relu(ref2) if relu else ref2).detach(), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ optimizer (csrc/sgd.hip)
+def test_fused_sgd_matches_torch_sgd(dev):
+    """cim_amd.optim.SGD == torch.optim.SGD (momentum, weight decay, two groups as tools/train.py:282-311) over several
+    steps, on tensors of odd sizes (tails, chunk boundaries) and an unaligned view; momentum buffers stay addressable
+    the way lib/utils/net.py:_CorrectMomentum scales them."""
+    from cim_amd.optim import SGD
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1000, 50), (16384,), (16385,), (7,), (3, 5, 7), (40000,)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    storage = torch.randn(1001, generator=g)
+    ref_p = [b.clone().requires_grad_(True) for b in base] + [storage.clone()[1:].requires_grad_(True)]
+    big = storage.clone().to(dev)
+    hip_p = [b.clone().to(dev).requires_grad_(True) for b in base] + [big[1:].detach().requires_grad_(True)]   # 4-byte aligned view
+    mk = lambda ps, cls: cls([dict(params=ps[:3], lr=0.05, weight_decay=0.01), dict(params=ps[3:], lr=0.1, weight_decay=0.0)],
+                             lr=0.05, momentum=0.9)
+    ref, hip = mk(ref_p, torch.optim.SGD), mk(hip_p, SGD)
+    for step in range(4):
+        for rp, hp in zip(ref_p, hip_p):
+            gr = torch.randn(rp.shape, generator=g)
+            rp.grad, hp.grad = gr.clone(), gr.clone().to(dev)
+        if step == 2:                                   # lr change + momentum correction as net.py does it
+            for opt in (ref, hip):
+                for grp in opt.param_groups:
+                    grp["lr"] *= 0.1
+                    for p in grp["params"]:
+                        opt.state[p]["momentum_buffer"] *= 0.1
+        ref.step()
+        hip.step()
+    for rp, hp in zip(ref_p, hip_p):
+        torch.testing.assert_close(hp.detach().cpu(), rp.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(hip.state[hp]["momentum_buffer"].cpu(), ref.state[rp]["momentum_buffer"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        SGD(hip_p, lr=0.1, momentum=0.9, nesterov=True)
