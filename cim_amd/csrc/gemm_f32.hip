@@ -216,6 +216,20 @@ __device__ __forceinline__ float4 x2_scale4(const unsigned* amax, int i0, int li
                        x2_scale(amax[min(i0 + 2, limit - 1)]), x2_scale(amax[min(i0 + 3, limit - 1)]));
 }
 
+// Thread -> (row quad, k pair) of the M/N-contiguous loaders.  A lane writes 4 bytes (its k pair) into 16 B row slots,
+// so the LDS bank of a write is 4*(slot mod 8) + (k pair & 3) (+16 for the second k-group): for the 32 lanes of a
+// ds_write_b32 group to cover all 32 banks they must span 4 k pairs x 8 slot residues - k pair from lane bits 0-1, the
+// quad's bit 0 from lane bit 2 and its bits 2-3 (which rotate the slot swizzle) from lane bits 3-4.  With one k pair per
+// wave (the first layout) all lanes wrote the same 4-byte column of slots 64 B apart: 8 banks, 4-way conflicts,
+// SQ_LDS_BANK_CONFLICT = 37-54 % of the LDS cycles of the kernels with such an operand (0 for K-contiguous ones).
+// Global side: a wave-load covers 4 k rows x 256 contiguous bytes.
+static_assert(BM == 256 && BN == 256 && NT == 512 && BK == 16, "mn_lane_map: 64 row quads x 8 k pairs over 512 threads");
+__device__ __forceinline__ void mn_lane_map(int tid, int& quad, int& kpair) {
+    const int l = tid & 63, w = tid >> 6;
+    kpair = (l & 3) | ((w & 1) << 2);
+    quad = ((l >> 2) & 1) | (((l >> 5) & 1) << 1) | (((l >> 3) & 3) << 2) | ((w >> 1) << 4);
+}
+
 // ---- A operand -------------------------------------------------------------------------------
 // K-contiguous: each thread owns float4 pieces (row, 4 consecutive k); BM*BK/4/NT = 2 pieces.
 template <int AL>
@@ -320,8 +334,7 @@ struct ALoaderM {
         x2_store_m(op, mq, krow0, v, sc, k < kend ? 1.0f : 0.0f, k + 1 < kend ? 1.0f : 0.0f);
     }
     __device__ __forceinline__ void init(const GemmArgs& g, int m0, int tid) {
-        mq = tid % COLS4;
-        krow0 = tid / COLS4;
+        mn_lane_map(tid, mq, krow0);
         const int m = m0 + mq * 4;
         if (AL == A_CONV_M) {   // m = (tap, ci); 4 consecutive m share the tap (Cin % 4 == 0)
             const int tap = m / g.Cin;
@@ -381,8 +394,7 @@ struct BLoaderN {   // element (k, n) at B[k*ldb + n]
         x2_store_m(op, nq, krow0, v, sc, k < kend ? 1.0f : 0.0f, k + 1 < kend ? 1.0f : 0.0f);
     }
     __device__ __forceinline__ void init(const GemmArgs& g, int n0, int tid) {
-        nq = tid % COLS4;
-        krow0 = tid / COLS4;
+        mn_lane_map(tid, nq, krow0);
         const int n = n0 + nq * 4;
         base = g.B + min(n, g.N - 4);           // branch-free: columns >= N re-read the last quad (never stored)
     }
