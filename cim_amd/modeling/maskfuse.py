@@ -11,7 +11,6 @@ materialised tensors (box_x, mask_x, cat) as in the reference.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..core.config import cfg
 from ..ops import conv3x3, gemm, linear, roi_align_maskcat
