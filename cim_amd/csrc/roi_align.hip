@@ -390,6 +390,12 @@ __device__ __forceinline__ ga_f2 ga_fma(float w, ga_f2 v, ga_f2 a) { return __bu
 #ifndef CIM_ROI_FU
 #define CIM_ROI_FU 8             // loads in flight per lane in the aggregated forward (4 or 8)
 #endif
+#ifndef CIM_ROI_FEXP
+#define CIM_ROI_FEXP 0           // ablations: 1 = no stores (0.131 ms incl. tables), 2 = no loads (0.100); product 0.157
+#endif
+#ifndef CIM_ROI_FZ
+#define CIM_ROI_FZ 1             // channel slices of the aggregated forward (grid.z); 2 / 4 (L2-sized slices) measured equal
+#endif
 constexpr int AG_MAXE = 64;     // entries per (ph, pw) list kept in LDS; larger bins take the sample-order kernel
 
 template <bool MASKCAT>
@@ -404,7 +410,10 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
     __shared__ int s_n[FW_MAXP], s_xlo[FW_MAXP], s_nx[FW_MAXP];
     __shared__ int s_rows[64];                   // rows with a non-zero weight in this bin row
     __shared__ int s_nrows;
-    const int k = blockIdx.x, ph = blockIdx.y, tid = threadIdx.x;
+    // grid.z splits the channels (CIM_ROI_FZ slices): with 2 slices one slice of the cfg2 map (2.9 MB) fits an XCD's 4 MB L2
+    const int k = blockIdx.x, ph = blockIdx.y, tid = threadIdx.x, NTH = blockDim.x;
+    const int cslice = ((C / 4 + gridDim.z - 1) / gridDim.z) * 4;
+    const int c_first = blockIdx.z * cslice + tid * 4, c_end = min(C, (int)(blockIdx.z + 1) * cslice);
     const float* rec = rec_all + (size_t)k * roi_rec_words(P, H, W);
     const float* wy = rec + ph * H;
     const float* wx = rec + P * H;
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
     const int OC = MASKCAT ? 2 * C : C;
     if (s_over) {      // block-uniform: a bin larger than the LDS list (ROI far larger than the map) -> sample by sample
         const RoiGeom g = roi_geom(rois + 5 * (size_t)k, scale, P, sampling_ratio, aligned);
-        for (int c = tid * 4; c < C; c += 256 * 4) {
+        for (int c = c_first; c < c_end; c += NTH * 4) {
             for (int pw = 0; pw < P; ++pw) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int iy = 0; iy < g.gh; ++iy) {
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
         }
         return;
     }
-    for (int e = tid; e < P * AG_MAXE; e += 256) {
+    for (int e = tid; e < P * AG_MAXE; e += NTH) {
         const int pw = e / AG_MAXE, i = e % AG_MAXE;
         const int nx = s_nx[pw];
         const int n = nrows * nx;
@@ -470,11 +479,15 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
         }
     }
     __syncthreads();
-    for (int c = tid * 4; c < C; c += 256 * 4) {
+    for (int c = c_first; c < c_end; c += NTH * 4) {
         const float* __restrict__ fc = fb + c;
         for (int pw = 0; pw < P; ++pw) {
             const int2* el = ent + pw * AG_MAXE;
+#if CIM_ROI_FEXP == 2
+            const int n = 0;
+#else
             const int n = s_n[pw];
+#endif
             ga_f2 al = {0.f, 0.f}, ah = {0.f, 0.f};
             int i = 0;
 #if CIM_ROI_FU == 8
@@ -513,6 +526,11 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
             }
             const float4 acc = make_float4(al.x, al.y, ah.x, ah.y);
             float* dst = out + (((size_t)k * P + ph) * P + pw) * OC + c;
+#if CIM_ROI_FEXP == 1      /* ablation: no stores */
+            if (acc.x != 123.456f) continue;
+#endif
+#if CIM_ROI_FEXP == 2      /* ablation: no loads (stores only) */
+#endif
             *reinterpret_cast<float4*>(dst) = acc;
             if (MASKCAT) *reinterpret_cast<float4*>(dst + C) = vmul(masks[((size_t)k * P + ph) * P + pw], acc);
         }
@@ -1092,8 +1110,9 @@ int launch_fwd(const float* feat, const float* rois, const float* masks, float* 
     if (ws != nullptr && C % 4 == 0 && P <= FW_MAXP && (long long)H * W * C < (1ll << 30) && H <= 64 &&
         getenv("CIM_ROI_FWD_EXACT") == nullptr) {
         hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), 0, st, rois, ws, K, P, H, W, scale, sr, aligned);
-        hipLaunchKernelGGL((roi_align_fwd_agg_kernel<MASKCAT>), grid, block, 0, st, feat, masks, out, C, H, W, P, ws, rois,
-                           scale, sr, aligned);
+        const int fz = (C >= 512 * CIM_ROI_FZ) ? CIM_ROI_FZ : 1;
+        hipLaunchKernelGGL((roi_align_fwd_agg_kernel<MASKCAT>), dim3(K, P, fz), dim3(fz > 1 ? 128 : 256), 0, st, feat, masks, out,
+                           C, H, W, P, ws, rois, scale, sr, aligned);
         return 0;
     }
     if (C % 4 == 0 && P <= FW_MAXP && (long long)H * W * C < (1ll << 30) && getenv("CIM_ROI_FWD_DIRECT") == nullptr)
