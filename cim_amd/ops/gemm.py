@@ -255,7 +255,9 @@ class Conv3x3Function(Function):
         t = (p + tile - 1) // tile
         mt = r * t * t
         fused = wino and getattr(ctx, "fused_scales", False)
-        if ctx.needs_input_grad[0]:
+
+        def data_grad():
+            st = _lib.stream_ptr()
             dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
             if wino:
                 # data gradient = the same convolution of dY with the 180-degree rotated, in/out-swapped filter
@@ -276,8 +278,10 @@ class Conv3x3Function(Function):
             else:
                 w2 = w.flip(2, 3).permute(2, 3, 0, 1).contiguous()                     # [3,3,Cout,Cin]
                 _lib.call("cim_conv3x3_f32", dy.data_ptr(), w2.data_ptr(), None, dxp.data_ptr(), r, p, cout, cin, 0, st)
-            dx = dxp.permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
+            return dxp.permute(0, 3, 1, 2)
+
+        def weight_grad():
+            st = _lib.stream_ptr()
             if wino:
                 D = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
                 dU = torch.empty((npos, cin, cout), dtype=torch.float32, device=dev)
@@ -296,6 +300,24 @@ class Conv3x3Function(Function):
                 _lib.call("cim_conv3x3_wgrad_f32", x.data_ptr(), dy.data_ptr(), dwh.data_ptr(), r, p, cin, cout, splits,
                           _lib.ptr(ws), st)
                 dw = dwh.permute(3, 2, 0, 1)
+            return dw
+
+        if OVERLAP and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # the two gradient paths are independent: on two HIP streams the weight-gradient GEMM (1152 tiles = 4.5
+            # rounds of 256 CUs) and the data-gradient GEMM fill each other's partly empty rounds, and the HBM-bound
+            # transform kernels of one path run under the MFMA-bound GEMM of the other
+            cur, side = torch.cuda.current_stream(), _side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                dw = weight_grad()
+            dx = data_grad()
+            cur.wait_stream(side)
+            dw.record_stream(cur)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = data_grad()
+            if ctx.needs_input_grad[1]:
+                dw = weight_grad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1, 2))
         return dx, dw, db, None, None, None
