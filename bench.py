@@ -261,12 +261,13 @@ def main():
         #   Winograd F(4x4,3x3) (CIM_CONV_ALGO=winograd4): 36 batched GEMMs [4N x 2Cf] x [2Cf x Cf]
         wino_ms = timer.mean_ms("wino_gemm_fwd")
         from cim_amd.ops import gemm as gemm_mod
-        tile = 4 if gemm_mod.CONV_ALGO == "winograd4" else 2
+        #   mixed tiling (CIM_CONV_ALGO=winograd7, default): 121 batched GEMMs [N x 2Cf] x [2Cf x Cf]
         if wino_ms:
-            npos, tiles = (tile + 2) ** 2, ((7 + tile - 1) // tile) ** 2
-            kname = "gemm_f32_kernel<A_KCONTIG,B_NCONTIG> x%d (MaskFuse conv3x3 fwd, Winograd F(%dx%d,3x3) domain)" \
-                % (npos, tile, tile)
-            conv_ms, conv_flops = wino_ms, 2.0 * npos * (tiles * n) * (2 * Cf) * Cf
+            _, npos, rows = gemm_mod._wino_geometry(gemm_mod.CONV_ALGO, 7, n)
+            what = {"winograd7": "Winograd 4+3 mixed tiling", "winograd4": "Winograd F(4x4,3x3)", "winograd": "Winograd F(2x2,3x3)"}
+            kname = "gemm_f32_kernel<A_KCONTIG,B_NCONTIG> x%d (MaskFuse conv3x3 fwd, %s domain)" \
+                % (npos, what.get(gemm_mod.CONV_ALGO, gemm_mod.CONV_ALGO))
+            conv_ms, conv_flops = wino_ms, 2.0 * npos * rows * (2 * Cf) * Cf
         else:
             kname = "gemm_f32_kernel<A_CONV_K,B_NCONTIG> (MaskFuse conv3x3 fwd, implicit GEMM)"
             conv_ms, conv_flops = timer.mean_ms("maskfuse_conv_fwd"), 2.0 * 49 * n * (2 * Cf * 9) * Cf

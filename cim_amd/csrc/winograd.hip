@@ -440,6 +440,301 @@ __global__ __launch_bounds__(256) void wino43_wgrad_out_kernel(const float* __re
 }
 
 
+// =============================================================================================
+// Mixed tiling of the 7 x 7 ROI map: one 4-wide and one 3-wide tile per axis (4 + 3 = 7) instead of two 4-wide tiles
+// (8 > 7: 49/64 of the F(4x4,3x3) tile grid is used).  Tile type (ka, kb), k = 0: the 4-wide tile, F(4,3) on
+// {0,1,-1,2,-1/2,inf}, 6 positions; k = 1: the 3-wide tile, F(3,3) on {0,1,-1,2,inf}, 5 positions.  36 + 30 + 30 + 25 =
+// 121 positions, ONE tile of each type per ROI: 121 multiplies per 49 outputs instead of 144 (-16 % flops in all three
+// contractions, and V / D / M shrink by the same factor).  `tile == 7` in the C entry points; P must be 7.
+// Matrices (wino43_mats.h, W7_*: [axis kind][..][..], zero padded): B^T, G, A^T; weight gradient: GD (dy transform), AW.
+// Layouts: V, D, M: [121][R][C];  U, dU: [121][K][N].
+struct W7 {
+    static constexpr int NP[2] = {6, 5};      // positions per axis
+    static constexpr int OUT[2] = {4, 3};     // outputs per axis
+    static constexpr int IN0[2] = {-1, 3};    // first input row / column of the tile's patch
+    static constexpr int OUT0[2] = {0, 4};    // first output row / column
+    static constexpr int QOFF[4] = {0, 36, 66, 96};   // first position of tile type ka * 2 + kb (121 in total)
+};
+
+__host__ __device__ constexpr float w7_abs_row_sum(const float (&M)[6], int n) {
+    float s = 0.0f;
+    for (int k = 0; k < n; ++k) s += M[k] < 0 ? -M[k] : M[k];
+    return s;
+}
+
+template <int KA, int KB, bool AMAX>
+__device__ __forceinline__ void w7_input_tile(const float* __restrict__ x, float* __restrict__ V, int r, int R, int C,
+                                              unsigned* __restrict__ row_amax) {
+    constexpr int NA = W7::NP[KA], NB = W7::NP[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
+    const size_t MC = (size_t)R * C;
+    float dmax = 0.0f;
+    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
+        float2 d[NA][NB];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int iy = W7::IN0[KA] + i;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int ix = W7::IN0[KB] + j;
+                d[i][j] = ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P)
+                              ? *reinterpret_cast<const float2*>(x + (((size_t)r * P + iy) * P + ix) * C + c)
+                              : f2(0.f);
+                if constexpr (AMAX) dmax = fmaxf(dmax, fmaxf(fabsf(d[i][j].x), fabsf(d[i][j].y)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            float2 trow[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                trow[j] = f2(0.f);
+#pragma unroll
+                for (int k = 0; k < NA; ++k)
+                    if (W7_BT[KA][i][k] != 0.0f) fma2(trow[j], W7_BT[KA][i][k], d[k][j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float2 v = f2(0.f);
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    if (W7_BT[KB][j][k] != 0.0f) fma2(v, W7_BT[KB][j][k], trow[k]);
+                *reinterpret_cast<float2*>(V + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c) = v;
+            }
+        }
+    }
+    if constexpr (AMAX) {       // row-scale bounds of this tile's positions (see wino43_input_kernel)
+        __shared__ float red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmax;
+        __syncthreads();
+        if (threadIdx.x < NA * NB) {
+            const float tile_max = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const int i = threadIdx.x / NB, j = threadIdx.x % NB;
+            float fi = 0.0f, fj = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                if (p == i) fi = w7_abs_row_sum(W7_BT[KA][p], NA);
+                if (p == j) fj = w7_abs_row_sum(W7_BT[KB][p], NB);
+            }
+            row_amax[(size_t)(Q0 + threadIdx.x) * R + r] = __float_as_uint(fi * fj * tile_max * 1.0001f);
+        }
+    }
+}
+
+// grid = (R, 4 tile types); block = 256 (2 channels per lane)
+template <bool AMAX>
+__global__ __launch_bounds__(256) void wino7_input_kernel(const float* __restrict__ x, float* __restrict__ V, int R, int C,
+                                                          unsigned* __restrict__ row_amax) {
+    const int r = blockIdx.x;
+    switch (blockIdx.y) {
+        case 0: w7_input_tile<0, 0, AMAX>(x, V, r, R, C, row_amax); break;
+        case 1: w7_input_tile<0, 1, AMAX>(x, V, r, R, C, row_amax); break;
+        case 2: w7_input_tile<1, 0, AMAX>(x, V, r, R, C, row_amax); break;
+        default: w7_input_tile<1, 1, AMAX>(x, V, r, R, C, row_amax); break;
+    }
+}
+
+template <int KA, int KB>
+__device__ __forceinline__ void w7_filter_tile(const float (&w)[3][3], float* __restrict__ U, size_t KN, size_t idx) {
+    constexpr int NA = W7::NP[KA], NB = W7::NP[KB], Q0 = W7::QOFF[KA * 2 + KB];
+    float t[NA][3];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) t[i][b] = W7_G[KA][i][0] * w[0][b] + W7_G[KA][i][1] * w[1][b] + W7_G[KA][i][2] * w[2][b];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            U[(size_t)(Q0 + i * NB + j) * KN + idx] = t[i][0] * W7_G[KB][j][0] + t[i][1] * W7_G[KB][j][1] + t[i][2] * W7_G[KB][j][2];
+}
+
+__global__ __launch_bounds__(256) void wino7_filter_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
+                                                           int Cin, int mode) {
+    const int Kd = mode ? Cout : Cin, Nd = mode ? Cin : Cout;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)Kd * Nd) return;
+    const int k = (int)(idx / Nd), n = (int)(idx % Nd);
+    const int co = mode ? k : n, ci = mode ? n : k;
+    const float* g = W + ((size_t)co * Cin + ci) * 9;
+    float w[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) w[a][b] = mode ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
+    const size_t KN = (size_t)Kd * Nd;
+    w7_filter_tile<0, 0>(w, U, KN, idx);
+    w7_filter_tile<0, 1>(w, U, KN, idx);
+    w7_filter_tile<1, 0>(w, U, KN, idx);
+    w7_filter_tile<1, 1>(w, U, KN, idx);
+}
+
+template <int KA, int KB>
+__device__ __forceinline__ void w7_output_tile(const float* __restrict__ M, const float* __restrict__ bias,
+                                               float* __restrict__ y, int r, int R, int C, int relu) {
+    constexpr int NA = W7::NP[KA], NB = W7::NP[KB], OA = W7::OUT[KA], OB = W7::OUT[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
+    const size_t MC = (size_t)R * C;
+    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
+        float2 s[OA][NB];
+#pragma unroll
+        for (int a = 0; a < OA; ++a)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) s[a][j] = f2(0.f);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float2 q = *reinterpret_cast<const float2*>(M + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c);
+#pragma unroll
+                for (int a = 0; a < OA; ++a)
+                    if (W7_AT[KA][a][i] != 0.0f) fma2(s[a][j], W7_AT[KA][a][i], q);
+            }
+        const float2 bv = bias ? *reinterpret_cast<const float2*>(bias + c) : f2(0.f);
+#pragma unroll
+        for (int a = 0; a < OA; ++a)
+#pragma unroll
+            for (int b = 0; b < OB; ++b) {
+                float2 v = bv;
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (W7_AT[KB][b][j] != 0.0f) fma2(v, W7_AT[KB][b][j], s[a][j]);
+                if (relu) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
+                *reinterpret_cast<float2*>(y + (((size_t)r * P + W7::OUT0[KA] + a) * P + W7::OUT0[KB] + b) * C + c) = v;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino7_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int R, int C, int relu) {
+    const int r = blockIdx.x;
+    switch (blockIdx.y) {
+        case 0: w7_output_tile<0, 0>(M, bias, y, r, R, C, relu); break;
+        case 1: w7_output_tile<0, 1>(M, bias, y, r, R, C, relu); break;
+        case 2: w7_output_tile<1, 0>(M, bias, y, r, R, C, relu); break;
+        default: w7_output_tile<1, 1>(M, bias, y, r, R, C, relu); break;
+    }
+}
+
+template <int KA, int KB>
+__device__ __forceinline__ void w7_dy_tile(const float* __restrict__ dy, float* __restrict__ D, int r, int R, int C) {
+    constexpr int NA = W7::NP[KA], NB = W7::NP[KB], OA = W7::OUT[KA], OB = W7::OUT[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
+    const size_t MC = (size_t)R * C;
+    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
+        float2 d[OA][OB];
+#pragma unroll
+        for (int a = 0; a < OA; ++a)
+#pragma unroll
+            for (int b = 0; b < OB; ++b)
+                d[a][b] = *reinterpret_cast<const float2*>(dy + (((size_t)r * P + W7::OUT0[KA] + a) * P + W7::OUT0[KB] + b) * C + c);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            float2 trow[OB];
+#pragma unroll
+            for (int b = 0; b < OB; ++b) {
+                trow[b] = f2(0.f);
+#pragma unroll
+                for (int a = 0; a < OA; ++a)
+                    if (W7_GD[KA][i][a] != 0.0f) fma2(trow[b], W7_GD[KA][i][a], d[a][b]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float2 v = f2(0.f);
+#pragma unroll
+                for (int b = 0; b < OB; ++b)
+                    if (W7_GD[KB][j][b] != 0.0f) fma2(v, W7_GD[KB][j][b], trow[b]);
+                *reinterpret_cast<float2*>(D + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c) = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino7_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int C) {
+    const int r = blockIdx.x;
+    switch (blockIdx.y) {
+        case 0: w7_dy_tile<0, 0>(dy, D, r, R, C); break;
+        case 1: w7_dy_tile<0, 1>(dy, D, r, R, C); break;
+        case 2: w7_dy_tile<1, 0>(dy, D, r, R, C); break;
+        default: w7_dy_tile<1, 1>(dy, D, r, R, C); break;
+    }
+}
+
+template <int KA, int KB>
+__device__ __forceinline__ void w7_wgrad_tile(const float* __restrict__ dU, size_t KN, size_t idx, float (&acc)[3][3]) {
+    constexpr int NA = W7::NP[KA], NB = W7::NP[KB], Q0 = W7::QOFF[KA * 2 + KB];
+    float s[3][NB];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) s[a][j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float q = dU[(size_t)(Q0 + i * NB + j) * KN + idx];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if (W7_AW[KA][a][i] != 0.0f) s[a][j] = fmaf(W7_AW[KA][a][i], q, s[a][j]);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (W7_AW[KB][b][j] != 0.0f) acc[a][b] = fmaf(W7_AW[KB][b][j], s[a][j], acc[a][b]);
+}
+
+__global__ __launch_bounds__(256) void wino7_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dW, int Cout,
+                                                              int Cin) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;     // (ci, co), co fastest
+    const size_t KN = (size_t)Cin * Cout;
+    if (idx >= KN) return;
+    const int ci = (int)(idx / Cout), co = (int)(idx % Cout);
+    float acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = 0.0f;
+    w7_wgrad_tile<0, 0>(dU, KN, idx, acc);
+    w7_wgrad_tile<0, 1>(dU, KN, idx, acc);
+    w7_wgrad_tile<1, 0>(dU, KN, idx, acc);
+    w7_wgrad_tile<1, 1>(dU, KN, idx, acc);
+    float* dst = dW + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) dst[a * 3 + b] = acc[a][b];
+}
+
+// column-scale bounds for the 121 positions (see wino43_bound_kernel): kind 0: B^T (input), 1: G (filter), 2: GD (dy)
+__global__ __launch_bounds__(256) void wino7_bound_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n,
+                                                          int group, int kind) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.0f;
+    for (int t = 0; t < group; ++t) a = fmaxf(a, __uint_as_float(in[(size_t)i * group + t]));
+    float f[2][6];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            float sum = 0.0f;
+            if (kind == 0) { for (int q = 0; q < 6; ++q) sum += fabsf(W7_BT[k][p][q]); }
+            else if (kind == 1) { for (int q = 0; q < 3; ++q) sum += fabsf(W7_G[k][p][q]); }
+            else { for (int q = 0; q < 4; ++q) sum += fabsf(W7_GD[k][p][q]); }
+            f[k][p] = sum;
+        }
+#pragma unroll
+    for (int ka = 0; ka < 2; ++ka)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int na = ka ? 5 : 6, nb = kb ? 5 : 6, q0 = W7::QOFF[ka * 2 + kb];
+            for (int p = 0; p < na * nb; ++p)
+                out[(size_t)(q0 + p) * n + i] = __float_as_uint(f[ka][p / nb] * f[kb][p % nb] * a * 1.0001f);
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // (c, h, w) flatten of the conv output and its adjoint, fused with the ReLU mask.
 // The reference flattens MaskFuse's NCHW conv output with .view(N, -1) (resnet50.py:135): seg_fc.0's weight columns
@@ -483,14 +778,15 @@ __global__ __launch_bounds__(256) void flatten_chw_kernel(const float* __restric
 
 #define WINO_GEOM_OK() CIM_CHECK_ARG(R > 0 && P > 0 && P <= 64 && C > 0 && C % 4 == 0)
 
-#define WINO_TILE_OK() CIM_CHECK_ARG(tile == 2 || tile == 4)
+#define WINO_TILE_OK() CIM_CHECK_ARG(tile == 2 || tile == 4 || (tile == 7 && P == 7))
 
 extern "C" int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, int tile, void* stream) {
     WINO_GEOM_OK();
     WINO_TILE_OK();
     CIM_CHECK_ARG(x && V);
     const int T = (P + tile - 1) / tile;
-    if (tile == 4) hipLaunchKernelGGL(wino43_input_kernel<false>, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C, (unsigned*)nullptr);
+    if (tile == 7) hipLaunchKernelGGL(wino7_input_kernel<false>, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), x, V, R, C, (unsigned*)nullptr);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_input_kernel<false>, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C, (unsigned*)nullptr);
     else hipLaunchKernelGGL(wino_input_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C);
     CIM_CHECK_LAUNCH();
     return 0;
@@ -499,17 +795,19 @@ extern "C" int cim_wino_input_transform(const float* x, float* V, int R, int P, 
 extern "C" int cim_wino_input_transform_amax(const float* x, float* V, uint32_t* row_amax, int R, int P, int C, int tile,
                                              void* stream) {
     WINO_GEOM_OK();
-    CIM_CHECK_ARG(x && V && row_amax && tile == 4);
+    CIM_CHECK_ARG(x && V && row_amax && (tile == 4 || (tile == 7 && P == 7)));
     const int T = (P + 3) / 4;
-    hipLaunchKernelGGL(wino43_input_kernel<true>, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C, row_amax);
+    if (tile == 7) hipLaunchKernelGGL(wino7_input_kernel<true>, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), x, V, R, C, row_amax);
+    else hipLaunchKernelGGL(wino43_input_kernel<true>, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C, row_amax);
     CIM_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int cim_wino_scale_bounds(const uint32_t* amax_in, uint32_t* bounds, int n, int group, int kind, int tile,
                                      void* stream) {
-    CIM_CHECK_ARG(amax_in && bounds && n > 0 && group > 0 && kind >= 0 && kind <= 2 && tile == 4);
-    hipLaunchKernelGGL(wino43_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax_in, bounds, n,
+    CIM_CHECK_ARG(amax_in && bounds && n > 0 && group > 0 && kind >= 0 && kind <= 2 && (tile == 4 || tile == 7));
+    if (tile == 7) hipLaunchKernelGGL(wino7_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax_in, bounds, n, group, kind);
+    else hipLaunchKernelGGL(wino43_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax_in, bounds, n,
                        group, kind);
     CIM_CHECK_LAUNCH();
     return 0;
@@ -517,9 +815,10 @@ extern "C" int cim_wino_scale_bounds(const uint32_t* amax_in, uint32_t* bounds, 
 
 extern "C" int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, int tile, void* stream) {
     CIM_CHECK_ARG(W && U && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1));
-    WINO_TILE_OK();
+    CIM_CHECK_ARG(tile == 2 || tile == 4 || tile == 7);
     const size_t n = (size_t)Cout * Cin;
-    if (tile == 4) hipLaunchKernelGGL(wino43_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U, Cout, Cin, mode);
+    if (tile == 7) hipLaunchKernelGGL(wino7_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U, Cout, Cin, mode);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U, Cout, Cin, mode);
     else hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U,
                        Cout, Cin, mode);
     CIM_CHECK_LAUNCH();
@@ -532,7 +831,8 @@ extern "C" int cim_wino_output_transform(const float* M, const float* bias, floa
     WINO_TILE_OK();
     CIM_CHECK_ARG(M && y);
     const int T = (P + tile - 1) / tile;
-    if (tile == 4) hipLaunchKernelGGL(wino43_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C, relu);
+    if (tile == 7) hipLaunchKernelGGL(wino7_output_kernel, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, C, relu);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C, relu);
     else hipLaunchKernelGGL(wino_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C,
                        relu);
     CIM_CHECK_LAUNCH();
@@ -544,7 +844,8 @@ extern "C" int cim_wino_dy_transform(const float* dy, float* D, int R, int P, in
     WINO_TILE_OK();
     CIM_CHECK_ARG(dy && D);
     const int T = (P + tile - 1) / tile;
-    if (tile == 4) hipLaunchKernelGGL(wino43_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
+    if (tile == 7) hipLaunchKernelGGL(wino7_dy_kernel, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), dy, D, R, C);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
     else hipLaunchKernelGGL(wino_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
     CIM_CHECK_LAUNCH();
     return 0;
@@ -552,9 +853,10 @@ extern "C" int cim_wino_dy_transform(const float* dy, float* D, int R, int P, in
 
 extern "C" int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, int tile, void* stream) {
     CIM_CHECK_ARG(dU && dW && Cout > 0 && Cin > 0);
-    WINO_TILE_OK();
+    CIM_CHECK_ARG(tile == 2 || tile == 4 || tile == 7);
     const size_t n = (size_t)Cout * Cin;
-    if (tile == 4) hipLaunchKernelGGL(wino43_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
+    if (tile == 7) hipLaunchKernelGGL(wino7_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
     else hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU,
                        dW, Cout, Cin);
     CIM_CHECK_LAUNCH();

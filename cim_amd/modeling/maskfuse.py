@@ -44,7 +44,7 @@ class MaskFuse(nn.Module):
         # max |box_x * mask| <= that times max |mask| ({0,1} masks: 1): a 6 MB pass instead of one over the
         # 400 MB cat tensor for the conv's weight-gradient operand scales (f16x2 engine)
         xc = None
-        if gemm.ENGINE == "f16x2" and gemm.CONV_ALGO == "winograd4":
+        if gemm.ENGINE == "f16x2" and gemm.CONV_ALGO in ("winograd4", "winograd7"):
             xn = x.detach().contiguous(memory_format=torch.channels_last)
             fa = gemm.amax(xn, xn.size(0) * xn.size(2) * xn.size(3), xn.size(1), xn.size(1), want_cols=True)[1]
             fm = (fa.view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)

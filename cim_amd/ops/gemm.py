@@ -159,11 +159,23 @@ def _bgemm(a, b, c, m, n, k, lda, ldb, a_mcontig, batch, a_bs, b_bs, c_bs, a_ama
 def _bounds(amax_in, n, group, kind, npos, dev):
     """[npos, n] column-scale bounds of a Winograd-domain operand from the |max| of the untransformed tensor."""
     out = torch.empty(npos * n, dtype=torch.int32, device=dev)
-    _lib.call("cim_wino_scale_bounds", amax_in.data_ptr(), out.data_ptr(), n, group, kind, 4, _lib.stream_ptr())
+    _lib.call("cim_wino_scale_bounds", amax_in.data_ptr(), out.data_ptr(), n, group, kind, 7 if npos == 121 else 4,
+              _lib.stream_ptr())
     return out
 
 
-CONV_ALGO = os.environ.get("CIM_CONV_ALGO", "winograd4")    # "winograd4" (F(4x4,3x3), default) | "winograd" (F(2x2,3x3)) | "direct"
+# "winograd7" (default: a 4-wide + a 3-wide tile per axis of the 7 x 7 map, 121 positions; other map sizes take winograd4)
+# | "winograd4" (F(4x4,3x3), 2 x 2 tiles of 36 positions) | "winograd" (F(2x2,3x3)) | "direct"
+CONV_ALGO = os.environ.get("CIM_CONV_ALGO", "winograd7")
+
+
+def _wino_geometry(algo, p, r):
+    """(tile code of the C entry points, positions, GEMM rows) of a Winograd algorithm on r maps of p x p."""
+    if algo == "winograd7":
+        return 7, 121, r                       # one tile of each of the 4 types per map
+    tile = 4 if algo == "winograd4" else 2
+    t = (p + tile - 1) // tile
+    return tile, (tile + 2) ** 2, r * t * t
 
 
 class Conv3x3Function(Function):
@@ -185,17 +197,18 @@ class Conv3x3Function(Function):
         st = _lib.stream_ptr()
         y = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
         ctx.algo = CONV_ALGO if (cin % 4 == 0 and cout % 4 == 0) else "direct"
-        ctx.tile = tile = 4 if ctx.algo == "winograd4" else 2
-        npos = (tile + 2) ** 2
+        if ctx.algo == "winograd7" and p != 7:
+            ctx.algo = "winograd4"
+        ctx.tile = tile = 0
         V = None
         if ctx.algo.startswith("winograd"):
-            t = (p + tile - 1) // tile
-            mt = r * t * t
+            ctx.tile, npos, mt = _wino_geometry(ctx.algo, p, r)
+            tile = ctx.tile
             V = torch.empty((npos, mt, cin), dtype=torch.float32, device=dev)
             U = torch.empty((npos, cin, cout), dtype=torch.float32, device=dev)
             M = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
             vr = uc = None
-            ctx.fused_scales = ENGINE == "f16x2" and tile == 4
+            ctx.fused_scales = ENGINE == "f16x2" and tile in (4, 7)
             if ctx.fused_scales:
                 # operand scales of the f16x2 engine without a pass over the 1.2 GB transformed tensors: all of them are
                 # upper BOUNDS from the |max| of the untransformed tensors (x per tile for the rows of V - inside the
@@ -251,9 +264,9 @@ class Conv3x3Function(Function):
         dx = dw = db = None
         wino = ctx.algo.startswith("winograd")
         tile = ctx.tile
-        npos = (tile + 2) ** 2
-        t = (p + tile - 1) // tile
-        mt = r * t * t
+        npos = mt = 0
+        if wino:
+            _, npos, mt = _wino_geometry(ctx.algo, p, r)
         fused = wino and getattr(ctx, "fused_scales", False)
 
         def data_grad():
