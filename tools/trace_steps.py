@@ -26,7 +26,7 @@ def main():
     # (multi_tensor_apply) - find the last optimizer dispatch before `first`
     start = 0
     for i in range(first, -1, -1):
-        if "multi_tensor_apply" in rows[i]["Kernel_Name"] or "FusedSgd" in rows[i]["Kernel_Name"]:
+        if any(t in rows[i]["Kernel_Name"] for t in ("multi_tensor_apply", "FusedSgd", "sgd_multi_kernel")):
             start = i + 1
             break
     sel = rows[start:]
