@@ -616,17 +616,26 @@ __global__ __launch_bounds__(256) void wino7_output_kernel(const float* __restri
     }
 }
 
-template <int KA, int KB>
-__device__ __forceinline__ void w7_dy_tile(const float* __restrict__ dy, float* __restrict__ D, int r, int R, int C) {
+// Output-gradient tile transform.  ADJ = false: D = GD dy GD^T (weight gradient, F(3,4) / F(3,3)).
+// ADJ = true: E = A dy A^T with A = (A^T)^T - the first stage of the data gradient written as the ADJOINT of the forward,
+//   y = A^T [U . (B^T d B)] A   =>   dx (+)= B [U^T . (A dy A^T)] B^T      (overlap-add over the tiles' patches),
+// which reuses the forward's U (contracted over the other channel index) instead of transforming a rotated filter;
+// with AMAX it also stores the row-scale bounds of E (column abs sums of A^T times the tile's max |dy|).
+template <int KA, int KB, bool ADJ, bool AMAX>
+__device__ __forceinline__ void w7_dy_tile(const float* __restrict__ dy, float* __restrict__ D, int r, int R, int C,
+                                           unsigned* __restrict__ row_amax) {
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], OA = W7::OUT[KA], OB = W7::OUT[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
     const size_t MC = (size_t)R * C;
+    float dmax = 0.0f;
     for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
         float2 d[OA][OB];
 #pragma unroll
         for (int a = 0; a < OA; ++a)
 #pragma unroll
-            for (int b = 0; b < OB; ++b)
+            for (int b = 0; b < OB; ++b) {
                 d[a][b] = *reinterpret_cast<const float2*>(dy + (((size_t)r * P + W7::OUT0[KA] + a) * P + W7::OUT0[KB] + b) * C + c);
+                if constexpr (AMAX) dmax = fmaxf(dmax, fmaxf(fabsf(d[a][b].x), fabsf(d[a][b].y)));
+            }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             float2 trow[OB];
@@ -634,28 +643,113 @@ __device__ __forceinline__ void w7_dy_tile(const float* __restrict__ dy, float* 
             for (int b = 0; b < OB; ++b) {
                 trow[b] = f2(0.f);
 #pragma unroll
-                for (int a = 0; a < OA; ++a)
-                    if (W7_GD[KA][i][a] != 0.0f) fma2(trow[b], W7_GD[KA][i][a], d[a][b]);
+                for (int a = 0; a < OA; ++a) {
+                    const float m = ADJ ? W7_AT[KA][a][i] : W7_GD[KA][i][a];
+                    if (m != 0.0f) fma2(trow[b], m, d[a][b]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 float2 v = f2(0.f);
 #pragma unroll
-                for (int b = 0; b < OB; ++b)
-                    if (W7_GD[KB][j][b] != 0.0f) fma2(v, W7_GD[KB][j][b], trow[b]);
+                for (int b = 0; b < OB; ++b) {
+                    const float m = ADJ ? W7_AT[KB][b][j] : W7_GD[KB][j][b];
+                    if (m != 0.0f) fma2(v, m, trow[b]);
+                }
                 *reinterpret_cast<float2*>(D + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c) = v;
             }
         }
     }
+    if constexpr (AMAX) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmax;
+        __syncthreads();
+        if (threadIdx.x < NA * NB) {
+            const float tile_max = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const int i = threadIdx.x / NB, j = threadIdx.x % NB;
+            float fi = 0.0f, fj = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    sa += fabsf(ADJ ? W7_AT[KA][a][p] : W7_GD[KA][p][a]);
+                    sb += fabsf(ADJ ? W7_AT[KB][a][p] : W7_GD[KB][p][a]);
+                }
+                if (p == i) fi = sa;
+                if (p == j) fj = sb;
+            }
+            row_amax[(size_t)(Q0 + threadIdx.x) * R + r] = __float_as_uint(fi * fj * tile_max * 1.0001f);
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void wino7_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int C) {
+template <bool ADJ, bool AMAX>
+__global__ __launch_bounds__(256) void wino7_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int C,
+                                                       unsigned* __restrict__ row_amax) {
     const int r = blockIdx.x;
     switch (blockIdx.y) {
-        case 0: w7_dy_tile<0, 0>(dy, D, r, R, C); break;
-        case 1: w7_dy_tile<0, 1>(dy, D, r, R, C); break;
-        case 2: w7_dy_tile<1, 0>(dy, D, r, R, C); break;
-        default: w7_dy_tile<1, 1>(dy, D, r, R, C); break;
+        case 0: w7_dy_tile<0, 0, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
+        case 1: w7_dy_tile<0, 1, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
+        case 2: w7_dy_tile<1, 0, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
+        default: w7_dy_tile<1, 1, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
+    }
+}
+
+// Last stage of the adjoint data gradient: dx[r, y, x, c] = sum over the four tile types of (B M B^T)[y - y0][x - x0]
+// (overlap-add: the 6- and 5-row patches share rows / columns 3 and 4).  A workgroup owns one ROI, a lane one channel
+// (all 49 output pixels accumulate in registers; 4 B per lane keeps that at ~110 VGPRs).
+template <int KA, int KB>
+__device__ __forceinline__ void w7_dx_tile(const float* __restrict__ M, size_t MC, size_t rc, float (&acc)[7][7]) {
+    constexpr int NA = W7::NP[KA], NB = W7::NP[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
+    float q[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) q[i][j] = M[(size_t)(Q0 + i * NB + j) * MC + rc];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {                 // patch row k = sum_i B^T[i][k] q[i][:]
+        const int yy = W7::IN0[KA] + k;
+        if (yy < 0 || yy >= P) continue;
+        float t[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            t[j] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (W7_BT[KA][i][k] != 0.0f) t[j] = fmaf(W7_BT[KA][i][k], q[i][j], t[j]);
+        }
+#pragma unroll
+        for (int l = 0; l < NB; ++l) {
+            const int xx = W7::IN0[KB] + l;
+            if (xx < 0 || xx >= P) continue;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (W7_BT[KB][j][l] != 0.0f) acc[yy][xx] = fmaf(W7_BT[KB][j][l], t[j], acc[yy][xx]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino7_dx_kernel(const float* __restrict__ M, float* __restrict__ dx, int R, int C) {
+    const int r = blockIdx.x;
+    const size_t MC = (size_t)R * C;
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += gridDim.y * 256) {
+        float acc[7][7];
+#pragma unroll
+        for (int y = 0; y < 7; ++y)
+#pragma unroll
+            for (int x = 0; x < 7; ++x) acc[y][x] = 0.0f;
+        const size_t rc = (size_t)r * C + c;
+        w7_dx_tile<0, 0>(M, MC, rc, acc);
+        w7_dx_tile<0, 1>(M, MC, rc, acc);
+        w7_dx_tile<1, 0>(M, MC, rc, acc);
+        w7_dx_tile<1, 1>(M, MC, rc, acc);
+#pragma unroll
+        for (int y = 0; y < 7; ++y)
+#pragma unroll
+            for (int x = 0; x < 7; ++x) dx[(((size_t)r * 7 + y) * 7 + x) * C + c] = acc[y][x];
     }
 }
 
@@ -844,7 +938,7 @@ extern "C" int cim_wino_dy_transform(const float* dy, float* D, int R, int P, in
     WINO_TILE_OK();
     CIM_CHECK_ARG(dy && D);
     const int T = (P + tile - 1) / tile;
-    if (tile == 7) hipLaunchKernelGGL(wino7_dy_kernel, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), dy, D, R, C);
+    if (tile == 7) hipLaunchKernelGGL((wino7_dy_kernel<false, false>), dim3(R, 4), dim3(256), 0, cim::as_stream(stream), dy, D, R, C, (unsigned*)nullptr);
     else if (tile == 4) hipLaunchKernelGGL(wino43_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
     else hipLaunchKernelGGL(wino_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
     CIM_CHECK_LAUNCH();
@@ -869,6 +963,26 @@ extern "C" int cim_flatten_chw(const float* src, const float* relu_y, float* dst
     CIM_CHECK_ARG(backward || relu_y == nullptr);
     if (backward) hipLaunchKernelGGL(flatten_chw_kernel<false>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C);
     else hipLaunchKernelGGL(flatten_chw_kernel<true>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_dy_adjoint_transform(const float* dy, float* E, uint32_t* row_amax, int R, int P, int C, int tile,
+                                             void* stream) {
+    WINO_GEOM_OK();
+    CIM_CHECK_ARG(dy && E && tile == 7 && P == 7);
+    if (row_amax) hipLaunchKernelGGL((wino7_dy_kernel<true, true>), dim3(R, 4), dim3(256), 0, cim::as_stream(stream), dy, E, R, C, row_amax);
+    else hipLaunchKernelGGL((wino7_dy_kernel<true, false>), dim3(R, 4), dim3(256), 0, cim::as_stream(stream), dy, E, R, C, (unsigned*)nullptr);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int P, int C, int tile, void* stream) {
+    WINO_GEOM_OK();
+    CIM_CHECK_ARG(M && dx && tile == 7 && P == 7 && R <= 2147483647);
+    int chunks = (C + 255) / 256;
+    if (chunks > 4) chunks = 4;
+    hipLaunchKernelGGL(wino7_dx_kernel, dim3(R, chunks), dim3(256), 0, cim::as_stream(stream), M, dx, R, C);
     CIM_CHECK_LAUNCH();
     return 0;
 }

@@ -140,20 +140,23 @@ class LinearFunction(Function):
         return dx, dw, db, None
 
 
-def _bgemm(a, b, c, m, n, k, lda, ldb, a_mcontig, batch, a_bs, b_bs, c_bs, a_amax=None, b_amax=None):
-    """`batch` GEMMs C[i] = A[i] . B[i] (B N-contiguous).  a_amax: per-row scales of A ([batch, m]: rows of a
-    K-contiguous A, columns of the stored matrix for an M-contiguous one); b_amax: per-column scales [batch, n]."""
+def _bgemm(a, b, c, m, n, k, lda, ldb, a_mcontig, batch, a_bs, b_bs, c_bs, a_amax=None, b_amax=None, b_kcontig=False):
+    """`batch` GEMMs C[i] = A[i] . B[i] (B N-contiguous, or [n][k] K-contiguous).  a_amax: per-row scales of A
+    ([batch, m]: rows of a K-contiguous A, columns of the stored matrix for an M-contiguous one); b_amax: per-column
+    scales [batch, n]."""
     if ENGINE != "f16x2":
         _lib.call("cim_gemm_f32_batched", a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, lda, ldb, n,
-                  int(a_mcontig), 0, batch, a_bs, b_bs, c_bs, _lib.stream_ptr())
+                  int(a_mcontig), int(b_kcontig), batch, a_bs, b_bs, c_bs, _lib.stream_ptr())
         return
     if a_amax is None:
         a_amax = (amax(a, k, m, lda, want_cols=True, batch=batch, bs=a_bs)[1] if a_mcontig
                   else amax(a, m, k, lda, want_rows=True, batch=batch, bs=a_bs)[0])
     if b_amax is None:
-        b_amax = amax(b, k, n, ldb, want_cols=True, batch=batch, bs=b_bs)[1]
+        b_amax = (amax(b, n, k, ldb, want_rows=True, batch=batch, bs=b_bs)[0] if b_kcontig
+                  else amax(b, k, n, ldb, want_cols=True, batch=batch, bs=b_bs)[1])
     _lib.call("cim_gemm_f16x2_batched", a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, lda, ldb, n,
-              int(a_mcontig), 0, batch, a_bs, b_bs, c_bs, a_amax.data_ptr(), b_amax.data_ptr(), _lib.stream_ptr())
+              int(a_mcontig), int(b_kcontig), batch, a_bs, b_bs, c_bs, a_amax.data_ptr(), b_amax.data_ptr(),
+              _lib.stream_ptr())
 
 
 def _bounds(amax_in, n, group, kind, npos, dev):
@@ -235,7 +238,8 @@ class Conv3x3Function(Function):
             whwio = w.permute(2, 3, 1, 0).contiguous()
             _lib.call("cim_conv3x3_f32", x.data_ptr(), whwio.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cin, cout,
                       int(relu), st)
-        ctx.save_for_backward(x, w, y if relu else None, V)
+        # mixed tiling: the data gradient is evaluated as the adjoint of this product and reuses U (no second filter transform)
+        ctx.save_for_backward(x, w, y if relu else None, V, U if (tile == 7 and ctx.needs_input_grad[0]) else None)
         ctx.relu = relu
         ctx.has_bias = b is not None
         ctx.flatten = bool(flatten_chw)
@@ -247,7 +251,7 @@ class Conv3x3Function(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y, V = ctx.saved_tensors
+        x, w, y, V, U = ctx.saved_tensors
         r, cin, p, _ = x.shape
         cout = w.shape[0]
         dev = x.device
@@ -272,7 +276,19 @@ class Conv3x3Function(Function):
         def data_grad():
             st = _lib.stream_ptr()
             dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
-            if wino:
+            if wino and tile == 7 and U is not None:
+                # adjoint of the forward: E = A dy A^T, Md[pos] = E[pos] . U[pos]^T (U read K-contiguously), dx = overlap-add B Md B^T
+                E = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
+                M2 = torch.empty((npos, mt, cin), dtype=torch.float32, device=dev)
+                er = uc2 = None
+                if fused:
+                    er = torch.empty(npos * mt, dtype=torch.int32, device=dev)
+                    uc2 = _bounds(ctx.w_cols, cin, 9, 1, npos, dev)      # per input channel: max over (co, taps)
+                _lib.call("cim_wino_dy_adjoint_transform", dy.data_ptr(), E.data_ptr(), _lib.ptr(er), r, p, cout, tile, st)
+                _bgemm(E, U, M2, mt, cin, cout, cout, cout, False, npos, mt * cout, cin * cout, mt * cin,
+                       a_amax=er, b_amax=uc2, b_kcontig=True)
+                _lib.call("cim_wino_dx_adjoint_output", M2.data_ptr(), dxp.data_ptr(), r, p, cin, tile, st)
+            elif wino:
                 # data gradient = the same convolution of dY with the 180-degree rotated, in/out-swapped filter
                 Vd = torch.empty((npos, mt, cout), dtype=torch.float32, device=dev)
                 U2 = torch.empty((npos, cout, cin), dtype=torch.float32, device=dev)

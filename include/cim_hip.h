@@ -253,6 +253,12 @@ int cim_flatten_chw(const float* src, const float* relu_y, float* dst, int R, in
  *   of the transform matrix (kind 0: B^T (input), 1: G (filter), 2: G4 (output gradient)). */
 int cim_wino_input_transform_amax(const float* x, float* V, uint32_t* row_amax, int R, int P, int C, int tile, void* stream);
 int cim_wino_scale_bounds(const uint32_t* amax_in, uint32_t* bounds, int n, int group, int kind, int tile, void* stream);
+/* Data gradient of the mixed tiling (tile = 7) as the ADJOINT of the forward - reuses the forward's U, no transform of a
+ * rotated filter:  E = A dy A^T per tile (cim_wino_dy_adjoint_transform; row_amax [121][R] optional: row-scale bounds of E),
+ * 121 GEMMs Md[pos] = E[pos] . U[pos]^T (U [121][Cin][Cout] read K-contiguously), dx = overlap-add of B Md B^T
+ * (cim_wino_dx_adjoint_output).  E [121][R][Cout], Md [121][R][Cin], dx [R,7,7,Cin]. */
+int cim_wino_dy_adjoint_transform(const float* dy, float* E, uint32_t* row_amax, int R, int P, int C, int tile, void* stream);
+int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int P, int C, int tile, void* stream);
 int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, int tile, void* stream);
 int cim_wino_output_transform(const float* M, const float* bias, float* y, int R, int P, int C, int relu, int tile, void* stream);
 int cim_wino_dy_transform(const float* dy, float* D, int R, int P, int C, int tile, void* stream);
