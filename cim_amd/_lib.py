@@ -29,7 +29,7 @@ SIGNATURES = {
     "cim_bn_act_fwd": [_P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, _P],
     "cim_bn_act_bwd_chunks": [c_int, c_int, c_int],
     "cim_bn_act_bwd": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
-    "cim_sgd_multi": [_P, c_int, c_float, _P],
+    "cim_sgd_multi": [_P, _P, c_int, c_float, _P],
     "cim_gemm_set_engine": [c_int],
     "cim_gemm_get_engine": [],
     "cim_gemm_f32_splits": [c_int, c_int, c_int],

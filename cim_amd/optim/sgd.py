@@ -6,6 +6,10 @@ lib/utils/net.py:47-83 `update_learning_rate` / `_CorrectMomentum` and the check
 rule - but ONE kernel launch per step for all parameters instead of one multi-tensor launch per ~20 tensors.
 Only what the reference uses is supported on the HIP path: fp32 CUDA/HIP parameters, dampening 0, no Nesterov,
 dense gradients, one momentum value; anything else raises (there is no silent fallback).
+
+Host cost per step: autograd hands out new gradient tensors every step, so the 40-byte record of every tensor is
+refreshed (one pass over the parameters, one 6 KB H2D copy); the chunk table only depends on the tensor sizes and is
+built once.
 """
 import numpy as np
 import torch
@@ -13,7 +17,8 @@ import torch
 from .. import _lib
 
 CHUNK = 16384          # elements per workgroup
-_REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("buf", "<u8"), ("n", "<i4"), ("aligned", "<i4"), ("lr", "<f4"), ("wd", "<f4")])
+_TENSOR = np.dtype([("p", "<u8"), ("g", "<u8"), ("buf", "<u8"), ("n", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+_CHUNK = np.dtype([("tensor", "<i4"), ("n", "<i4"), ("offset", "<i8")])
 
 
 class SGD(torch.optim.Optimizer):
@@ -22,11 +27,23 @@ class SGD(torch.optim.Optimizer):
             raise NotImplementedError("cim_amd.optim.SGD: dampening / Nesterov are not used by the reference and not provided")
         defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
         super().__init__(params, defaults)
-        self._pinned = None
-        self._table = None
-        self._copied = None         # event: the last H2D copy of the staging buffer
-        self._key = None            # identity of the table on the device (pointers, lr, wd of every tensor)
-        self._total = 0
+        self._layout = None         # tuple of element counts the chunk table on the device was built for
+        self._chunks = None         # device chunk table
+        self._n_chunks = 0
+        self._stage = None          # (pinned host array, device array, event of the last H2D copy) of the tensor records
+        self._last = None           # tensor records of the last step (skip the copy when nothing changed)
+
+    def _build_chunks(self, sizes, dev):
+        counts = np.array([(n + CHUNK - 1) // CHUNK for n in sizes], dtype=np.int64)
+        total = int(counts.sum())
+        owner = np.repeat(np.arange(len(sizes)), counts)
+        first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        tab = np.empty(total, dtype=_CHUNK)
+        tab["tensor"] = owner
+        tab["offset"] = (np.arange(total) - first[owner]) * CHUNK
+        tab["n"] = CHUNK
+        self._chunks = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(dev)
+        self._n_chunks, self._layout = total, tuple(sizes)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -58,40 +75,25 @@ class SGD(torch.optim.Optimizer):
                 if buf is None:
                     buf = st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 dev = p.device
-                n, pp, gp, bp = p.numel(), p.data_ptr(), g.data_ptr(), buf.data_ptr()
-                aligned = int(pp % 16 == 0 and gp % 16 == 0 and bp % 16 == 0)
-                recs.append((pp, gp, bp, n, aligned, lr, wd, g))
+                recs.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr, wd, g))
         if not recs:
             return loss
-        key = tuple(r[:7] for r in recs)
-        if key == self._key:        # same tensors as last step (flat-gradient data-parallel mode): the table is still valid
-            _lib.call("cim_sgd_multi", self._table.data_ptr(), self._total, momentum, _lib.stream_ptr())
-            return loss
-        # chunk table (vectorised): every tensor contributes ceil(n / CHUNK) records
-        counts = np.array([(r[3] + CHUNK - 1) // CHUNK for r in recs], dtype=np.int64)
-        total = int(counts.sum())
-        owner = np.repeat(np.arange(len(recs)), counts)
-        first = np.concatenate([[0], np.cumsum(counts)[:-1]])
-        off = (np.arange(total) - first[owner]) * CHUNK
-        n_of = np.array([r[3] for r in recs], dtype=np.int64)[owner]
-        tab = np.empty(total, dtype=_REC)
-        for name, idx in (("p", 0), ("g", 1), ("buf", 2)):
-            tab[name] = np.array([r[idx] for r in recs], dtype=np.uint64)[owner] + (off * 4).astype(np.uint64)
-        tab["n"] = np.minimum(CHUNK, n_of - off)
-        tab["aligned"] = np.array([r[4] for r in recs], dtype=np.int32)[owner]
-        tab["lr"] = np.array([r[5] for r in recs], dtype=np.float32)[owner]
-        tab["wd"] = np.array([r[6] for r in recs], dtype=np.float32)[owner]
-        nbytes = tab.nbytes
-        if self._pinned is None or self._pinned.numel() < nbytes:
-            self._pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-            self._table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._copied = None
-        if self._copied is not None:
-            self._copied.synchronize()          # the previous H2D copy out of the staging buffer (long done in practice)
-        self._pinned[:nbytes].numpy()[:] = tab.view(np.uint8).reshape(-1)
-        self._table[:nbytes].copy_(self._pinned[:nbytes], non_blocking=True)
-        self._copied = torch.cuda.Event()
-        self._copied.record()
-        self._key, self._total = key, total
-        _lib.call("cim_sgd_multi", self._table.data_ptr(), total, momentum, _lib.stream_ptr())
+        sizes = tuple(r[3] for r in recs)
+        if sizes != self._layout:
+            self._build_chunks(sizes, dev)
+            self._stage = self._last = None
+        tab = np.array([r[:6] for r in recs], dtype=_TENSOR)
+        if self._last is None or not np.array_equal(tab, self._last):
+            nbytes = tab.nbytes
+            if self._stage is None:
+                self._stage = [torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.empty(nbytes, dtype=torch.uint8, device=dev), None]
+            pinned, table, copied = self._stage
+            if copied is not None:
+                copied.synchronize()            # the previous H2D copy out of the staging buffer (long done in practice)
+            pinned.numpy()[:] = tab.view(np.uint8).reshape(-1)
+            table.copy_(pinned, non_blocking=True)
+            self._stage[2] = torch.cuda.Event()
+            self._stage[2].record()
+            self._last = tab
+        _lib.call("cim_sgd_multi", self._stage[1].data_ptr(), self._chunks.data_ptr(), self._n_chunks, momentum, _lib.stream_ptr())
         return loss

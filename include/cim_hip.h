@@ -312,17 +312,22 @@ int cim_head_act_bwd(const float* scores, const float* grad_scores, float* grad_
  * Fused multi-tensor SGD with momentum and weight decay: torch.optim.SGD's update (dampening 0, no Nesterov) as
  * constructed at tools/train.py:282-311 and stepped at :438, ONE launch for all tensors:
  *     g' = g + wd*p ;  buf = momentum*buf + g' ;  p = p - lr*buf        (buf zero-initialised by the caller)
- * `table` is a DEVICE array of n_chunks records; a workgroup streams one record.  Chunks of one tensor are consecutive
- * element ranges (the host uses 16384 elements); `aligned` != 0 promises 16-byte alignment of the three pointers. */
-typedef struct cim_sgd_chunk {
-    uint64_t p;        /* float* parameter chunk (device address) */
-    uint64_t g;        /* const float* gradient chunk */
-    uint64_t buf;      /* float* momentum buffer chunk */
-    int32_t n;         /* elements */
-    int32_t aligned;
+ * `tensors` and `chunks` are DEVICE arrays: one record per tensor (refreshed whenever a pointer, lr or wd changes) and one
+ * per chunk of a tensor (the host uses 16384-element chunks; offsets are multiples of 4 elements); a workgroup streams
+ * one chunk.  16-byte accesses are used when the three pointers of a tensor are 16-byte aligned. */
+typedef struct cim_sgd_tensor {
+    uint64_t p;        /* float* parameter (device address) */
+    uint64_t g;        /* const float* gradient */
+    uint64_t buf;      /* float* momentum buffer */
+    int64_t n;         /* elements */
     float lr, wd;
+} cim_sgd_tensor;
+typedef struct cim_sgd_chunk {
+    int32_t tensor;    /* index into `tensors` */
+    int32_t n;         /* elements of this chunk (clamped to the tensor's end in the kernel) */
+    int64_t offset;    /* first element */
 } cim_sgd_chunk;
-int cim_sgd_multi(const cim_sgd_chunk* table, int n_chunks, float momentum, void* stream);
+int cim_sgd_multi(const cim_sgd_tensor* tensors, const cim_sgd_chunk* chunks, int n_chunks, float momentum, void* stream);
 
 #ifdef __cplusplus
 }
