@@ -212,6 +212,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __rest
 
 __device__ __forceinline__ float2 f2(float v) { return make_float2(v, v); }
 __device__ __forceinline__ void fma2(float2& a, float s, float2 v) { a.x = fmaf(s, v.x, a.x); a.y = fmaf(s, v.y, a.y); }
+__device__ __forceinline__ void fma4(float4& a, float s, float4 v) {
+    a.x = fmaf(s, v.x, a.x); a.y = fmaf(s, v.y, a.y); a.z = fmaf(s, v.z, a.z); a.w = fmaf(s, v.w, a.w);
+}
 
 // AMAX: also emit row_amax[pos][m], an UPPER BOUND of max |V[pos][m][:]| as IEEE bit patterns (the f16x2 GEMM engine's
 // per-row operand scales, cim_hip.h): |(B^T d B)[i][j]| <= (sum_k |B^T[i][k]|)(sum_k |B^T[j][k]|) max|d| with max|d| over
@@ -627,36 +630,37 @@ __device__ __forceinline__ void w7_dy_tile(const float* __restrict__ dy, float* 
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], OA = W7::OUT[KA], OB = W7::OUT[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
     const size_t MC = (size_t)R * C;
     float dmax = 0.0f;
-    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
-        float2 d[OA][OB];
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {      // 16 B per lane: the 4 x 4 tile fits the register budget
+        float4 d[OA][OB];
 #pragma unroll
         for (int a = 0; a < OA; ++a)
 #pragma unroll
             for (int b = 0; b < OB; ++b) {
-                d[a][b] = *reinterpret_cast<const float2*>(dy + (((size_t)r * P + W7::OUT0[KA] + a) * P + W7::OUT0[KB] + b) * C + c);
-                if constexpr (AMAX) dmax = fmaxf(dmax, fmaxf(fabsf(d[a][b].x), fabsf(d[a][b].y)));
+                d[a][b] = *reinterpret_cast<const float4*>(dy + (((size_t)r * P + W7::OUT0[KA] + a) * P + W7::OUT0[KB] + b) * C + c);
+                if constexpr (AMAX)
+                    dmax = fmaxf(dmax, fmaxf(fmaxf(fabsf(d[a][b].x), fabsf(d[a][b].y)), fmaxf(fabsf(d[a][b].z), fabsf(d[a][b].w))));
             }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            float2 trow[OB];
+            float4 trow[OB];
 #pragma unroll
             for (int b = 0; b < OB; ++b) {
-                trow[b] = f2(0.f);
+                trow[b] = f4(0.f);
 #pragma unroll
                 for (int a = 0; a < OA; ++a) {
                     const float m = ADJ ? W7_AT[KA][a][i] : W7_GD[KA][i][a];
-                    if (m != 0.0f) fma2(trow[b], m, d[a][b]);
+                    if (m != 0.0f) fma4(trow[b], m, d[a][b]);
                 }
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                float2 v = f2(0.f);
+                float4 v = f4(0.f);
 #pragma unroll
                 for (int b = 0; b < OB; ++b) {
                     const float m = ADJ ? W7_AT[KB][b][j] : W7_GD[KB][j][b];
-                    if (m != 0.0f) fma2(v, m, trow[b]);
+                    if (m != 0.0f) fma4(v, m, trow[b]);
                 }
-                *reinterpret_cast<float2*>(D + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c) = v;
+                *reinterpret_cast<float4*>(D + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c) = v;
             }
         }
     }
