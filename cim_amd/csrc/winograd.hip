@@ -805,32 +805,24 @@ __global__ __launch_bounds__(256) void wino7_wgrad_out_kernel(const float* __res
         for (int b = 0; b < 3; ++b) dst[a * 3 + b] = acc[a][b];
 }
 
-// column-scale bounds for the 121 positions (see wino43_bound_kernel): kind 0: B^T (input), 1: G (filter), 2: GD (dy)
+// column-scale bounds for the 121 positions (see wino43_bound_kernel): kind 0: B^T (input), 1: G (filter), 2: GD (dy).
+// grid = (ceil(n / 256), 121): one thread per (column, position)
 __global__ __launch_bounds__(256) void wino7_bound_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n,
                                                           int group, int kind) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
     if (i >= n) return;
+    const int type = q < 36 ? 0 : q < 66 ? 1 : q < 96 ? 2 : 3;
+    const int ka = type >> 1, kb = type & 1, nb = kb ? 5 : 6, pl = q - W7::QOFF[type];
+    const int pi = pl / nb, pj = pl % nb;
+    float fa = 0.0f, fb = 0.0f;
+    const int len = kind == 0 ? 6 : kind == 1 ? 3 : 4;
+    for (int t = 0; t < len; ++t) {
+        fa += fabsf(kind == 0 ? W7_BT[ka][pi][t] : kind == 1 ? W7_G[ka][pi][t % 3] : W7_GD[ka][pi][t % 4]);
+        fb += fabsf(kind == 0 ? W7_BT[kb][pj][t] : kind == 1 ? W7_G[kb][pj][t % 3] : W7_GD[kb][pj][t % 4]);
+    }
     float a = 0.0f;
     for (int t = 0; t < group; ++t) a = fmaxf(a, __uint_as_float(in[(size_t)i * group + t]));
-    float f[2][6];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int p = 0; p < 6; ++p) {
-            float sum = 0.0f;
-            if (kind == 0) { for (int q = 0; q < 6; ++q) sum += fabsf(W7_BT[k][p][q]); }
-            else if (kind == 1) { for (int q = 0; q < 3; ++q) sum += fabsf(W7_G[k][p][q]); }
-            else { for (int q = 0; q < 4; ++q) sum += fabsf(W7_GD[k][p][q]); }
-            f[k][p] = sum;
-        }
-#pragma unroll
-    for (int ka = 0; ka < 2; ++ka)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int na = ka ? 5 : 6, nb = kb ? 5 : 6, q0 = W7::QOFF[ka * 2 + kb];
-            for (int p = 0; p < na * nb; ++p)
-                out[(size_t)(q0 + p) * n + i] = __float_as_uint(f[ka][p / nb] * f[kb][p % nb] * a * 1.0001f);
-        }
+    out[(size_t)q * n + i] = __float_as_uint(fa * fb * a * 1.0001f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -904,7 +896,7 @@ extern "C" int cim_wino_input_transform_amax(const float* x, float* V, uint32_t*
 extern "C" int cim_wino_scale_bounds(const uint32_t* amax_in, uint32_t* bounds, int n, int group, int kind, int tile,
                                      void* stream) {
     CIM_CHECK_ARG(amax_in && bounds && n > 0 && group > 0 && kind >= 0 && kind <= 2 && (tile == 4 || tile == 7));
-    if (tile == 7) hipLaunchKernelGGL(wino7_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax_in, bounds, n, group, kind);
+    if (tile == 7) hipLaunchKernelGGL(wino7_bound_kernel, dim3((n + 255) / 256, 121), dim3(256), 0, cim::as_stream(stream), amax_in, bounds, n, group, kind);
     else hipLaunchKernelGGL(wino43_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax_in, bounds, n,
                        group, kind);
     CIM_CHECK_LAUNCH();

@@ -227,22 +227,24 @@ def test_conv3x3_full_size_linearity(dev):
         assert float((got - ref[j, :, p // 7, p % 7]).abs().max()) < 1e-4
 
 
-def test_wino_fused_scales(dev):
-    """The f16x2 engine's Winograd operand scales: the row bounds stored by the input transform and the column bounds
-    derived from the untransformed tensors dominate the true maxima of the transformed operands (never below - that
-    would overflow fp16 - and within the transform's gain above)."""
+@pytest.mark.parametrize("tile", [4, 7])
+def test_wino_fused_scales(dev, tile):
+    """The f16x2 engine's Winograd operand scales (both tilings): the row bounds stored by the input / adjoint-dy
+    transforms and the column bounds derived from the untransformed tensors dominate the true maxima of the transformed
+    operands (never below - that would overflow fp16 - and within the transforms' gain above)."""
     from cim_amd import _lib
     from cim_amd.ops import gemm as G
     g = torch.Generator().manual_seed(9)
     R, P, C, Cout = 13, 7, 72, 40
     x = (torch.randn(R, P, P, C, generator=g) * torch.exp2(torch.randint(-6, 7, (1, 1, 1, C), generator=g).float())).to(dev)
     w = torch.randn(Cout, C, 3, 3, generator=g).to(dev)
-    mt, npos, st = R * 4, 36, _lib.stream_ptr()
+    npos, mt = (36, R * 4) if tile == 4 else (121, R)
+    st = _lib.stream_ptr()
     V = torch.empty(npos, mt, C, device=dev)
     vr = torch.empty(npos * mt, dtype=torch.int32, device=dev)
-    _lib.call("cim_wino_input_transform_amax", x.data_ptr(), V.data_ptr(), vr.data_ptr(), R, P, C, 4, st)
+    _lib.call("cim_wino_input_transform_amax", x.data_ptr(), V.data_ptr(), vr.data_ptr(), R, P, C, tile, st)
     V0 = torch.empty_like(V)
-    _lib.call("cim_wino_input_transform", x.data_ptr(), V0.data_ptr(), R, P, C, 4, st)
+    _lib.call("cim_wino_input_transform", x.data_ptr(), V0.data_ptr(), R, P, C, tile, st)
     assert torch.equal(V, V0)
     rb, true_rows = vr.view(torch.float32).view(npos, mt), V.abs().amax(dim=2)
     assert bool((rb >= true_rows).all()) and bool((rb <= 49.01 * x.abs().max()).all())
@@ -252,15 +254,23 @@ def test_wino_fused_scales(dev):
     assert bool((vb >= true).all()) and bool((vb <= 49.01 * x.abs().amax(dim=(0, 1, 2))[None, :]).all())
     for mode, n, kd in ((0, Cout, C), (1, C, Cout)):
         U = torch.empty(npos, kd, n, device=dev)
-        _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), Cout, C, mode, 4, st)
+        _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), Cout, C, mode, tile, st)
         wr, wc = G.amax(w, Cout, C * 9, C * 9, True, True)
         ub = (G._bounds(wr, Cout, 1, 1, npos, dev) if mode == 0 else G._bounds(wc, C, 9, 1, npos, dev))
         assert bool((ub.view(torch.float32).view(npos, n) >= U.abs().amax(dim=1)).all()), mode
+        if mode == 0 and tile == 7:          # the adjoint data gradient reads U K-contiguously: its "columns" are the rows [ci] of U[pos]
+            ub2 = G._bounds(wc, C, 9, 1, npos, dev).view(torch.float32).view(npos, C)
+            assert bool((ub2 >= U.abs().amax(dim=2)).all())
     dy = torch.randn(R, P, P, Cout, generator=g).to(dev)
     D = torch.empty(npos, mt, Cout, device=dev)
-    _lib.call("cim_wino_dy_transform", dy.data_ptr(), D.data_ptr(), R, P, Cout, 4, st)
+    _lib.call("cim_wino_dy_transform", dy.data_ptr(), D.data_ptr(), R, P, Cout, tile, st)
     db = G._bounds(G.amax(dy, R * P * P, Cout, Cout, want_cols=True)[1], Cout, 1, 2, npos, dev)
     assert bool((db.view(torch.float32).view(npos, Cout) >= D.abs().amax(dim=1)).all())
+    if tile == 7:
+        E = torch.empty(npos, mt, Cout, device=dev)
+        er = torch.empty(npos * mt, dtype=torch.int32, device=dev)
+        _lib.call("cim_wino_dy_adjoint_transform", dy.data_ptr(), E.data_ptr(), er.data_ptr(), R, P, Cout, tile, st)
+        assert bool((er.view(torch.float32).view(npos, mt) >= E.abs().amax(dim=2)).all())
 
 
 @pytest.mark.parametrize("Cout", [64, 192, 48])
