@@ -51,7 +51,7 @@ class SGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        recs, momentum, dev = [], None, None
+        recs, touched, momentum, dev = [], [], None, None
         for group in self.param_groups:
             if group.get("dampening", 0.0) != 0.0 or group.get("nesterov", False):
                 raise NotImplementedError("cim_amd.optim.SGD: dampening / Nesterov")
@@ -76,6 +76,8 @@ class SGD(torch.optim.Optimizer):
                     buf = st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 dev = p.device
                 recs.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr, wd, g))
+                touched.append(p)
+                touched.append(buf)
         if not recs:
             return loss
         sizes = tuple(r[3] for r in recs)
@@ -96,4 +98,7 @@ class SGD(torch.optim.Optimizer):
             self._stage[2].record()
             self._last = tab
         _lib.call("cim_sgd_multi", self._stage[1].data_ptr(), self._chunks.data_ptr(), self._n_chunks, momentum, _lib.stream_ptr())
+        # the kernel wrote parameters and momentum buffers through raw pointers: tell autograd's version counters, so that
+        # anything keyed by Tensor._version (saved-tensor checks, caches) sees the in-place update
+        torch.autograd.graph.increment_version(touched)
         return loss

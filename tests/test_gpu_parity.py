@@ -607,7 +607,9 @@ def test_fused_sgd_matches_torch_sgd(dev):
                     for p in grp["params"]:
                         opt.state[p]["momentum_buffer"] *= 0.1
         ref.step()
+        v0 = [p._version for p in hip_p]
         hip.step()
+        assert all(p._version > v for p, v in zip(hip_p, v0))          # raw-pointer update is visible to version counters
     for rp, hp in zip(ref_p, hip_p):
         torch.testing.assert_close(hp.detach().cpu(), rp.detach(), rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(hip.state[hp]["momentum_buffer"].cpu(), ref.state[rp]["momentum_buffer"], rtol=1e-5, atol=1e-6)
