@@ -16,14 +16,104 @@
 
 namespace {
 
+// wave-wide maximum on the VALU (see amax_wave in gemm_f32.hip): valid in lane 63
+__device__ __forceinline__ unsigned sgd_wave_max(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));
+    return v;
+}
+
+__device__ __forceinline__ float4 sgd_update4(float4& pv, const float4& gv, float4& bv, float momentum, float lr, float wd) {
+    bv.x = fmaf(momentum, bv.x, fmaf(wd, pv.x, gv.x));
+    bv.y = fmaf(momentum, bv.y, fmaf(wd, pv.y, gv.y));
+    bv.z = fmaf(momentum, bv.z, fmaf(wd, pv.z, gv.z));
+    bv.w = fmaf(momentum, bv.w, fmaf(wd, pv.w, gv.w));
+    pv.x = fmaf(-lr, bv.x, pv.x);
+    pv.y = fmaf(-lr, bv.y, pv.y);
+    pv.z = fmaf(-lr, bv.z, pv.z);
+    pv.w = fmaf(-lr, bv.w, pv.w);
+    return pv;
+}
+
 __global__ __launch_bounds__(256) void sgd_multi_kernel(const cim_sgd_tensor* __restrict__ tensors,
                                                         const cim_sgd_chunk* __restrict__ chunks, float momentum) {
     const cim_sgd_chunk ch = chunks[blockIdx.x];
     const cim_sgd_tensor t = tensors[ch.tensor];
+    const float lr = t.lr, wd = t.wd;
+    if (t.cols > 0) {
+        // matrix mode ([rows][cols] weights of the MaskFuse contractions): a 64-row x 1024-column tile per workgroup, a lane
+        // owns 4 consecutive columns - the update of the flat mode plus the per-row / per-column max |w_new| the f16x2 GEMM
+        // engine needs as operand scales (saves its pass over the 822 MB fc1 weight).  ch.offset = first row, ch.n = first column.
+        const int r0 = (int)ch.offset, r1 = min((int)t.rows, r0 + 64);
+        const int c = ch.n + threadIdx.x * 4;
+        const bool cin = c < t.cols;
+        const size_t base = (size_t)r0 * t.cols + (cin ? c : 0);
+        float* __restrict__ p = reinterpret_cast<float*>(t.p) + base;
+        const float* __restrict__ g = reinterpret_cast<const float*>(t.g) + base;
+        float* __restrict__ b = reinterpret_cast<float*>(t.buf) + base;
+        unsigned* row_amax = reinterpret_cast<unsigned*>(t.row_amax);
+        unsigned* col_amax = reinterpret_cast<unsigned*>(t.col_amax);
+        const bool lead = (threadIdx.x & 63) == 63;
+        uint4 cm = make_uint4(0, 0, 0, 0);
+        const size_t ld = (size_t)t.cols;
+        int r = r0;
+        for (; r + 4 <= r1; r += 4, p += 4 * ld, g += 4 * ld, b += 4 * ld) {      // 4 rows (12 x 16 B loads) in flight per lane
+            float4 pv[4], gv[4], bv[4];
+            unsigned m[4] = {0, 0, 0, 0};
+            if (cin) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pv[i] = *reinterpret_cast<const float4*>(p + i * ld);
+                    gv[i] = *reinterpret_cast<const float4*>(g + i * ld);
+                    bv[i] = *reinterpret_cast<const float4*>(b + i * ld);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sgd_update4(pv[i], gv[i], bv[i], momentum, lr, wd);
+                    *reinterpret_cast<float4*>(b + i * ld) = bv[i];
+                    *reinterpret_cast<float4*>(p + i * ld) = pv[i];
+                    const unsigned ax = __float_as_uint(pv[i].x) & 0x7fffffffu, ay = __float_as_uint(pv[i].y) & 0x7fffffffu;
+                    const unsigned az = __float_as_uint(pv[i].z) & 0x7fffffffu, aw = __float_as_uint(pv[i].w) & 0x7fffffffu;
+                    cm.x = max(cm.x, ax); cm.y = max(cm.y, ay); cm.z = max(cm.z, az); cm.w = max(cm.w, aw);
+                    m[i] = max(max(ax, ay), max(az, aw));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned mm = sgd_wave_max(m[i]);
+                if (lead) atomicMax(row_amax + r + i, mm);
+            }
+        }
+        for (; r < r1; ++r, p += ld, g += ld, b += ld) {
+            unsigned m = 0;
+            if (cin) {
+                float4 pv = *reinterpret_cast<const float4*>(p);
+                const float4 gv = *reinterpret_cast<const float4*>(g);
+                float4 bv = *reinterpret_cast<const float4*>(b);
+                sgd_update4(pv, gv, bv, momentum, lr, wd);
+                *reinterpret_cast<float4*>(b) = bv;
+                *reinterpret_cast<float4*>(p) = pv;
+                const unsigned ax = __float_as_uint(pv.x) & 0x7fffffffu, ay = __float_as_uint(pv.y) & 0x7fffffffu;
+                const unsigned az = __float_as_uint(pv.z) & 0x7fffffffu, aw = __float_as_uint(pv.w) & 0x7fffffffu;
+                cm.x = max(cm.x, ax); cm.y = max(cm.y, ay); cm.z = max(cm.z, az); cm.w = max(cm.w, aw);
+                m = max(max(ax, ay), max(az, aw));
+            }
+            m = sgd_wave_max(m);
+            if (lead) atomicMax(row_amax + r, m);
+        }
+        if (cin) {
+            atomicMax(col_amax + c, cm.x); atomicMax(col_amax + c + 1, cm.y);
+            atomicMax(col_amax + c + 2, cm.z); atomicMax(col_amax + c + 3, cm.w);
+        }
+        return;
+    }
     float* __restrict__ p = reinterpret_cast<float*>(t.p) + ch.offset;
     const float* __restrict__ g = reinterpret_cast<const float*>(t.g) + ch.offset;
     float* __restrict__ b = reinterpret_cast<float*>(t.buf) + ch.offset;
-    const float lr = t.lr, wd = t.wd;
     const int n = min(ch.n, (int)(t.n - ch.offset));
     // 16-byte accesses need the three chunk bases aligned (chunk offsets are multiples of 4 elements)
     const bool aligned = ((t.p | t.g | t.buf) & 15) == 0;
@@ -32,14 +122,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const cim_sgd_tensor* __
         float4 pv = *reinterpret_cast<const float4*>(p + i);
         const float4 gv = *reinterpret_cast<const float4*>(g + i);
         float4 bv = *reinterpret_cast<const float4*>(b + i);
-        bv.x = fmaf(momentum, bv.x, fmaf(wd, pv.x, gv.x));
-        bv.y = fmaf(momentum, bv.y, fmaf(wd, pv.y, gv.y));
-        bv.z = fmaf(momentum, bv.z, fmaf(wd, pv.z, gv.z));
-        bv.w = fmaf(momentum, bv.w, fmaf(wd, pv.w, gv.w));
-        pv.x = fmaf(-lr, bv.x, pv.x);
-        pv.y = fmaf(-lr, bv.y, pv.y);
-        pv.z = fmaf(-lr, bv.z, pv.z);
-        pv.w = fmaf(-lr, bv.w, pv.w);
+        sgd_update4(pv, gv, bv, momentum, lr, wd);
         *reinterpret_cast<float4*>(b + i) = bv;
         *reinterpret_cast<float4*>(p + i) = pv;
     }

@@ -48,6 +48,22 @@ def amax(x, rows, cols, ld, want_rows=False, want_cols=False, batch=1, bs=0, out
     return ra, ca
 
 
+# |max| arrays of weight matrices handed in by a producer that already streamed over the weight (the fused SGD kernel):
+# data_ptr -> (version counter, rows, cols, row array, column array).  An entry is valid only for that exact version.
+_WEIGHT_SCALES = {}
+
+
+def register_weight_scales(w, rows, cols, row_amax, col_amax):
+    _WEIGHT_SCALES[w.data_ptr()] = (w._version, rows, cols, row_amax, col_amax)
+
+
+def _registered_scales(w, rows, cols):
+    e = _WEIGHT_SCALES.get(w.data_ptr())
+    if e is not None and e[0] == w._version and e[1] == rows and e[2] == cols:
+        return e[3], e[4]
+    return None
+
+
 def gemm(a, b, m, n, k, lda, ldb, a_mcontig=False, b_kcontig=False, bias=None, relu=False, out=None,
          a_amax=None, b_amax=None):
     """C[m,n] = A.B (+bias)(ReLU).  a/b are dense device tensors interpreted by the layout flags.
@@ -98,9 +114,11 @@ class LinearFunction(Function):
         n = w.shape[0]
         xr = xc = wr = wc = None
         if ENGINE == "f16x2":        # one pass per operand: the row scales serve this product, the column scales the backward
-            z = _zeros_i32(x.device, m, k if ctx.needs_input_grad[1] else 0, n, k if ctx.needs_input_grad[0] else 0)
+            reg = _registered_scales(w, n, k)        # by-product of the optimizer step, if it ran cim_amd.optim.SGD
+            z = _zeros_i32(x.device, m, k if ctx.needs_input_grad[1] else 0,
+                           0 if reg else n, 0 if reg or not ctx.needs_input_grad[0] else k)
             xr, xc = amax(x, m, k, k, True, ctx.needs_input_grad[1], out=z[0:2])
-            wr, wc = amax(w, n, k, k, True, ctx.needs_input_grad[0], out=z[2:4])
+            wr, wc = reg if reg else amax(w, n, k, k, True, ctx.needs_input_grad[0], out=z[2:4])
         y = gemm(x, w, m, n, k, k, k, b_kcontig=True, bias=b, relu=relu, a_amax=xr, b_amax=wr)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.scales = (xc, wc)
@@ -219,8 +237,9 @@ class Conv3x3Function(Function):
                 vr = torch.empty(npos * mt, dtype=torch.int32, device=dev)
                 _lib.call("cim_wino_input_transform_amax", x.data_ptr(), V.data_ptr(), vr.data_ptr(), r, p, cin, tile, st)
                 need_xc = ctx.needs_input_grad[1] and x_col_amax is None
-                z = _zeros_i32(dev, cout, cin * 9 if ctx.needs_input_grad[0] else 0, cin if need_xc else 0)
-                w_rows, w_cols = amax(w, cout, cin * 9, cin * 9, True, ctx.needs_input_grad[0], out=z[0:2])
+                reg = _registered_scales(w, cout, cin * 9)
+                z = _zeros_i32(dev, 0 if reg else cout, 0 if reg or not ctx.needs_input_grad[0] else cin * 9, cin if need_xc else 0)
+                w_rows, w_cols = reg if reg else amax(w, cout, cin * 9, cin * 9, True, ctx.needs_input_grad[0], out=z[0:2])
                 uc = _bounds(w_rows, cout, 1, 1, npos, dev)
                 ctx.w_cols = w_cols
                 if ctx.needs_input_grad[1]:

@@ -7,9 +7,15 @@ rule - but ONE kernel launch per step for all parameters instead of one multi-te
 Only what the reference uses is supported on the HIP path: fp32 CUDA/HIP parameters, dampening 0, no Nesterov,
 dense gradients, one momentum value; anything else raises (there is no silent fallback).
 
-Host cost per step: autograd hands out new gradient tensors every step, so the 40-byte record of every tensor is
-refreshed (one pass over the parameters, one 6 KB H2D copy); the chunk table only depends on the tensor sizes and is
+Host cost per step: autograd hands out new gradient tensors every step, so the 64-byte record of every tensor is
+refreshed (one pass over the parameters, one 10 KB H2D copy); the chunk table only depends on the tensor sizes and is
 built once.
+
+Weights of >= 2^20 elements are updated in the kernel's matrix mode, which also emits max |w_new| per row and per column:
+exactly what the f16x2 contraction engine needs as operand scales of `nn.Linear` / conv weights.  They are registered with
+`cim_amd.ops.gemm.register_weight_scales` under the weight's new version counter, so the next forward skips its pass over
+the weight (0.29 ms per step at cfg2, mostly the 822 MB fc1 weight); any other in-place change of the weight bumps the
+version and the ops fall back to their own pass.
 """
 import numpy as np
 import torch
@@ -17,8 +23,20 @@ import torch
 from .. import _lib
 
 CHUNK = 16384          # elements per workgroup
-_TENSOR = np.dtype([("p", "<u8"), ("g", "<u8"), ("buf", "<u8"), ("n", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+_TENSOR = np.dtype([("p", "<u8"), ("g", "<u8"), ("buf", "<u8"), ("n", "<i8"), ("lr", "<f4"), ("wd", "<f4"),
+                    ("rows", "<i4"), ("cols", "<i4"), ("row_amax", "<u8"), ("col_amax", "<u8")])
 _CHUNK = np.dtype([("tensor", "<i4"), ("n", "<i4"), ("offset", "<i8")])
+MATRIX_MIN = 1 << 20   # weights of at least this many elements are updated in matrix mode (row / column |max| by-product)
+TILE_ROWS, TILE_COLS = 64, 1024
+
+
+def _matrix_shape(p):
+    """(rows, cols) when the parameter qualifies for the kernel's matrix mode, else None."""
+    if p.dim() < 2 or p.numel() < MATRIX_MIN:
+        return None
+    rows = p.shape[0]
+    cols = p.numel() // rows
+    return (rows, cols) if cols % 4 == 0 else None
 
 
 class SGD(torch.optim.Optimizer):
@@ -33,17 +51,23 @@ class SGD(torch.optim.Optimizer):
         self._stage = None          # (pinned host array, device array, event of the last H2D copy) of the tensor records
         self._last = None           # tensor records of the last step (skip the copy when nothing changed)
 
-    def _build_chunks(self, sizes, dev):
-        counts = np.array([(n + CHUNK - 1) // CHUNK for n in sizes], dtype=np.int64)
-        total = int(counts.sum())
-        owner = np.repeat(np.arange(len(sizes)), counts)
-        first = np.concatenate([[0], np.cumsum(counts)[:-1]])
-        tab = np.empty(total, dtype=_CHUNK)
-        tab["tensor"] = owner
-        tab["offset"] = (np.arange(total) - first[owner]) * CHUNK
-        tab["n"] = CHUNK
+    def _build_chunks(self, layout, dev):
+        """layout: per tensor (numel, rows, cols) with rows = cols = 0 for flat tensors."""
+        parts = []
+        for ti, (n, rows, cols) in enumerate(layout):
+            if cols > 0:        # matrix mode: 64 x 1024 tiles, offset = first row, n = first column
+                r0, c0 = np.meshgrid(np.arange(0, rows, TILE_ROWS), np.arange(0, cols, TILE_COLS), indexing="ij")
+                tab = np.empty(r0.size, dtype=_CHUNK)
+                tab["offset"], tab["n"] = r0.reshape(-1), c0.reshape(-1)
+            else:
+                cnt = (n + CHUNK - 1) // CHUNK
+                tab = np.empty(cnt, dtype=_CHUNK)
+                tab["offset"], tab["n"] = np.arange(cnt, dtype=np.int64) * CHUNK, CHUNK
+            tab["tensor"] = ti
+            parts.append(tab)
+        tab = np.concatenate(parts)
         self._chunks = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(dev)
-        self._n_chunks, self._layout = total, tuple(sizes)
+        self._n_chunks, self._layout = int(tab.shape[0]), tuple(layout)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -75,16 +99,31 @@ class SGD(torch.optim.Optimizer):
                 if buf is None:
                     buf = st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 dev = p.device
-                recs.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr, wd, g))
+                pp, gp, bp = p.data_ptr(), g.data_ptr(), buf.data_ptr()
+                ms = _matrix_shape(p) if ((pp | gp | bp) & 15) == 0 else None
+                recs.append((pp, gp, bp, p.numel(), lr, wd, ms[0] if ms else 0, ms[1] if ms else 0, g, p))
                 touched.append(p)
                 touched.append(buf)
         if not recs:
             return loss
-        sizes = tuple(r[3] for r in recs)
-        if sizes != self._layout:
-            self._build_chunks(sizes, dev)
+        layout = tuple((r[3], r[6], r[7]) for r in recs)
+        if layout != self._layout:
+            self._build_chunks(layout, dev)
             self._stage = self._last = None
-        tab = np.array([r[:6] for r in recs], dtype=_TENSOR)
+        # row / column |max| arrays of the matrix-mode tensors: fresh (zeroed) storage every step - consumers of the
+        # previous step's arrays (autograd graphs kept alive) never see them change
+        n_amax = sum(r[6] + r[7] for r in recs)
+        amax_buf = torch.zeros(max(n_amax, 1), dtype=torch.int32, device=dev)
+        base, off, slices = amax_buf.data_ptr(), 0, []
+        rows_list = []
+        for r in recs:
+            ra = ca = 0
+            if r[7] > 0:
+                ra, ca = base + 4 * off, base + 4 * (off + r[6])
+                slices.append((r[9], amax_buf[off:off + r[6]], amax_buf[off + r[6]:off + r[6] + r[7]], r[6], r[7]))
+                off += r[6] + r[7]
+            rows_list.append(r[:8] + (ra, ca))
+        tab = np.array(rows_list, dtype=_TENSOR)
         if self._last is None or not np.array_equal(tab, self._last):
             nbytes = tab.nbytes
             if self._stage is None:
@@ -101,4 +140,8 @@ class SGD(torch.optim.Optimizer):
         # the kernel wrote parameters and momentum buffers through raw pointers: tell autograd's version counters, so that
         # anything keyed by Tensor._version (saved-tensor checks, caches) sees the in-place update
         torch.autograd.graph.increment_version(touched)
+        if slices:      # hand the by-product scales to the contraction ops (valid for exactly this version of the weight)
+            from ..ops import gemm
+            for p, ra, ca, rows, cols in slices:
+                gemm.register_weight_scales(p, rows, cols, ra, ca)
         return loss

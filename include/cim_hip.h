@@ -321,6 +321,12 @@ typedef struct cim_sgd_tensor {
     uint64_t buf;      /* float* momentum buffer */
     int64_t n;         /* elements */
     float lr, wd;
+    /* matrix mode (cols > 0): the tensor is a [rows][cols] matrix (cols % 4 == 0, 16-byte aligned pointers), its chunks are
+     * 64-row x 1024-column tiles (chunk.offset = first row, chunk.n = first column) and the launch also accumulates
+     * max |w_new| per row / per column (IEEE bit patterns, atomicMax) into the caller-zeroed arrays row_amax [rows] /
+     * col_amax [cols] - the operand scales of the f16x2 contraction engine (cim_amax_rowcol) as a by-product. */
+    int32_t rows, cols;
+    uint64_t row_amax, col_amax;
 } cim_sgd_tensor;
 typedef struct cim_sgd_chunk {
     int32_t tensor;    /* index into `tensors` */

@@ -615,3 +615,37 @@ def test_fused_sgd_matches_torch_sgd(dev):
         torch.testing.assert_close(hip.state[hp]["momentum_buffer"].cpu(), ref.state[rp]["momentum_buffer"], rtol=1e-5, atol=1e-6)
     with pytest.raises(NotImplementedError):
         SGD(hip_p, lr=0.1, momentum=0.9, nesterov=True)
+
+
+def test_fused_sgd_matrix_mode_hands_scales_to_the_contractions(dev):
+    """Weights of >= 2^20 elements take the SGD kernel's matrix mode: same update as torch.optim.SGD, and the row / column
+    max |w_new| it registers are exactly what cim_amax_rowcol computes - valid for this version of the weight only."""
+    from cim_amd.optim import SGD
+    from cim_amd.ops import gemm as G, linear
+    g = torch.Generator().manual_seed(5)
+    rows, cols = 1036, 1028                                  # ragged against the 64 x 1024 tiles (and the 4-row unroll)
+    w0 = torch.randn(rows, cols, generator=g)
+    small0 = torch.randn(77, generator=g)
+    rp = [w0.clone().requires_grad_(True), small0.clone().requires_grad_(True)]
+    hp = [w0.clone().to(dev).requires_grad_(True), small0.clone().to(dev).requires_grad_(True)]
+    ref = torch.optim.SGD(rp, lr=0.1, momentum=0.9, weight_decay=0.01)
+    hip = SGD(hp, lr=0.1, momentum=0.9, weight_decay=0.01)
+    for _ in range(3):
+        for a, b in zip(rp, hp):
+            gr = torch.randn(a.shape, generator=g)
+            a.grad, b.grad = gr.clone(), gr.clone().to(dev)
+        ref.step()
+        hip.step()
+    torch.testing.assert_close(hp[0].detach().cpu(), rp[0].detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(hp[1].detach().cpu(), rp[1].detach(), rtol=1e-5, atol=1e-6)
+    reg = G._registered_scales(hp[0], rows, cols)
+    assert reg is not None
+    ra, ca = G.amax(hp[0].detach(), rows, cols, cols, True, True)
+    assert torch.equal(reg[0], ra) and torch.equal(reg[1], ca)
+    x = torch.randn(50, cols, generator=g).to(dev)
+    y_reg = linear(x, hp[0])                                 # uses the registered scales
+    with torch.no_grad():
+        hp[0].mul_(1.0)                                      # any other in-place change invalidates them
+    assert G._registered_scales(hp[0], rows, cols) is None
+    y_own = linear(x, hp[0])
+    assert torch.equal(y_reg, y_own)
