@@ -8,9 +8,12 @@ thread per GPU inside one process, re-broadcasts all parameters every forward an
 outputs (SURVEY.md 2.3, broken for >1 GPU, S7).  Here each rank owns ONE device and one image;
 the only collective is the gradient all-reduce:
 
-  * gradients live in ONE flat fp32 buffer (param.grad are views into it), so zeroing is one
-    memset and the all-reduce needs no packing copies;
-  * the buffer is cut into buckets in reverse parameter order (= backward completion order);
+  * the gradients of the many small parameters live in ONE flat fp32 buffer (param.grad are views into it), so
+    zeroing is one memset and their all-reduce needs no packing copies; a BIG parameter (>= `big_bytes`: the two fc
+    weights and the 3x3 conv of MaskFuse, 96 % of the 1 GB) is its own bucket and is reduced IN PLACE in the tensor
+    autograd hands over (its .grad is reset to None each step, so autograd steals the incoming gradient instead of
+    adding it into a zeroed view: no 1 GB memset and no 3 GB accumulate pass per step);
+  * buckets are ordered in reverse parameter order (= backward completion order);
     a bucket's all-reduce is launched from a post-accumulate-grad hook as soon as its last
     gradient is written, so RCCL traffic overlaps the rest of backward;
   * sum-all-reduce of (loss / world) gradients == the reference's `loss.mean(dim=0)` over GPUs
@@ -25,7 +28,8 @@ from torch import nn
 
 class DataParallel(nn.Module):
     def __init__(self, module, device_ids=None, output_device=None, dim=0, cpu_keywords=(), minibatch=False,
-                 batch_outputs=True, bucket_bytes=64 << 20, process_group=None, force_flat_grads=False):
+                 batch_outputs=True, bucket_bytes=64 << 20, process_group=None, force_flat_grads=False,
+                 big_bytes=16 << 20):
         super().__init__()
         self.module = module
         self.cpu_keywords = list(cpu_keywords)
@@ -41,6 +45,7 @@ class DataParallel(nn.Module):
         self._pending = []
         self._next_bucket = 0
         self._force_flat = force_flat_grads
+        self._big_bytes = big_bytes
         self._build_flat_grads(bucket_bytes)
 
     # ------------------------------------------------------------------ flat gradient storage
@@ -54,21 +59,30 @@ class DataParallel(nn.Module):
             # they are (no accumulate-into-view add per parameter, no 1 GB memset per step); the
             # reference's DataParallel is a pass-through on one GPU too (data_parallel.py:107-108)
             return
-        total = sum(p.numel() for p in params)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        big = set(p for p in params if p.numel() * 4 >= self._big_bytes)
+        self._big = [p for p in params if p in big]
+        total = sum(p.numel() for p in params if p not in big)
+        self.flat_grad = torch.zeros(max(total, 1), dtype=torch.float32, device=self.device)
         # reverse registration order ~ order in which backward produces gradients
         off = 0
         spans = []
         for p in reversed(params):
+            if p in big:
+                p.grad = None
+                spans.append((p, None, None))
+                continue
             n = p.numel()
             p.grad = self.flat_grad[off:off + n].view_as(p)
             spans.append((p, off, off + n))
             off += n
-        # buckets: contiguous spans of ~bucket_bytes; a huge tensor (seg_fc.0: 822 MB) is one bucket
+        # buckets: contiguous spans of ~bucket_bytes of the flat buffer; a big tensor (seg_fc.0: 822 MB) is its own bucket
         self.buckets = []
         cur = None
         for p, a, b in spans:
-            if cur is None or (cur["end"] - cur["start"]) * 4 >= bucket_bytes:
+            if a is None:
+                self.buckets.append(dict(tensor=p, params=[p], ready=0))
+                cur = None
+            elif cur is None or (cur["end"] - cur["start"]) * 4 >= bucket_bytes:
                 cur = dict(start=a, end=b, params=[p], ready=0)
                 self.buckets.append(cur)
             else:
@@ -87,8 +101,8 @@ class DataParallel(nn.Module):
             return
         bk = self.buckets[self._bucket_of[p]]
         bk["ready"] += 1
-        if p.grad.data_ptr() < self.flat_grad.data_ptr() or \
-                p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * 4:
+        if "tensor" not in bk and (p.grad.data_ptr() < self.flat_grad.data_ptr() or
+                                   p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * 4):
             raise RuntimeError("DataParallel: a .grad was replaced (use zero_grad(set_to_none=False) / "
                                "DataParallel.zero_grad())")
         self._launch_ready_buckets()
@@ -102,8 +116,16 @@ class DataParallel(nn.Module):
             if not force and bk["ready"] < len(bk["params"]):
                 break
             bk["ready"] = 0
-            self._pending.append(dist.all_reduce(self.flat_grad[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM,
-                                                 group=self.process_group, async_op=True))
+            if "tensor" in bk:
+                p = bk["tensor"]
+                if p.grad is None:          # this rank's autograd produced nothing for it: still take part in the collective
+                    p.grad = torch.zeros_like(p)
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                buf = p.grad
+            else:
+                buf = self.flat_grad[bk["start"]:bk["end"]]
+            self._pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
             self._next_bucket += 1
 
     def zero_grad(self, set_to_none=False):
@@ -114,6 +136,8 @@ class DataParallel(nn.Module):
                 p.grad = None
         else:
             self.flat_grad.zero_()
+            for p in self._big:             # autograd steals the next gradient tensor instead of accumulating into a view
+                p.grad = None
 
     @contextlib.contextmanager
     def no_sync(self):

@@ -37,20 +37,27 @@ def _data(rank):
     return torch.randn(5, 6, generator=g)
 
 
-def _worker(rank, world, port, out):
+def _grads(dp):
+    """All gradients in reverse parameter order (flat-buffer views and in-place reduced big tensors alike)."""
+    params = [p for p in dp.module.parameters() if p.requires_grad]
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in reversed(params)]).clone()
+
+
+def _worker(rank, world, port, out, big_bytes=16 << 20):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from cim_amd.nn import DataParallel
     torch.manual_seed(0)
-    dp = DataParallel(Tiny(), cpu_keywords=["im_info"], minibatch=True, bucket_bytes=64)
+    dp = DataParallel(Tiny(), cpu_keywords=["im_info"], minibatch=True, bucket_bytes=64, big_bytes=big_bytes)
     assert len(dp.buckets) > 1 and dp.world_size == world
+    assert any("tensor" in b for b in dp.buckets) == (big_bytes < (16 << 20))
     # step 1: plain synchronised backward
     dp.zero_grad()
     o = dp(data=[_data(rank)], scale=[torch.tensor(1.0)])
     (o["losses"]["l"].sum() * dp.loss_scale()).backward()
     dp.finish_gradient_sync()
-    g1 = dp.flat_grad.clone()
+    g1 = _grads(dp)
     # step 2: accumulate one un-synced micro-step, then a synced one (iter_size = 2)
     dp.zero_grad()
     with dp.no_sync():
@@ -59,14 +66,14 @@ def _worker(rank, world, port, out):
     o = dp(data=[_data(rank + 10)], scale=[torch.tensor(2.0)])
     (o["losses"]["l"].sum() * dp.loss_scale()).backward()
     dp.finish_gradient_sync()
-    g2 = dp.flat_grad.clone()
+    g2 = _grads(dp)
     # step 3: rank 1 skips one head entirely (its parameters get no gradient on that rank):
     # the strict bucket order must still pair up the collectives of both ranks
     dp.zero_grad()
     o = dp(data=[_data(rank)], scale=[torch.tensor(1.0)], skip_b=[rank == 1])
     (o["losses"]["l"].sum() * dp.loss_scale()).backward()
     dp.finish_gradient_sync()
-    g3 = dp.flat_grad.clone()
+    g3 = _grads(dp)
     if rank == 0:
         torch.save({"g1": g1, "g2": g2, "g3": g3}, out)
     dist.destroy_process_group()
@@ -80,9 +87,13 @@ def _local_grad(data, scale, skip_b=False):
     return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in reversed(params)])
 
 
-def test_dp_allreduce_world2(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("big_bytes", [16 << 20, 100])       # all parameters in the flat buffer / weight matrices reduced in place
+def test_dp_allreduce_world2(tmp_path, big_bytes):
     out = str(tmp_path / "g.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, big_bytes), nprocs=2, join=True)
     got = torch.load(out)
     want1 = (_local_grad(_data(0), 1.0) + _local_grad(_data(1), 1.0)) / 2
     torch.testing.assert_close(got["g1"], want1, rtol=1e-5, atol=1e-6)
