@@ -30,7 +30,11 @@ def _defaults():
     c.MODEL = AttrDict(TYPE="generalized_rcnn", CONV_BODY="", NUM_CLASSES=-1,
                        LOAD_IMAGENET_PRETRAINED_WEIGHTS=False, EXTRA=AttrDict())
     c.SOLVER = AttrDict(BASE_LR=0.0005, WEIGHT_DECAY=0.0005, MOMENTUM=0.9, TYPE="SGD",
-                        BIAS_DOUBLE_LR=True, BIAS_WEIGHT_DECAY=False)
+                        BIAS_DOUBLE_LR=True, BIAS_WEIGHT_DECAY=False,
+                        # schedule keys read by cim_amd/optim/solver.py (defaults of lib/core/config.py:277-343)
+                        LR_POLICY="step", GAMMA=0.1, STEPS=[], MAX_ITER=40000,
+                        WARM_UP_ITERS=500, WARM_UP_FACTOR=1.0 / 3.0, WARM_UP_METHOD="linear",
+                        SCALE_MOMENTUM=True, SCALE_MOMENTUM_THRESHOLD=1.1, LOG_LR_CHANGE_THRESHOLD=1.1)
     c.FAST_RCNN = AttrDict(ROI_BOX_HEAD="", MLP_HEAD_DIM=1024, ROI_XFORM_METHOD="RoIPoolF",
                            ROI_XFORM_SAMPLING_RATIO=0, ROI_XFORM_RESOLUTION=14, MASK_SIZE=7)
     c.VGG = AttrDict(IMAGENET_PRETRAINED_WEIGHTS="", FREEZE_AT=2)

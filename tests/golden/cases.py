@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import torch
 
 _REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if _REPO not in sys.path:
@@ -79,3 +80,22 @@ def e2e_inputs():
     iou, asy = oracle_mask_iou.mask_iou_maps(inp["full_masks"])
     inp["iou"], inp["asy"] = iou, asy
     return inp
+
+
+# ---- learning-rate schedule / momentum-history case (tests/golden/lr_schedule.npz)
+LR_CASE = dict(BASE_LR=0.01, WARM_UP_ITERS=6, WARM_UP_FACTOR=1.0 / 3.0, WARM_UP_METHOD="linear", STEPS=[0, 9, 12], GAMMA=0.1,
+               MOMENTUM=0.9, WEIGHT_DECAY=0.0005, n_steps=15)
+
+
+def lr_toy_model():
+    """Two weights + two biases with closed-form values (shared with tests/test_host_cpu.py)."""
+    m = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    with torch.no_grad():
+        for k, p in enumerate(m.parameters()):
+            p.copy_(torch.sin(torch.arange(p.numel(), dtype=torch.float32) * 0.37 + k).view_as(p))
+    return m
+
+
+def lr_toy_grads(m, step):
+    for k, p in enumerate(m.parameters()):
+        p.grad = torch.cos(torch.arange(p.numel(), dtype=torch.float32) * 0.11 + 0.5 * step + k).view_as(p)

@@ -34,7 +34,8 @@ sys.path.insert(0, HERE)
 import _ref_shims  # noqa: E402
 from cim_amd import synthetic  # noqa: E402
 from oracle import mask_iou as oracle_mask_iou  # noqa: E402  (only to build INPUT maps)
-from cases import E2E, MINING_CASES, THRESHOLDS, case_inputs, e2e_inputs, procedural, procedural_init  # noqa: E402
+from cases import (E2E, LR_CASE, MINING_CASES, THRESHOLDS, case_inputs, e2e_inputs, lr_toy_grads, lr_toy_model, procedural,  # noqa: E402
+                   procedural_init)
 
 class FrameTap:
     """sys.settrace tap on heads.py frames: snapshots named locals of CIM_label / MIST_label
@@ -381,6 +382,64 @@ def gen_hrnet():
     print("hrnet", tuple(y.shape), len(model.state_dict()), "trainable", len(trainable), "with grad", len(with_grad))
 
 
+def gen_lr():
+    """The reference's lib/utils/net.py (update_learning_rate / decay_learning_rate / clip_gradient) driven by the
+    schedule statements of tools/train.py:282-311,376-414 (inline in main() there, so restated here) on a toy model
+    with torch.optim.SGD: learning rates of both groups, parameters and momentum history after every step."""
+    cfgmod = importlib.import_module("core.config")
+    net_utils = importlib.import_module("utils.net")
+    cfg = cfgmod.cfg
+    for k in ("BASE_LR", "WARM_UP_ITERS", "WARM_UP_FACTOR", "WARM_UP_METHOD", "STEPS", "GAMMA", "MOMENTUM", "WEIGHT_DECAY"):
+        cfg.SOLVER[k] = LR_CASE[k]
+    m = lr_toy_model()
+    bias = [v for k, v in m.named_parameters() if "bias" in k]
+    nonbias = [v for k, v in m.named_parameters() if "bias" not in k]
+    params = [{"params": nonbias, "lr": 0, "weight_decay": cfg.SOLVER.WEIGHT_DECAY},
+              {"params": bias, "lr": 0 * (cfg.SOLVER.BIAS_DOUBLE_LR + 1),
+               "weight_decay": cfg.SOLVER.WEIGHT_DECAY if cfg.SOLVER.BIAS_WEIGHT_DECAY else 0}]
+    opt = torch.optim.SGD(params, momentum=cfg.SOLVER.MOMENTUM)
+    lr = opt.param_groups[0]["lr"]
+    decay_steps_ind = None
+    for i in range(1, len(cfg.SOLVER.STEPS)):
+        if cfg.SOLVER.STEPS[i] >= 0:
+            decay_steps_ind = i
+            break
+    if decay_steps_ind is None:
+        decay_steps_ind = len(cfg.SOLVER.STEPS)
+    lrs, flat, hist = [], [], []
+    for step in range(LR_CASE["n_steps"]):
+        if step < cfg.SOLVER.WARM_UP_ITERS:
+            alpha = step / cfg.SOLVER.WARM_UP_ITERS
+            warmup_factor = cfg.SOLVER.WARM_UP_FACTOR * (1 - alpha) + alpha
+            lr_new = cfg.SOLVER.BASE_LR * warmup_factor
+            net_utils.update_learning_rate(opt, lr, lr_new)
+            lr = opt.param_groups[0]["lr"]
+        elif step == cfg.SOLVER.WARM_UP_ITERS:
+            net_utils.update_learning_rate(opt, lr, cfg.SOLVER.BASE_LR)
+            lr = opt.param_groups[0]["lr"]
+        if decay_steps_ind < len(cfg.SOLVER.STEPS) and step == cfg.SOLVER.STEPS[decay_steps_ind]:
+            lr_new = lr * cfg.SOLVER.GAMMA
+            net_utils.update_learning_rate(opt, lr, lr_new)
+            lr = opt.param_groups[0]["lr"]
+            decay_steps_ind += 1
+        lr_toy_grads(m, step)
+        opt.step()
+        lrs.append([g["lr"] for g in opt.param_groups])
+        flat.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy().copy())
+        hist.append(torch.cat([opt.state[p]["momentum_buffer"].reshape(-1) for p in m.parameters()]).numpy().copy())
+    store = dict(lrs=np.array(lrs, dtype=np.float64), params=np.stack(flat), history=np.stack(hist))
+    # decay_learning_rate: every group keeps its own ratio; history rescaled (ratio 1/0.1 > threshold)
+    net_utils.decay_learning_rate(opt, lr, 0.1)
+    store["decay_lrs"] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
+    store["decay_history"] = torch.cat([opt.state[p]["momentum_buffer"].reshape(-1) for p in m.parameters()]).numpy().copy()
+    # clip_gradient: above and below the threshold
+    for name, clip in (("clip_small", 0.5), ("clip_large", 100.0)):
+        lr_toy_grads(m, 3)
+        net_utils.clip_gradient(m, clip)
+        store[name] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **store)
+
+
 def main():
     _ref_shims.install()
     heads = importlib.import_module("modeling.heads")
@@ -391,6 +450,7 @@ def main():
     gen_mask_iou_witness()
     gen_e2e()
     gen_hrnet()
+    gen_lr()
 
 
 if __name__ == "__main__":

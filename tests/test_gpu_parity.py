@@ -649,3 +649,23 @@ def test_fused_sgd_matrix_mode_hands_scales_to_the_contractions(dev):
     assert G._registered_scales(hp[0], rows, cols) is None
     y_own = linear(x, hp[0])
     assert torch.equal(y_reg, y_own)
+
+
+def test_fused_sgd_under_reference_lr_schedule(golden_dir):
+    """cim_amd.optim.make_optimizer (fused HIP SGD, tools/train.py:282-311 groups) stepped through the reference's
+    warm-up / decay / momentum-correction schedule: parameters and momentum history against the golden trace of
+    torch.optim.SGD under lib/utils/net.py (fp32 update rule, different FMA contraction: 1e-6 relative)."""
+    from test_host_cpu import _run_lr_schedule
+    from cim_amd.optim import SGD, make_optimizer
+    g = np.load(os.path.join(golden_dir, "lr_schedule.npz"))
+    made = []
+
+    def make(m):
+        made.append(make_optimizer(m))
+        return made[-1]
+
+    out = _run_lr_schedule(make, device="cuda")
+    assert isinstance(made[0], SGD)
+    assert np.array_equal(out["lrs"], g["lrs"]) and np.array_equal(out["decay_lrs"], g["decay_lrs"])
+    for k in ("params", "history", "decay_history", "clip_small", "clip_large"):
+        np.testing.assert_allclose(out[k], g[k], rtol=2e-6, atol=1e-7, err_msg=k)

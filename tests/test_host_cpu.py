@@ -119,3 +119,56 @@ def test_hrnet_w48_matches_reference(golden_dir):
     np.testing.assert_allclose(float(m.final_layer[0].weight.grad.norm()), float(g["grad_norm_final"]), rtol=1e-3)
     np.testing.assert_allclose(float(m.stage3[0].branches[0][0].conv1.weight.grad.norm()), float(g["grad_norm_stage3"]), rtol=1e-3)
     assert all(not b.training for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))
+
+
+def _run_lr_schedule(make_opt, device="cpu"):
+    """The loop of tools/train.py:385-432 reduced to schedule + optimizer step, through cim_amd's host mirror."""
+    from cases import LR_CASE, lr_toy_grads, lr_toy_model
+    from cim_amd.core.config import cfg, reset_cfg
+    from cim_amd.optim.solver import LRSchedule
+    from cim_amd.utils import net as net_utils
+    reset_cfg()
+    for k in ("BASE_LR", "WARM_UP_ITERS", "WARM_UP_FACTOR", "WARM_UP_METHOD", "STEPS", "GAMMA", "MOMENTUM", "WEIGHT_DECAY"):
+        cfg.SOLVER[k] = LR_CASE[k]
+    m = lr_toy_model().to(device)
+    opt = make_opt(m)
+    sched = LRSchedule(opt)
+    lrs, flat, hist = [], [], []
+
+    def history():
+        return torch.cat([opt.state[p]["momentum_buffer"].reshape(-1) for p in m.parameters()]).cpu().numpy()
+
+    for step in range(LR_CASE["n_steps"]):
+        sched.before_step(step)
+        lr_toy_grads(m, step)
+        for p in m.parameters():
+            p.grad = p.grad.to(device)
+        opt.step()
+        lrs.append([g["lr"] for g in opt.param_groups])
+        flat.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy())
+        hist.append(history())
+    out = dict(lrs=np.array(lrs), params=np.stack(flat), history=np.stack(hist))
+    net_utils.decay_learning_rate(opt, sched.lr, 0.1)
+    out["decay_lrs"] = np.array([g["lr"] for g in opt.param_groups])
+    out["decay_history"] = history()
+    for name, clip in (("clip_small", 0.5), ("clip_large", 100.0)):
+        lr_toy_grads(m, 3)
+        for p in m.parameters():
+            p.grad = p.grad.to(device)
+        net_utils.clip_gradient(m, clip)
+        out[name] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    reset_cfg()
+    return out
+
+
+def test_lr_schedule_and_momentum_correction_match_reference(golden_dir):
+    """cim_amd.utils.net + cim_amd.optim.solver against lib/utils/net.py driven by train.py's schedule (golden:
+    learning rates of both groups bit-equal, parameters / momentum history of torch.optim.SGD bit-equal)."""
+    from cim_amd.core.config import cfg
+    from cim_amd.optim.solver import param_groups
+    g = np.load(os.path.join(golden_dir, "lr_schedule.npz"))
+    out = _run_lr_schedule(lambda m: torch.optim.SGD(param_groups(m), momentum=cfg.SOLVER.MOMENTUM))
+    assert np.array_equal(out["lrs"], g["lrs"]) and np.array_equal(out["decay_lrs"], g["decay_lrs"])
+    assert out["lrs"][0, 1] == 2 * out["lrs"][0, 0]                     # BIAS_DOUBLE_LR
+    for k in ("params", "history", "decay_history", "clip_small", "clip_large"):
+        assert np.array_equal(out[k], g[k]), k
