@@ -6,7 +6,8 @@ import os
 from ctypes import c_float, c_int, c_longlong, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcim_hip.so")
+# CIM_HIP_LIB: an ablation build (python -m cim_amd.build --out=...) for whole-step A/B runs; must export the same ABI
+LIB_PATH = os.environ.get("CIM_HIP_LIB") or os.path.join(HERE, "libcim_hip.so")
 
 # name -> argtypes (all return int)
 _P = c_void_p

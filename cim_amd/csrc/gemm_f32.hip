@@ -52,6 +52,9 @@ constexpr int SLAB = BK * (LDS_A + LDS_B);       // floats per LDS buffer
 enum ALayout { A_KCONTIG = 0, A_MCONTIG = 1, A_CONV_K = 2, A_CONV_M = 3 };
 enum BLayout { B_NCONTIG = 0, B_KCONTIG = 1 };
 
+#ifndef CIM_X2_NT
+#define CIM_X2_NT 0             // 1 = nontemporal stores of the f16x2 engine's final outputs
+#endif
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -971,7 +974,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_f16x2_kernel(const GemmArgs g_in) 
                 if (m >= g.M) continue;
                 float v = acc[i][j][r] * s_isa[ml] * isb + bv;
                 if (g.relu) v = fmaxf(v, 0.0f);
+#if CIM_X2_NT
+                if (g.c_split_stride == 0) __builtin_nontemporal_store(v, &C[(size_t)m * g.ldc + n]);      // final output: streamed
+                else C[(size_t)m * g.ldc + n] = v;                                                          // split-K partial: re-read at once
+#else
                 C[(size_t)m * g.ldc + n] = v;
+#endif
             }
         }
     }

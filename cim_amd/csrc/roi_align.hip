@@ -396,6 +396,9 @@ __device__ __forceinline__ ga_f2 ga_fma(float w, ga_f2 v, ga_f2 a) { return __bu
 #ifndef CIM_ROI_FZ
 #define CIM_ROI_FZ 1             // channel slices of the aggregated forward (grid.z); 2 / 4 (L2-sized slices) measured equal
 #endif
+#ifndef CIM_ROI_FNT
+#define CIM_ROI_FNT 1            // 1 = nontemporal stores of the pooled output
+#endif
 constexpr int AG_MAXE = 64;     // entries per (ph, pw) list kept in LDS; larger bins take the sample-order kernel
 
 template <bool MASKCAT>
@@ -531,8 +534,17 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
 #endif
 #if CIM_ROI_FEXP == 2      /* ablation: no loads (stores only) */
 #endif
+#if CIM_ROI_FNT
+            typedef float ga_f4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(ga_f4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<ga_f4*>(dst));
+            if (MASKCAT) {
+                const float4 mo = vmul(masks[((size_t)k * P + ph) * P + pw], acc);
+                __builtin_nontemporal_store(ga_f4{mo.x, mo.y, mo.z, mo.w}, reinterpret_cast<ga_f4*>(dst + C));
+            }
+#else
             *reinterpret_cast<float4*>(dst) = acc;
             if (MASKCAT) *reinterpret_cast<float4*>(dst + C) = vmul(masks[((size_t)k * P + ph) * P + pw], acc);
+#endif
         }
     }
 }

@@ -17,6 +17,18 @@
 namespace {
 
 // wave-wide maximum on the VALU (see amax_wave in gemm_f32.hip): valid in lane 63
+#ifndef CIM_SGD_NT
+#define CIM_SGD_NT 1            // 1 = nontemporal stores of the updated parameter / history (matrix mode)
+#endif
+typedef float sgd_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sgd_store(float* p, const float4& v) {
+#if CIM_SGD_NT
+    __builtin_nontemporal_store(sgd_v4{v.x, v.y, v.z, v.w}, reinterpret_cast<sgd_v4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 __device__ __forceinline__ unsigned sgd_wave_max(unsigned v) {
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
@@ -74,8 +86,8 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const cim_sgd_tensor* __
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     sgd_update4(pv[i], gv[i], bv[i], momentum, lr, wd);
-                    *reinterpret_cast<float4*>(b + i * ld) = bv[i];
-                    *reinterpret_cast<float4*>(p + i * ld) = pv[i];
+                    sgd_store(b + i * ld, bv[i]);
+                    sgd_store(p + i * ld, pv[i]);
                     const unsigned ax = __float_as_uint(pv[i].x) & 0x7fffffffu, ay = __float_as_uint(pv[i].y) & 0x7fffffffu;
                     const unsigned az = __float_as_uint(pv[i].z) & 0x7fffffffu, aw = __float_as_uint(pv[i].w) & 0x7fffffffu;
                     cm.x = max(cm.x, ax); cm.y = max(cm.y, ay); cm.z = max(cm.z, az); cm.w = max(cm.w, aw);
@@ -95,8 +107,8 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const cim_sgd_tensor* __
                 const float4 gv = *reinterpret_cast<const float4*>(g);
                 float4 bv = *reinterpret_cast<const float4*>(b);
                 sgd_update4(pv, gv, bv, momentum, lr, wd);
-                *reinterpret_cast<float4*>(b) = bv;
-                *reinterpret_cast<float4*>(p) = pv;
+                sgd_store(b, bv);
+                sgd_store(p, pv);
                 const unsigned ax = __float_as_uint(pv.x) & 0x7fffffffu, ay = __float_as_uint(pv.y) & 0x7fffffffu;
                 const unsigned az = __float_as_uint(pv.z) & 0x7fffffffu, aw = __float_as_uint(pv.w) & 0x7fffffffu;
                 cm.x = max(cm.x, ax); cm.y = max(cm.y, ay); cm.z = max(cm.z, az); cm.w = max(cm.w, aw);

@@ -451,6 +451,33 @@ __global__ __launch_bounds__(256) void wino43_wgrad_out_kernel(const float* __re
 // contractions, and V / D / M shrink by the same factor).  `tile == 7` in the C entry points; P must be 7.
 // Matrices (wino43_mats.h, W7_*: [axis kind][..][..], zero padded): B^T, G, A^T; weight gradient: GD (dy transform), AW.
 // Layouts: V, D, M: [121][R][C];  U, dU: [121][K][N].
+#ifndef CIM_W7_NT
+#define CIM_W7_NT 1             // 1 = nontemporal stores of the transform outputs (streamed once, consumed by the next kernel)
+#endif
+typedef float w7_v2 __attribute__((ext_vector_type(2)));
+typedef float w7_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void w7_store(float* p, float v) {
+#if CIM_W7_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void w7_store(float* p, float2 v) {
+#if CIM_W7_NT
+    __builtin_nontemporal_store(w7_v2{v.x, v.y}, reinterpret_cast<w7_v2*>(p));
+#else
+    *reinterpret_cast<float2*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void w7_store(float* p, float4 v) {
+#if CIM_W7_NT
+    __builtin_nontemporal_store(w7_v4{v.x, v.y, v.z, v.w}, reinterpret_cast<w7_v4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 struct W7 {
     static constexpr int NP[2] = {6, 5};      // positions per axis
     static constexpr int OUT[2] = {4, 3};     // outputs per axis
@@ -501,7 +528,7 @@ __device__ __forceinline__ void w7_input_tile(const float* __restrict__ x, float
 #pragma unroll
                 for (int k = 0; k < NB; ++k)
                     if (W7_BT[KB][j][k] != 0.0f) fma2(v, W7_BT[KB][j][k], trow[k]);
-                *reinterpret_cast<float2*>(V + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c) = v;
+                w7_store(V + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c, v);
             }
         }
     }
@@ -550,7 +577,7 @@ __device__ __forceinline__ void w7_filter_tile(const float (&w)[3][3], float* __
     for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            U[(size_t)(Q0 + i * NB + j) * KN + idx] = t[i][0] * W7_G[KB][j][0] + t[i][1] * W7_G[KB][j][1] + t[i][2] * W7_G[KB][j][2];
+            w7_store(U + (size_t)(Q0 + i * NB + j) * KN + idx, t[i][0] * W7_G[KB][j][0] + t[i][1] * W7_G[KB][j][1] + t[i][2] * W7_G[KB][j][2]);
 }
 
 __global__ __launch_bounds__(256) void wino7_filter_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
@@ -603,7 +630,7 @@ __device__ __forceinline__ void w7_output_tile(const float* __restrict__ M, cons
                 for (int j = 0; j < NB; ++j)
                     if (W7_AT[KB][b][j] != 0.0f) fma2(v, W7_AT[KB][b][j], s[a][j]);
                 if (relu) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
-                *reinterpret_cast<float2*>(y + (((size_t)r * P + W7::OUT0[KA] + a) * P + W7::OUT0[KB] + b) * C + c) = v;
+                w7_store(y + (((size_t)r * P + W7::OUT0[KA] + a) * P + W7::OUT0[KB] + b) * C + c, v);
             }
     }
 }
@@ -660,7 +687,7 @@ __device__ __forceinline__ void w7_dy_tile(const float* __restrict__ dy, float* 
                     const float m = ADJ ? W7_AT[KB][b][j] : W7_GD[KB][j][b];
                     if (m != 0.0f) fma4(v, m, trow[b]);
                 }
-                *reinterpret_cast<float4*>(D + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c) = v;
+                w7_store(D + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c, v);
             }
         }
     }
@@ -753,7 +780,7 @@ __global__ __launch_bounds__(256) void wino7_dx_kernel(const float* __restrict__
 #pragma unroll
         for (int y = 0; y < 7; ++y)
 #pragma unroll
-            for (int x = 0; x < 7; ++x) dx[(((size_t)r * 7 + y) * 7 + x) * C + c] = acc[y][x];
+            for (int x = 0; x < 7; ++x) w7_store(dx + (((size_t)r * 7 + y) * 7 + x) * C + c, acc[y][x]);
     }
 }
 

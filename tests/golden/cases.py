@@ -98,4 +98,4 @@ def lr_toy_model():
 
 def lr_toy_grads(m, step):
     for k, p in enumerate(m.parameters()):
-        p.grad = torch.cos(torch.arange(p.numel(), dtype=torch.float32) * 0.11 + 0.5 * step + k).view_as(p)
+        p.grad = torch.cos(torch.arange(p.numel(), dtype=torch.float32) * 0.11 + 0.5 * step + k).view_as(p).to(p.device)

@@ -141,8 +141,6 @@ def _run_lr_schedule(make_opt, device="cpu"):
     for step in range(LR_CASE["n_steps"]):
         sched.before_step(step)
         lr_toy_grads(m, step)
-        for p in m.parameters():
-            p.grad = p.grad.to(device)
         opt.step()
         lrs.append([g["lr"] for g in opt.param_groups])
         flat.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy())
@@ -153,8 +151,6 @@ def _run_lr_schedule(make_opt, device="cpu"):
     out["decay_history"] = history()
     for name, clip in (("clip_small", 0.5), ("clip_large", 100.0)):
         lr_toy_grads(m, 3)
-        for p in m.parameters():
-            p.grad = p.grad.to(device)
         net_utils.clip_gradient(m, clip)
         out[name] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
     reset_cfg()
