@@ -478,6 +478,40 @@ __device__ __forceinline__ void w7_store(float* p, float4 v) {
 #endif
 }
 
+// lane vector width of the transform kernels (channels per lane): 16-byte accesses stream at 6.6-6.8 TB/s where the
+// 4- / 8-byte ones reach 4.3-5.0 (tools/bench_wino.py), as long as the tile still fits the register file
+#ifndef CIM_W7_VIN
+#define CIM_W7_VIN 4            // input transform  x -> V      (2 | 4)
+#endif
+#ifndef CIM_W7_VOUT
+#define CIM_W7_VOUT 4           // output transform M -> y      (2 | 4)
+#endif
+#ifndef CIM_W7_VDX
+#define CIM_W7_VDX 2            // adjoint output   Md -> dx    (1 | 2 | 4)
+#endif
+#ifndef CIM_W7_VWG
+#define CIM_W7_VWG 1            // weight-gradient output dU -> dW (1 | 4; measured 0.254 | 0.297 ms)
+#endif
+template <int N> struct w7_vec;
+template <> struct w7_vec<1> { typedef float T; };
+template <> struct w7_vec<2> { typedef float2 T; };
+template <> struct w7_vec<4> { typedef float4 T; };
+__device__ __forceinline__ void vzero(float& a) { a = 0.0f; }
+__device__ __forceinline__ void vzero(float2& a) { a = make_float2(0.f, 0.f); }
+__device__ __forceinline__ void vzero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vfma(float& a, float s, float v) { a = fmaf(s, v, a); }
+__device__ __forceinline__ void vfma(float2& a, float s, float2 v) { fma2(a, s, v); }
+__device__ __forceinline__ void vfma(float4& a, float s, float4 v) { fma4(a, s, v); }
+__device__ __forceinline__ float vamax(float v) { return fabsf(v); }
+__device__ __forceinline__ float vamax(float2 v) { return fmaxf(fabsf(v.x), fabsf(v.y)); }
+__device__ __forceinline__ float vamax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ void vrelu(float& v) { v = fmaxf(v, 0.f); }
+__device__ __forceinline__ void vrelu(float2& v) { v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)); }
+__device__ __forceinline__ void vrelu(float4& v) { v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
+__device__ __forceinline__ float vget(float v, int) { return v; }
+__device__ __forceinline__ float vget(const float4& v, int l) { return l == 0 ? v.x : l == 1 ? v.y : l == 2 ? v.z : v.w; }
+template <typename T> __device__ __forceinline__ T vload(const float* p) { return *reinterpret_cast<const T*>(p); }
+
 struct W7 {
     static constexpr int NP[2] = {6, 5};      // positions per axis
     static constexpr int OUT[2] = {4, 3};     // outputs per axis
@@ -492,42 +526,43 @@ __host__ __device__ constexpr float w7_abs_row_sum(const float (&M)[6], int n) {
     return s;
 }
 
-template <int KA, int KB, bool AMAX>
+template <int KA, int KB, bool AMAX, int VW>
 __device__ __forceinline__ void w7_input_tile(const float* __restrict__ x, float* __restrict__ V, int r, int R, int C,
                                               unsigned* __restrict__ row_amax) {
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
+    typedef typename w7_vec<VW>::T VT;
     const size_t MC = (size_t)R * C;
     float dmax = 0.0f;
-    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
-        float2 d[NA][NB];
+    for (int c = threadIdx.x * VW; c < C; c += 256 * VW) {
+        VT d[NA][NB];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int iy = W7::IN0[KA] + i;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int ix = W7::IN0[KB] + j;
-                d[i][j] = ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P)
-                              ? *reinterpret_cast<const float2*>(x + (((size_t)r * P + iy) * P + ix) * C + c)
-                              : f2(0.f);
-                if constexpr (AMAX) dmax = fmaxf(dmax, fmaxf(fabsf(d[i][j].x), fabsf(d[i][j].y)));
+                if ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) d[i][j] = vload<VT>(x + (((size_t)r * P + iy) * P + ix) * C + c);
+                else vzero(d[i][j]);
+                if constexpr (AMAX) dmax = fmaxf(dmax, vamax(d[i][j]));
             }
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            float2 trow[NB];
+            VT trow[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                trow[j] = f2(0.f);
+                vzero(trow[j]);
 #pragma unroll
                 for (int k = 0; k < NA; ++k)
-                    if (W7_BT[KA][i][k] != 0.0f) fma2(trow[j], W7_BT[KA][i][k], d[k][j]);
+                    if (W7_BT[KA][i][k] != 0.0f) vfma(trow[j], W7_BT[KA][i][k], d[k][j]);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                float2 v = f2(0.f);
+                VT v;
+                vzero(v);
 #pragma unroll
                 for (int k = 0; k < NB; ++k)
-                    if (W7_BT[KB][j][k] != 0.0f) fma2(v, W7_BT[KB][j][k], trow[k]);
+                    if (W7_BT[KB][j][k] != 0.0f) vfma(v, W7_BT[KB][j][k], trow[k]);
                 w7_store(V + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c, v);
             }
         }
@@ -552,16 +587,16 @@ __device__ __forceinline__ void w7_input_tile(const float* __restrict__ x, float
     }
 }
 
-// grid = (R, 4 tile types); block = 256 (2 channels per lane)
+// grid = (R, 4 tile types); block = 256 (CIM_W7_VIN channels per lane)
 template <bool AMAX>
 __global__ __launch_bounds__(256) void wino7_input_kernel(const float* __restrict__ x, float* __restrict__ V, int R, int C,
                                                           unsigned* __restrict__ row_amax) {
     const int r = blockIdx.x;
     switch (blockIdx.y) {
-        case 0: w7_input_tile<0, 0, AMAX>(x, V, r, R, C, row_amax); break;
-        case 1: w7_input_tile<0, 1, AMAX>(x, V, r, R, C, row_amax); break;
-        case 2: w7_input_tile<1, 0, AMAX>(x, V, r, R, C, row_amax); break;
-        default: w7_input_tile<1, 1, AMAX>(x, V, r, R, C, row_amax); break;
+        case 0: w7_input_tile<0, 0, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
+        case 1: w7_input_tile<0, 1, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
+        case 2: w7_input_tile<1, 0, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
+        default: w7_input_tile<1, 1, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
     }
 }
 
@@ -600,36 +635,39 @@ __global__ __launch_bounds__(256) void wino7_filter_kernel(const float* __restri
     w7_filter_tile<1, 1>(w, U, KN, idx);
 }
 
-template <int KA, int KB>
+template <int KA, int KB, int VW>
 __device__ __forceinline__ void w7_output_tile(const float* __restrict__ M, const float* __restrict__ bias,
                                                float* __restrict__ y, int r, int R, int C, int relu) {
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], OA = W7::OUT[KA], OB = W7::OUT[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
+    typedef typename w7_vec<VW>::T VT;
     const size_t MC = (size_t)R * C;
-    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
-        float2 s[OA][NB];
+    for (int c = threadIdx.x * VW; c < C; c += 256 * VW) {
+        VT s[OA][NB];
 #pragma unroll
         for (int a = 0; a < OA; ++a)
 #pragma unroll
-            for (int j = 0; j < NB; ++j) s[a][j] = f2(0.f);
+            for (int j = 0; j < NB; ++j) vzero(s[a][j]);
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const float2 q = *reinterpret_cast<const float2*>(M + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c);
+                const VT q = vload<VT>(M + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c);
 #pragma unroll
                 for (int a = 0; a < OA; ++a)
-                    if (W7_AT[KA][a][i] != 0.0f) fma2(s[a][j], W7_AT[KA][a][i], q);
+                    if (W7_AT[KA][a][i] != 0.0f) vfma(s[a][j], W7_AT[KA][a][i], q);
             }
-        const float2 bv = bias ? *reinterpret_cast<const float2*>(bias + c) : f2(0.f);
+        VT bv;
+        if (bias) bv = vload<VT>(bias + c);
+        else vzero(bv);
 #pragma unroll
         for (int a = 0; a < OA; ++a)
 #pragma unroll
             for (int b = 0; b < OB; ++b) {
-                float2 v = bv;
+                VT v = bv;
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
-                    if (W7_AT[KB][b][j] != 0.0f) fma2(v, W7_AT[KB][b][j], s[a][j]);
-                if (relu) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
+                    if (W7_AT[KB][b][j] != 0.0f) vfma(v, W7_AT[KB][b][j], s[a][j]);
+                if (relu) vrelu(v);
                 w7_store(y + (((size_t)r * P + W7::OUT0[KA] + a) * P + W7::OUT0[KB] + b) * C + c, v);
             }
     }
@@ -639,10 +677,10 @@ __global__ __launch_bounds__(256) void wino7_output_kernel(const float* __restri
                                                            float* __restrict__ y, int R, int C, int relu) {
     const int r = blockIdx.x;
     switch (blockIdx.y) {
-        case 0: w7_output_tile<0, 0>(M, bias, y, r, R, C, relu); break;
-        case 1: w7_output_tile<0, 1>(M, bias, y, r, R, C, relu); break;
-        case 2: w7_output_tile<1, 0>(M, bias, y, r, R, C, relu); break;
-        default: w7_output_tile<1, 1>(M, bias, y, r, R, C, relu); break;
+        case 0: w7_output_tile<0, 0, CIM_W7_VOUT>(M, bias, y, r, R, C, relu); break;
+        case 1: w7_output_tile<0, 1, CIM_W7_VOUT>(M, bias, y, r, R, C, relu); break;
+        case 2: w7_output_tile<1, 0, CIM_W7_VOUT>(M, bias, y, r, R, C, relu); break;
+        default: w7_output_tile<1, 1, CIM_W7_VOUT>(M, bias, y, r, R, C, relu); break;
     }
 }
 
@@ -732,25 +770,25 @@ __global__ __launch_bounds__(256) void wino7_dy_kernel(const float* __restrict__
 // Last stage of the adjoint data gradient: dx[r, y, x, c] = sum over the four tile types of (B M B^T)[y - y0][x - x0]
 // (overlap-add: the 6- and 5-row patches share rows / columns 3 and 4).  A workgroup owns one ROI, a lane one channel
 // (all 49 output pixels accumulate in registers; 4 B per lane keeps that at ~110 VGPRs).
-template <int KA, int KB>
-__device__ __forceinline__ void w7_dx_tile(const float* __restrict__ M, size_t MC, size_t rc, float (&acc)[7][7]) {
+template <int KA, int KB, typename VT>
+__device__ __forceinline__ void w7_dx_tile(const float* __restrict__ M, size_t MC, size_t rc, VT (&acc)[7][7]) {
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
-    float q[NA][NB];
+    VT q[NA][NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) q[i][j] = M[(size_t)(Q0 + i * NB + j) * MC + rc];
+        for (int j = 0; j < NB; ++j) q[i][j] = vload<VT>(M + (size_t)(Q0 + i * NB + j) * MC + rc);
 #pragma unroll
     for (int k = 0; k < NA; ++k) {                 // patch row k = sum_i B^T[i][k] q[i][:]
         const int yy = W7::IN0[KA] + k;
         if (yy < 0 || yy >= P) continue;
-        float t[NB];
+        VT t[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            t[j] = 0.0f;
+            vzero(t[j]);
 #pragma unroll
             for (int i = 0; i < NA; ++i)
-                if (W7_BT[KA][i][k] != 0.0f) t[j] = fmaf(W7_BT[KA][i][k], q[i][j], t[j]);
+                if (W7_BT[KA][i][k] != 0.0f) vfma(t[j], W7_BT[KA][i][k], q[i][j]);
         }
 #pragma unroll
         for (int l = 0; l < NB; ++l) {
@@ -758,25 +796,28 @@ __device__ __forceinline__ void w7_dx_tile(const float* __restrict__ M, size_t M
             if (xx < 0 || xx >= P) continue;
 #pragma unroll
             for (int j = 0; j < NB; ++j)
-                if (W7_BT[KB][j][l] != 0.0f) acc[yy][xx] = fmaf(W7_BT[KB][j][l], t[j], acc[yy][xx]);
+                if (W7_BT[KB][j][l] != 0.0f) vfma(acc[yy][xx], W7_BT[KB][j][l], t[j]);
         }
     }
 }
 
+// grid = (R, channel chunks); block = 256 (CIM_W7_VDX channels per lane)
 __global__ __launch_bounds__(256) void wino7_dx_kernel(const float* __restrict__ M, float* __restrict__ dx, int R, int C) {
+    constexpr int VW = CIM_W7_VDX;
+    typedef typename w7_vec<VW>::T VT;
     const int r = blockIdx.x;
     const size_t MC = (size_t)R * C;
-    for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += gridDim.y * 256) {
-        float acc[7][7];
+    for (int c = (blockIdx.y * 256 + threadIdx.x) * VW; c < C; c += gridDim.y * 256 * VW) {
+        VT acc[7][7];
 #pragma unroll
         for (int y = 0; y < 7; ++y)
 #pragma unroll
-            for (int x = 0; x < 7; ++x) acc[y][x] = 0.0f;
+            for (int x = 0; x < 7; ++x) vzero(acc[y][x]);
         const size_t rc = (size_t)r * C + c;
-        w7_dx_tile<0, 0>(M, MC, rc, acc);
-        w7_dx_tile<0, 1>(M, MC, rc, acc);
-        w7_dx_tile<1, 0>(M, MC, rc, acc);
-        w7_dx_tile<1, 1>(M, MC, rc, acc);
+        w7_dx_tile<0, 0, VT>(M, MC, rc, acc);
+        w7_dx_tile<0, 1, VT>(M, MC, rc, acc);
+        w7_dx_tile<1, 0, VT>(M, MC, rc, acc);
+        w7_dx_tile<1, 1, VT>(M, MC, rc, acc);
 #pragma unroll
         for (int y = 0; y < 7; ++y)
 #pragma unroll
@@ -784,22 +825,22 @@ __global__ __launch_bounds__(256) void wino7_dx_kernel(const float* __restrict__
     }
 }
 
-template <int KA, int KB>
-__device__ __forceinline__ void w7_wgrad_tile(const float* __restrict__ dU, size_t KN, size_t idx, float (&acc)[3][3]) {
+template <int KA, int KB, typename VT>
+__device__ __forceinline__ void w7_wgrad_tile(const float* __restrict__ dU, size_t KN, size_t idx, VT (&acc)[3][3]) {
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], Q0 = W7::QOFF[KA * 2 + KB];
-    float s[3][NB];
+    VT s[3][NB];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) s[a][j] = 0.0f;
+        for (int j = 0; j < NB; ++j) vzero(s[a][j]);
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const float q = dU[(size_t)(Q0 + i * NB + j) * KN + idx];
+            const VT q = vload<VT>(dU + (size_t)(Q0 + i * NB + j) * KN + idx);
 #pragma unroll
             for (int a = 0; a < 3; ++a)
-                if (W7_AW[KA][a][i] != 0.0f) s[a][j] = fmaf(W7_AW[KA][a][i], q, s[a][j]);
+                if (W7_AW[KA][a][i] != 0.0f) vfma(s[a][j], W7_AW[KA][a][i], q);
         }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -807,29 +848,35 @@ __device__ __forceinline__ void w7_wgrad_tile(const float* __restrict__ dU, size
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int j = 0; j < NB; ++j)
-                if (W7_AW[KB][b][j] != 0.0f) acc[a][b] = fmaf(W7_AW[KB][b][j], s[a][j], acc[a][b]);
+                if (W7_AW[KB][b][j] != 0.0f) vfma(acc[a][b], W7_AW[KB][b][j], s[a][j]);
 }
 
+// one lane = VW consecutive output channels of one input channel (VW = 4 needs Cout % 4 == 0, else the launcher takes VW = 1)
+template <int VW>
 __global__ __launch_bounds__(256) void wino7_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dW, int Cout,
                                                               int Cin) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;     // (ci, co), co fastest
+    typedef typename w7_vec<VW>::T VT;
+    const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * VW;     // (ci, co), co fastest
     const size_t KN = (size_t)Cin * Cout;
     if (idx >= KN) return;
     const int ci = (int)(idx / Cout), co = (int)(idx % Cout);
-    float acc[3][3];
+    VT acc[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) acc[a][b] = 0.0f;
-    w7_wgrad_tile<0, 0>(dU, KN, idx, acc);
-    w7_wgrad_tile<0, 1>(dU, KN, idx, acc);
-    w7_wgrad_tile<1, 0>(dU, KN, idx, acc);
-    w7_wgrad_tile<1, 1>(dU, KN, idx, acc);
-    float* dst = dW + ((size_t)co * Cin + ci) * 9;
+        for (int b = 0; b < 3; ++b) vzero(acc[a][b]);
+    w7_wgrad_tile<0, 0, VT>(dU, KN, idx, acc);
+    w7_wgrad_tile<0, 1, VT>(dU, KN, idx, acc);
+    w7_wgrad_tile<1, 0, VT>(dU, KN, idx, acc);
+    w7_wgrad_tile<1, 1, VT>(dU, KN, idx, acc);
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int l = 0; l < VW; ++l) {
+        float* dst = dW + ((size_t)(co + l) * Cin + ci) * 9;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) dst[a * 3 + b] = acc[a][b];
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) dst[a * 3 + b] = vget(acc[a][b], l);
+    }
 }
 
 // column-scale bounds for the 121 positions (see wino43_bound_kernel): kind 0: B^T (input), 1: G (filter), 2: GD (dy).
@@ -972,7 +1019,9 @@ extern "C" int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int C
     CIM_CHECK_ARG(dU && dW && Cout > 0 && Cin > 0);
     CIM_CHECK_ARG(tile == 2 || tile == 4 || tile == 7);
     const size_t n = (size_t)Cout * Cin;
-    if (tile == 7) hipLaunchKernelGGL(wino7_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
+    if (tile == 7 && CIM_W7_VWG == 4 && Cout % 4 == 0)
+        hipLaunchKernelGGL(wino7_wgrad_out_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
+    else if (tile == 7) hipLaunchKernelGGL(wino7_wgrad_out_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
     else if (tile == 4) hipLaunchKernelGGL(wino43_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
     else hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU,
                        dW, Cout, Cin);
@@ -1003,7 +1052,7 @@ extern "C" int cim_wino_dy_adjoint_transform(const float* dy, float* E, uint32_t
 extern "C" int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int P, int C, int tile, void* stream) {
     WINO_GEOM_OK();
     CIM_CHECK_ARG(M && dx && tile == 7 && P == 7 && R <= 2147483647);
-    int chunks = (C + 255) / 256;
+    int chunks = (C + 256 * CIM_W7_VDX - 1) / (256 * CIM_W7_VDX);
     if (chunks > 4) chunks = 4;
     hipLaunchKernelGGL(wino7_dx_kernel, dim3(R, chunks), dim3(256), 0, cim::as_stream(stream), M, dx, R, C);
     CIM_CHECK_LAUNCH();
