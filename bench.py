@@ -65,6 +65,9 @@ class KernelTimer:
         return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
 
 
+MINING_CALLS = ("cim_asy_flag", "cim_seed_select", "cim_contain_argmax", "cim_arbitrate", "cim_assign")
+
+
 def instrument(model, timer):
     orig_call = _lib.call
 
@@ -87,6 +90,9 @@ def instrument(model, timer):
                 return orig_call(name, *args)
         if name == "cim_conv3x3_wgrad_f32":
             with timer.span("maskfuse_conv_wgrad"):
+                return orig_call(name, *args)
+        if name in MINING_CALLS:            # a-4 ... a-6: every mining / assignment launch of the three CIM layers
+            with timer.span("mining"):
                 return orig_call(name, *args)
         return orig_call(name, *args)
 
@@ -306,6 +312,22 @@ def main():
                 hbm.append(dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=ach / HBM_PEAK_GBS, ms=ms, algorithmic_bytes=ra_bytes,
                                 traffic=pk["hbm_bytes_mean"] if pk else None))
+        # mining + assignment (a-4 ... a-6), all launches of a step summed.  Algorithmic bytes after SURVEY.md 8(d), with the
+        # per-class seed count and the pseudo-GT count at their upper bounds (S_c = K, G = classes x K):
+        #   2N^2 (containment flags, once per step) + layers x [classes x (4N + 2K^2 + 2NK) + 2N G + 12 N (C+1)]
+        mining_spans = timer.spans.get("mining", [])
+        if mining_spans:
+            per_step = len(mining_spans) / args.steps
+            mining_ms = float(np.sum([a.elapsed_time(b) for a, b in mining_spans])) / args.steps
+            n_cls = int((inp["labels"] > 0).sum())
+            K = int(np.ceil(cfg.p_seed * n))
+            C1 = int(cfg.MODEL.NUM_CLASSES) + 1
+            mining_bytes = 2.0 * n * n + cfg.REFINE_TIMES * (n_cls * (4.0 * n + 2.0 * K * K + 2.0 * n * K) + 2.0 * n * n_cls * K + 12.0 * n * C1)
+            ach = mining_bytes / (mining_ms * 1e-3) / 1e9
+            hbm.append(dict(kernel="mining + assignment (cim_asy_flag, cim_seed_select, cim_contain_argmax, cim_arbitrate, cim_assign)",
+                            bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, ms=mining_ms,
+                            algorithmic_bytes=mining_bytes, traffic=None, launches_per_step=per_step,
+                            note="launch-latency-bound: ~%d dependent launches of a few MB per step (SURVEY.md 8d)" % round(per_step)))
         metric = "images/sec training step (ResNet-50 VOC, ~1k proposals/img) at 1/2/4/8 GPU" \
             if args.config == "resnet50_voc" else "images/sec training step (%s)" % args.config      # BASELINE.json
         line = dict(metric=metric,
