@@ -241,6 +241,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("CIM_BENCH_PER_STEP") == "1" and rank == 0:      # debugging aid: synchronized time of every step from the first
+        for i in range(args.warmup + args.steps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            print("step %d: %.2f ms" % (i, 1e3 * (time.perf_counter() - t1)), file=sys.stderr)
     for _ in range(args.warmup):
         step()
     timer.enabled = True

@@ -820,9 +820,12 @@ __global__ __launch_bounds__(TILE_THREADS) void roi_align_bwd_tile_kernel(const 
 // (8 x 16 B loads with the mask-cat prologue fused) in flight per lane - one gradient load feeds GH*GW FMAs, so
 // neighbouring pixels share the loads of the bins they share (a bin spans ~3.6 x 4.1 pixels at the benchmark's
 // ROI sizes: a 2 x 2 block reads each gradient vector ~5.5 times instead of ~15).
-constexpr int GA_MAXE = 1024;      // entries per LDS window
+#ifndef CIM_ROI_GE
+#define CIM_ROI_GE 1024            // entries per LDS window
+#endif
+constexpr int GA_MAXE = CIM_ROI_GE;
 #ifndef CIM_ROI_GS
-#define CIM_ROI_GS 256             // ROIs per workgroup (<= 256: one per lane in the inspection phase)
+#define CIM_ROI_GS 128             // ROIs per workgroup (<= 256: one per lane in the inspection phase)
 #endif
 #ifndef CIM_ROI_GU
 #define CIM_ROI_GU 4               // entries in flight per lane in the streaming phase (4 or 8)
@@ -1287,8 +1290,15 @@ static int launch_bwd_px16(const float* go, const float* rois, const float* mask
     return 0;
 }
 
+#ifndef CIM_ROI_GPAD
+#define CIM_ROI_GPAD 0
+#endif
+// 3 x 4 pixel blocks, 128 ROIs per group (2 workgroups per CU at 56 KB of LDS): 0.258 ms at cfg2.  Measured alternatives
+// (tools/bench_roi.py): 2x4/256 0.310, 2x4/128 capped to 2 per CU 0.258, 4x4/128 0.282, 2x8/128 0.290, 3x3/128 0.272,
+// 3x5/128 0.278, 3x6/128 0.407, 4x8/64 0.462; 3x4 with 64 / 96 / 144 / 168 / 200 / 256 ROIs: 0.358 / 0.291 / 0.257 / 0.264 /
+// 0.293 / 0.281; 512- or 256-entry windows (4-5 workgroups per CU): 0.40-0.42; one workgroup per CU: 0.273.
 #ifndef CIM_ROI_GH
-#define CIM_ROI_GH 2
+#define CIM_ROI_GH 3
 #endif
 #ifndef CIM_ROI_GW
 #define CIM_ROI_GW 4
@@ -1305,7 +1315,14 @@ static int launch_bwd_gather(const float* go, const float* rois, const float* ma
         hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * (size_t)B * H * W * C, st);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((roi_align_bwd_gather_kernel<GH, GW, MASKCAT>), dim3(tiles, B * groups, (C + 1023) / 1024), dim3(256), 0,
+    // CIM_ROI_GPAD: unused dynamic LDS, only there to cap the workgroups per CU (fewer resident workgroups re-read less:
+    // the neighbouring tiles that share gradient vectors then run closer together in time)
+    auto kern = roi_align_bwd_gather_kernel<GH, GW, MASKCAT>;
+    if (CIM_ROI_GPAD > 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CIM_ROI_GPAD);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, B * groups, (C + 1023) / 1024), dim3(256), CIM_ROI_GPAD,
                        st, go, masks, gin, C, H, W, K, P, B, groups > 1 ? 1 : 0, ws);
     return 0;
 }

@@ -15,7 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 "$ROOT/tools/pmc_traffic.py" /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE winograd7 > "$OUT/pmc_traffic.json"
 for cfg in vgg16_voc resnet50_coco2017 hrnet48_coco2017; do
-  python3 "$ROOT/bench.py" --config $cfg --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1
+  python3 "$ROOT/bench.py" --config $cfg --steps 10 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1
 done > "$OUT/bench_other_configs.json"
 python3 "$ROOT/tools/bench_roi.py" 2>/dev/null | tail -1 > "$OUT/bench_roi.json"
 python3 "$ROOT/tools/bench_wino.py" 2>/dev/null | tail -8 > "$OUT/bench_wino.txt"
