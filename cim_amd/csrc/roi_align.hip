@@ -853,15 +853,20 @@ __global__ __launch_bounds__(256, CIM_ROI_GOCC) void roi_align_bwd_gather_kernel
     const int tiles_x = (W + GW - 1) / GW;
     // XCD-aware tile order (speed only): workgroup i runs on XCD i % 8; give each XCD a contiguous run of pixel
     // tiles so neighbouring tiles - which share most of their bins' gradient vectors - re-read them from ONE L2
-    int tile = blockIdx.x;
+    int tile = blockIdx.x, by = blockIdx.y;
 #ifndef CIM_ROI_NO_XCD
-    {
-        const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = tile & 7, i = tile >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    if (gridDim.z == 1) {      // (with channel chunks in grid.z the slices start on different XCDs: keep the plain order)
+        // workgroups are dealt to the XCDs round robin in dispatch order (x fastest, then y): remap the LINEAR index so
+        // that XCD c works on a contiguous run of (group, tile) pairs
+        const int nt = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+        const int q = nt >> 3, r = nt & 7, xcd = lin & 7, i = lin >> 3;
+        const int j = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        tile = j % gridDim.x;
+        by = j / gridDim.x;
     }
 #endif
     const int y0 = (tile / tiles_x) * GH, x0 = (tile % tiles_x) * GW;
-    const int b = blockIdx.y % B, kgroup = blockIdx.y / B;
+    const int b = by % B, kgroup = by / B;
     const int recw = roi_rec_words(P, H, W);
     const int OC = MASKCAT ? 2 * C : C, PP = P * P;
 
