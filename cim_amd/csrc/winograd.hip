@@ -511,6 +511,18 @@ __device__ __forceinline__ void vrelu(float4& v) { v = make_float4(fmaxf(v.x, 0.
 __device__ __forceinline__ float vget(float v, int) { return v; }
 __device__ __forceinline__ float vget(const float4& v, int l) { return l == 0 ? v.x : l == 1 ? v.y : l == 2 ? v.z : v.w; }
 template <typename T> __device__ __forceinline__ T vload(const float* p) { return *reinterpret_cast<const T*>(p); }
+#ifndef CIM_W7_NTL
+#define CIM_W7_NTL 1            // 1 = nontemporal loads of the transform inputs that are read exactly once (M, Md, dU)
+#endif
+template <typename T> __device__ __forceinline__ T vload_once(const float* p) {
+#if CIM_W7_NTL
+    if constexpr (sizeof(T) == 4) return __builtin_nontemporal_load(p);
+    else if constexpr (sizeof(T) == 8) { const w7_v2 v = __builtin_nontemporal_load(reinterpret_cast<const w7_v2*>(p)); return make_float2(v.x, v.y); }
+    else { const w7_v4 v = __builtin_nontemporal_load(reinterpret_cast<const w7_v4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+#else
+    return vload<T>(p);
+#endif
+}
 
 struct W7 {
     static constexpr int NP[2] = {6, 5};      // positions per axis
@@ -651,7 +663,7 @@ __device__ __forceinline__ void w7_output_tile(const float* __restrict__ M, cons
         for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const VT q = vload<VT>(M + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c);
+                const VT q = vload_once<VT>(M + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c);
 #pragma unroll
                 for (int a = 0; a < OA; ++a)
                     if (W7_AT[KA][a][i] != 0.0f) vfma(s[a][j], W7_AT[KA][a][i], q);
@@ -777,7 +789,7 @@ __device__ __forceinline__ void w7_dx_tile(const float* __restrict__ M, size_t M
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) q[i][j] = vload<VT>(M + (size_t)(Q0 + i * NB + j) * MC + rc);
+        for (int j = 0; j < NB; ++j) q[i][j] = vload_once<VT>(M + (size_t)(Q0 + i * NB + j) * MC + rc);
 #pragma unroll
     for (int k = 0; k < NA; ++k) {                 // patch row k = sum_i B^T[i][k] q[i][:]
         const int yy = W7::IN0[KA] + k;
@@ -837,7 +849,7 @@ __device__ __forceinline__ void w7_wgrad_tile(const float* __restrict__ dU, size
     for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const VT q = vload<VT>(dU + (size_t)(Q0 + i * NB + j) * KN + idx);
+            const VT q = vload_once<VT>(dU + (size_t)(Q0 + i * NB + j) * KN + idx);
 #pragma unroll
             for (int a = 0; a < 3; ++a)
                 if (W7_AW[KA][a][i] != 0.0f) vfma(s[a][j], W7_AW[KA][a][i], q);
