@@ -21,6 +21,17 @@ namespace {
 #define CIM_SGD_NT 1            // 1 = nontemporal stores of the updated parameter / history (matrix mode)
 #endif
 typedef float sgd_v4 __attribute__((ext_vector_type(4)));
+#ifndef CIM_SGD_NTL
+#define CIM_SGD_NTL 0           // 1 = nontemporal loads too: measured slower (0.919 vs 0.864 ms at cfg2)
+#endif
+__device__ __forceinline__ float4 sgd_load(const float* p) {
+#if CIM_SGD_NTL
+    const sgd_v4 v = __builtin_nontemporal_load(reinterpret_cast<const sgd_v4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
 __device__ __forceinline__ void sgd_store(float* p, const float4& v) {
 #if CIM_SGD_NT
     __builtin_nontemporal_store(sgd_v4{v.x, v.y, v.z, v.w}, reinterpret_cast<sgd_v4*>(p));
@@ -79,9 +90,9 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const cim_sgd_tensor* __
             if (cin) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    pv[i] = *reinterpret_cast<const float4*>(p + i * ld);
-                    gv[i] = *reinterpret_cast<const float4*>(g + i * ld);
-                    bv[i] = *reinterpret_cast<const float4*>(b + i * ld);
+                    pv[i] = sgd_load(p + i * ld);
+                    gv[i] = sgd_load(g + i * ld);
+                    bv[i] = sgd_load(b + i * ld);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -103,9 +114,9 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const cim_sgd_tensor* __
         for (; r < r1; ++r, p += ld, g += ld, b += ld) {
             unsigned m = 0;
             if (cin) {
-                float4 pv = *reinterpret_cast<const float4*>(p);
-                const float4 gv = *reinterpret_cast<const float4*>(g);
-                float4 bv = *reinterpret_cast<const float4*>(b);
+                float4 pv = sgd_load(p);
+                const float4 gv = sgd_load(g);
+                float4 bv = sgd_load(b);
                 sgd_update4(pv, gv, bv, momentum, lr, wd);
                 sgd_store(b, bv);
                 sgd_store(p, pv);
