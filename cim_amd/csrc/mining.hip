@@ -50,6 +50,70 @@ __device__ __forceinline__ uint32_t orderable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Bitonic sort of NP = R * 1024 keys held R per lane (element e = r * 1024 + tid): partners at distance < 64 are in the
+// same wave (__shfl_xor, no barrier), at distance >= 1024 in the same lane (registers); only the distances 64 ... 512 go
+// through LDS - 10 exchanges (two barriers each) instead of the 55 barrier stages of the all-LDS network.  Keys are a
+// total order, so any correct sort gives the stable descending argsort of heads.py:354.
+template <int R>      // R = 1 or 2
+__device__ __forceinline__ void seed_sort_regs(unsigned long long (&k)[R], unsigned long long* __restrict__ keys, int tid) {
+    constexpr int NP = R * 1024;
+#pragma unroll 1
+    for (int size = 2; size <= NP; size <<= 1) {
+#pragma unroll 1
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 1024) {
+                if constexpr (R == 2) {              // stride == 1024: both elements live in this lane
+                    const bool up = (tid & size) == 0;
+                    const unsigned long long a = k[0], b = k[R - 1];
+                    if ((a > b) == up) { k[0] = b; k[R - 1] = a; }
+                }
+            } else if (stride >= 64) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) keys[r * 1024 + tid] = k[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = r * 1024 + tid;
+                    const unsigned long long o = keys[e ^ stride];
+                    const bool lower = (e & stride) == 0, up = (e & size) == 0;
+                    const bool take_min = lower == up;
+                    k[r] = take_min ? (o < k[r] ? o : k[r]) : (o > k[r] ? o : k[r]);
+                }
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = r * 1024 + tid;
+                    const unsigned long long o = __shfl_xor(k[r], stride);
+                    const bool lower = (e & stride) == 0, up = (e & size) == 0;
+                    const bool take_min = lower == up;
+                    k[r] = take_min ? (o < k[r] ? o : k[r]) : (o > k[r] ? o : k[r]);
+                }
+            }
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void seed_topk_regs(const float* __restrict__ score, int score_ld, int col, int N,
+                                               unsigned long long* __restrict__ keys, int32_t* __restrict__ kidx,
+                                               int32_t* __restrict__ topk_out, int K, int tid) {
+    unsigned long long k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = r * 1024 + tid;
+        k[r] = ~0ull;
+        if (i < N) k[r] = ((unsigned long long)(~orderable(score[(size_t)i * score_ld + col])) << 32) | (unsigned)i;
+    }
+    seed_sort_regs<R>(k, keys, tid);
+    if (tid < K) {                                   // K <= 1024: the K smallest keys sit in k[0] of lanes 0 .. K-1
+        const int32_t id = (int32_t)(k[0] & 0xffffffffu);
+        kidx[tid] = id;
+        topk_out[tid] = id;
+    }
+    __syncthreads();
+}
+
 // grid = n_cls, block = 1024.  Dynamic LDS: [max(NP*8, K*KW*8)] bytes + K*4 bytes.
 __global__ __launch_bounds__(1024) void seed_select_kernel(const float* __restrict__ score, int score_ld, int score_off,
                                                            const uint16_t* __restrict__ iou, int N, int NP,
@@ -66,36 +130,42 @@ __global__ __launch_bounds__(1024) void seed_select_kernel(const float* __restri
 
     // key = (descending score, ascending index): a total order -> the sort is the stable
     // descending argsort of heads.py:354 (App. B item 4).
-    for (int i = tid; i < NP; i += 1024) {
-        unsigned long long key = ~0ull;
-        if (i < N) {
-            const float s = score[(size_t)i * score_ld + score_off + c];
-            key = ((unsigned long long)(~orderable(s)) << 32) | (unsigned)i;
-        }
-        keys[i] = key;
-    }
-    __syncthreads();
-    for (int size = 2; size <= NP; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < NP / 2; t += 1024) {
-                const int lo = (t / stride) * (2 * stride) + (t % stride);
-                const int hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const unsigned long long a = keys[lo], b = keys[hi];
-                if ((a > b) == up) {
-                    keys[lo] = b;
-                    keys[hi] = a;
-                }
+    if (NP == 1024) {
+        seed_topk_regs<1>(score, score_ld, score_off + c, N, keys, kidx, topk_idx + (size_t)ci * K, K, tid);
+    } else if (NP == 2048) {
+        seed_topk_regs<2>(score, score_ld, score_off + c, N, keys, kidx, topk_idx + (size_t)ci * K, K, tid);
+    } else {
+        for (int i = tid; i < NP; i += 1024) {
+            unsigned long long key = ~0ull;
+            if (i < N) {
+                const float s = score[(size_t)i * score_ld + score_off + c];
+                key = ((unsigned long long)(~orderable(s)) << 32) | (unsigned)i;
             }
-            __syncthreads();
+            keys[i] = key;
         }
+        __syncthreads();
+        for (int size = 2; size <= NP; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < NP / 2; t += 1024) {
+                    const int lo = (t / stride) * (2 * stride) + (t % stride);
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const unsigned long long a = keys[lo], b = keys[hi];
+                    if ((a > b) == up) {
+                        keys[lo] = b;
+                        keys[hi] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int r = tid; r < K; r += 1024) {
+            const int32_t id = (int32_t)(keys[r] & 0xffffffffu);
+            kidx[r] = id;
+            topk_idx[(size_t)ci * K + r] = id;
+        }
+        __syncthreads();
     }
-    for (int r = tid; r < K; r += 1024) {
-        const int32_t id = (int32_t)(keys[r] & 0xffffffffu);
-        kidx[r] = id;
-        topk_idx[(size_t)ci * K + r] = id;
-    }
-    __syncthreads();
 
     // Suppression bit-matrix over the K x K gathered sub-block of the mask-IoU map:
     // bit (i, j) set <=> NOT (iou[idx_i, idx_j] < nms_thr)   (heads.py:250-254, fp16 compare).
