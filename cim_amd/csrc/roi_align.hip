@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_rowsum_kernel(const float* 
     __shared__ float s_wy[RS_MAXD];
     __shared__ int s_rows[RS_MAXD];
     __shared__ int s_nrows;
-    const int k = blockIdx.x, ph = blockIdx.y, tid = threadIdx.x;
+    const int k = blockIdx.x, ph = blockIdx.y, tid = threadIdx.x, NTH = blockDim.x;      // NTH = min(256, C / 4 rounded up to a wave)
     const float* rec = rec_all + (size_t)k * roi_rec_words(P, H, W);
     const float* wy = rec + ph * H;
     const float* wx = rec + P * H;
@@ -594,14 +594,14 @@ __global__ __launch_bounds__(256) void roi_align_fwd_rowsum_kernel(const float* 
         }
         s_nrows = n;
     }
-    for (int e = tid; e < ncols * 8; e += 256) {
+    for (int e = tid; e < ncols * 8; e += NTH) {
         const int xi = e >> 3, pw = e & 7;
         s_wx[xi][pw] = pw < P ? wx[pw * W + xlo + xi] : 0.0f;
     }
     __syncthreads();
     const int nrows = s_nrows;
     const int OC = MASKCAT ? 2 * C : C;
-    for (int c = tid * 4; c < C; c += 256 * 4) {
+    for (int c = tid * 4; c < C; c += NTH * 4) {
         const float* __restrict__ fc = fb + c;
         ga_f2 al[7], ah[7];
 #pragma unroll
@@ -1254,7 +1254,8 @@ int launch_fwd(const float* feat, const float* rois, const float* masks, float* 
         getenv("CIM_ROI_FWD_EXACT") == nullptr) {
         hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), sizeof(float) * roi_rec_words(P, H, W), st, rois, ws, K, P, H, W, scale, sr, aligned);
         if (CIM_ROI_FROW && P <= 7 && W <= RS_MAXD && getenv("CIM_ROI_FWD_LIST") == nullptr) {
-            hipLaunchKernelGGL((roi_align_fwd_rowsum_kernel<MASKCAT>), dim3(K, P), dim3(256), 0, st, feat, masks, out, C, H, W, P, ws);
+            const int nth = C >= 1024 ? 256 : ((C / 4 + 63) / 64) * 64;       // narrow maps (VGG: 512 channels): no idle waves
+            hipLaunchKernelGGL((roi_align_fwd_rowsum_kernel<MASKCAT>), dim3(K, P), dim3(nth), 0, st, feat, masks, out, C, H, W, P, ws);
             return 0;
         }
         const int fz = (C >= 512 * CIM_ROI_FZ) ? CIM_ROI_FZ : 1;
