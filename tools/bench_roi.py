@@ -49,6 +49,8 @@ for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):   
         getattr(alt, name).argtypes = argt
     f = lambda: alt.cim_roi_align_maskcat_fwd_ws(feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), cat.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
     bw = lambda: alt.cim_roi_align_maskcat_bwd(gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
-    print(os.path.basename(path), "fwd_ms %.4f bwd_ms %.4f" % (timeit(f), timeit(bw)))
+    fwd(); torch.cuda.synchronize(); ref_cat = cat.clone(); cat.zero_()
+    f(); torch.cuda.synchronize()
+    print(os.path.basename(path), "fwd_ms %.4f bwd_ms %.4f  max |fwd - base| %.3g" % (timeit(f), timeit(bw), float((cat - ref_cat).abs().max())))
 print(json.dumps(dict(config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, fwd_ms=tf, fwd_frac=nbytes / tf / 1e6 / 8000,
                       bwd_ms=tb, bwd_frac=nbytes / tb / 1e6 / 8000)))
