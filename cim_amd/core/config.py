@@ -57,13 +57,59 @@ def _defaults():
     return c
 
 
-cfg = _defaults()
+class _CfgProxy:
+    """The `cfg` every cim_amd module imports.  It forwards every access to a TARGET AttrDict: this
+    module's own defaults, or - after `bind(reference_cfg)`, which `cim_amd.install_as_lib()` calls when
+    the reference's `core.config` gets imported - the reference's own global `cfg` object
+    (lib/core/config.py:22-23).  So `tools/train.py` and this package read and write ONE config: nothing
+    is copied, and modules that did `from ..core.config import cfg` before the binding see it too."""
+
+    __slots__ = ("_target",)
+
+    def __init__(self, target):
+        object.__setattr__(self, "_target", target)
+
+    def bind(self, target):
+        object.__setattr__(self, "_target", target)
+
+    def target(self):
+        return self._target
+
+    def __getattr__(self, name):
+        return getattr(self._target, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._target, name, value)
+
+    def __getitem__(self, k):
+        return self._target[k]
+
+    def __setitem__(self, k, v):
+        self._target[k] = v
+
+    def __contains__(self, k):
+        return k in self._target
+
+    def __iter__(self):
+        return iter(self._target)
+
+    def __len__(self):
+        return len(self._target)
+
+    def __repr__(self):
+        return "cfg -> " + repr(self._target)
+
+
+_own = _defaults()
+cfg = _CfgProxy(_own)
 __C = cfg
 
 
 def reset_cfg():
-    cfg.clear()
-    cfg.update(_defaults())
+    """Back to this module's own defaults (also undoes a binding to the reference's cfg)."""
+    _own.clear()
+    _own.update(_defaults())
+    cfg.bind(_own)
 
 
 def _to_attr(d):
@@ -85,13 +131,13 @@ def _merge(a, b):
 def merge_cfg_from_file(cfg_filename):
     with open(cfg_filename, "r") as f:
         y = _to_attr(yaml.safe_load(f))
-    _merge(y, cfg)
+    _merge(y, cfg.target())
 
 
 def merge_cfg_from_list(cfg_list):
     assert len(cfg_list) % 2 == 0
     for full_key, v in zip(cfg_list[0::2], cfg_list[1::2]):
-        d = cfg
+        d = cfg.target()
         keys = full_key.split(".")
         for sub in keys[:-1]:
             assert sub in d, "Non-existent key: {}".format(full_key)

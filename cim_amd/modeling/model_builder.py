@@ -106,6 +106,22 @@ class Generalized_RCNN(nn.Module):
                                                Anti_noise_sampling=cfg.Anti_noise_sampling)
                                for t in range(cfg.REFINE_TIMES)]
         self.using_CIM = [True, True, True]
+        self._init_modules()
+
+    def _init_modules(self):
+        """model_builder.py:101-115: ImageNet weights through the reference's own helper modules (resolved by their
+        reference names, i.e. with lib/ on sys.path as under tools/train.py); the ResNet body loads torchvision's
+        weights itself (resnet50.py:20)."""
+        if cfg.MODEL.LOAD_IMAGENET_PRETRAINED_WEIGHTS:
+            for flag, helper in (("VGG_CLS_FEATURE", "utils.vgg_weights_helper"),
+                                 ("HRNET_CLS_FEATURE", "utils.hrnet_weights_helper")):
+                if cfg[flag]:
+                    try:
+                        mod = importlib.import_module(helper)
+                    except ImportError as e:
+                        raise ImportError("cfg.MODEL.LOAD_IMAGENET_PRETRAINED_WEIGHTS needs the reference's %s on "
+                                          "sys.path (run under tools/train.py) - %s" % (helper, e))
+                    mod.load_pretrained_imagenet_weights(self)
         if cfg.TRAIN.FREEZE_CONV_BODY:
             for p in self.Conv_Body.parameters():
                 p.requires_grad = False

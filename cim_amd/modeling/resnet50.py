@@ -72,7 +72,22 @@ class resnet(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if cfg.MODEL.LOAD_IMAGENET_PRETRAINED_WEIGHTS:          # resnet50.py:20: torchvision's ImageNet weights
+            self.load_torchvision_state_dict(_torchvision_resnet50_state_dict())
+            print("Load pre-trained weight for resnet !!")
         self._init_modules()
+
+    def load_torchvision_state_dict(self, sd):
+        """torchvision ResNet-50 keys -> this body's keys (conv1 -> res1.0, bn1 -> res1.1, layer<i> -> res<i+1>;
+        layer4 / fc are not part of the C4 body)."""
+        ren = {"conv1.": "res1.0.", "bn1.": "res1.1.", "layer1.": "res2.", "layer2.": "res3.", "layer3.": "res4."}
+        own = {}
+        for k, v in sd.items():
+            for a, b in ren.items():
+                if k.startswith(a):
+                    own[b + k[len(a):]] = v
+        missing, unexpected = self.load_state_dict(own, strict=False)
+        assert not unexpected and all("num_batches_tracked" in m for m in missing), (missing, unexpected)
 
     def _init_modules(self):
         assert cfg.ResNet.FREEZE_AT in [0, 2, 3, 4, 5]
@@ -99,6 +114,15 @@ class resnet(nn.Module):
         for i in range(self.block_counts):
             x = getattr(self, "res%d" % (i + 1))(x)
         return x
+
+
+def _torchvision_resnet50_state_dict():
+    try:
+        from torchvision import models
+    except ImportError as e:
+        raise ImportError("cfg.MODEL.LOAD_IMAGENET_PRETRAINED_WEIGHTS for the ResNet body needs torchvision "
+                          "(the reference wraps torchvision.models.resnet50, resnet50.py:12,20): %s" % e)
+    return models.resnet50(pretrained=True).state_dict()
 
 
 def torch_resnet50():

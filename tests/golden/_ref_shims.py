@@ -27,6 +27,7 @@ def _module(name, **attrs):
 def install(roi_align_cls=None, resnet50_factory=None):
     collections.Sequence = collections.abc.Sequence
     collections.Mapping = collections.abc.Mapping
+    collections.Iterable = collections.abc.Iterable          # lib/utils/misc.py:3
     _module("torch._six", string_classes=(str, bytes), int_classes=(int,))
     _module("pynvml", nvmlInit=lambda: None)
 
