@@ -1,48 +1,271 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of the CIM per-image training step (BASELINE.json).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one synthetic image per GPU through the whole hot path: backbone fwd -> fused
-ROIAlign+mask-cat -> MaskFuse -> 8 heads -> 3 x CIM mining (+ host anti-noise sampling) -> 4 losses
--> backward -> gradient all-reduce (RCCL) -> SGD step.  Workload at N=1 = BASELINE configs[1]
-(resnet50_voc, bs=1, 1000 proposals, 516x688 image).  Weak scaling: one image per rank.
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+A "step" = one synthetic image per GPU through the whole hot path: backbone fwd -> fused ROIAlign+mask-cat ->
+MaskFuse -> 8 heads -> 3 x CIM mining incl. anti-noise sampling (on the device) -> 4 losses -> backward ->
+gradient all-reduce (RCCL) -> SGD step.  Workload at N=1 = BASELINE configs[1] (resnet50_voc, bs=1,
+~1000 proposals per image).  The timed loop cycles through --images (default 8) DISTINCT synthetic images per rank:
+800 ... 1200 proposals (mean 1000), three of the training scales of configs/resnet50_voc.yaml:34 (688 = the median,
+576, 864), different class sets, pseudo-GT counts and PRM clusters - nothing is cached per image.
+Weak scaling: one image per rank.  Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`,
+`roofline_hbm`, `cpu_baseline` and `extra` (sustained >= 5 s loop, iter_size = 4, per-step host->device upload,
+and for N > 1: all-reduce time and overlap).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
-
-from cim_amd import _lib, mask_iou, synthetic  # noqa: E402
-from cim_amd.core.config import cfg  # noqa: E402
-from cim_amd.core.presets import apply_preset  # noqa: E402
-from cim_amd.modeling.model_builder import Generalized_RCNN  # noqa: E402
-from cim_amd.nn import DataParallel  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TF = 2516.6   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (256 CU x 4096 flop/clk x 2.4 GHz)
 
+# the 8 images of a cycle: (proposals, longest side); mean N = 1000, mean pixel count 1.07 x the 688 scale
+IMAGE_MIX = [(1000, 688), (800, 576), (1200, 864), (900, 688), (1100, 688), (1000, 864), (850, 576), (1150, 688)]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="resnet50_voc")
+    ap.add_argument("--images", type=int, default=8, help="distinct synthetic images per rank the loop cycles through")
+    ap.add_argument("--fixed-image", action="store_true", help="round-1 workload: ONE image (N = config default) repeated")
+    ap.add_argument("--iter-size", type=int, default=1, help="images per optimizer step (tools/train.py --iter_size)")
+    ap.add_argument("--sustained", type=float, default=5.0, help="seconds of the extra sustained loop (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra loops (sustained, iter_size=4, upload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="proposals in the CPU sample (0 = all)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
+                                                       "multi-rank check on a box with fewer GPUs than ranks)")
+    ap.add_argument("--miopen-find", action="store_true",
+                    help="let MIOpen time its solvers for the backbone convs (default: immediate mode)")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as CHILD processes (torch.distributed.run)
+    before this process has touched the GPU, relay rank 0's JSON line, exit with the children's code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    sys.exit(proc.returncode if proc.returncode else (0 if line is not None else 1))
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")        # Work._get_duration() for allreduce_ms
+    run(args)
+
+
+# ------------------------------------------------------------------------------------------------ the measurement
+def run(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cim_amd import _lib, mask_iou, synthetic
+    from cim_amd.core.config import cfg
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling import heads
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    from cim_amd.nn import DataParallel
+    from cim_amd.ops import gemm as gemm_mod
+
+    if os.environ.get("CIM_BENCH_WATCHDOG"):        # debugging aid: dump all thread stacks if a phase stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CIM_BENCH_WATCHDOG"]), repeat=True)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    if args.backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # functional check: ranks may share a GPU
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    torch.backends.cudnn.benchmark = args.miopen_find      # backbone convs (a-11) go through MIOpen
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    _lib.load()                                                # no HIP extension -> fail loudly
+
+    apply_preset(args.config)
+    torch.manual_seed(cfg.RNG_SEED)                            # identical initial weights on every rank
+    model = Generalized_RCNN()
+    init_for_synthetic(model)
+    model = model.to(dev).train()
+    timer = KernelTimer(torch, np)
+    instrument(_lib, timer)
+    dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True)
+    opt = make_optimizer(model, torch)
+    Cf = model.Conv_Body.dim_out
+
+    # ---- the images of the cycle: host (pinned) copies + device-resident copies
+    base_n = synthetic.CONFIGS[args.config]["n"]
+    base_t = synthetic.CONFIGS[args.config]["target"]
+    mix = [(base_n, base_t)] if args.fixed_image else \
+        [(int(round(n * base_n / 1000.0)), t) for n, t in (IMAGE_MIX * ((args.images + 7) // 8))[:args.images]]
+    host_batches, dev_batches, infos = [], [], []
+    for j, (n, target) in enumerate(mix):
+        inp = synthetic.make_image_inputs(args.config, seed=cfg.RNG_SEED + 1000 * rank + j, n=n, target=target)
+        iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
+        t = lambda a: torch.from_numpy(a).unsqueeze(0)
+        hb = dict(data=torch.from_numpy(inp["data"]), rois=t(inp["rois"]), masks=t(inp["masks"]), labels=t(inp["labels"]),
+                  mat=t(inp["mat"]), index=t(inp["index"]), iou_map=iou.cpu(), asy_iou_map=asy.cpu())
+        hb = {k: v.pin_memory() for k, v in hb.items()}
+        host_batches.append(hb)
+        dev_batches.append({k: v.to(dev) for k, v in hb.items()})
+        H, W = inp["image_hw"]
+        infos.append(dict(n=n, H=H, W=W, n_cls=int((inp["labels"] > 0).sum())))
+        del inp
+    torch.cuda.synchronize()
+    np.random.seed(cfg.RNG_SEED + rank)                        # the anti-noise sampling stream
+    state = dict(i=0, feat={})
+
+    def one_image(upload):
+        j = state["i"] % len(dev_batches)
+        state["i"] += 1
+        if upload:      # what nn.DataParallel does with the loader's CPU tensors (lib/nn/parallel/_functions.py:70-82)
+            b = {k: v.to(dev, non_blocking=True) for k, v in host_batches[j].items()}
+        else:
+            b = dev_batches[j]
+        timer.image = j
+        out = dp(**{k: [v] for k, v in b.items()}, gtrois=[None])
+        state["feat"][j] = tuple(out["blob_conv"].shape[-2:])
+        loss = sum(v.sum() for v in out["losses"].values())
+        loss.backward()          # gradient all-reduce + NumPy-generator settle happen inside (end-of-backward callbacks)
+        return loss
+
+    def step(iter_size=1, upload=False):
+        dp.zero_grad()
+        for _ in range(iter_size):
+            loss = one_image(upload)
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(n_steps, **kw):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            loss = step(**kw)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt)
+        assert torch.isfinite(loss), "non-finite loss in the timed region"
+        return el
+
+    dp.iter_size = args.iter_size
+    if os.environ.get("CIM_BENCH_PER_STEP") == "1" and rank == 0:      # debugging aid: synchronized time of every step from the first
+        for i in range(args.warmup + args.steps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(args.iter_size)
+            torch.cuda.synchronize()
+            print("step %d: %.2f ms" % (i, 1e3 * (time.perf_counter() - t1)), file=sys.stderr)
+    for _ in range(args.warmup):
+        step(args.iter_size)
+    timer.enabled = True
+    if world > 1:
+        dp.comm_works = []
+    elapsed = timed(args.steps, iter_size=args.iter_size)          # ---- THE timed region: exactly --steps steps
+    timer.enabled = False
+    comm_works = getattr(dp, "comm_works", None)
+    dp.comm_works = None
+    images = world * args.steps * args.iter_size
+
+    extra = {}
+    if not args.no_extra:
+        if args.sustained > 0:                                       # same loop for >= --sustained seconds (clocks settle)
+            per = elapsed / args.steps
+            k = max(args.steps, int(np.ceil(args.sustained / per)))
+            el = timed(k, iter_size=args.iter_size)
+            extra["sustained"] = dict(seconds=el, steps=k, images_per_s=world * k * args.iter_size / el,
+                                      ms_per_step=1e3 * el / k)
+        k4 = max(4, args.steps // 4)
+        dp.iter_size = 4
+        step(4)
+        el = timed(k4, iter_size=4)                                  # the reference's operating point (scripts/train_CIM.sh:8)
+        extra["iter_size_4"] = dict(images_per_s=world * k4 * 4 / el, ms_per_image=1e3 * el / (k4 * 4), optimizer_steps=k4)
+        dp.iter_size = args.iter_size
+        step(args.iter_size, upload=True)
+        el = timed(args.steps, iter_size=args.iter_size, upload=True)   # inputs (image, rois, masks, labels, mat, both maps) from pinned host memory every step
+        up_bytes = float(np.mean([sum(v.numel() * v.element_size() for v in hb.values()) for hb in host_batches]))
+        extra["with_h2d_upload"] = dict(images_per_s=images / el, ms_per_step=1e3 * el / args.steps, bytes_per_image=up_bytes)
+        if world > 1:                                                # compute-only steps (no collectives) -> what the all-reduce costs
+            with dp.no_sync():
+                step(args.iter_size)
+                el_ns = timed(args.steps, iter_size=args.iter_size)
+            ar_ms = None
+            if comm_works:
+                try:
+                    ar_ms = float(sum(w._get_duration() for w in comm_works)) / args.steps
+                except Exception as e:          # timing not available in this build of ProcessGroupNCCL
+                    extra["allreduce_ms_error"] = "%s: %s" % (type(e).__name__, e)
+            exposed = 1e3 * (elapsed - el_ns) / args.steps
+            grad_bytes = 4.0 * sum(p.numel() for p in model.parameters() if p.requires_grad)
+            extra["comm"] = dict(allreduce_ms=ar_ms, exposed_ms=exposed, ms_per_step_no_sync=1e3 * el_ns / args.steps,
+                                 overlap_frac=(1.0 - exposed / ar_ms) if ar_ms else None, gradient_bytes=grad_bytes,
+                                 ring_bound_ms=1e3 * 2.0 * (world - 1) / world * grad_bytes / 153e9,
+                                 buckets=len(dp.buckets))
+    heads.settle_rng()
+
+    if rank == 0:
+        line = report(args, world, elapsed, images, timer, infos, state["feat"], Cf, cfg, gemm_mod, np)
+        line["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
 
 class KernelTimer:
-    """HIP events around selected C-ABI launches / module calls, recorded on the launch stream
-    inside the timed region (torch.cuda.Event records on torch's current stream, which is the
-    stream every launch here uses)."""
+    """HIP events around selected C-ABI launches, recorded on the launch stream inside the timed region
+    (torch.cuda.Event records on torch's current stream, which is the stream every launch here uses)."""
 
-    def __init__(self):
+    def __init__(self, torch, np):
+        self.torch, self.np = torch, np
         self.spans = {}
         self.enabled = False
+        self.image = 0
 
     def span(self, name):
         timer = self
@@ -50,27 +273,26 @@ class KernelTimer:
         class _Ctx:
             def __enter__(self):
                 if timer.enabled:
-                    self.a = torch.cuda.Event(enable_timing=True)
-                    self.b = torch.cuda.Event(enable_timing=True)
+                    self.a = timer.torch.cuda.Event(enable_timing=True)
+                    self.b = timer.torch.cuda.Event(enable_timing=True)
                     self.a.record()
 
             def __exit__(self, *exc):
                 if timer.enabled:
                     self.b.record()
-                    timer.spans.setdefault(name, []).append((self.a, self.b))
+                    timer.spans.setdefault(name, []).append((self.a, self.b, timer.image))
         return _Ctx()
 
-    def mean_ms(self, name):
-        ev = self.spans.get(name, [])
-        return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+    def launches(self, name):
+        """[(ms, image index)] of every timed launch."""
+        return [(a.elapsed_time(b), j) for a, b, j in self.spans.get(name, [])]
 
 
-MINING_CALLS = ("cim_asy_flag", "cim_seed_select", "cim_contain_argmax", "cim_arbitrate", "cim_assign")
+MINING_CALLS = ("cim_asy_flag", "cim_mining_step")
 
 
-def instrument(model, timer):
+def instrument(_lib, timer):
     orig_call = _lib.call
-
     state = {"conv": 0, "bg": 0}
 
     def call(name, *args):
@@ -80,18 +302,18 @@ def instrument(model, timer):
                 state["conv"] = state["bg"] = 0
             with timer.span("cim_roi_align_maskcat_bwd" if "bwd" in name else "cim_roi_align_maskcat_fwd"):
                 return orig_call(name, *args)
-        if name == "cim_conv3x3_f32":       # per step: 1st launch = forward, 2nd = data gradient
+        if name == "cim_conv3x3_f32":       # per image: 1st launch = forward, 2nd = data gradient
             state["conv"] += 1
             with timer.span("maskfuse_conv_fwd" if state["conv"] == 1 else "maskfuse_conv_dgrad"):
                 return orig_call(name, *args)
-        if name in ("cim_gemm_f32_batched", "cim_gemm_f16x2_batched"):  # Winograd-domain GEMMs, per step: forward, data grad, weight grad
+        if name in ("cim_gemm_f32_batched", "cim_gemm_f16x2_batched"):  # Winograd-domain GEMMs, per image: forward, data grad, weight grad
             state["bg"] += 1
             with timer.span(("wino_gemm_fwd", "wino_gemm_dgrad", "wino_gemm_wgrad")[min(state["bg"], 3) - 1]):
                 return orig_call(name, *args)
         if name == "cim_conv3x3_wgrad_f32":
             with timer.span("maskfuse_conv_wgrad"):
                 return orig_call(name, *args)
-        if name in MINING_CALLS:            # a-4 ... a-6: every mining / assignment launch of the three CIM layers
+        if name in MINING_CALLS:            # a-4 ... a-6: every mining / sampling / assignment launch of the three CIM layers
             with timer.span("mining"):
                 return orig_call(name, *args)
         return orig_call(name, *args)
@@ -105,6 +327,7 @@ def init_for_synthetic(model):
     identity and the residual sum would grow ~2x in variance per block; damp the last BN scale of
     every bottleneck (as zero-init-residual schemes do) so activations stay O(1) and the
     synthetic training steps stay finite.  Architecture and work per step are unchanged."""
+    import torch
     for m in model.modules():
         if hasattr(m, "bn3"):                                   # bottleneck (ResNet-50, HRNet stem / head)
             torch.nn.init.constant_(m.bn3.weight, 0.25)
@@ -112,17 +335,18 @@ def init_for_synthetic(model):
             torch.nn.init.constant_(m.bn2.weight, 0.25)
 
 
-def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
-    separate runs of this script, tools/pmc_traffic.py); None when the file is absent."""
-    path = os.path.join(REPO, "profiles", "r1", "pmc_traffic.json")
+def pmc_traffic(config):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs of this
+    script, tools/pmc_traffic.py).  Only a profile of THIS workload counts: files are named per config and record the
+    image mix they were taken on; anything else -> {} and `traffic: null`."""
+    path = os.path.join(REPO, "profiles", "r2", "pmc_traffic_%s.json" % config)
     if not os.path.exists(path):
         return {}
     with open(path) as f:
         return json.load(f)
 
 
-def make_optimizer(model):
+def make_optimizer(model, torch):
     """Param groups of tools/train.py:282-311 (bias: lr x2, no weight decay), SGD momentum 0.9."""
     bias, nonbias = [], []
     for name, p in model.named_parameters():
@@ -136,8 +360,109 @@ def make_optimizer(model):
     return SGD(groups, lr=lr, momentum=0.9)
 
 
+def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, np):
+    engine = gemm_mod.ENGINE
+    products = {"f16x2": 3.0, "bf16x3": 6.0, "fp32": 1.0}[engine]
+    kern = {"f16x2": "gemm_f16x2_kernel", "bf16x3": "gemm_bf16x3_kernel", "fp32": "gemm_f32_kernel"}[engine]
+    # dominant kernel: the MFMA GEMM of the MaskFuse 3x3 conv forward (a-2).  Algorithmic flops of ONE launch on image j:
+    #   Winograd 4+3 mixed tiling (CIM_CONV_ALGO=winograd7, default): 121 batched GEMMs [N_j x 2Cf] x [2Cf x Cf]
+    #   Winograd F(4x4,3x3) / F(2x2,3x3): 36 x [4N x 2Cf] / 16 x [16N x 2Cf];  direct: 2 * 49N * 18Cf * Cf   
+    wino = timer.launches("wino_gemm_fwd")
+    if wino:
+        ms = [m for m, _ in wino]
+        flops = []
+        for _, j in wino:
+            _, npos, rows = gemm_mod._wino_geometry(gemm_mod.CONV_ALGO, 7, infos[j]["n"])
+            flops.append(2.0 * npos * rows * (2 * Cf) * Cf)
+        what = {"winograd7": "Winograd 4+3 mixed tiling", "winograd4": "Winograd F(4x4,3x3)", "winograd": "Winograd F(2x2,3x3)"}
+        kname = "%s<A_KCONTIG,B_NCONTIG> x%d (MaskFuse conv3x3 fwd, %s domain)" % (kern, npos, what.get(gemm_mod.CONV_ALGO, gemm_mod.CONV_ALGO))
+    else:
+        direct = timer.launches("maskfuse_conv_fwd")
+        ms = [m for m, _ in direct]
+        flops = [2.0 * 49 * infos[j]["n"] * (2 * Cf * 9) * Cf for _, j in direct]
+        kname = "%s<A_CONV_K,B_NCONTIG> (MaskFuse conv3x3 fwd, implicit GEMM)" % kern
+    # split engines: every algorithmic fp32 multiply-add is executed as several half-precision MFMA products with fp32
+    # accumulation, so the kernel is priced against the bf16/f16 MFMA peak with achieved = products x algorithmic flops / time
+    # (f16x2: 3 products, bf16x3: 6; fp32: v_mfma_f32_32x32x2_f32 against its own peak).
+    conv_ms = float(np.mean(ms))
+    alg_tf = float(np.sum(flops)) / (float(np.sum(ms)) * 1e-3) / 1e12
+    roofline = dict(bound="mfma", kernel=kname, achieved=products * alg_tf,
+                    peak=FP32_MFMA_PEAK_TF if engine == "fp32" else BF16_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None,
+                    ms=conv_ms, launches=len(ms), algorithmic_flops_per_launch=float(np.mean(flops)),
+                    engine={"f16x2": "f16x2: 3 f16 MFMA products per fp32 multiply-add (scaled two-term split), fp32 accumulate",
+                            "bf16x3": "bf16x3: 6 bf16 MFMA products per fp32 multiply-add, fp32 accumulate",
+                            "fp32": "fp32: v_mfma_f32_32x32x2_f32"}[engine],
+                    algorithmic_tflops=alg_tf, fp32_mfma_peak=FP32_MFMA_PEAK_TF)
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    pmc = pmc_traffic(args.config)
+    mix_tag = "fixed" if args.fixed_image else "mix%d" % len(infos)
+    pmc_ok = pmc.get("_workload") == mix_tag and pmc.get("_conv_algo") == gemm_mod.CONV_ALGO and pmc.get("_engine") == engine
+    if pmc_ok and wino and pmc.get("wino_gemm_fwd"):
+        roofline["traffic"] = pmc["wino_gemm_fwd"]["hbm_bytes_mean"]
+    # HBM-bound hand-written kernels: fused ROIAlign+mask-cat fwd / bwd; algorithmic bytes of one launch on image j:
+    #   4 (Cf Hf Wf + 5N + 49N) + 4 N 2Cf 49                                                                   
+    hbm = []
+
+    def ra_bytes(j):
+        Hf, Wf = feat[j]
+        n = infos[j]["n"]
+        return 4.0 * (Cf * Hf * Wf + 5 * n + 49 * n) + 4.0 * n * 2 * Cf * 49
+
+    for name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_bwd"):
+        ls = timer.launches(name)
+        if ls:
+            tot_b = float(np.sum([ra_bytes(j) for _, j in ls]))
+            tot_ms = float(np.sum([m for m, _ in ls]))
+            ach = tot_b / (tot_ms * 1e-3) / 1e9
+            pk = pmc.get(name) if pmc_ok else None
+            hbm.append(dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                            ms=tot_ms / len(ls), launches=len(ls), algorithmic_bytes=tot_b / len(ls),
+                            traffic=pk["hbm_bytes_mean"] if pk else None))
+    # mining + sampling + assignment (a-4 ... a-6), all launches of an image summed.  Algorithmic bytes after SURVEY.md 8(d),
+    # with the per-class seed count and the pseudo-GT count at their upper bounds (S_c = K, G = classes x K):
+    #   2N^2 (containment flags, once per image) + layers x [classes x (4N + 2K^2 + 2NK) + 2N G + 12 N (C+1)]
+    ls = timer.launches("mining")
+    if ls:
+        C1 = int(cfg.MODEL.NUM_CLASSES) + 1
+        n_img = len(set((i // len(MINING_CALLS)) for i in range(len(ls))))
+        tot_ms = float(np.sum([m for m, _ in ls]))
+        tot_b = 0.0
+        for _, j in ls[::len(MINING_CALLS)]:
+            n, n_cls = infos[j]["n"], infos[j]["n_cls"]
+            K = int(np.ceil(cfg.p_seed * n))
+            tot_b += 2.0 * n * n + cfg.REFINE_TIMES * (n_cls * (4.0 * n + 2.0 * K * K + 2.0 * n * K) + 2.0 * n * n_cls * K + 12.0 * n * C1)
+        ach = tot_b / (tot_ms * 1e-3) / 1e9
+        hbm.append(dict(kernel="mining + sampling + assignment (cim_asy_flag + cim_mining_step: 5 kernel launches per image, no host round trip)",
+                        bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                        ms=tot_ms / n_img, algorithmic_bytes=tot_b / n_img, traffic=None, kernel_launches_per_image=5,
+                        note="launch-latency-bound: 5 dependent launches over a few MB per image (SURVEY.md 8d)"))
+    metric = "images/sec training step (ResNet-50 VOC, ~1k proposals/img) at 1/2/4/8 GPU" \
+        if args.config == "resnet50_voc" else "images/sec training step (%s)" % args.config      # BASELINE.json
+    ns = [i["n"] for i in infos]
+    shapes = sorted(set("%dx%d" % (i["H"], i["W"]) for i in infos))
+    workload = "%s bs=1/GPU, %d distinct images cycled: %d-%d proposals (mean %d), images 3x{%s}, feature %d ch, iter_size=%d" \
+        % (args.config, len(infos), min(ns), max(ns), round(float(np.mean(ns))), ",".join(shapes), Cf, args.iter_size)
+    return dict(metric=metric, value=images / elapsed, unit="images/s", n_gpus=world, steps=args.steps,
+                warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+                scaling="weak", vs_baseline=None, dtype="fp32", data="synthetic",
+                dtype_note={"f16x2": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
+                                     "two-term fp16 operand split (3 MFMA products, dropped term <= 2^-22, rms 2^-25.6) - "
+                                     "measured error vs fp64 in the class of the f32-multiply engine (CIM_GEMM_ENGINE=fp32)",
+                            "bf16x3": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated as an exact "
+                                      "3 x bf16 operand split (6 MFMA products, dropped terms < 2^-23) - measured error vs fp64 "
+                                      "below the f32-multiply engine's (CIM_GEMM_ENGINE=fp32)",
+                            "fp32": "fp32 multiplies and accumulation"}[engine],
+                config=dict(workload=workload, parallelism="dp%d" % world, inputs="resident in HBM (extra.with_h2d_upload: "
+                            "uploaded from pinned host memory inside every step)"),
+                roofline=roofline, roofline_hbm=hbm)
+
+
 def cpu_baseline(config, budget_n=0):
     """The oracle's CPU restatement of the same step, timed on this host (bounded sample)."""
+    import torch
+    from cim_amd import synthetic
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
     from oracle import cpu_step, mask_iou as omi
     apply_preset(config)
     torch.manual_seed(3)
@@ -165,197 +490,10 @@ def cpu_baseline(config, budget_n=0):
     linear = tm["roialign_fwd"] + tm["head_fwd"] + tm["losses_fwd"] + tm["head_bwd"] + tm["mining"]
     est = fixed + linear * scale
     return dict(value=1.0 / est, unit="images/s", cores=threads, kind="port",
-                sample="oracle/cpu_step.py fwd+bwd of %s: backbone on the full image, ROIAlign/MaskFuse/heads/"
-                       "mining/losses/backward on the first %d of %d proposals, proposal-linear phases scaled x%.1f "
-                       "(measured %.1f s; phases %s)" % (config, budget_n, n, scale, wall,
-                                                         {k: round(v, 2) for k, v in tm.items()}))
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="resnet50_voc")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="proposals in the CPU sample (0 = all)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
-                                                       "multi-rank check on a box with fewer GPUs than ranks)")
-    ap.add_argument("--miopen-find", action="store_true",
-                    help="let MIOpen time its solvers for the backbone convs (default: immediate mode)")
-    args = ap.parse_args()
-
-    if os.environ.get("CIM_BENCH_WATCHDOG"):        # debugging aid: dump all thread stacks if a phase stalls
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["CIM_BENCH_WATCHDOG"]), repeat=True)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    if args.backend != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # functional check: ranks may share a GPU
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    torch.backends.cudnn.benchmark = args.miopen_find      # backbone convs (a-11) go through MIOpen
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
-    _lib.load()                                                # no HIP extension -> fail loudly
-
-    apply_preset(args.config)
-    torch.manual_seed(cfg.RNG_SEED)                            # identical initial weights on every rank
-    model = Generalized_RCNN()
-    init_for_synthetic(model)
-    model = model.to(dev).train()
-    timer = KernelTimer()
-    instrument(model, timer)
-    dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True)
-    opt = make_optimizer(model)
-
-    inp = synthetic.make_image_inputs(args.config, seed=cfg.RNG_SEED + rank)     # one image per rank
-    n = inp["rois"].shape[0]
-    iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
-    t = lambda a: [torch.from_numpy(a).unsqueeze(0).to(dev)]
-    batch = dict(data=[torch.from_numpy(inp["data"]).to(dev)], rois=t(inp["rois"]), masks=t(inp["masks"]),
-                 labels=t(inp["labels"]), gtrois=[None], mat=t(inp["mat"]), index=t(inp["index"]),
-                 iou_map=[iou], asy_iou_map=[asy])
-    np.random.seed(cfg.RNG_SEED + rank)                        # the anti-noise sampling stream
-
-    feat_hw = [0, 0]
-
-    def step():
-        dp.zero_grad()
-        out = dp(**batch)
-        feat_hw[:] = out["blob_conv"].shape[-2:]
-        loss = sum(v.sum() for v in out["losses"].values()) * dp.loss_scale()
-        loss.backward()
-        dp.finish_gradient_sync()
-        opt.step()
-        return loss
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if os.environ.get("CIM_BENCH_PER_STEP") == "1" and rank == 0:      # debugging aid: synchronized time of every step from the first
-        for i in range(args.warmup + args.steps):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            step()
-            torch.cuda.synchronize()
-            print("step %d: %.2f ms" % (i, 1e3 * (time.perf_counter() - t1)), file=sys.stderr)
-    for _ in range(args.warmup):
-        step()
-    timer.enabled = True
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
-    assert torch.isfinite(loss), "non-finite loss in the timed region"
-
-    if rank == 0:
-        H, W = inp["image_hw"]
-        Cf = model.Conv_Body.dim_out
-        Hf, Wf = feat_hw
-        # dominant kernel: the exact-fp32 MFMA GEMM of the MaskFuse 3x3 conv forward (a-2).
-        #   Winograd F(2x2,3x3) (default): 16 batched GEMMs [16N x 2Cf] x [2Cf x Cf] = 2*16*16N*2Cf*Cf flops
-        #   direct implicit GEMM (CIM_CONV_ALGO=direct): 2*49N*18Cf*Cf flops        
-        #   Winograd F(4x4,3x3) (CIM_CONV_ALGO=winograd4): 36 batched GEMMs [4N x 2Cf] x [2Cf x Cf]
-        wino_ms = timer.mean_ms("wino_gemm_fwd")
-        from cim_amd.ops import gemm as gemm_mod
-        #   mixed tiling (CIM_CONV_ALGO=winograd7, default): 121 batched GEMMs [N x 2Cf] x [2Cf x Cf]
-        if wino_ms:
-            _, npos, rows = gemm_mod._wino_geometry(gemm_mod.CONV_ALGO, 7, n)
-            what = {"winograd7": "Winograd 4+3 mixed tiling", "winograd4": "Winograd F(4x4,3x3)", "winograd": "Winograd F(2x2,3x3)"}
-            kname = "gemm_f32_kernel<A_KCONTIG,B_NCONTIG> x%d (MaskFuse conv3x3 fwd, %s domain)" \
-                % (npos, what.get(gemm_mod.CONV_ALGO, gemm_mod.CONV_ALGO))
-            conv_ms, conv_flops = wino_ms, 2.0 * npos * rows * (2 * Cf) * Cf
-        else:
-            kname = "gemm_f32_kernel<A_CONV_K,B_NCONTIG> (MaskFuse conv3x3 fwd, implicit GEMM)"
-            conv_ms, conv_flops = timer.mean_ms("maskfuse_conv_fwd"), 2.0 * 49 * n * (2 * Cf * 9) * Cf
-        # split engines: every algorithmic fp32 multiply-add is executed as several half-precision MFMA products with
-        # fp32 accumulation, so the kernel is priced against the bf16/f16 MFMA peak with
-        # achieved = products x algorithmic flops / time.  f16x2 (default): 3 products (scaled two-term fp16 split);
-        # bf16x3: 6 products (exact three-term bf16 split); fp32: v_mfma_f32_32x32x2_f32 against its own peak.
-        engine = gemm_mod.ENGINE
-        products = {"f16x2": 3.0, "bf16x3": 6.0, "fp32": 1.0}[engine]
-        kern = {"f16x2": "gemm_f16x2_kernel", "bf16x3": "gemm_bf16x3_kernel", "fp32": "gemm_f32_kernel"}[engine]
-        alg_tf = conv_flops / (conv_ms * 1e-3) / 1e12
-        kname = kname.replace("gemm_f32_kernel", kern)
-        roofline = dict(bound="mfma", kernel=kname, achieved=products * alg_tf,
-                        peak=FP32_MFMA_PEAK_TF if engine == "fp32" else BF16_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None,
-                        ms=conv_ms,
-                        engine={"f16x2": "f16x2: 3 f16 MFMA products per fp32 multiply-add (scaled two-term split), fp32 accumulate",
-                                "bf16x3": "bf16x3: 6 bf16 MFMA products per fp32 multiply-add, fp32 accumulate",
-                                "fp32": "fp32: v_mfma_f32_32x32x2_f32"}[engine],
-                        algorithmic_tflops=alg_tf, fp32_mfma_peak=FP32_MFMA_PEAK_TF)
-        roofline["frac"] = roofline["achieved"] / roofline["peak"]
-        pmc = pmc_traffic()
-        g00 = pmc.get(kern + "<0, 0>")
-        if wino_ms and g00 and pmc.get("_conv_algo", "winograd") == gemm_mod.CONV_ALGO:      # first <A_KCONTIG,B_NCONTIG> launch of a step = the Winograd forward GEMM
-            roofline["traffic"] = (g00["fetch_kib_per_dispatch"][0] + g00["write_kib_per_dispatch"][0]) * 1024
-        # HBM-bound hand-written kernels: fused ROIAlign+mask-cat fwd / bwd
-        ra_bytes = 4.0 * (Cf * Hf * Wf + 5 * n + 49 * n) + 4.0 * n * 2 * Cf * 49
-        hbm = []
-        for name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_bwd"):
-            ms = timer.mean_ms(name)
-            if ms:
-                ach = ra_bytes / (ms * 1e-3) / 1e9
-                pk = None
-                for kn, kv in pmc.items():        # whichever forward / backward kernel variant the profiled run used
-                    if kn.startswith("roi_align_fwd" if name.endswith("fwd") else "roi_align_bwd"):
-                        pk = kv
-                hbm.append(dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                                frac=ach / HBM_PEAK_GBS, ms=ms, algorithmic_bytes=ra_bytes,
-                                traffic=pk["hbm_bytes_mean"] if pk else None))
-        # mining + assignment (a-4 ... a-6), all launches of a step summed.  Algorithmic bytes after SURVEY.md 8(d), with the
-        # per-class seed count and the pseudo-GT count at their upper bounds (S_c = K, G = classes x K):
-        #   2N^2 (containment flags, once per step) + layers x [classes x (4N + 2K^2 + 2NK) + 2N G + 12 N (C+1)]
-        mining_spans = timer.spans.get("mining", [])
-        if mining_spans:
-            per_step = len(mining_spans) / args.steps
-            mining_ms = float(np.sum([a.elapsed_time(b) for a, b in mining_spans])) / args.steps
-            n_cls = int((inp["labels"] > 0).sum())
-            K = int(np.ceil(cfg.p_seed * n))
-            C1 = int(cfg.MODEL.NUM_CLASSES) + 1
-            mining_bytes = 2.0 * n * n + cfg.REFINE_TIMES * (n_cls * (4.0 * n + 2.0 * K * K + 2.0 * n * K) + 2.0 * n * n_cls * K + 12.0 * n * C1)
-            ach = mining_bytes / (mining_ms * 1e-3) / 1e9
-            hbm.append(dict(kernel="mining + assignment (cim_asy_flag, cim_seed_select, cim_contain_argmax, cim_arbitrate, cim_assign)",
-                            bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, ms=mining_ms,
-                            algorithmic_bytes=mining_bytes, traffic=None, launches_per_step=per_step,
-                            note="launch-latency-bound: ~%d dependent launches of a few MB per step (SURVEY.md 8d)" % round(per_step)))
-        metric = "images/sec training step (ResNet-50 VOC, ~1k proposals/img) at 1/2/4/8 GPU" \
-            if args.config == "resnet50_voc" else "images/sec training step (%s)" % args.config      # BASELINE.json
-        line = dict(metric=metric,
-                    value=world * args.steps / elapsed, unit="images/s", n_gpus=world, steps=args.steps,
-                    warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
-                    scaling="weak", vs_baseline=None, dtype="fp32", data="synthetic",
-                    dtype_note={"f16x2": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
-                                         "two-term fp16 operand split (3 MFMA products, dropped term <= 2^-22, rms 2^-25.6) - "
-                                         "measured error vs fp64 in the class of the f32-multiply engine (CIM_GEMM_ENGINE=fp32)",
-                                "bf16x3": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated as an exact "
-                                          "3 x bf16 operand split (6 MFMA products, dropped terms < 2^-23) - measured error vs fp64 "
-                                          "below the f32-multiply engine's (CIM_GEMM_ENGINE=fp32)",
-                                "fp32": "fp32 multiplies and accumulation"}[engine],
-                    config=dict(workload="%s bs=1/GPU, %d proposals, image 3x%dx%d, feature %dx%dx%d, iter_size=1"
-                                         % (args.config, n, H, W, Cf, Hf, Wf), parallelism="dp%d" % world),
-                    roofline=roofline, roofline_hbm=hbm)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+                sample="oracle/cpu_step.py fwd+bwd of %s (the 1000-proposal 516x688 image of the mix): backbone on the full "
+                       "image, ROIAlign/MaskFuse/heads/mining/losses/backward on the first %d of %d proposals, "
+                       "proposal-linear phases scaled x%.1f (measured %.1f s; phases %s)"
+                       % (config, budget_n, n, scale, wall, {k: round(v, 2) for k, v in tm.items()}))
 
 
 if __name__ == "__main__":

@@ -24,9 +24,8 @@ SIGNATURES = {
     "cim_mask_pack": [_P, _P, c_int, c_int, _P],
     "cim_mask_iou_pair": [_P, c_int, c_int, _P, _P, _P, _P],
     "cim_asy_flag": [_P, c_int, c_float, _P, _P],
-    "cim_seed_select": [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P],
-    "cim_contain_argmax": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, _P, _P],
-    "cim_arbitrate": [_P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P],
+    "cim_mining_step": [_P, _P],
+    "cim_mining_lds_bytes": [c_int, c_int],
     "cim_bn_act_fwd": [_P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, _P],
     "cim_bn_act_bwd_chunks": [c_int, c_int, c_int],
     "cim_bn_act_bwd": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
@@ -56,9 +55,9 @@ SIGNATURES = {
     "cim_losses_fwd": [_P, _P],
     "cim_head_act_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
-    "cim_assign": [_P, c_int, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P],
 }
 
+ABI_VERSION = 2          # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 
@@ -82,10 +81,13 @@ def load():
     lib.cim_last_error.restype = ctypes.c_char_p
     lib.cim_last_error.argtypes = []
     lib.cim_abi_version.restype = c_int
+    if lib.cim_abi_version() != ABI_VERSION:
+        raise CimHipError("%s exports ABI %d, this package binds ABI %d: rebuild with `python -m cim_amd.build`"
+                          % (LIB_PATH, lib.cim_abi_version(), ABI_VERSION))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = c_longlong if name == "cim_roi_align_bwd_workspace" else c_int
+        fn.restype = c_longlong if name in ("cim_roi_align_bwd_workspace", "cim_mining_lds_bytes") else c_int
     # CIM_GEMM_ENGINE = f16x2 (default; own entry points, chosen in cim_amd/ops/gemm.py) | bf16x3 | fp32.
     # cim_gemm_f32 / cim_conv3x3_f32 (operands without scales) run bf16x3 unless fp32 is asked for.
     lib.cim_gemm_set_engine(0 if os.environ.get("CIM_GEMM_ENGINE", "f16x2") == "fp32" else 1)
@@ -93,7 +95,7 @@ def load():
     return lib
 
 
-VALUE_RETURNING = {"cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_gemm_get_engine"}      # return a count, not a status
+VALUE_RETURNING = {"cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_gemm_get_engine"}      # return a count, not a status
 
 
 def call(name, *args):

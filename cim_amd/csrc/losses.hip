@@ -166,25 +166,93 @@ __device__ void mil_job(const cim_loss_args& a, float* red) {
     if (tid == 0) { out[0] = bag; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f; }
 }
 
-__device__ void pcl_job(const cim_loss_args& a, float* red) {
+__device__ float block_min(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = INFINITY;
+    for (int w = 0; w < NT / 64; ++w) s = fminf(s, red[w]);
+    return s;
+}
+
+// The cluster structure of `mat` (heads.py:14-21), in LDS: row_val [N] = the row's non-zero entry (0: none),
+// row_col [N] = its column, row_cluster [N] = rank of that id among the distinct ids (ascending = torch.unique order),
+// csize [K].  Returns the number of clusters; *bg = rank of the id found in column 0 (-1: none).
+__device__ int pcl_plan(const cim_loss_args& a, float* red, float* row_val, int16_t* row_col, int16_t* row_cluster,
+                        int* csize, int* bg) {
+    const int N = a.N, C1 = a.C1, tid = threadIdx.x;
+    float bgv_lo = INFINITY, bgv_hi = -INFINITY;
+    int err = 0;
+    for (int n = tid; n < N; n += NT) {
+        int cnt = 0, col = -1;
+        float val = 0.0f;
+        for (int c = 0; c < C1; ++c) {
+            const float v = a.mat[(size_t)n * C1 + c];
+            if (v != 0.0f) {
+                if (cnt == 0) { col = c; val = v; }
+                ++cnt;
+            }
+        }
+        if (cnt > 1) err |= 4;
+        row_val[n] = val;
+        row_col[n] = (int16_t)col;
+        row_cluster[n] = -1;
+        if (col == 0) { bgv_lo = fminf(bgv_lo, val); bgv_hi = fmaxf(bgv_hi, val); }
+    }
+    const float bg_lo = block_min(bgv_lo, red);
+    const float bg_hi = -block_min(-bgv_hi, red);
+    if (bg_lo != INFINITY && bg_lo != bg_hi) err |= 8;      // heads.py:20: assert len(unique ids in column 0) <= 1
+    int K = 0;
+    *bg = -1;
+    float last = -INFINITY;
+    for (;;) {
+        float m = INFINITY;
+        for (int n = tid; n < N; n += NT)
+            if (row_col[n] >= 0 && row_val[n] > last) m = fminf(m, row_val[n]);
+        m = block_min(m, red);
+        if (m == INFINITY) break;
+        if (K >= CIM_PCL_MAX_CLUSTERS) { err |= 16; break; }
+        float cnt = 0.0f;
+        for (int n = tid; n < N; n += NT)
+            if (row_col[n] >= 0 && row_val[n] == m) { row_cluster[n] = (int16_t)K; cnt += 1.0f; }
+        cnt = block_sum(cnt, red);
+        if (tid == 0) csize[K] = (int)cnt;
+        if (bg_lo != INFINITY && m == bg_lo) *bg = K;
+        last = m;
+        ++K;
+    }
+    if (err && a.status) atomicOr(a.status, err);
+    __syncthreads();
+    return K;
+}
+
+__device__ void pcl_job(const cim_loss_args& a, float* red, unsigned char* scratch) {
     const int N = a.N, C1 = a.C1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     float* g = a.grad + (size_t)1 * N * C1;                 // component 1: d pcl / d predict_cls
     for (int i = tid; i < N * C1; i += NT) g[i] = 0.f;
-    __syncthreads();
+    float* row_val = reinterpret_cast<float*>(scratch);                       // [N]
+    int16_t* row_col = reinterpret_cast<int16_t*>(row_val + N);               // [N]
+    int16_t* row_cluster = row_col + N;                                       // [N]
+    __shared__ int csize[CIM_PCL_MAX_CLUSTERS];
+    int bg_cluster;
+    const int K = pcl_plan(a, red, row_val, row_col, row_cluster, csize, &bg_cluster);
     float den = 1e-6f;                                      // heads.py:22
-    for (int k = 0; k < a.K; ++k) den += (float)a.cluster_size[k];
+    for (int k = 0; k < K; ++k) den += (float)csize[k];
     const float scale = 12.0f / den;                        // heads.py:40-41
     float acc = 0.0f;
     // (cluster, column) pairs over the 16 waves
-    for (int job = wave; job < a.K * C1; job += NT / 64) {
+    for (int job = wave; job < K * C1; job += NT / 64) {
         const int k = job / C1, c = job % C1;
-        const float nk = (float)a.cluster_size[k];
-        if (k == a.bg_cluster) {                            // heads.py:33-38: every member row vs its own pattern
+        const float nk = (float)csize[k];
+        if (k == bg_cluster) {                              // heads.py:33-38: every member row vs its own pattern
             float s = 0.0f;
             for (int n = lane; n < N; n += 64) {
-                if (a.row_cluster[n] != k) continue;
+                if (row_cluster[n] != k) continue;
                 const float x = a.pc[(size_t)n * C1 + c], p = clampf(x);
-                const float t = (a.row_col[n] == c) ? 1.0f : 0.0f;
+                const float t = (row_col[n] == c) ? 1.0f : 0.0f;
                 s += -(t * logf(p) + (1.0f - t) * logf(1.0f - p));
                 g[(size_t)n * C1 + c] = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(x);
             }
@@ -195,9 +263,9 @@ __device__ void pcl_job(const cim_loss_args& a, float* red) {
             float s = 0.0f;
             int any = 0;
             for (int n = lane; n < N; n += 64) {
-                if (a.row_cluster[n] != k) continue;
+                if (row_cluster[n] != k) continue;
                 s += a.pc[(size_t)n * C1 + c];
-                any |= (a.row_col[n] == c);
+                any |= (row_col[n] == c);
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); any |= __shfl_xor(any, o); }
@@ -205,7 +273,7 @@ __device__ void pcl_job(const cim_loss_args& a, float* red) {
             if (lane == 0) acc += nk * (-(t * logf(p) + (1.0f - t) * logf(1.0f - p))) / (float)C1;
             const float dv = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(v);   // n_k * (1/n_k)
             for (int n = lane; n < N; n += 64)
-                if (a.row_cluster[n] == k) g[(size_t)n * C1 + c] = dv;
+                if (row_cluster[n] == k) g[(size_t)n * C1 + c] = dv;
         }
     }
     acc = block_sum(acc, red);
@@ -216,11 +284,11 @@ __device__ void pcl_job(const cim_loss_args& a, float* red) {
 __global__ __launch_bounds__(NT) void losses_kernel(const cim_loss_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red = reinterpret_cast<float*>(smem);            // [16]
-    int* hot = reinterpret_cast<int*>(smem + 64);           // [N]
+    int* hot = reinterpret_cast<int*>(smem + 64);           // [N] (refinement jobs) / the PCL job's 8N bytes of row tables
     const int job = blockIdx.x;
     if (job < a.R) refine_job(a, job, red, hot);
     else if (job == a.R) mil_job(a, red);
-    else pcl_job(a, red);
+    else pcl_job(a, red, smem + 64);
 }
 
 }  // namespace
@@ -228,12 +296,14 @@ __global__ __launch_bounds__(NT) void losses_kernel(const cim_loss_args a) {
 extern "C" int cim_losses_fwd(const cim_loss_args* args, void* stream) {
     CIM_CHECK_ARG(args != nullptr);
     const cim_loss_args& a = *args;
-    CIM_CHECK_ARG(a.N > 0 && a.N <= 15000 && a.C1 > 1 && a.R >= 0 && a.R <= 3 && a.K >= 0);
-    CIM_CHECK_ARG(a.pc && a.pd && a.labels && a.part && a.grad);
+    CIM_CHECK_ARG(a.N > 0 && a.N <= 15000 && a.C1 > 1 && a.C1 <= 32767 && a.R >= 0 && a.R <= 3);
+    CIM_CHECK_ARG(a.pc && a.pd && a.labels && a.part && a.grad && a.mat && (a.R == 0 || a.layer_valid));
     for (int i = 0; i < a.R; ++i)
-        CIM_CHECK_ARG(a.rc[i] && a.ri[i] && (!a.layer_valid[i] || (a.pseudo_labels[i] && a.pseudo_iou_f16[i] && a.loss_weights[i])));
-    CIM_CHECK_ARG(a.K == 0 || (a.row_cluster && a.row_col && a.cluster_size));
-    const size_t lds = 64 + sizeof(int) * (size_t)a.N;
+        CIM_CHECK_ARG(a.rc[i] && a.ri[i] && a.pseudo_labels[i] && a.pseudo_iou_f16[i] && a.loss_weights[i]);
+    const size_t lds = 64 + 8 * (size_t)a.N;
+    if (lds > 64 * 1024)
+        CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(losses_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(losses_kernel, dim3(a.R + 2), dim3(NT), lds, cim::as_stream(stream), a);
     CIM_CHECK_LAUNCH();
     return 0;

@@ -1,12 +1,18 @@
 // Complete-Instances-Mining kernels for gfx950: containment flag, per-class seed selection
 // (stable top-K + greedy mask-IoU NMS), containment argmax, cross-class arbitration,
-// IoU-based pseudo-label assignment.
+// anti-noise sampling (NumPy's np.random.choice restated on pre-drawn MT19937 uniforms),
+// IoU-based pseudo-label assignment - for ALL CIM layers of a training step in 4 launches
+// (+ 1 per distinct con_thr for the containment flags), with no host round trip.
 //
 // Replaces CIM_layer.{instance_nms, MIST_label, CIM_label, forward} of
 // /root/reference/lib/modeling/heads.py:237-503.  All results are integer indices or exact
 // copies of inputs, so they are bit-identical to the reference CPU path; the tie / compare
 // rules are the ones listed in SURVEY.md App. B.  Everything here is HBM/latency-bound
 // integer and fp16-compare work: no MFMA, LDS for the sort / NMS bit-matrix / scans.
+//
+// The image's class list is never known to the host: every kernel reads `labels` [C] on the device
+// (class c is active iff labels[c] != 0, heads.py:340) and the per-class outputs are indexed by the
+// class id itself ([C][K] arrays), inactive classes exit at once.
 #include "common.h"
 #include "../../include/cim_hip.h"
 #include <limits.h>
@@ -114,33 +120,35 @@ __device__ __forceinline__ void seed_topk_regs(const float* __restrict__ score, 
     __syncthreads();
 }
 
-// grid = n_cls, block = 1024.  Dynamic LDS: [max(NP*8, K*KW*8)] bytes + K*4 bytes.
-__global__ __launch_bounds__(1024) void seed_select_kernel(const float* __restrict__ score, int score_ld, int score_off,
-                                                           const uint16_t* __restrict__ iou, int N, int NP,
-                                                           const int32_t* __restrict__ classes, int K, int KW,
-                                                           float nms_thr, size_t idx_off,
-                                                           int32_t* __restrict__ topk_idx, int32_t* __restrict__ seeds,
-                                                           int32_t* __restrict__ n_seeds) {
+
+// ================================================================== fused step: launch 1
+// grid = (C, R), block = 1024: workgroup (c, l) = class c of CIM layer l.  Dynamic LDS: [max(NP*8, K*KW*8)] + K*4 bytes.
+__global__ __launch_bounds__(1024) void step_seed_kernel(const cim_mining_args a, int NP, int KW, size_t idx_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     int32_t* kidx = reinterpret_cast<int32_t*>(smem + idx_off);
-    const int ci = blockIdx.x;
-    const int c = classes[ci];
-    const int tid = threadIdx.x;
-
+    const int c = blockIdx.x, l = blockIdx.y;
+    const cim_mining_layer& L = a.layer[l];
+    const int tid = threadIdx.x, N = a.N, K = a.K;
+    if (c == 0 && l == 0 && tid == 0) *a.status = 0;                    // error bits of this step (launches 3 / losses OR into it)
+    int32_t* __restrict__ topk_out = L.topk + (size_t)c * K;
+    int32_t* __restrict__ seeds = L.seeds + (size_t)c * K;
+    if (a.labels[c] == 0.0f) {                                          // heads.py:340: only the image's classes
+        if (tid == 0) L.n_seeds[c] = 0;
+        return;
+    }
+    const float* __restrict__ score = L.seed_score;
+    const int score_ld = L.seed_ld, col = L.seed_off + c;
     // key = (descending score, ascending index): a total order -> the sort is the stable
     // descending argsort of heads.py:354 (App. B item 4).
     if (NP == 1024) {
-        seed_topk_regs<1>(score, score_ld, score_off + c, N, keys, kidx, topk_idx + (size_t)ci * K, K, tid);
+        seed_topk_regs<1>(score, score_ld, col, N, keys, kidx, topk_out, K, tid);
     } else if (NP == 2048) {
-        seed_topk_regs<2>(score, score_ld, score_off + c, N, keys, kidx, topk_idx + (size_t)ci * K, K, tid);
+        seed_topk_regs<2>(score, score_ld, col, N, keys, kidx, topk_out, K, tid);
     } else {
         for (int i = tid; i < NP; i += 1024) {
             unsigned long long key = ~0ull;
-            if (i < N) {
-                const float s = score[(size_t)i * score_ld + score_off + c];
-                key = ((unsigned long long)(~orderable(s)) << 32) | (unsigned)i;
-            }
+            if (i < N) key = ((unsigned long long)(~orderable(score[(size_t)i * score_ld + col])) << 32) | (unsigned)i;
             keys[i] = key;
         }
         __syncthreads();
@@ -150,10 +158,10 @@ __global__ __launch_bounds__(1024) void seed_select_kernel(const float* __restri
                     const int lo = (t / stride) * (2 * stride) + (t % stride);
                     const int hi = lo + stride;
                     const bool up = ((lo & size) == 0);
-                    const unsigned long long a = keys[lo], b = keys[hi];
-                    if ((a > b) == up) {
-                        keys[lo] = b;
-                        keys[hi] = a;
+                    const unsigned long long x = keys[lo], y = keys[hi];
+                    if ((x > y) == up) {
+                        keys[lo] = y;
+                        keys[hi] = x;
                     }
                 }
                 __syncthreads();
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(1024) void seed_select_kernel(const float* __restri
         for (int r = tid; r < K; r += 1024) {
             const int32_t id = (int32_t)(keys[r] & 0xffffffffu);
             kidx[r] = id;
-            topk_idx[(size_t)ci * K + r] = id;
+            topk_out[r] = id;
         }
         __syncthreads();
     }
@@ -171,11 +179,12 @@ __global__ __launch_bounds__(1024) void seed_select_kernel(const float* __restri
     // bit (i, j) set <=> NOT (iou[idx_i, idx_j] < nms_thr)   (heads.py:250-254, fp16 compare).
     unsigned long long* sup = keys;  // keys are dead from here on
     const int wave = tid >> 6, lane = tid & 63;
+    const float nms_thr = L.nms_thr;
     for (int t = wave; t < K * KW; t += 16) {
         const int i = t / KW, w = t % KW;
         const int j = w * 64 + lane;
         bool bit = false;
-        if (j < K) bit = !(h2f(iou[(size_t)kidx[i] * N + kidx[j]]) < nms_thr);
+        if (j < K) bit = !(h2f(a.iou[(size_t)kidx[i] * N + kidx[j]]) < nms_thr);
         const unsigned long long word = __ballot(bit);
         if (lane == 0) sup[(size_t)i * KW + w] = word;
     }
@@ -188,39 +197,38 @@ __global__ __launch_bounds__(1024) void seed_select_kernel(const float* __restri
         for (int i = 0; i < K; ++i) {
             const unsigned long long rw = __shfl(removed, i >> 6);
             if (!((rw >> (i & 63)) & 1ull)) {
-                if (lane == 0) seeds[(size_t)ci * K + cnt] = kidx[i];
+                if (lane == 0) seeds[cnt] = kidx[i];
                 ++cnt;
                 if (lane < KW) removed |= sup[(size_t)i * KW + lane];
             }
         }
-        for (int r = cnt + lane; r < K; r += 64) seeds[(size_t)ci * K + r] = -1;
-        if (lane == 0) n_seeds[ci] = cnt;
+        for (int r = cnt + lane; r < K; r += 64) seeds[r] = -1;
+        if (lane == 0) L.n_seeds[c] = cnt;
     }
 }
 
-// ---------------------------------------------------------------- heads.py:386-395
-// grid = (K, n_cls), block = 256: one workgroup per seed column of the containment map.
-__global__ __launch_bounds__(256) void contain_argmax_kernel(const uint16_t* __restrict__ asy,
-                                                             const uint8_t* __restrict__ flag,
-                                                             const float* __restrict__ det, int det_ld, int det_off,
-                                                             int det_cstride, int N, const int32_t* __restrict__ classes,
-                                                             int K, float thr, const int32_t* __restrict__ seeds,
-                                                             const int32_t* __restrict__ n_seeds,
-                                                             int32_t* __restrict__ res_idx) {
-    const int s = blockIdx.x, ci = blockIdx.y;
-    if (s >= n_seeds[ci]) {
-        if (threadIdx.x == 0) res_idx[(size_t)ci * K + s] = -1;
+// ================================================================== fused step: launch 2 (heads.py:386-395)
+// grid = (K, C, R), block = 256: one workgroup per seed column of the containment map; inactive classes,
+// exhausted seed slots and MIST layers (no containment step) leave at once.
+__global__ __launch_bounds__(256) void step_contain_kernel(const cim_mining_args a) {
+    const int s = blockIdx.x, c = blockIdx.y, l = blockIdx.z;
+    const cim_mining_layer& L = a.layer[l];
+    if (!L.using_cim || a.labels[c] == 0.0f) return;
+    const int K = a.K, N = a.N;
+    if (s >= L.n_seeds[c]) {
+        if (threadIdx.x == 0) L.res[(size_t)c * K + s] = -1;
         return;
     }
-    const int c = classes[ci];
-    const int seed = seeds[(size_t)ci * K + s];
+    const uint8_t* __restrict__ flag = a.flags + (size_t)L.flag_slot * N;
+    const float thr = L.con_thr;
+    const int seed = L.seeds[(size_t)c * K + s];
     float best = -INFINITY;
     int besti = INT_MAX;
     int any = 0;
     for (int i = threadIdx.x; i < N; i += 256) {
-        const bool cond = (h2f(asy[(size_t)i * N + seed]) > thr) && flag[i];
+        const bool cond = (h2f(a.asy[(size_t)i * N + seed]) > thr) && flag[i];
         any |= cond;
-        const float v = cond ? det[(size_t)i * det_ld + det_off + c * det_cstride] : 0.0f;   // heads.py:393
+        const float v = cond ? L.det[(size_t)i * L.det_ld + L.det_off + c * L.det_cs] : 0.0f;   // heads.py:393
         if (v > best) {  // ascending i per thread: strict '>' keeps the first maximum
             best = v;
             besti = i;
@@ -249,85 +257,234 @@ __global__ __launch_bounds__(256) void contain_argmax_kernel(const uint16_t* __r
                 best = sv[w];
                 besti = si[w];
             }
-        res_idx[(size_t)ci * K + s] = any ? besti : -1;
+        L.res[(size_t)c * K + s] = any ? besti : -1;
     }
 }
 
-// ---------------------------------------------------------------- heads.py:397-405 / 306-314
-// One workgroup; classes applied sequentially (App. B item 7), then an ordered compaction.
-__global__ __launch_bounds__(1024) void arbitrate_kernel(const int32_t* __restrict__ cand,
-                                                         const int32_t* __restrict__ classes, int n_cls, int K, int N,
-                                                         const float* __restrict__ wa, int wa_ld, int wa_off,
-                                                         const float* __restrict__ wb, int wb_ld, int wb_off,
-                                                         int wb_cstride, int32_t* __restrict__ gt_class,
-                                                         float* __restrict__ gt_weight, int32_t* __restrict__ gt_pack) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint8_t* mark = smem;                                              // [N]
-    int32_t* part = reinterpret_cast<int32_t*>(smem + ((N + 15) & ~15));  // [1024]
-    const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += 1024) {
-        gt_class[i] = 0;
-        gt_weight[i] = -1.0f;                                          // heads.py:336
+// ================================================================== fused step: launch 3
+// ONE workgroup walks the layers in order (the uniforms are consumed in the order of the reference's sequential
+// CIM_layer calls): cross-class arbitration (heads.py:397-405 / 306-314), ordered compaction (App. B item 8),
+// anti-noise sampling (heads.py:447-473), compaction of the survivors.
+//
+// Sampling = np.random.choice(class_idx, size=n, replace=True, p=prob / prob.sum()) + np.unique, restated
+// (numpy/random/mtrand.pyx, RandomState.choice):
+//     prob  = gt_weights[class_idx]                       f32
+//     total = prob.sum()                                  f32, NumPy's pairwise summation (np_pairwise_sum below)
+//     p     = prob / total                                f32 division (evaluated in f64 and rounded once: exact)
+//     cdf   = cumsum(f64(p)); cdf /= cdf[-1]              sequential f64 accumulation
+//     idx   = searchsorted(cdf, u, side='right')          u = the next n doubles of the global MT19937 stream
+// The host draws the uniforms (np.random.random_sample) BEFORE the launch, at most `max_uniforms` of them, and
+// rewinds its generator to `used` afterwards (cim_amd/modeling/heads.py: RngLedger): same values, same stream position.
+
+// numpy/core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum (PW_BLOCKSIZE = 128, 8 accumulators).  NumPy's version
+// recurses on halves above 128 elements; here the recursion is unrolled by a template depth (D = 4: n <= 2048).
+__device__ __forceinline__ float np_pairwise_leaf(const float* a, int n) {      // n <= 128
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
     }
-    for (int ci = 0; ci < n_cls; ++ci) {
-        const int c = classes[ci];
-        for (int i = tid; i < N; i += 1024) mark[i] = 0;
+    float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i + 0]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+template <int D>
+__device__ float np_pairwise_sum(const float* a, int n) {
+    if (n <= 128) return np_pairwise_leaf(a, n);
+    if constexpr (D == 0) {
+        return np_pairwise_leaf(a, 128);           // unreachable for n <= 128 << depth (checked by the caller)
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        const float lo = np_pairwise_sum<D - 1>(a, n2);
+        const float hi = np_pairwise_sum<D - 1>(a + n2, n - n2);
+        return lo + hi;
+    }
+}
+
+__device__ int block_exclusive_scan(int v, int* part, int* total) {      // 1024 lanes; returns the exclusive prefix
+    const int tid = threadIdx.x;
+    __syncthreads();
+    part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int x = (tid >= o) ? part[tid - o] : 0;
         __syncthreads();
-        for (int r = tid; r < K; r += 1024) {
-            const int32_t p = cand[(size_t)ci * K + r];
-            if (p >= 0) mark[p] = 1;                                   // torch.unique: set semantics
-        }
+        part[tid] += x;
         __syncthreads();
+    }
+    *total = part[1023];
+    return part[tid] - v;
+}
+
+__global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_mining_args a) {
+#pragma clang fp contract(off)                      // the sums below restate NumPy's: no fused multiply-adds
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = a.N, K = a.K, C = a.C, tid = threadIdx.x;
+    // LDS: cdf f64 [K] | part i32 [1024] | prob f32 [K] | pos i32 [K] | gclass i32 [N] | gweight f32 [N] | mark u8 [N]
+    double* cdf = reinterpret_cast<double*>(smem);
+    int32_t* part = reinterpret_cast<int32_t*>(cdf + K);
+    float* prob = reinterpret_cast<float*>(part + 1024);
+    int32_t* pos = reinterpret_cast<int32_t*>(prob + K);
+    int32_t* gclass = pos + K;
+    float* gweight = reinterpret_cast<float*>(gclass + N);
+    uint8_t* mark = reinterpret_cast<uint8_t*>(gweight + N);
+    __shared__ int s_used;
+    __shared__ float s_total;
+    if (tid == 0) s_used = 0;
+    const int chunk = (N + 1023) / 1024;
+    const int lo = min(N, tid * chunk), hi = min(N, lo + chunk);
+
+    for (int l = 0; l < a.R; ++l) {
+        const cim_mining_layer& L = a.layer[l];
         for (int i = tid; i < N; i += 1024) {
-            if (!mark[i]) continue;
-            float w = wa[(size_t)i * wa_ld + wa_off + c];
-            if (wb) w = w * wb[(size_t)i * wb_ld + wb_off + c * wb_cstride];   // preds = cls * det, heads.py:330
-            if (w > gt_weight[i]) {                                    // strict '>' (heads.py:397)
-                gt_class[i] = c + 1;
-                gt_weight[i] = w;
+            gclass[i] = 0;
+            gweight[i] = -1.0f;                                          // heads.py:336
+        }
+        // ---- arbitration: classes applied sequentially in ascending order, strict '>' (App. B item 7)
+        const int32_t* __restrict__ cand = L.using_cim ? L.res : L.seeds;
+        for (int c = 0; c < C; ++c) {
+            if (a.labels[c] == 0.0f) continue;                           // uniform over the workgroup
+            for (int i = tid; i < N; i += 1024) mark[i] = 0;
+            __syncthreads();
+            for (int r = tid; r < K; r += 1024) {
+                const int32_t p = cand[(size_t)c * K + r];
+                if (p >= 0) mark[p] = 1;                                 // torch.unique: set semantics
+            }
+            __syncthreads();
+            for (int i = tid; i < N; i += 1024) {
+                if (!mark[i]) continue;
+                float w = L.wa[(size_t)i * L.wa_ld + L.wa_off + c];
+                if (L.wb) w = w * L.wb[(size_t)i * L.wb_ld + L.wb_off + c * L.wb_cs];   // preds = cls * det, heads.py:330
+                if (w > gweight[i]) {                                    // strict '>' (heads.py:397)
+                    gclass[i] = c + 1;
+                    gweight[i] = w;
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < N; i += 1024) {
+            L.gt_class[i] = gclass[i];
+            L.gt_weight[i] = gweight[i];
+        }
+        // ---- ordered compaction of {i : gclass[i] > 0} -> pre-sampling list (ascending proposal index)
+        int cnt = 0;
+        for (int i = lo; i < hi; ++i) cnt += gclass[i] > 0;
+        int G;
+        int p0 = block_exclusive_scan(cnt, part, &G);
+        for (int i = lo; i < hi; ++i)
+            if (gclass[i] > 0) {
+                L.pre_idx[p0] = i;
+                L.pre_keep[p0] = 1;
+                ++p0;
+            }
+        __syncthreads();                                                 // pre_idx visible to the workgroup (global, same block)
+        // ---- anti-noise sampling, class by class in ascending order (heads.py:451-466)
+        if (L.anti_noise && G > 0) {
+            for (int c = 0; c < C; ++c) {
+                if (a.labels[c] == 0.0f) continue;
+                // members of class c in list order: positions j with gclass[pre_idx[j]] == c + 1 (G <= N: chunked like above)
+                const int gchunk = (G + 1023) / 1024;
+                const int glo = min(G, tid * gchunk), ghi = min(G, glo + gchunk);
+                int m = 0;
+                for (int j = glo; j < ghi; ++j) m += gclass[L.pre_idx[j]] == c + 1;
+                int Gc;
+                int q0 = block_exclusive_scan(m, part, &Gc);
+                if (Gc == 0) continue;                                   // heads.py:454-455 (uniform)
+                if (Gc > K) {                                            // cannot happen (<= K candidates per class); stay memory-safe
+                    if (tid == 0) atomicOr(a.status, 1);
+                    continue;
+                }
+                for (int j = glo; j < ghi; ++j) {
+                    const int i = L.pre_idx[j];
+                    if (gclass[i] == c + 1) {
+                        pos[q0] = j;
+                        prob[q0] = gweight[i];
+                        ++q0;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) s_total = np_pairwise_sum<4>(prob, Gc);
+                __syncthreads();
+                const float total = s_total;
+                if (tid == 0) {
+                    double acc = 0.0;
+                    for (int j = 0; j < Gc; ++j) {
+                        const float pj = (float)((double)prob[j] / (double)total);   // == f32 division, correctly rounded
+                        acc = (j == 0) ? (double)pj : acc + (double)pj;              // np.cumsum: out[0] = p[0]
+                        cdf[j] = acc;
+                    }
+                }
+                __syncthreads();
+                const double last = cdf[Gc - 1];
+                __syncthreads();
+                for (int j = tid; j < Gc; j += 1024) {
+                    cdf[j] = cdf[j] / last;
+                    L.pre_keep[pos[j]] = 0;                              // inds[class_idx] = 0
+                }
+                __syncthreads();
+                const int base = s_used;
+                if (base + Gc > a.max_uniforms) {                        // the host drew too few (cannot happen: bound = R * min(N, classes * K))
+                    if (tid == 0) atomicOr(a.status, 2);
+                } else {
+                    for (int j = tid; j < Gc; j += 1024) {
+                        const double u = a.uniforms[base + j];
+                        int b = 0, e = Gc;                               // searchsorted(side='right'): first index with cdf > u
+                        while (b < e) {
+                            const int mid = (b + e) >> 1;
+                            if (cdf[mid] <= u) b = mid + 1; else e = mid;
+                        }
+                        if (b >= Gc) b = Gc - 1;                         // u < 1 == cdf[-1]: unreachable; memory safety
+                        L.pre_keep[pos[b]] = 1;                          // inds[np.unique(sampled)] = 1
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) s_used = base + Gc;
+                __syncthreads();
+            }
+        }
+        // ---- survivors, in list order -> post-sampling list
+        {
+            const int gchunk = (G + 1023) / 1024;
+            const int glo = min(G, tid * gchunk), ghi = min(G, glo + gchunk);
+            int m = 0;
+            for (int j = glo; j < ghi; ++j) m += L.pre_keep[j] != 0;
+            int Gk;
+            int q0 = block_exclusive_scan(m, part, &Gk);
+            for (int j = glo; j < ghi; ++j)
+                if (L.pre_keep[j]) {
+                    const int i = L.pre_idx[j];
+                    L.gt_idx[q0] = i;
+                    L.gt_cls[q0] = gclass[i];
+                    L.gt_w[q0] = gweight[i];
+                    ++q0;
+                }
+            if (tid == 0) {
+                L.counts[0] = G;
+                L.counts[1] = Gk;
+                a.layer_valid[l] = G > 0 ? 1 : 0;                        // heads.py:429-430: no pseudo GT -> layer skipped
             }
         }
         __syncthreads();
     }
-    // ordered compaction of {i : gt_class[i] > 0} (ascending i, App. B item 8)
-    const int chunk = (N + 1023) / 1024;
-    const int lo = tid * chunk, hi = min(N, lo + chunk);
-    int cnt = 0;
-    for (int i = lo; i < hi; ++i) cnt += gt_class[i] > 0;
-    part[tid] = cnt;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = (tid >= o) ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    // gt_pack = [G | idx[N] | class[N] | weight bits[N]] so the host needs ONE D2H copy
-    int pos = part[tid] - cnt;
-    for (int i = lo; i < hi; ++i)
-        if (gt_class[i] > 0) {
-            gt_pack[1 + pos] = i;
-            gt_pack[1 + N + pos] = gt_class[i];
-            gt_pack[1 + 2 * N + pos] = __float_as_int(gt_weight[i]);
-            ++pos;
-        }
-    if (tid == 1023) gt_pack[0] = part[1023];
+    if (tid == 0) a.used[0] = s_used;
 }
 
-// ---------------------------------------------------------------- heads.py:435,477-501
-// One wave per proposal row: gather the G pseudo-GT columns of the fp16 mask-IoU map,
-// first-index arg-max, then the ignore / background / IoU-label rules.
-__global__ __launch_bounds__(256) void assign_kernel(const uint16_t* __restrict__ iou, int N,
-                                                     const int32_t* __restrict__ gt_idx,
-                                                     const int32_t* __restrict__ gt_cls, const float* __restrict__ gt_w,
-                                                     int G, int C1, float cls_thr, float iou_thr,
-                                                     float* __restrict__ pseudo_labels,
-                                                     uint16_t* __restrict__ pseudo_iou, float* __restrict__ loss_w,
-                                                     int32_t* __restrict__ max_idx) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= N) return;
-    const uint16_t* __restrict__ r = iou + (size_t)row * N;
+// ================================================================== fused step: launch 4 (heads.py:435,477-501)
+// grid = (ceil(N/4), R): one wave per proposal row and layer: gather the G' surviving pseudo-GT columns of the fp16
+// mask-IoU map, first-index arg-max, then the ignore / background / IoU-label rules.
+__device__ __forceinline__ void assign_row(const uint16_t* __restrict__ r, int row, int lane, const int32_t* __restrict__ gt_idx,
+                                           const int32_t* __restrict__ gt_cls, const float* __restrict__ gt_w, int G, int C1,
+                                           float cls_thr, float iou_thr, float* __restrict__ pseudo_labels,
+                                           uint16_t* __restrict__ pseudo_iou, float* __restrict__ loss_w,
+                                           int32_t* __restrict__ max_idx) {
     float best = -INFINITY;
     int bestj = INT_MAX;
     uint16_t bestbits = 0;
@@ -372,6 +529,17 @@ __global__ __launch_bounds__(256) void assign_kernel(const uint16_t* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void step_assign_kernel(const cim_mining_args a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const cim_mining_layer& L = a.layer[blockIdx.y];
+    if (row >= a.N) return;
+    const int G = L.counts[1];
+    if (G <= 0) return;                                                  // layer skipped: its outputs are never read
+    assign_row(a.iou + (size_t)row * a.N, row, lane, L.gt_idx, L.gt_cls, L.gt_w, G, a.C + 1, L.cls_thr, L.iou_thr,
+               L.pseudo_labels, L.pseudo_iou, L.loss_weights, L.max_idx);
+}
+
 }  // namespace
 
 extern "C" int cim_asy_flag(const uint16_t* asy_f16, int N, float con_thr, uint8_t* flag, void* stream) {
@@ -386,64 +554,52 @@ extern "C" int cim_asy_flag(const uint16_t* asy_f16, int N, float con_thr, uint8
     return 0;
 }
 
-extern "C" int cim_seed_select(const float* seed_score, int score_ld, int score_off, const uint16_t* iou_f16, int N,
-                               const int32_t* classes, int n_cls, int K, float nms_thr, int32_t* topk_idx,
-                               int32_t* seeds, int32_t* n_seeds, void* stream) {
-    CIM_CHECK_ARG(N > 0 && N <= 8192 && K > 0 && K <= 1024 && K <= N && n_cls >= 0);
-    if (n_cls == 0) return 0;
-    CIM_CHECK_ARG(seed_score && iou_f16 && classes && topk_idx && seeds && n_seeds);
+extern "C" long long cim_mining_lds_bytes(int N, int K) {
+    return (long long)K * 8 + 1024 * 4 + (long long)K * 8 + (long long)N * 9 + 16;
+}
+
+extern "C" int cim_mining_step(const cim_mining_args* args, void* stream) {
+    CIM_CHECK_ARG(args != nullptr);
+    cim_mining_args a = *args;
+    const int N = a.N, K = a.K, C = a.C, R = a.R;
+    CIM_CHECK_ARG(N > 0 && N <= 8192 && K > 0 && K <= 1024 && K <= N && C > 0 && C <= 1024 && R >= 1 && R <= CIM_MAX_LAYERS);
+    CIM_CHECK_ARG(a.labels && a.iou && a.uniforms && a.max_uniforms >= 0 && a.used && a.status && a.layer_valid);
+    bool any_cim = false;
+    for (int l = 0; l < R; ++l) {
+        cim_mining_layer& L = a.layer[l];
+        CIM_CHECK_ARG(L.seed_score && L.wa && L.topk && L.seeds && L.n_seeds && L.res && L.gt_class && L.gt_weight);
+        CIM_CHECK_ARG(L.pre_idx && L.pre_keep && L.gt_idx && L.gt_cls && L.gt_w && L.counts);
+        CIM_CHECK_ARG(L.pseudo_labels && L.pseudo_iou && L.loss_weights && L.max_idx);
+        CIM_CHECK_ARG(!L.using_cim || (L.det && L.flag_slot >= 0 && L.flag_slot < CIM_MAX_LAYERS));
+        any_cim |= L.using_cim != 0;
+        // Python-float thresholds -> the binary16 value the reference's fp16 tensors are compared against
+        L.nms_thr = cim::round_to_f16(L.nms_thr);
+        L.cls_thr = cim::round_to_f16(L.cls_thr);
+        L.iou_thr = cim::round_to_f16(L.iou_thr);
+        L.con_thr = cim::round_to_f16(L.con_thr);
+    }
+    CIM_CHECK_ARG(!any_cim || (a.asy && a.flags));                       // MIST-only steps never touch the containment map
+    hipStream_t st = cim::as_stream(stream);
     int NP = 2;
     while (NP < N) NP <<= 1;
     const int KW = (K + 63) / 64;
     size_t big = (size_t)NP * 8;
     if ((size_t)K * KW * 8 > big) big = (size_t)K * KW * 8;
     big = (big + 15) & ~(size_t)15;
-    const size_t lds = big + (size_t)K * 4;
-    CIM_CHECK_ARG(lds <= 160 * 1024);
-    if (lds > 64 * 1024)
-        CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seed_select_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(seed_select_kernel, dim3(n_cls), dim3(1024), lds, cim::as_stream(stream), seed_score, score_ld,
-                       score_off, iou_f16, N, NP, classes, K, KW, cim::round_to_f16(nms_thr), big, topk_idx, seeds,
-                       n_seeds);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int cim_contain_argmax(const uint16_t* asy_f16, const uint8_t* flag, const float* det, int det_ld,
-                                  int det_off, int det_cstride, int N, const int32_t* classes, int n_cls, int K,
-                                  float con_thr, const int32_t* seeds, const int32_t* n_seeds, int32_t* res_idx,
-                                  void* stream) {
-    CIM_CHECK_ARG(N > 0 && K > 0 && n_cls >= 0 && n_cls <= 65535);
-    if (n_cls == 0) return 0;
-    CIM_CHECK_ARG(asy_f16 && flag && det && classes && seeds && n_seeds && res_idx);
-    hipLaunchKernelGGL(contain_argmax_kernel, dim3(K, n_cls), dim3(256), 0, cim::as_stream(stream), asy_f16, flag, det,
-                       det_ld, det_off, det_cstride, N, classes, K, cim::round_to_f16(con_thr), seeds, n_seeds,
-                       res_idx);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int cim_arbitrate(const int32_t* cand, const int32_t* classes, int n_cls, int K, int N, const float* wa,
-                             int wa_ld, int wa_off, const float* wb, int wb_ld, int wb_off, int wb_cstride,
-                             int32_t* gt_class, float* gt_weight, int32_t* gt_pack, void* stream) {
-    CIM_CHECK_ARG(N > 0 && N <= 65536 && K > 0 && n_cls >= 0);
-    CIM_CHECK_ARG(gt_class && gt_weight && gt_pack && (n_cls == 0 || (cand && classes && wa)));
-    const size_t lds = ((N + 15) & ~15) + 1024 * sizeof(int32_t);
-    hipLaunchKernelGGL(arbitrate_kernel, dim3(1), dim3(1024), lds, cim::as_stream(stream), cand, classes, n_cls, K, N,
-                       wa, wa_ld, wa_off, wb, wb_ld, wb_off, wb_cstride, gt_class, gt_weight, gt_pack);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int cim_assign(const uint16_t* iou_f16, int N, const int32_t* gt_idx, const int32_t* gt_cls,
-                          const float* gt_w, int G, int C1, float cls_thr, float iou_thr, float* pseudo_labels,
-                          uint16_t* pseudo_iou_f16, float* loss_weights, int32_t* max_idx, void* stream) {
-    CIM_CHECK_ARG(N > 0 && G > 0 && C1 > 0);
-    CIM_CHECK_ARG(iou_f16 && gt_idx && gt_cls && gt_w && pseudo_labels && pseudo_iou_f16 && loss_weights && max_idx);
-    hipLaunchKernelGGL(assign_kernel, dim3((N + 3) / 4), dim3(256), 0, cim::as_stream(stream), iou_f16, N, gt_idx,
-                       gt_cls, gt_w, G, C1, cim::round_to_f16(cls_thr), cim::round_to_f16(iou_thr), pseudo_labels,
-                       pseudo_iou_f16, loss_weights, max_idx);
+    const size_t lds1 = big + (size_t)K * 4;
+    CIM_CHECK_ARG(lds1 <= 160 * 1024);
+    if (lds1 > 64 * 1024)
+        CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(step_seed_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    hipLaunchKernelGGL(step_seed_kernel, dim3(C, R), dim3(1024), lds1, st, a, NP, KW, big);
+    if (any_cim) hipLaunchKernelGGL(step_contain_kernel, dim3(K, C, R), dim3(256), 0, st, a);
+    const size_t lds3 = (size_t)cim_mining_lds_bytes(N, K);
+    CIM_CHECK_ARG(lds3 <= 160 * 1024);
+    if (lds3 > 64 * 1024)
+        CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(step_arbitrate_sample_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    hipLaunchKernelGGL(step_arbitrate_sample_kernel, dim3(1), dim3(1024), lds3, st, a);
+    hipLaunchKernelGGL(step_assign_kernel, dim3((N + 3) / 4, R), dim3(256), 0, st, a);
     CIM_CHECK_LAUNCH();
     return 0;
 }

@@ -11,6 +11,8 @@ because the reference draws it from the process-global legacy NumPy RNG (heads.p
 bit-identical pseudo labels require the identical stream.  There is no CPU fallback.
 """
 import ctypes
+import os
+import warnings
 
 import numpy as np
 import torch
@@ -145,50 +147,26 @@ class _LossArgs(ctypes.Structure):
                 ("rc", ctypes.c_void_p * 3), ("ri", ctypes.c_void_p * 3),
                 ("pseudo_labels", ctypes.c_void_p * 3), ("pseudo_iou_f16", ctypes.c_void_p * 3),
                 ("loss_weights", ctypes.c_void_p * 3), ("weight_scale", ctypes.c_float * 3),
-                ("layer_valid", ctypes.c_int * 3), ("labels", ctypes.c_void_p),
-                ("row_cluster", ctypes.c_void_p), ("row_col", ctypes.c_void_p), ("cluster_size", ctypes.c_void_p),
-                ("K", ctypes.c_int), ("bg_cluster", ctypes.c_int),
+                ("layer_valid", ctypes.c_void_p), ("labels", ctypes.c_void_p),
+                ("mat", ctypes.c_void_p), ("status", ctypes.c_void_p),
                 ("N", ctypes.c_int), ("C1", ctypes.c_int), ("R", ctypes.c_int),
                 ("part", ctypes.c_void_p), ("grad", ctypes.c_void_p)]
 
 
-class PCLPlan:
-    """Cluster structure of the PRM matrix `mat` (reference heads.py:14-36), built once per image
-    on the host: per-row cluster index and column, cluster sizes, background cluster.  `None` is
-    returned by `build` for matrices with more than one non-zero per row (general torch path)."""
-
-    def __init__(self, row_cluster, row_col, sizes, bg, device):
-        self.K = int(len(sizes))
-        self.bg = int(bg)
-        self.row_cluster = torch.from_numpy(row_cluster).to(device)
-        self.row_col = torch.from_numpy(row_col).to(device)
-        self.sizes = torch.from_numpy(sizes).to(device)
-
-    @staticmethod
-    def build(mat, device):
-        m = mat.detach().cpu().numpy() if torch.is_tensor(mat) else np.asarray(mat)
-        nz = m != 0
-        if (nz.sum(1) > 1).any():
-            return None
-        row_col = nz.argmax(1).astype(np.int32)
-        vals = m[np.arange(m.shape[0]), row_col]
-        ids = np.unique(vals[vals != 0])
-        col0 = np.unique(m[:, 0][m[:, 0] != 0])
-        assert len(col0) <= 1                                      # heads.py:20
-        row_cluster = np.full(m.shape[0], -1, dtype=np.int32)
-        sizes = np.zeros(len(ids), dtype=np.int32)
-        for k, v in enumerate(ids):
-            sel = vals == v
-            row_cluster[sel] = k
-            sizes[k] = int(sel.sum())
-        bg = int(np.nonzero(ids == col0[0])[0][0]) if len(col0) == 1 else -1
-        return PCLPlan(row_cluster, row_col, sizes, bg, device)
+STATUS_BITS = {1: "a class produced more than K pseudo ground truths (internal)",
+               2: "the pre-drawn uniforms were exhausted (internal)",
+               4: "`mat` has rows with several non-zero entries: the fused PCL loss handles the reference's "
+                  "one-cluster-per-row format (tools/pre/AGPL_label_assign.py:137-185) - set CIM_PCL_GENERAL=1 for the "
+                  "general ATen formulation",
+               8: "several distinct cluster ids in column 0 of `mat` (heads.py:20 asserts at most one)",
+               16: "more PRM clusters in `mat` than the fused PCL loss supports - set CIM_PCL_GENERAL=1"}
 
 
 class FusedLossFunction(torch.autograd.Function):
     """All four losses of the training step in one HIP launch (cim_amd/csrc/losses.hip).
     Returns a tensor [4] = (bag_loss, pcl_loss, cls_loss, iou_loss) with the per-layer lmda weights
-    applied and iou NOT yet multiplied by 3 (model_builder.py:199 does that)."""
+    applied and iou NOT yet multiplied by 3 (model_builder.py:199 does that).  Nothing is read back: which layers
+    count (`valid`, from the mining launches) and the PRM cluster structure of `mat` are resolved on the device."""
 
     @staticmethod
     def forward(ctx, meta, pc, pd, *scores):
@@ -206,20 +184,17 @@ class FusedLossFunction(torch.autograd.Function):
         keep = []
         for i in range(R):
             a.rc[i], a.ri[i] = rc[i].data_ptr(), ri[i].data_ptr()
-            ps = meta["pseudo"][i]
-            a.layer_valid[i] = 0 if ps is None else 1
+            y, t16, w = (x.contiguous() for x in meta["pseudo"][i])
+            assert t16.dtype == torch.float16 and y.dtype == torch.float32 and w.dtype == torch.float32
+            keep += [y, t16, w]
+            a.pseudo_labels[i], a.pseudo_iou_f16[i], a.loss_weights[i] = y.data_ptr(), t16.data_ptr(), w.data_ptr()
             a.weight_scale[i] = float(meta["scales"][i])
-            if ps is not None:
-                y, t16, w = (ps[0].contiguous(), ps[1].contiguous(), ps[2].contiguous())
-                assert t16.dtype == torch.float16 and y.dtype == torch.float32 and w.dtype == torch.float32
-                keep += [y, t16, w]
-                a.pseudo_labels[i], a.pseudo_iou_f16[i], a.loss_weights[i] = y.data_ptr(), t16.data_ptr(), w.data_ptr()
         labels = meta["labels"].reshape(-1).to(torch.float32).contiguous()
-        plan = meta["plan"]
-        a.labels = labels.data_ptr()
-        a.K, a.bg_cluster = plan.K, plan.bg
-        if plan.K:
-            a.row_cluster, a.row_col, a.cluster_size = plan.row_cluster.data_ptr(), plan.row_col.data_ptr(), plan.sizes.data_ptr()
+        mat = meta["mat"].to(torch.float32).contiguous()
+        assert tuple(mat.shape) == (N, C1), "mat must be [N, C+1]"
+        valid, status = meta["valid"], meta["status"]
+        a.labels, a.mat = labels.data_ptr(), mat.data_ptr()
+        a.layer_valid, a.status = _lib.ptr(valid), status.data_ptr()
         a.N, a.C1, a.R = N, C1, R
         a.part, a.grad = part.data_ptr(), grad.data_ptr()
         _lib.call("cim_losses_fwd", ctypes.byref(a), _lib.stream_ptr())
@@ -231,6 +206,10 @@ class FusedLossFunction(torch.autograd.Function):
     def backward(ctx, g):
         (G,) = ctx.saved_tensors
         R = ctx.R
+        # when the whole backward pass has been queued: bring the host's NumPy generator to the position the
+        # mining consumed (no stall: the GPU finished the mining long before the host gets here)
+        if _rng.pending is not None:
+            torch.autograd.Variable._execution_engine.queue_callback(settle_rng)
         g_bag, g_pcl, g_cls, g_iou = g[0], g[1], g[2], g[3]
         d_pc = g_bag * G[0] + g_pcl * G[1]
         d_pd = g_bag * G[2]
@@ -239,13 +218,36 @@ class FusedLossFunction(torch.autograd.Function):
         return (None, d_pc, d_pd, *d_rc, *d_ri)
 
 
-def fused_losses(predict_cls, predict_det, ref_cls_score, ref_iou_score, labels, pseudo, scales, plan):
-    """pseudo[i] = (pseudo_labels, pseudo_iou_labels, loss_weights) of CIM_layer i, or None;
-    scales[i] = lmda.  Returns (bag_loss, pcl_loss, cls_loss, iou_loss) as 0-dim tensors."""
+def fused_losses(predict_cls, predict_det, ref_cls_score, ref_iou_score, labels, pseudo, scales, mat,
+                 valid=None, status=None):
+    """pseudo[i] = (pseudo_labels, pseudo_iou_labels, loss_weights) of CIM_layer i (or None: layer skipped on the
+    host's say-so); scales[i] = lmda; mat = the PRM cluster matrix [N,C+1]; valid = device int32 [R] from
+    `mine_step` (1 = the layer found pseudo ground truths), status = device int32 [1] error word.
+    Returns (bag_loss, pcl_loss, cls_loss, iou_loss) as 0-dim tensors."""
     R = len(ref_cls_score)
-    meta = dict(R=R, pseudo=list(pseudo), scales=list(scales), labels=labels, plan=plan)
+    dev = predict_cls.device
+    pseudo = list(pseudo)
+    if valid is None or any(ps is None for ps in pseudo):
+        host_valid = torch.tensor([0 if ps is None else 1 for ps in pseudo], dtype=torch.int32)
+        valid = host_valid.to(dev) if valid is None else valid * host_valid.to(dev)
+        some = next((ps for ps in pseudo if ps is not None), None)
+        if some is None:
+            n, c1 = predict_cls.shape
+            some = (predict_cls.new_zeros((n, c1)), torch.zeros(n, dtype=torch.float16, device=dev), predict_cls.new_zeros(n))
+        pseudo = [some if ps is None else ps for ps in pseudo]
+    own_status = status is None
+    if own_status:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+    meta = dict(R=R, pseudo=pseudo, scales=list(scales), labels=labels, mat=mat, valid=valid, status=status)
     out = FusedLossFunction.apply(meta, predict_cls, predict_det, *ref_cls_score, *ref_iou_score)
+    if own_status:                     # stand-alone use (tests): report format errors right away
+        check_status(int(status.item()))
     return out[0], out[1], out[2], out[3]
+
+
+def check_status(word):
+    if word:
+        raise _lib.CimHipError("; ".join(msg for bit, msg in STATUS_BITS.items() if word & bit))
 
 
 # --------------------------------------------------------------------------- scoring heads
@@ -310,43 +312,98 @@ class HeadActFunction(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- mining
-class MiningContext:
-    """Per-image state shared by the REFINE_TIMES CIM_layer calls of one training step:
-    image classes (host + device), the containment flag (the three layers share con_thr, so
-    the N x N scan of heads.py:338 is done once instead of three times) and workspaces."""
+class _MiningLayer(ctypes.Structure):
+    """Mirror of `cim_mining_layer` in include/cim_hip.h."""
+    _P, _I, _F = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+    _fields_ = [("seed_score", _P), ("seed_ld", _I), ("seed_off", _I),
+                ("det", _P), ("det_ld", _I), ("det_off", _I), ("det_cs", _I),
+                ("wa", _P), ("wa_ld", _I), ("wa_off", _I),
+                ("wb", _P), ("wb_ld", _I), ("wb_off", _I), ("wb_cs", _I),
+                ("nms_thr", _F), ("cls_thr", _F), ("iou_thr", _F), ("con_thr", _F),
+                ("using_cim", _I), ("anti_noise", _I), ("flag_slot", _I), ("reserved_", _I),
+                ("topk", _P), ("seeds", _P), ("n_seeds", _P), ("res", _P),
+                ("gt_class", _P), ("gt_weight", _P), ("pre_idx", _P), ("pre_keep", _P),
+                ("gt_idx", _P), ("gt_cls", _P), ("gt_w", _P), ("counts", _P),
+                ("pseudo_labels", _P), ("pseudo_iou", _P), ("loss_weights", _P), ("max_idx", _P)]
 
-    def __init__(self, labels, n, device, labels_host=None):
-        if labels_host is None:
-            lab = labels.detach().reshape(-1)
-            labels_host = lab.cpu().numpy() if lab.is_cuda else lab.numpy()
-        lab_host = np.asarray(labels_host).reshape(-1)
-        self.labels_host = lab_host
-        self.classes_host = np.nonzero(lab_host)[0].astype(np.int32)
-        self.num_classes = lab_host.shape[0]
-        self.n = n
-        self.device = device
-        self.classes_dev = torch.from_numpy(self.classes_host).to(device)
-        self.flags = {}
-        self._pinned = {}
-        self.slots = 0          # CIM_layer calls enqueued on this context (one pinned staging pair each)
 
-    def asy_flag(self, asy_iou_map, con_thr):
-        key = (asy_iou_map.data_ptr(), float(con_thr))
-        f = self.flags.get(key)
-        if f is None:
-            f = torch.empty(self.n, dtype=torch.uint8, device=self.device)
-            _lib.call("cim_asy_flag", asy_iou_map.data_ptr(), self.n, float(con_thr), f.data_ptr(), _lib.stream_ptr())
-            self.flags[key] = f
-        return f
+MAX_LAYERS = 4      # CIM_MAX_LAYERS
 
-    def pinned(self, which, nwords):
-        """Page-locked staging buffers, one pair per CIM_layer call of the step: 'down<i>' (D2H pseudo-GT list)
-        and 'up<i>' (H2D survivors).  Served by PyTorch's caching host allocator."""
-        buf = self._pinned.get(which)
-        if buf is None or buf.numel() < nwords:
-            buf = torch.empty(nwords, dtype=torch.int32).pin_memory()
-            self._pinned[which] = buf
-        return buf
+
+class _MiningArgs(ctypes.Structure):
+    """Mirror of `cim_mining_args` in include/cim_hip.h."""
+    _P, _I = ctypes.c_void_p, ctypes.c_int32
+    _fields_ = [("N", _I), ("C", _I), ("K", _I), ("R", _I),
+                ("labels", _P), ("iou", _P), ("asy", _P), ("flags", _P), ("uniforms", _P),
+                ("max_uniforms", _I), ("reserved_", _I),
+                ("used", _P), ("status", _P), ("layer_valid", _P),
+                ("layer", _MiningLayer * MAX_LAYERS)]
+
+
+class _RngLedger:
+    """Keeps the process-global legacy NumPy generator bit-compatible with the reference while the anti-noise
+    sampling (heads.py:451-466: np.random.choice per class, on the host, from the generator the data loader's
+    epoch sampler shares - lib/roi_data/loader.py:94) runs on the device:
+
+      draw()    snapshots the MT19937 state and draws the MAXIMUM number of doubles a step can consume
+                (np.random.random_sample: the very call RandomState.choice makes), which go to the device;
+      commit()  after the step's launches: asynchronous D2H of {used, status, counts} + an event;
+      settle()  waits for that event (long complete when called from the end of backward), restores the snapshot
+                and re-draws exactly `used` doubles: the generator ends where the reference's would.
+
+    settle() runs automatically at the end of the backward pass (FusedLossFunction.backward queues it as an
+    autograd-engine callback) and before the next draw(); `settle_rng()` does it on demand; CIM_MINING_SYNC=1
+    settles inside the forward (one stall per step, the round-1 behaviour)."""
+
+    def __init__(self):
+        self.pending = None
+        self.snapshot = None
+
+    def draw(self, n):
+        self.settle()
+        before = np.random.get_state()
+        u = np.random.random_sample(n)
+        self.snapshot = (before, np.random.get_state())
+        return u
+
+    def commit(self, meta_dev):
+        host = torch.empty(meta_dev.numel(), dtype=torch.int32, pin_memory=True)
+        host.copy_(meta_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (self.snapshot, host, ev)
+        self.snapshot = None
+        return host, ev
+
+    def settle(self):
+        if self.pending is None:
+            return
+        snapshot, host, ev = self.pending
+        self.pending = None
+        ev.synchronize()
+        used, status = int(host[0]), int(host[1])
+        if snapshot is not None:
+            before, after = snapshot
+            now = np.random.get_state()
+            if now[2] == after[2] and np.array_equal(now[1], after[1]):
+                np.random.set_state(before)
+                if used > 0:
+                    np.random.random_sample(used)
+            else:       # the caller re-seeded / used the generator in between: its state wins, nothing to rewind
+                warnings.warn("np.random was re-seeded or used between a training forward and the end of its backward "
+                              "pass: the anti-noise sampling's draws are not rewound (call "
+                              "cim_amd.modeling.heads.settle_rng() right after the forward to avoid this)")
+        check_status(status)
+
+
+_rng = _RngLedger()
+MINING_SYNC = os.environ.get("CIM_MINING_SYNC", "0") == "1"
+
+
+def settle_rng():
+    """Bring np.random to the stream position the last training forward consumed (see _RngLedger).  Call it before
+    using the global NumPy generator between `model(**inputs)` and the end of `loss.backward()`."""
+    _rng.settle()
 
 
 def _f16_map(t, name, n):
@@ -361,9 +418,145 @@ def _f16_map(t, name, n):
     return t.contiguous()
 
 
+class MiningResult:
+    """Device-side outputs of `mine_step`.  pseudo[i] = (pseudo_labels [N,C+1] f32, pseudo_iou_labels [N] f16,
+    loss_weights [N] f32) of layer i - meaningful only where valid[i] != 0 (the reference returns (None, None, None)
+    for such a layer, heads.py:429-430, and the model skips it: here the losses kernel reads valid[i])."""
+
+    def __init__(self):
+        self.pseudo = []
+        self.valid = None            # device int32 [R]
+        self.status = None           # device int32 [1]
+        self.meta = None             # device int32 [2 + 2R]: used, status, (G, G') per layer
+        self.debug = []              # per layer: dict of device tensors (tests / CIM_layer.last)
+        self.host = None
+        self.keep_alive = None
+
+    def commit(self):
+        """Queue the D2H of the step's bookkeeping words; the NumPy generator is settled later (see _RngLedger)."""
+        self.host, _ = _rng.commit(self.meta)
+        if MINING_SYNC:
+            _rng.settle()
+        return self
+
+
+@torch.no_grad()
+def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None):
+    """The mining + assignment of all CIM layers of one training step (reference: the three CIM_layer.forward calls
+    of model_builder.py:170-187) in 5 launches, nothing read back.  layers: CIM_layer modules (thresholds);
+    scores[i] = (predict_cls, predict_det) fed to layer i; labels [1,C] / [C] device tensor."""
+    R = len(layers)
+    assert 1 <= R <= MAX_LAYERS
+    using_CIM = [True] * R if using_CIM is None else list(using_CIM)
+    cls0 = scores[0][0]
+    if not cls0.is_cuda:
+        raise _lib.CimHipError("CIM_layer: the HIP path needs CUDA/HIP tensors (no CPU fallback)")
+    dev = cls0.device
+    N = cls0.shape[0]
+    labels = labels.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+    C = labels.shape[0]
+    assert C == 20 or C == 80                                            # heads.py:266,324
+    C1 = C + 1
+    K = int(np.ceil(layers[0].p_seed * N))                               # heads.py:332
+    assert all(int(np.ceil(l.p_seed * N)) == K for l in layers), "the layers of one step share p_seed"
+    iou_map = _f16_map(iou_map, "iou_map", N)
+    any_cim = any(using_CIM)
+    if any_cim:
+        asy_iou_map = _f16_map(asy_iou_map, "asy_iou_map", N)
+    st = _lib.stream_ptr()
+
+    # containment flags: one N x N scan per DISTINCT con_thr (the reference rescans in every layer, heads.py:338)
+    thr_slots = []
+    for l, u in zip(layers, using_CIM):
+        if u and float(l.con_thr) not in thr_slots:
+            thr_slots.append(float(l.con_thr))
+    u8 = torch.empty((max(len(thr_slots), 1) + R, N), dtype=torch.uint8, device=dev)
+    flags, pre_keep = u8[:max(len(thr_slots), 1)], u8[max(len(thr_slots), 1):]
+    for slot, thr in enumerate(thr_slots):
+        _lib.call("cim_asy_flag", asy_iou_map.data_ptr(), N, thr, flags[slot].data_ptr(), st)
+
+    per_i = 3 * C * K + C + 5 * N
+    ints = torch.empty(R * per_i + 2 + 3 * R, dtype=torch.int32, device=dev)
+    meta = ints[R * per_i:R * per_i + 2 + 2 * R]                          # used, status, (G, G') x R
+    valid = ints[R * per_i + 2 + 2 * R:]
+    f32 = torch.empty((R, 2, N), dtype=torch.float32, device=dev)
+    n_anti = sum(1 for l in layers if l.Anti_noise_sampling)
+    max_u = n_anti * min(N, C * K)
+    if max_u:
+        u_host = torch.empty(max_u, dtype=torch.float64, pin_memory=True)
+        u_host.numpy()[:] = _rng.draw(max_u)
+        uniforms = u_host.to(dev, non_blocking=True)
+    else:
+        _rng.settle()
+        uniforms = torch.empty(1, dtype=torch.float64, device=dev)
+
+    a = _MiningArgs()
+    a.N, a.C, a.K, a.R = N, C, K, R
+    a.labels, a.iou, a.asy = labels.data_ptr(), iou_map.data_ptr(), _lib.ptr(asy_iou_map if any_cim else None)
+    a.flags, a.uniforms, a.max_uniforms = flags.data_ptr(), uniforms.data_ptr(), max_u
+    a.used, a.status, a.layer_valid = meta[0:1].data_ptr(), meta[1:2].data_ptr(), valid.data_ptr()
+    out = MiningResult()
+    keep = [labels, iou_map, asy_iou_map, uniforms, u8, ints, f32]
+    for i, (layer, (pcls, pdet)) in enumerate(zip(layers, scores)):
+        L = a.layer[i]
+        cls = pcls.detach().to(torch.float32).contiguous()
+        assert cls.shape[0] == N
+        cls_off = 1 if cls.shape[-1] - 1 == C else 0
+        if using_CIM[i]:
+            det = pdet.detach().to(torch.float32).contiguous()
+            if det.shape[-1] - 1 == C:
+                det_off, det_cs = 1, 1
+            elif det.shape[-1] == C:
+                det_off, det_cs = 0, 1
+            elif det.shape[-1] == 1:
+                det_off, det_cs = 0, 0
+            else:
+                raise NotImplementedError("Detector only supports class-specific and class-agnostic methods")
+            L.seed_score, L.seed_ld, L.seed_off = cls.data_ptr(), cls.shape[-1], cls_off
+            L.det, L.det_ld, L.det_off, L.det_cs = det.data_ptr(), det.shape[-1], det_off, det_cs
+            L.wa, L.wa_ld, L.wa_off = cls.data_ptr(), cls.shape[-1], cls_off
+            L.wb, L.wb_ld, L.wb_off, L.wb_cs = det.data_ptr(), det.shape[-1], det_off, det_cs
+            L.flag_slot = thr_slots.index(float(layer.con_thr))
+            keep += [cls, det]
+        else:                                                            # MIST_label, heads.py:421-427,261-316
+            preds = (cls * pdet.detach().to(torch.float32) if pdet is not None else cls).contiguous()
+            L.seed_score, L.seed_ld, L.seed_off = preds.data_ptr(), preds.shape[-1], cls_off
+            L.wa, L.wa_ld, L.wa_off = preds.data_ptr(), preds.shape[-1], cls_off
+            L.det = L.wb = None
+            keep.append(preds)
+        L.nms_thr, L.cls_thr, L.iou_thr, L.con_thr = float(layer.nms_thr), float(layer.cls_thr), float(layer.iou_thr), float(layer.con_thr)
+        L.using_cim, L.anti_noise = int(bool(using_CIM[i])), int(bool(layer.Anti_noise_sampling))
+        w = ints[i * per_i:(i + 1) * per_i]
+        o = 0
+        views = {}
+        for name, n in (("topk", C * K), ("seeds", C * K), ("res", C * K), ("n_seeds", C), ("gt_class", N),
+                        ("pre_idx", N), ("gt_idx", N), ("gt_cls", N), ("max_idx", N)):
+            views[name] = w[o:o + n]
+            o += n
+            setattr(L, name, views[name].data_ptr())
+        L.counts = meta[2 + 2 * i:4 + 2 * i].data_ptr()
+        L.gt_weight, L.gt_w = f32[i, 0].data_ptr(), f32[i, 1].data_ptr()
+        L.pre_keep = pre_keep[i].data_ptr()
+        pseudo_labels = torch.empty((N, C1), dtype=torch.float32, device=dev)
+        pseudo_iou = torch.empty((N,), dtype=torch.float16, device=dev)
+        loss_weights = torch.empty((N,), dtype=torch.float32, device=dev)
+        L.pseudo_labels, L.pseudo_iou, L.loss_weights = pseudo_labels.data_ptr(), pseudo_iou.data_ptr(), loss_weights.data_ptr()
+        out.pseudo.append((pseudo_labels, pseudo_iou, loss_weights))
+        views.update(gt_weight=f32[i, 0], gt_w=f32[i, 1], pre_keep=pre_keep[i], counts=meta[2 + 2 * i:4 + 2 * i],
+                     asy_flag=flags[L.flag_slot] if using_CIM[i] else None, C=C, K=K)
+        out.debug.append(views)
+    _lib.call("cim_mining_step", ctypes.byref(a), st)
+    out.valid, out.status, out.meta, out.keep_alive = valid, meta[1:2], meta, keep
+    return out
+
+
 class CIM_layer(nn.Module):
     """Complete Instances Mining (reference heads.py:222-503): top-p seeds -> mask-IoU NMS ->
-    containment mining -> cross-class arbitration -> anti-noise sampling -> IoU assignment."""
+    containment mining -> cross-class arbitration -> anti-noise sampling -> IoU assignment.
+
+    `forward` keeps the reference's one-call interface, including `(None, None, None)` when no pseudo ground truth
+    is found - which needs the host to look at the result, so it waits for the device once.  The model does not call
+    it: `Generalized_RCNN.forward` runs all layers of a step through `mine_step` without any read-back."""
 
     def __init__(self, p_seed=0.1, cls_thr=0.25, iou_thr=0.5, con_thr=0.85, Anti_noise_sampling=True):
         super().__init__()
@@ -376,138 +569,21 @@ class CIM_layer(nn.Module):
         self.last = {}                  # device-side intermediates of the last call (tests / debugging)
 
     @torch.no_grad()
-    def forward(self, predict_cls, predict_det, rois, labels, iou_map=None, asy_iou_map=None, using_CIM=True,
-                _ctx=None):
-        return self.finish(self.enqueue(predict_cls, predict_det, rois, labels, iou_map, asy_iou_map, using_CIM, _ctx))
-
-    @torch.no_grad()
-    def enqueue(self, predict_cls, predict_det, rois, labels, iou_map=None, asy_iou_map=None, using_CIM=True,
-                _ctx=None):
-        """Device half of forward(): seed selection, containment mining, arbitration and the asynchronous D2H copy
-        of the pseudo-GT list.  The layers of one step read only the heads' outputs, so the model enqueues all of
-        them before it waits for the first (`finish`, in layer order: the NumPy RNG stream is consumed exactly as
-        by the reference's sequential calls) - one host stall per step instead of one per layer."""
-        if not predict_cls.is_cuda:
-            raise _lib.CimHipError("CIM_layer: the HIP path needs CUDA/HIP tensors (no CPU fallback)")
-        dev = predict_cls.device
-        N = predict_cls.shape[0]
-        iou_map = _f16_map(iou_map, "iou_map", N)
-        ctx = _ctx if _ctx is not None else MiningContext(labels, N, dev)
-        C = ctx.num_classes
-        assert C == 20 or C == 80                                        # heads.py:266,324
-        C1 = C + 1
-        n_cls = int(ctx.classes_host.shape[0])
-        K = int(np.ceil(self.p_seed * N))                                # heads.py:332
-        st = _lib.stream_ptr()
-
-        cls = predict_cls.detach().to(torch.float32).contiguous()
-        cls_off = 1 if cls.shape[-1] - 1 == C else 0
-        if using_CIM:
-            asy_iou_map = _f16_map(asy_iou_map, "asy_iou_map", N)
-            det = predict_det.detach().to(torch.float32).contiguous()
-            if det.shape[-1] - 1 == C:
-                det_off, det_cs = 1, 1
-            elif det.shape[-1] == C:
-                det_off, det_cs = 0, 1
-            elif det.shape[-1] == 1:
-                det_off, det_cs = 0, 0
-            else:
-                raise NotImplementedError("Detector only supports class-specific and class-agnostic methods")
-            seed_score, wa, wb = cls, cls, det
-        else:
-            preds = cls * predict_det.detach().to(torch.float32) if predict_det is not None else cls
-            preds = preds.contiguous()
-            seed_score, wa, wb = preds, preds, None
-            det_off = det_cs = 0
-
-        ws = torch.empty((3 * max(n_cls, 1) * K + max(n_cls, 1),), dtype=torch.int32, device=dev)
-        topk = ws[0:n_cls * K]
-        seeds = ws[n_cls * K:2 * n_cls * K]
-        res = ws[2 * n_cls * K:3 * n_cls * K]
-        n_seeds = ws[3 * max(n_cls, 1) * K:3 * max(n_cls, 1) * K + max(n_cls, 1)]
-        gt_class = torch.empty(N, dtype=torch.int32, device=dev)
-        gt_weight = torch.empty(N, dtype=torch.float32, device=dev)
-        gt_pack = torch.empty(1 + 3 * N, dtype=torch.int32, device=dev)
-
-        if n_cls > 0:
-            _lib.call("cim_seed_select", seed_score.data_ptr(), seed_score.shape[-1], cls_off, iou_map.data_ptr(), N,
-                      ctx.classes_dev.data_ptr(), n_cls, K, float(self.nms_thr), topk.data_ptr(), seeds.data_ptr(),
-                      n_seeds.data_ptr(), st)
-            if using_CIM:
-                flag = ctx.asy_flag(asy_iou_map, self.con_thr)
-                _lib.call("cim_contain_argmax", asy_iou_map.data_ptr(), flag.data_ptr(), det.data_ptr(),
-                          det.shape[-1], det_off, det_cs, N, ctx.classes_dev.data_ptr(), n_cls, K,
-                          float(self.con_thr), seeds.data_ptr(), n_seeds.data_ptr(), res.data_ptr(), st)
-                cand = res
-            else:
-                cand = seeds
-        else:
-            cand = ws
-        _lib.call("cim_arbitrate", _lib.ptr(cand), ctx.classes_dev.data_ptr(), n_cls, K, N,
-                  wa.data_ptr(), wa.shape[-1], cls_off,
-                  _lib.ptr(wb), (wb.shape[-1] if wb is not None else 0), det_off, det_cs,
-                  gt_class.data_ptr(), gt_weight.data_ptr(), gt_pack.data_ptr(), st)
-
-        # ---- the one host round trip of the layer: pseudo-GT list for the NumPy sampling
-        slot = ctx.slots
-        ctx.slots += 1
-        host = ctx.pinned("down%d" % slot, 1 + 3 * N)
-        host[:1 + 3 * N].copy_(gt_pack, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record()
-        return dict(ctx=ctx, slot=slot, host=host, done=done, N=N, C1=C1, n_cls=n_cls, K=K, topk=topk, seeds=seeds,
-                    n_seeds=n_seeds, res=res, gt_class=gt_class, gt_weight=gt_weight, iou_map=iou_map,
-                    asy_iou_map=asy_iou_map, using_CIM=using_CIM, dev=dev, keep_alive=(gt_pack, ws, cls))
-
-    @torch.no_grad()
-    def finish(self, s):
-        """Host half of forward(): wait for this layer's D2H copy, anti-noise sampling on the global NumPy RNG,
-        H2D of the survivors, IoU assignment."""
-        ctx, N, C1, n_cls, K, dev = s["ctx"], s["N"], s["C1"], s["n_cls"], s["K"], s["dev"]
-        topk, seeds, n_seeds, res, gt_class, gt_weight = (s[k] for k in ("topk", "seeds", "n_seeds", "res", "gt_class", "gt_weight"))
-        iou_map, asy_iou_map, using_CIM = s["iou_map"], s["asy_iou_map"], s["using_CIM"]
-        st = _lib.stream_ptr()
-        s["done"].synchronize()
-        hp = s["host"].numpy()
-        G = int(hp[0])
-        self.last = dict(topk=topk.view(n_cls, K) if n_cls else topk, seeds=seeds.view(n_cls, K) if n_cls else seeds,
-                         n_seeds=n_seeds[:n_cls], res=res.view(n_cls, K) if n_cls else res,
-                         gt_class=gt_class, gt_weight=gt_weight, G=G,
-                         asy_flag=ctx.asy_flag(asy_iou_map, self.con_thr) if (using_CIM and n_cls > 0) else None)
+    def forward(self, predict_cls, predict_det, rois, labels, iou_map=None, asy_iou_map=None, using_CIM=True):
+        res = mine_step([self], [(predict_cls, predict_det)], labels, iou_map, asy_iou_map, [using_CIM]).commit()
+        _rng.settle()                                                    # waits for the device: G decides the return value
+        d = res.debug[0]
+        G, Gk = int(res.host[2]), int(res.host[3])
+        C, K = d["C"], d["K"]
+        classes = torch.nonzero(labels.detach().reshape(-1)).reshape(-1).to(d["topk"].device)
+        pick = lambda name: d[name].view(C, K).index_select(0, classes)
+        self.last = dict(topk=pick("topk"), seeds=pick("seeds"), res=pick("res"),
+                         n_seeds=d["n_seeds"].index_select(0, classes), gt_class=d["gt_class"], gt_weight=d["gt_weight"],
+                         G=G, asy_flag=d["asy_flag"] if classes.numel() else None)
         if G == 0:                                                       # heads.py:429-430
             return None, None, None
-        gt_idx = hp[1:1 + G].copy()
-        gt_cls = hp[1 + N:1 + N + G].copy()
-        gt_w = hp[1 + 2 * N:1 + 2 * N + G].copy().view(np.float32)
-
-        if self.Anti_noise_sampling:                                     # heads.py:438-473
-            keep = np.ones(G, dtype=bool)
-            for c in ctx.classes_host:
-                class_idx = np.nonzero(gt_cls == c + 1)[0]
-                if len(class_idx) == 0:
-                    continue
-                prob = gt_w[class_idx]
-                sampled = np.random.choice(class_idx, size=len(class_idx), replace=True, p=prob / prob.sum())
-                keep[class_idx] = False
-                keep[np.unique(sampled)] = True
-            self.last["sample_keep"] = keep
-            gt_idx, gt_cls, gt_w = gt_idx[keep], gt_cls[keep], gt_w[keep]
-        Gk = int(gt_idx.shape[0])
-
-        up = ctx.pinned("up%d" % s["slot"], 3 * N)      # per layer: the previous layer's H2D may still be in flight
-        upn = up.numpy()
-        upn[0:Gk] = gt_idx
-        upn[Gk:2 * Gk] = gt_cls
-        upn[2 * Gk:3 * Gk] = gt_w.view(np.int32)
-        dev_gt = torch.empty(3 * Gk, dtype=torch.int32, device=dev)
-        dev_gt.copy_(up[:3 * Gk], non_blocking=True)
-
-        pseudo_labels = torch.empty((N, C1), dtype=torch.float32, device=dev)
-        pseudo_iou = torch.empty((N,), dtype=torch.float16, device=dev)
-        loss_weights = torch.empty((N,), dtype=torch.float32, device=dev)
-        max_idx = torch.empty((N,), dtype=torch.int32, device=dev)
-        _lib.call("cim_assign", iou_map.data_ptr(), N, dev_gt[0:Gk].data_ptr(), dev_gt[Gk:2 * Gk].data_ptr(),
-                  dev_gt[2 * Gk:3 * Gk].data_ptr(), Gk, C1, float(self.cls_thr), float(self.iou_thr),
-                  pseudo_labels.data_ptr(), pseudo_iou.data_ptr(), loss_weights.data_ptr(), max_idx.data_ptr(), st)
-        self.last["max_overlap_idx"] = max_idx
-        return pseudo_labels, pseudo_iou, loss_weights
+        if self.Anti_noise_sampling:
+            self.last["sample_keep"] = d["pre_keep"][:G].cpu().numpy().astype(bool)
+        self.last["max_overlap_idx"] = d["max_idx"]
+        self.last["gt_idx"] = d["gt_idx"][:Gk]
+        return res.pseudo[0]

@@ -8,6 +8,10 @@ training and `{'blob_conv', 'refine_score'}` in eval; attributes `Conv_Body`, `B
 `cls_iou_model`, `CIM_layer_list`, `using_CIM`; `roi_feature_transform`, `convbody_net`,
 `detectron_weight_mapping`.
 
+The training forward never waits for the device: there is no host copy of `labels` / `mat`, no per-image cache,
+the mining's host-visible results (stream position of the NumPy generator, format errors) are settled at the end
+of the backward pass (heads._RngLedger).
+
 Extension: `forward` also accepts `iou_map=` / `asy_iou_map=` float16 device
 tensors [N,N] (e.g. built on device by cim_amd.mask_iou) so that no disk I/O happens inside
 the step; when absent the reference's pickle path (model_builder.py:147-159) is used.
@@ -72,6 +76,7 @@ def _load_map(directory, stem, what, device, index):
         raise NotImplementedError("Please generate or download " + what)
 
 
+PCL_GENERAL = os.environ.get("CIM_PCL_GENERAL", "0") == "1"            # losses in ATen ops (general `mat` format)
 GRAPH_BACKBONE = os.environ.get("CIM_GRAPH_BACKBONE", "0") == "1"     # opt-in: measured SLOWER on ROCm 7.2 (see _conv_body)
 GRAPH_AFTER = 3         # graph a shape from its 3rd occurrence
 GRAPH_SHAPES = 4        # distinct image shapes kept as graphs
@@ -130,18 +135,7 @@ class Generalized_RCNN(nn.Module):
                 iou_map=None, asy_iou_map=None):
         with torch.set_grad_enabled(self.training):
             im_data = data
-            labels_host = mat_host = None
             if self.training:
-                if not labels.is_cuda:
-                    labels_host = labels.detach().reshape(-1).numpy().copy()
-                else:       # device-resident labels: one read-back per tensor version, not a device sync every step
-                    key = (labels.data_ptr(), labels._version, tuple(labels.shape))
-                    cache = self.__dict__.get("_labels_cache")
-                    if cache is None or cache[0] != key:
-                        cache = self.__dict__["_labels_cache"] = (key, labels.detach().reshape(-1).cpu().numpy().copy())
-                    labels_host = cache[1]
-                if not mat.is_cuda:
-                    mat_host = mat.detach().squeeze(dim=0).numpy()
                 dev, dt = im_data.device, im_data.dtype
                 rois = rois.squeeze(dim=0).to(device=dev, dtype=dt)
                 masks = masks.squeeze(dim=0).to(device=dev, dtype=dt)
@@ -163,28 +157,28 @@ class Generalized_RCNN(nn.Module):
                 iou_map = _load_map(cfg.iou_dir, stem, "iou_map", labels.device, index)
                 asy_iou_map = _load_map(cfg.asy_iou_dir, stem, "asy_iou_map", labels.device, index)
 
-            n = predict_cls.shape[0]
-            ctx = heads.MiningContext(labels, n, predict_cls.device, labels_host=labels_host)
-            pseudo, scales, pending = [], [], []
-            for i, layer in enumerate(self.CIM_layer_list):                  # device halves of all layers first ...
-                src_cls, src_det = (predict_cls, predict_det) if i == 0 else (ref_cls_score[i - 1], ref_iou_score[i - 1])
-                pending.append(layer.enqueue(src_cls, src_det, rois, labels, iou_map, asy_iou_map,
-                                             using_CIM=self.using_CIM[i], _ctx=ctx))
-            for i, layer in enumerate(self.CIM_layer_list):                  # ... then the host halves, in layer order
-                out = layer.finish(pending[i])
-                pseudo.append(None if out[0] is None else out)               # model_builder.py:189-190
-                scales.append(3 if i == 0 else 1)                            # lmda, model_builder.py:172
-            plan = self._pcl_plan(mat, mat_host)
-            if plan is not None and cfg.REFINE_TIMES <= 3:
+            # model_builder.py:170-187: layer 0 mines on the MIL scores, layer i on the (i-1)-th refinement's; every
+            # layer reads head outputs only, so all of them run in ONE fused set of launches - no host round trip:
+            # classes, pseudo-GT counts, the anti-noise sampling and "no pseudo GT -> skip the layer" stay on the device
+            scores = [(predict_cls, predict_det) if i == 0 else (ref_cls_score[i - 1], ref_iou_score[i - 1])
+                      for i in range(len(self.CIM_layer_list))]
+            mined = heads.mine_step(self.CIM_layer_list, scores, labels, iou_map, asy_iou_map, self.using_CIM)
+            scales = [3 if i == 0 else 1 for i in range(len(self.CIM_layer_list))]      # lmda, model_builder.py:172
+            if cfg.REFINE_TIMES <= 3 and not PCL_GENERAL:
                 # all four losses + their gradient components in one HIP launch (csrc/losses.hip)
                 bag, pcl, cls_l, iou_l = heads.fused_losses(predict_cls, predict_det, ref_cls_score, ref_iou_score,
-                                                            labels, pseudo, scales, plan)
+                                                            labels, mined.pseudo, scales, mat,
+                                                            valid=mined.valid, status=mined.status)
+                mined.commit()
                 losses = dict(bag_loss=bag, pcl_loss=pcl, cls_loss=cls_l, iou_loss=3 * iou_l)   # model_builder.py:199
-            else:   # general `mat` (several non-zeros per row): the reference's formulation in ATen ops
+            else:   # general `mat` (several non-zeros per row) / more than 3 refinements: the reference's formulation
+                    # in ATen ops; which layers count is decided on the host as the reference does (one device wait)
+                mined.commit()
+                heads.settle_rng()
                 zero = seg_x.new_zeros(())
                 losses = dict(bag_loss=zero.clone(), pcl_loss=zero.clone(), cls_loss=zero.clone(), iou_loss=zero.clone())
-                for i, ps in enumerate(pseudo):
-                    if ps is None:
+                for i, ps in enumerate(mined.pseudo):
+                    if int(mined.host[2 + 2 * i]) == 0:                          # model_builder.py:189-190
                         continue
                     cls_loss, iou_loss, bag_loss = heads.cls_iou_loss(ref_cls_score[i], ref_iou_score[i], ps[0], ps[1],
                                                                       scales[i] * ps[2], labels)
@@ -193,6 +187,7 @@ class Generalized_RCNN(nn.Module):
                     losses["bag_loss"] = losses["bag_loss"] + bag_loss
                 losses["bag_loss"] = losses["bag_loss"] + heads.mil_bag_loss(predict_cls, predict_det, labels)
                 losses["pcl_loss"] = losses["pcl_loss"] + heads.PCL_loss(predict_cls, mat, labels)
+            self.__dict__["_last_mining"] = mined              # debugging / tests: device-side intermediates of the step
             return_dict["losses"] = {k: v.unsqueeze(0) for k, v in losses.items()}
             return return_dict
 
@@ -226,17 +221,6 @@ class Generalized_RCNN(nn.Module):
         if g is False:
             return self.Conv_Body(im_data)
         return g(im_data)
-
-    def _pcl_plan(self, mat, mat_host):
-        """PRM cluster plan of this image.  Built from the host copy when the loader handed a CPU
-        tensor; for a device-resident `mat` it is read back once and cached by storage identity."""
-        if mat_host is not None:
-            return heads.PCLPlan.build(mat_host, mat.device)
-        key = (mat.data_ptr(), mat._version, tuple(mat.shape))
-        cache = getattr(self, "_plan_cache", None)
-        if cache is None or cache[0] != key:
-            self._plan_cache = (key, heads.PCLPlan.build(mat, mat.device))
-        return self._plan_cache[1]
 
     def roi_feature_transform(self, blobs_in, rois, method="RoIPoolF", resolution=7, spatial_scale=1.0 / 16.0,
                               sampling_ratio=0):

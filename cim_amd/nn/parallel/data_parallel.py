@@ -16,9 +16,17 @@ the only collective is the gradient all-reduce:
   * buckets are ordered in reverse parameter order (= backward completion order);
     a bucket's all-reduce is launched from a post-accumulate-grad hook as soon as its last
     gradient is written, so RCCL traffic overlaps the rest of backward;
-  * sum-all-reduce of (loss / world) gradients == the reference's `loss.mean(dim=0)` over GPUs
-    (lib/utils/training_stats.py:100).
+  * the all-reduce AVERAGES over ranks (RCCL's AVG; SUM + one scale on backends without it) == the reference's
+    `loss.mean(dim=0)` over GPUs (lib/utils/training_stats.py:100) - the driver does not rescale its loss;
+  * the driver loop needs NO extra call: whatever was not reduced by the hooks is reduced, and all collectives are
+    waited for, in an autograd-engine callback at the end of `loss.backward()` (tools/train.py:436-438 unchanged);
+    with gradient accumulation (`--iter_size k`, train.py:420) set `iter_size=k` (or CIM_ITER_SIZE=k) and only the
+    k-th backward after `zero_grad()` communicates (leaving it at 1 is still correct - averaging is linear - but
+    reduces k times);
+  * construction broadcasts rank 0's parameters and buffers (a per-rank checkpoint load or a nondeterministic
+    initialisation cannot make the replicas diverge silently).
 """
+import os
 import contextlib
 
 import torch
@@ -29,7 +37,7 @@ from torch import nn
 class DataParallel(nn.Module):
     def __init__(self, module, device_ids=None, output_device=None, dim=0, cpu_keywords=(), minibatch=False,
                  batch_outputs=True, bucket_bytes=64 << 20, process_group=None, force_flat_grads=False,
-                 big_bytes=16 << 20):
+                 big_bytes=16 << 20, iter_size=None):
         super().__init__()
         self.module = module
         self.cpu_keywords = list(cpu_keywords)
@@ -42,11 +50,27 @@ class DataParallel(nn.Module):
         self.device_ids = [self.device.index] if self.device.type == "cuda" else []
         self.output_device = self.device
         self._sync = True
+        self._avg_op = None
         self._pending = []
         self._next_bucket = 0
         self._force_flat = force_flat_grads
         self._big_bytes = big_bytes
+        self.iter_size = int(os.environ.get("CIM_ITER_SIZE", "1")) if iter_size is None else int(iter_size)
+        self._backwards = 0          # backward passes since zero_grad()
+        self._cb_queued = False
+        self.comm_works = None       # optional (bench.py): list that receives every collective's Work object
+        if self.world_size > 1:
+            self._broadcast_module_state()
         self._build_flat_grads(bucket_bytes)
+
+    def _broadcast_module_state(self):
+        tensors = [p.data for p in self.module.parameters()] + [b.data for b in self.module.buffers()]
+        pg = self.process_group if self.process_group is not None else dist.group.WORLD
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        for group in by_dtype.values():
+            dist._broadcast_coalesced(pg, group, 256 << 20, 0)
 
     # ------------------------------------------------------------------ flat gradient storage
     def _build_flat_grads(self, bucket_bytes):
@@ -61,7 +85,7 @@ class DataParallel(nn.Module):
             return
         big = set(p for p in params if p.numel() * 4 >= self._big_bytes)
         self._big = [p for p in params if p in big]
-        total = sum(p.numel() for p in params if p not in big)
+        total = sum((p.numel() + 3) & ~3 for p in params if p not in big)
         self.flat_grad = torch.zeros(max(total, 1), dtype=torch.float32, device=self.device)
         # reverse registration order ~ order in which backward produces gradients
         off = 0
@@ -74,7 +98,7 @@ class DataParallel(nn.Module):
             n = p.numel()
             p.grad = self.flat_grad[off:off + n].view_as(p)
             spans.append((p, off, off + n))
-            off += n
+            off += (n + 3) & ~3      # 16-byte aligned views: float4 accesses / matrix mode of the fused SGD stay enabled
         # buckets: contiguous spans of ~bucket_bytes of the flat buffer; a big tensor (seg_fc.0: 822 MB) is its own bucket
         self.buckets = []
         cur = None
@@ -96,8 +120,14 @@ class DataParallel(nn.Module):
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
 
+    def _sync_this_backward(self):
+        return self._sync and (self._backwards + 1) % max(self.iter_size, 1) == 0
+
     def _on_grad_ready(self, p):
-        if not self._sync:
+        if not self._cb_queued:       # first gradient of this backward pass: finish the reduction when the pass ends
+            self._cb_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        if not self._sync_this_backward():
             return
         bk = self.buckets[self._bucket_of[p]]
         bk["ready"] += 1
@@ -125,12 +155,34 @@ class DataParallel(nn.Module):
                 buf = p.grad
             else:
                 buf = self.flat_grad[bk["start"]:bk["end"]]
-            self._pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+            self._all_reduce_mean(buf)
             self._next_bucket += 1
+
+    def _all_reduce_mean(self, buf):
+        if self._avg_op is None:
+            self._avg_op = dist.get_backend(self.process_group) == "nccl"
+        if self._avg_op:
+            w = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.process_group, async_op=True)
+            self._pending.append((w, None))
+        else:
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            self._pending.append((w, buf))
+        if self.comm_works is not None:
+            self.comm_works.append(w)
+
+    def _end_of_backward(self):
+        self._cb_queued = False
+        if self.world_size > 1 and self._sync_this_backward():
+            self.finish_gradient_sync()
+        self._backwards += 1
 
     def zero_grad(self, set_to_none=False):
         """One memset of the flat buffer (param.grad stay views into it); without a flat buffer
         (single process) the gradients are simply dropped."""
+        if self._pending or self._next_bucket:
+            raise RuntimeError("DataParallel.zero_grad(): gradient all-reduces of the previous backward are still in "
+                               "flight (a backward pass was interrupted?) - call finish_gradient_sync() first")
+        self._backwards = 0
         if self.flat_grad is None:
             for p in self._params:
                 p.grad = None
@@ -150,18 +202,24 @@ class DataParallel(nn.Module):
 
     def finish_gradient_sync(self):
         """Reduce whatever has not been reduced yet (in bucket order) and wait for the in-flight
-        all-reduces.  Call after backward, before optimizer.step()."""
-        if self.world_size > 1 and self._sync:
+        all-reduces.  Runs by itself at the end of every backward pass that
+        communicates (`_end_of_backward`); calling it again is a no-op."""
+        if self.world_size > 1 and self._sync and (self._next_bucket or any(bk["ready"] for bk in self.buckets)
+                                                   or not self._cb_queued):
             self._launch_ready_buckets(force=True)
-        for w in self._pending:
+        for w, buf in self._pending:
             w.wait()
+            if buf is not None:
+                buf.div_(self.world_size)
         self._pending = []
         self._next_bucket = 0
         for bk in self.buckets:
             bk["ready"] = 0
 
     def loss_scale(self):
-        return 1.0 / self.world_size
+        """Kept for drivers written against the first version of this wrapper: the all-reduce averages, so the loss
+        needs no rescaling."""
+        return 1.0
 
     # ------------------------------------------------------------------ forward
     def _to_device(self, k, v):

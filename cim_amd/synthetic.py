@@ -87,16 +87,18 @@ def make_mat(masks, labels_pos, num_classes, rng):
     return mat
 
 
-def make_image_inputs(config="resnet50_voc", seed=3, n=None, with_image=True):
+def make_image_inputs(config="resnet50_voc", seed=3, n=None, with_image=True, target=None):
     """One synthetic training image.  Returns a dict of NumPy arrays:
     data[1,3,H,W] f32, rois[N,5] f32, masks[N,7,7] f32, labels[1,C] f32, mat[N,C+1] f32,
-    index[N] i64, full_masks[N,h,w] bool, boxes[N,4] i64, im_scale."""
+    index[N] i64, full_masks[N,h,w] bool, boxes[N,4] i64, im_scale.
+    target = longest image side after scaling (one of cfg.TRAIN.SCALES, configs/resnet50_voc.yaml:34; default: the
+    config's median scale)."""
     cfg = CONFIGS[config]
     rng = np.random.RandomState(seed)
     h, w = cfg["orig_hw"]
     n = cfg["n"] if n is None else n
     C = cfg["classes"]
-    im_scale = float(cfg["target"]) / float(max(h, w))                 # utils/blob.py:165
+    im_scale = float(target or cfg["target"]) / float(max(h, w))       # utils/blob.py:165
     H, W = int(round(h * im_scale)), int(round(w * im_scale))
     full_masks, boxes = make_masks(n, h, w, rng)
     rois = np.zeros((n, 5), dtype=np.float32)

@@ -105,50 +105,70 @@ int cim_mask_iou_pair(const uint64_t* packed, int N, int words, int32_t* area,
 /* heads.py:338: flag[i] = (#{j : asy[i,j] > con_thr}) < 0.9*N     (flag: uint8 [N]) */
 int cim_asy_flag(const uint16_t* asy_f16, int N, float con_thr, uint8_t* flag, void* stream);
 
-/* Step 1 (heads.py:354-380 / 279-304): for each of the n_cls image classes (class ids in
- * `classes`, ascending), stable-descending top-K of seed_score[:, c] and greedy NMS over
- * the K x K sub-block of iou (keep dst iff iou < nms_thr, fp16 compare).
- *   seed_score: f32, element (i, c) at seed_score[i*score_ld + score_off + c]
- *   topk_idx  [n_cls, K] int32  (keep_sort_idx)
- *   seeds     [n_cls, K] int32  (keep_nms_idx, selection order; entries >= n_seeds are -1)
- *   n_seeds   [n_cls]    int32
- * Limits: N <= 8192, K <= 1024. */
-int cim_seed_select(const float* seed_score, int score_ld, int score_off, const uint16_t* iou_f16, int N,
-                    const int32_t* classes, int n_cls, int K, float nms_thr,
-                    int32_t* topk_idx, int32_t* seeds, int32_t* n_seeds, void* stream);
+/* The whole mining + assignment of ONE training step - all REFINE_TIMES CIM layers - without a host round trip:
+ * 4 launches (seed selection; containment arg-max; arbitration + anti-noise sampling; assignment).
+ * Replaces, per layer, CIM_layer.forward = CIM_label / MIST_label + instance_nms + the sampling loop + the assignment,
+ * lib/modeling/heads.py:237-503, as called three times per image from lib/modeling/model_builder.py:170-187.
+ *
+ * The image's classes are read on the device: class c is active iff labels[c] != 0 (heads.py:340); per-class outputs
+ * are indexed by the class id c itself.
+ *
+ * Per layer (cim_mining_layer):
+ *   seed_score  top-K ranking score, element (i, c) at seed_score[i*seed_ld + seed_off + c]        (heads.py:354 / :279)
+ *   det         containment arg-max score, element (i, c) at det[i*det_ld + det_off + c*det_cs]; det_cs = 0 selects the
+ *               class-agnostic detector (heads.py:346-347); unused (may be NULL) when using_cim == 0 (MIST_label)
+ *   wa, wb      arbitration weight (i, c) = wa[i*wa_ld + wa_off + c] * (wb ? wb[i*wb_ld + wb_off + c*wb_cs] : 1)
+ *               (preds = cls * det, heads.py:330,397; MIST: the product tensor itself, wb = NULL, :306)
+ *   nms_thr, cls_thr, iou_thr, con_thr   Python-float thresholds (rounded to binary16 inside)
+ *   using_cim   1: CIM_label (seeds -> containing proposals), 0: MIST_label (seeds are the pseudo GTs)
+ *   anti_noise  1: resample each class's pseudo GTs in proportion to their weight (heads.py:447-473)
+ *   flag_slot   which of the `flags` arrays (one per distinct con_thr, written by cim_asy_flag beforehand) this layer uses
+ * Outputs per layer:
+ *   topk [C,K] i32 (keep_sort_idx), seeds [C,K] i32 (keep_nms_idx in selection order, -1 beyond n_seeds[c]),
+ *   n_seeds [C] i32, res [C,K] i32 (res_idx per seed, -1: no containing proposal / no seed; CIM layers only)
+ *   gt_class [N] i32 (0 / class id + 1), gt_weight [N] f32 (-1 where unset)             after arbitration
+ *   pre_idx [N] i32, pre_keep [N] u8: the G pseudo GTs in ascending proposal order and the sampling keep-mask over them
+ *   gt_idx [N] i32, gt_cls [N] i32, gt_w [N] f32: the G' survivors;  counts [2] i32 = { G, G' }
+ *   pseudo_labels [N,C+1] f32, pseudo_iou [N] binary16 {0,1}, loss_weights [N] f32, max_idx [N] i32   (heads.py:477-501;
+ *   NOT written when G == 0: the reference returns (None, None, None) and the model skips the layer, :429-430)
+ * Step-wide:
+ *   flags [n_slots, N] u8 (cim_asy_flag), uniforms [max_uniforms] f64 = the next doubles of the host's MT19937 stream
+ *   (np.random.random_sample), consumed in the order of the reference's sequential calls; used [1] i32 = how many were
+ *   consumed; layer_valid [R] i32 = (G > 0); status [1] i32 error bits (0 = ok; 1: class list longer than K, 2: uniforms
+ *   exhausted; the losses launch ORs 4 / 8 into it, see cim_loss_args).
+ * Limits: N <= 8192, K <= 1024, R <= CIM_MAX_LAYERS. */
+#define CIM_MAX_LAYERS 4
+typedef struct cim_mining_layer {
+    const float* seed_score; int32_t seed_ld, seed_off;
+    const float* det;        int32_t det_ld, det_off, det_cs;
+    const float* wa;         int32_t wa_ld, wa_off;
+    const float* wb;         int32_t wb_ld, wb_off, wb_cs;
+    float nms_thr, cls_thr, iou_thr, con_thr;
+    int32_t using_cim, anti_noise, flag_slot, reserved_;
+    int32_t* topk; int32_t* seeds; int32_t* n_seeds; int32_t* res;
+    int32_t* gt_class; float* gt_weight;
+    int32_t* pre_idx; uint8_t* pre_keep;
+    int32_t* gt_idx; int32_t* gt_cls; float* gt_w; int32_t* counts;
+    float* pseudo_labels; uint16_t* pseudo_iou; float* loss_weights; int32_t* max_idx;
+} cim_mining_layer;
 
-/* Step 2 (heads.py:386-395): for every seed s of class c, among proposals i with
- * asy[i,s] > con_thr and flag[i], the first index maximising det[i,c]
- * (det: element (i,c) at det[i*det_ld + det_off + c*det_cstride]; det_cstride = 0 selects the
- * class-agnostic detector, heads.py:346-347).  res_idx [n_cls,K] int32, -1 where the seed
- * has no containing proposal (column dropped at heads.py:392) or s >= n_seeds. */
-int cim_contain_argmax(const uint16_t* asy_f16, const uint8_t* flag, const float* det, int det_ld, int det_off,
-                       int det_cstride, int N, const int32_t* classes, int n_cls, int K, float con_thr,
-                       const int32_t* seeds, const int32_t* n_seeds, int32_t* res_idx, void* stream);
+typedef struct cim_mining_args {
+    int32_t N, C, K, R;
+    const float* labels;             /* [C] image labels */
+    const uint16_t* iou;             /* [N,N] binary16 mask-IoU map */
+    const uint16_t* asy;             /* [N,N] binary16 containment map */
+    const uint8_t* flags;            /* [n_slots, N] from cim_asy_flag */
+    const double* uniforms;          /* [max_uniforms] */
+    int32_t max_uniforms, reserved_;
+    int32_t* used;                   /* [1] */
+    int32_t* status;                 /* [1] */
+    int32_t* layer_valid;            /* [R] */
+    cim_mining_layer layer[CIM_MAX_LAYERS];
+} cim_mining_args;
 
-/* Cross-class arbitration + compaction (heads.py:397-405 for CIM, :306-314 for MIST).
- * cand [n_cls,K] int32 candidate proposals per class (-1 = none; duplicates allowed),
- * weight element (i,c) = wa[i*wa_ld + wa_off + c] * (wb ? wb[i*wb_ld + wb_off + c*wb_cstride] : 1).
- * Classes are applied sequentially in ascending order with the strict '>' rule.
- * Outputs: gt_class [N] int32 (0 = not a pseudo GT, else class id + 1), gt_weight [N] f32
- * (-1 where unset), and gt_pack [1 + 3N] int32 = { G, idx[N], class[N], weight_bits[N] } with
- * the G pseudo GTs compacted in ascending proposal order (one D2H copy feeds the host-side
- * anti-noise sampling of heads.py:447-473). */
-int cim_arbitrate(const int32_t* cand, const int32_t* classes, int n_cls, int K, int N,
-                  const float* wa, int wa_ld, int wa_off,
-                  const float* wb, int wb_ld, int wb_off, int wb_cstride,
-                  int32_t* gt_class, float* gt_weight, int32_t* gt_pack, void* stream);
-
-/* ------------------------------------------------------------------ assignment (a-6)
- * Replaces lib/modeling/heads.py:435,477-501.  gt_idx [G] int32 ascending proposal indices of
- * the surviving pseudo GTs (after anti-noise sampling, done on the host with NumPy's global
- * RNG exactly as heads.py:447-473), gt_cls [G] int32 (class id + 1), gt_w [G] f32.
- * Outputs: pseudo_labels [N, C1] f32 one-hot rows (C1 = classes + 1), pseudo_iou_f16 [N]
- * ({0,1} in binary16, like the reference), loss_weights [N] f32, max_idx [N] int32. */
-int cim_assign(const uint16_t* iou_f16, int N, const int32_t* gt_idx, const int32_t* gt_cls, const float* gt_w,
-               int G, int C1, float cls_thr, float iou_thr,
-               float* pseudo_labels, uint16_t* pseudo_iou_f16, float* loss_weights, int32_t* max_idx,
-               void* stream);
+/* Dynamic LDS of the arbitration + sampling launch (must be <= 160 KiB). */
+long long cim_mining_lds_bytes(int N, int K);
+int cim_mining_step(const cim_mining_args* args, void* stream);
 
 /* ------------------------------------------------------------------ backbone BatchNorm chains (a-11)
  * Frozen-statistics BatchNorm (+ residual) (+ ReLU) of the ResNet / HRNet bodies, lib/modeling/resnet50.py:17-44,53-77
@@ -274,9 +294,10 @@ int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, int til
  *        0: d bag(mil)/d predict_cls   1: d pcl/d predict_cls   2: d bag(mil)/d predict_det
  *        3+4i: d cls_i/d refine_cls[i]   4+4i: d bag_i/d refine_cls[i]
  *        5+4i: d iou_i/d refine_iou[i]   6+4i: d bag_i/d refine_iou[i]
- * PCL cluster plan (host-built from `mat`, heads.py:14-21): row_cluster [N] = index of the row's
- * cluster (-1: none), row_col [N] = column of its non-zero entry, cluster_size [K], bg_cluster =
- * index of the background cluster (-1: none). */
+ * The PCL cluster structure of `mat` (heads.py:14-21: distinct non-zero ids ascending, member rows, the column of each
+ * row's entry, the background cluster = the id found in column 0) is derived inside the launch by the PCL workgroup:
+ * no host copy of `mat`, no per-image plan.  layer_valid comes straight from cim_mining_step. */
+#define CIM_PCL_MAX_CLUSTERS 256
 typedef struct cim_loss_args {
     const float* pc;                 /* predict_cls */
     const float* pd;                 /* predict_det */
@@ -286,12 +307,12 @@ typedef struct cim_loss_args {
     const uint16_t* pseudo_iou_f16[3]; /* [N] binary16 {0,1} */
     const float* loss_weights[3];    /* [N] (unscaled) */
     float weight_scale[3];           /* lmda: 3 for layer 0, else 1 (model_builder.py:172) */
-    int layer_valid[3];              /* 0: CIM_layer returned None -> layer skipped */
+    const int32_t* layer_valid;      /* DEVICE [R]: 0 = CIM_layer found no pseudo GT -> layer skipped (cim_mining_step) */
     const float* labels;             /* [C1-1] image labels */
-    const int32_t* row_cluster;
-    const int32_t* row_col;
-    const int32_t* cluster_size;
-    int K, bg_cluster;
+    const float* mat;                /* [N,C1] PRM cluster matrix (heads.py:10-41): <= 1 non-zero (= cluster id) per row */
+    int32_t* status;                 /* DEVICE [1] error bits, OR-ed: 4 = a row of mat has several non-zeros (use the
+                                        general ATen formulation), 8 = several distinct ids in column 0 (heads.py:20),
+                                        16 = more than CIM_PCL_MAX_CLUSTERS clusters */
     int N, C1, R;
     float* part;
     float* grad;

@@ -413,8 +413,7 @@ def test_fused_losses_match_reference_and_autograd(dev, name, golden_dir):
     inp = case_inputs(MINING_CASES[name])
     t = lambda a: torch.from_numpy(a).to(dev)
     labels = t(inp["labels"])
-    plan = heads.PCLPlan.build(inp["mat"], dev)
-    assert plan is not None and plan.K >= 2
+    mat = t(inp["mat"])
     for valid in ([True, True, True], [True, False, True]):
         pc = t(inp["layers"][0][0]).requires_grad_(True)
         pd = t(inp["layers"][0][1]).requires_grad_(True)
@@ -423,7 +422,7 @@ def test_fused_losses_match_reference_and_autograd(dev, name, golden_dir):
         pseudo = [(t(m["l%d_pseudo_labels" % i]), t(m["l%d_pseudo_iou_labels" % i]), t(m["l%d_loss_weights" % i]))
                   if valid[i] else None for i in range(3)]
         scales = [3, 1, 1]
-        bag, pcl, cls_l, iou_l = heads.fused_losses(pc, pd, rc, ri, labels, pseudo, scales, plan)
+        bag, pcl, cls_l, iou_l = heads.fused_losses(pc, pd, rc, ri, labels, pseudo, scales, mat)
         up = torch.tensor([0.7, 1.3, 2.0, 0.5], device=dev)
         (up[0] * bag + up[1] * pcl + up[2] * cls_l + up[3] * iou_l).backward()
         got = [x.grad.clone() for x in [pc, pd] + rc + ri]
@@ -480,6 +479,8 @@ def test_model_pickle_path_and_eval_branch(dev, tmp_path):
               gtrois=None, mat=t(inp["mat"]), index=t(inp["index"]))
     np.random.seed(3)
     a = model(path="/data/VOC2012/JPEGImages/2008_000123.jpg", **kw)
+    from cim_amd.modeling import heads
+    heads.settle_rng()                                        # no backward here: settle the generator by hand
     np.random.seed(3)
     b = model(iou_map=torch.from_numpy(iou).to(dev), asy_iou_map=torch.from_numpy(asy).to(dev), **kw)
     for k in ("bag_loss", "pcl_loss", "cls_loss", "iou_loss"):

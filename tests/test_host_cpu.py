@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     build.build()
     header = open(os.path.join(REPO, "include", "cim_hip.h")).read()
     declared = set(re.findall(r"\b(cim_[a-z0-9_]+)\s*\(", header))
-    assert {"cim_roi_align_fwd", "cim_assign", "cim_mask_iou_pair", "cim_seed_select"} <= declared
+    assert {"cim_roi_align_fwd", "cim_mining_step", "cim_mask_iou_pair", "cim_asy_flag", "cim_losses_fwd"} <= declared
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), "missing export: " + name
