@@ -48,15 +48,22 @@ def _worker(rank, world, port, out, big_bytes=16 << 20):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from cim_amd.nn import DataParallel
-    torch.manual_seed(0)
+    torch.manual_seed(rank)            # ranks start from DIFFERENT weights: DataParallel must broadcast rank 0's
     dp = DataParallel(Tiny(), cpu_keywords=["im_info"], minibatch=True, bucket_bytes=64, big_bytes=big_bytes)
     assert len(dp.buckets) > 1 and dp.world_size == world
     assert any("tensor" in b for b in dp.buckets) == (big_bytes < (16 << 20))
-    # step 1: plain synchronised backward
+    # construction broadcast rank 0's parameters (rank 1 was initialised differently on purpose)
+    ref = Tiny.__new__(Tiny)
+    torch.manual_seed(0)
+    Tiny.__init__(ref)
+    for a, b in zip(dp.module.parameters(), ref.parameters()):
+        assert torch.equal(a, b)
+    # step 1: plain synchronised backward - exactly the reference driver's calls (tools/train.py:419-438):
+    # zero_grad, forward, backward; the reduction finishes by itself at the end of backward
     dp.zero_grad()
     o = dp(data=[_data(rank)], scale=[torch.tensor(1.0)])
-    (o["losses"]["l"].sum() * dp.loss_scale()).backward()
-    dp.finish_gradient_sync()
+    o["losses"]["l"].sum().backward()
+    assert not dp._pending and dp._next_bucket == 0
     g1 = _grads(dp)
     # step 2: accumulate one un-synced micro-step, then a synced one (iter_size = 2)
     dp.zero_grad()
@@ -67,6 +74,14 @@ def _worker(rank, world, port, out, big_bytes=16 << 20):
     (o["losses"]["l"].sum() * dp.loss_scale()).backward()
     dp.finish_gradient_sync()
     g2 = _grads(dp)
+    # the same accumulation driven by iter_size (the unchanged driver loop: no no_sync() in tools/train.py:420-438)
+    dp.iter_size = 2
+    dp.zero_grad()
+    for d, sc in ((_data(rank), 0.5), (_data(rank + 10), 2.0)):
+        o = dp(data=[d], scale=[torch.tensor(sc)])
+        o["losses"]["l"].sum().backward()
+    g2b = _grads(dp)
+    dp.iter_size = 1
     # step 3: rank 1 skips one head entirely (its parameters get no gradient on that rank):
     # the strict bucket order must still pair up the collectives of both ranks
     dp.zero_grad()
@@ -75,7 +90,7 @@ def _worker(rank, world, port, out, big_bytes=16 << 20):
     dp.finish_gradient_sync()
     g3 = _grads(dp)
     if rank == 0:
-        torch.save({"g1": g1, "g2": g2, "g3": g3}, out)
+        torch.save({"g1": g1, "g2": g2, "g2b": g2b, "g3": g3}, out)
     dist.destroy_process_group()
 
 
@@ -101,6 +116,7 @@ def test_dp_allreduce_world2(tmp_path, big_bytes):
     want2 = (_local_grad(_data(0), 0.5) + _local_grad(_data(1), 0.5)
              + _local_grad(_data(10), 2.0) + _local_grad(_data(11), 2.0)) / 2
     torch.testing.assert_close(got["g2"], want2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got["g2b"], want2, rtol=1e-5, atol=1e-6)
     want3 = (_local_grad(_data(0), 1.0) + _local_grad(_data(1), 1.0, skip_b=True)) / 2
     torch.testing.assert_close(got["g3"], want3, rtol=1e-5, atol=1e-6)
 
@@ -112,7 +128,8 @@ def test_dp_single_process_passthrough():
     assert dp.world_size == 1 and hasattr(dp, "module")
     o = dp(data=[_data(0)], scale=[torch.tensor(1.0)])
     o["losses"]["l"].sum().backward()
-    torch.testing.assert_close(dp.flat_grad, _local_grad(_data(0), 1.0))
+    torch.testing.assert_close(_grads(dp), _local_grad(_data(0), 1.0))      # (views are 16-byte aligned: the buffer has padding)
+    assert all(p.grad.data_ptr() % 16 == 0 for p in dp.module.parameters() if p.requires_grad)
     dp.zero_grad()
     assert float(dp.flat_grad.abs().sum()) == 0 and dp.module.a.weight.grad.data_ptr() >= dp.flat_grad.data_ptr()
     # default single-process mode: no flat buffer, gradients handed over by autograd as they are

@@ -1,0 +1,136 @@
+"""-m gpu: data parallel on the REAL model.
+
+  * iter_size = 4 gradient accumulation (the reference's operating point, scripts/train_CIM.sh:8,
+    tools/train.py:420-438) on Generalized_RCNN: four different images, the unchanged driver calls.
+  * two ranks, each with its own image handed over as CPU tensors through nn.DataParallel(minibatch=True):
+    gradients == mean of the per-rank gradients.  `nccl` (RCCL, one rank per GPU) when the box has >= 2 GPUs - skipped
+    otherwise -, and always `gloo` with both ranks on cuda:0 (the hooks, buckets, in-place big-tensor reduction and the
+    construction-time broadcast are backend-independent)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_batch(seed, n=40, dev=None):
+    from cim_amd import mask_iou, synthetic
+    inp = synthetic.make_image_inputs("resnet50_voc", seed=seed, n=n)
+    inp["data"] = inp["data"][:, :, :160, :224].copy()
+    inp["rois"][:, 1:] *= np.float32(0.3)
+    t = lambda a: torch.from_numpy(a).unsqueeze(0)                # CPU tensors with the loader's batch dimension
+    iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
+    return dict(data=[torch.from_numpy(inp["data"])], rois=[t(inp["rois"])], masks=[t(inp["masks"])], labels=[t(inp["labels"])],
+                gtrois=[None], mat=[t(inp["mat"])], index=[t(inp["index"])], iou_map=[iou], asy_iou_map=[asy])
+
+
+def _model(dev, seed=0):
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    apply_preset("resnet50_voc")
+    torch.manual_seed(seed)
+    return Generalized_RCNN().to(dev).train()
+
+
+def _flat_grads(model):
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float()
+                      for p in model.parameters() if p.requires_grad])
+
+
+def _loss(out):
+    return sum(v.sum() for v in out["losses"].values())
+
+
+def test_iter_size_4_accumulation_real_model():
+    from cim_amd.nn import DataParallel
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    batches = [_small_batch(100 + i, n=32 + 8 * i, dev=dev) for i in range(4)]       # different N per image
+    dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True, iter_size=4)
+    singles = []
+    for b in batches:                                    # warm-up: MIOpen may switch solvers after its first call on a shape
+        _loss(dp(**b)).backward()
+    for i, b in enumerate(batches):
+        dp.zero_grad()
+        np.random.seed(500 + i)
+        _loss(dp(**b)).backward()
+        singles.append(_flat_grads(model).clone())
+    dp.zero_grad()
+    for i, b in enumerate(batches):                      # tools/train.py:419-438 verbatim: no extra calls
+        np.random.seed(500 + i)
+        _loss(dp(**b)).backward(retain_graph=True)
+    acc = _flat_grads(model)
+    want = sum(singles)
+    rel = float((acc - want).norm() / want.norm())
+    # not bit-equal: MIOpen may run a backbone convolution with a different solver from one call to the next
+    # (measured 1.7e-4); a wrong accumulation (an image missing or counted twice) would be O(1)
+    assert rel < 2e-3, rel
+    assert float((acc - singles[0]).norm() / want.norm()) > 0.1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, backend, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cim_amd.modeling import heads
+    from cim_amd.nn import DataParallel
+    model = _model(dev, seed=rank)                       # DIFFERENT initial weights per rank: construction must broadcast rank 0's
+    dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True, big_bytes=1 << 20, bucket_bytes=4 << 20)
+    ref = _model(dev, seed=0)
+    for (n, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
+        assert torch.equal(a, b), "parameter %s was not broadcast from rank 0" % n
+    assert any("tensor" in b for b in dp.buckets) and len(dp.buckets) > 3
+    checks = []
+    for step in range(2):                                # two steps: a different image per rank AND per step
+        batch = _small_batch(10 * step + rank, n=40 + 8 * rank, dev=dev)
+        # local gradient of this rank's image on an unwrapped copy
+        ref.load_state_dict(model.state_dict())
+        ref.zero_grad(set_to_none=True)
+        np.random.seed(7 + rank)
+        _loss(ref(**{k: (v[0].to(dev) if torch.is_tensor(v[0]) else v[0]) for k, v in batch.items()})).backward()
+        local = _flat_grads(ref)
+        mean = local.clone()
+        dist.all_reduce(mean)
+        mean /= world
+        dp.zero_grad()
+        np.random.seed(7 + rank)
+        _loss(dp(**batch)).backward()                    # reduction completes inside (end-of-backward callback)
+        assert not dp._pending
+        got = _flat_grads(model)
+        torch.cuda.synchronize()
+        checks.append((float((got - mean).norm() / mean.norm()), float((local - mean).norm() / mean.norm())))
+        heads.settle_rng()
+    if rank == 0:
+        torch.save(checks, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_real_model(tmp_path, backend):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL test needs >= 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    out = str(tmp_path / "checks.pt")
+    mp.spawn(_worker, args=(2, _free_port(), backend, out), nprocs=2, join=True)
+    for err, spread in torch.load(out):
+        assert spread > 1e-2, "the two ranks' gradients should differ (different images)"
+        assert err < 2e-3, "all-reduced gradient differs from the mean of the per-rank gradients: %.3g" % err
