@@ -15,9 +15,10 @@ SIGNATURES = {
     "cim_roi_align_fwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
     "cim_roi_align_fwd_ws": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
     "cim_roi_align_maskcat_fwd_ws": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
-    "cim_roi_align_bwd_ws": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, c_int, _P],
-    "cim_roi_align_maskcat_bwd_ws": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, c_int, _P],
+    "cim_roi_align_bwd_ws": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, c_int, _P, _P],
+    "cim_roi_align_maskcat_bwd_ws": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, c_int, _P, _P],
     "cim_roi_align_bwd_workspace": [c_int, c_int, c_int, c_int],
+    "cim_roi_align_bwd_scratch": [c_int, c_int, c_int, c_int, c_int],
     "cim_roi_align_bwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
     "cim_roi_align_maskcat_fwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
     "cim_roi_align_maskcat_bwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
@@ -57,7 +58,7 @@ SIGNATURES = {
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }
 
-ABI_VERSION = 2          # cim_abi_version() of include/cim_hip.h this binding was written against
+ABI_VERSION = 3          # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 
@@ -87,7 +88,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = c_longlong if name in ("cim_roi_align_bwd_workspace", "cim_mining_lds_bytes") else c_int
+        fn.restype = c_longlong if name in ("cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_mining_lds_bytes") else c_int
     # CIM_GEMM_ENGINE = f16x2 (default; own entry points, chosen in cim_amd/ops/gemm.py) | bf16x3 | fp32.
     # cim_gemm_f32 / cim_conv3x3_f32 (operands without scales) run bf16x3 unless fp32 is asked for.
     lib.cim_gemm_set_engine(0 if os.environ.get("CIM_GEMM_ENGINE", "f16x2") == "fp32" else 1)
@@ -95,7 +96,7 @@ def load():
     return lib
 
 
-VALUE_RETURNING = {"cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_gemm_get_engine"}      # return a count, not a status
+VALUE_RETURNING = {"cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_gemm_get_engine"}      # return a count, not a status
 
 
 def call(name, *args):

@@ -1159,6 +1159,268 @@ __global__ __launch_bounds__(256, CIM_ROI_GOCC) void roi_align_bwd_gather_kernel
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward, region form (default): the gather above with the sharing made explicit.
+//
+// What bounds the gather kernel is that every gradient vector is re-read by each of the ~3.7 pixel blocks its bin
+// touches, from workgroups on different XCDs: 1.5 GB through the fabric for 401 MB of gradients.  Here a workgroup of
+// 16 waves owns a REGION of 12 x 16 feature pixels (4 x 4 sub-blocks of 3 x 4, one per wave, 12 float4 accumulators per
+// lane) x a 256-channel slice (lanes along C, 16 B per lane) for one group of ROIs.  The gradient slices of the bins that
+// touch the region are brought in ONCE per workgroup - all 1024 lanes stream a window of 32 entries (64 KB with the
+// mask-cat halves, combined on the way: g_lo + m g_hi) into LDS, double buffered, the next window's loads in flight
+// while the waves consume the current one - and every wave reads from LDS the entries whose bin touches its sub-block
+// (a ballot over the window's row / column masks picks them).  Re-read factor of a 12 x 16 region at the benchmark's bin
+// size (3.6 x 4.1 px): (15.6 / 12)(20.1 / 16) = 1.6 instead of 3.7; registers per lane as in the 3 x 4 gather.
+// Entry record in LDS: gradient offset, mask, separable weights wy[4 sub-rows][4] (3 used) and wx[4 sub-columns][4], touch mask.
+// Regions are dispatched centre first (they carry the most entries); groups meet in grad_in through atomicAdd.
+// ROIs per workgroup (template parameter GS): 64 up to 1535 ROIs, 128 from there on (measured at cfg2 / cfg4, ms:
+// 1000 ROIs 0.207 / 0.312, 2000 ROIs 0.407 / 0.352; 32: 0.66, 96: 0.26, 160: 0.38, 256: 0.56 at 1000 ROIs)
+#ifndef CIM_ROI_RG_EXP
+#define CIM_ROI_RG_EXP 0            // ablations: 1 = no consume phase, 2 = no gradient loads, 3 = records only
+#endif
+constexpr int RG_SBH = 3, RG_SBW = 4, RG_WR = 4, RG_WC = 4;
+constexpr int RG_RH = RG_SBH * RG_WR, RG_RW = RG_SBW * RG_WC;          // 12 x 16 pixels
+constexpr int RG_NT = 64 * RG_WR * RG_WC;                               // 1024 threads
+constexpr int RG_WIN = 32;                                              // entries per staging window
+constexpr int RG_MAXE = 256;                                            // entries per super-window (records in LDS)
+static inline int rg_group_size(int K) { return K >= 1536 ? 128 : 64; }
+constexpr int RG_REC = 36;                                              // words per entry record: off, m, touch, pad, wy[16], wx[16]
+constexpr int RG_MAXREG = 256;
+struct RegionOrder { unsigned char o[RG_MAXREG]; };
+
+template <bool MASKCAT, int RG_GS>
+__global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float* __restrict__ grad_out,
+                                                                     const float* __restrict__ masks,
+                                                                     float* __restrict__ grad_in, int C, int H, int W, int K,
+                                                                     int P, int B, int use_atomic,
+                                                                     const float* __restrict__ rec_all,
+                                                                     const RegionOrder region_order, int n_regions,
+                                                                     int regions_x, int n_slices, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float rg_smem[];
+    float (*stage)[RG_WIN][256] = reinterpret_cast<float (*)[RG_WIN][256]>(rg_smem);   // [2][32][256]: 64 KB
+    float* erec = rg_smem + 2 * RG_WIN * 256;                                         // [MAXE][REC]: 36 KB
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // work order: region (centre first) slowest, then ROI group, then channel slice
+    int lin = blockIdx.x;
+    const int slice = lin % n_slices;
+    lin /= n_slices;
+    const int groups_total = gridDim.x / (n_slices * n_regions);                      // B * groups
+    const int by = lin % groups_total;
+    const int region = region_order.o[lin / groups_total];
+    const int b = by % B, kgroup = by / B;
+    const int y0 = (region / regions_x) * RG_RH, x0 = (region % regions_x) * RG_RW;
+    const int wr = wave / RG_WC, wc = wave % RG_WC;
+    const int sy0 = y0 + wr * RG_SBH, sx0 = x0 + wc * RG_SBW;
+    const int recw = roi_rec_words(P, H, W);
+    const int OC = MASKCAT ? 2 * C : C, PP = P * P;
+
+    ga_f2 accl[12], acch[12];
+#pragma unroll
+    for (int p = 0; p < 12; ++p) accl[p] = acch[p] = ga_f2{0.f, 0.f};
+
+    // ---- inspection: thread t < GS looks at ROI kgroup * GS + t and leaves a descriptor in LDS
+    __shared__ int d_base[RG_GS + 1];          // first entry index of the ROI (exclusive prefix sum), [GS] = total
+    __shared__ int d_bins[RG_GS];              // phl | pwl << 8 | npw << 16
+    __shared__ float d_inv[RG_GS];             // 1 / count
+    {
+        const int k = kgroup * RG_GS + tid;
+        int phl = 0, phh = -1, pwl = 0, pwh = -1;
+        float inv_count = 0.0f;
+        if (tid < RG_GS && k < K) {
+            const float* rec = rec_all + (size_t)k * recw;
+            const int* yr = reinterpret_cast<const int*>(rec + P * (H + W));
+            const int* xr = yr + H;
+            if (yr[H + W + 5] == b) {
+                int lo = P, hi = -1;
+#pragma unroll
+                for (int i = 0; i < RG_RH; ++i) {
+                    const int r = yr[min(y0 + i, H - 1)];
+                    if (y0 + i < H && !(r & 0x10000)) { lo = min(lo, r & 0xff); hi = max(hi, (r >> 8) & 0xff); }
+                }
+                phl = lo; phh = hi;
+                lo = P; hi = -1;
+#pragma unroll
+                for (int j = 0; j < RG_RW; ++j) {
+                    const int r = xr[min(x0 + j, W - 1)];
+                    if (x0 + j < W && !(r & 0x10000)) { lo = min(lo, r & 0xff); hi = max(hi, (r >> 8) & 0xff); }
+                }
+                pwl = lo; pwh = hi;
+                inv_count = 1.0f / reinterpret_cast<const float*>(yr)[H + W + 4];
+            }
+        }
+        const int nph = max(phh - phl + 1, 0), npw = max(pwh - pwl + 1, 0);
+        const int n_mine = (nph > 0 && npw > 0) ? nph * npw : 0;
+        int incl = n_mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int wbase = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w)
+            if (w < wave) wbase += s_wave[w];
+        if (tid < RG_GS) {
+            d_base[tid] = wbase + incl - n_mine;
+            d_bins[tid] = phl | (pwl << 8) | (max(npw, 1) << 16);
+            d_inv[tid] = inv_count;
+        }
+        if (tid == RG_GS - 1) d_base[RG_GS] = wbase + incl;
+        __syncthreads();
+    }
+    const int total = (CIM_ROI_RG_EXP == 6) ? 0 : d_base[RG_GS];
+
+    // loader role of this thread inside a staging window: entry le = tid / 32, two float4 of the slice's 64
+    const int le = tid >> 5, lq = (tid & 31) * 2;
+    const int cbase = slice * 256;
+    // consumer role: lane's 4 channels of the slice
+    const int my_touch = (7 << (RG_SBH * wr)) | ((15 << (RG_SBW * wc)) << 16);
+
+    for (int w0 = 0; w0 < total; w0 += RG_MAXE) {
+        __syncthreads();                                   // previous super-window fully consumed
+        // ---- entry records of [w0, w0 + MAXE): 4 threads per entry, each 3 rows of wy and 4 columns of wx
+        {
+            const int e = tid >> 2, part = tid & 3;
+            const int ge = w0 + e;
+            int rm = 0, cm = 0;
+            if (ge < total) {
+                int lo = 0, hi = RG_GS - 1;                // last ROI with d_base <= ge (ROIs without entries repeat a base)
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (d_base[mid] <= ge) lo = mid; else hi = mid - 1;
+                }
+                const int bins = d_bins[lo], local = ge - d_base[lo];
+                const int npw = bins >> 16, ph = (bins & 0xff) + local / npw, pw = ((bins >> 8) & 0xff) + local % npw;
+                const int k = kgroup * RG_GS + lo;
+                const float* rec = rec_all + (size_t)k * recw;
+                const float* wy = rec + ph * H;
+                const float* wx = rec + P * H + pw * W;
+                const float inv_count = d_inv[lo];
+                float* r = erec + e * RG_REC;
+#pragma unroll
+                for (int i = 0; i < RG_SBH; ++i) {
+                    const int y = y0 + part * RG_SBH + i;
+                    const float v = (y < H) ? wy[y] * inv_count : 0.0f;
+                    r[4 + part * 4 + i] = v;
+                    if (v != 0.0f) rm |= 1 << (part * RG_SBH + i);
+                }
+#pragma unroll
+                for (int j = 0; j < RG_SBW; ++j) {
+                    const int x = x0 + part * RG_SBW + j;
+                    const float v = (x < W) ? wx[x] : 0.0f;
+                    r[20 + part * 4 + j] = v;
+                    if (v != 0.0f) cm |= 1 << (part * RG_SBW + j);
+                }
+                if (part == 0) {
+                    reinterpret_cast<int*>(r)[0] = (((k * P) + ph) * P + pw) * OC;      // < 2^31: checked by the launcher
+                    r[1] = MASKCAT ? masks[(size_t)k * PP + ph * P + pw] : 0.0f;
+                }
+            }
+            rm |= __shfl_xor(rm, 1); rm |= __shfl_xor(rm, 2);
+            cm |= __shfl_xor(cm, 1); cm |= __shfl_xor(cm, 2);
+            if (ge < total && part == 0) reinterpret_cast<int*>(erec + e * RG_REC)[2] = rm | (cm << 16);
+        }
+        __syncthreads();
+        const int n = min(RG_MAXE, total - w0);
+        const int nwin = (CIM_ROI_RG_EXP == 3 || CIM_ROI_RG_EXP == 5) ? 0 : (n + RG_WIN - 1) / RG_WIN;
+        // ---- software pipeline over the staging windows: the next window's loads are in flight while this one is consumed
+        // (two windows in flight - a second register set - measured no faster: 0.213 vs 0.207 ms)
+        struct Regs { float4 r0, r1, h0, h1; float m; };
+        auto gload = [&](Regs& R, int win) {
+            const int e = win * RG_WIN + le;
+            R.r0 = R.r1 = R.h0 = R.h1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            R.m = 0.0f;
+            if (e < n && CIM_ROI_RG_EXP != 2) {
+                const float* rr = erec + e * RG_REC;
+                const int off = reinterpret_cast<const int*>(rr)[0];
+                const int c0 = min(cbase + lq * 4, C - 4), c1 = min(cbase + lq * 4 + 4, C - 4);
+                R.r0 = *reinterpret_cast<const float4*>(grad_out + off + c0);
+                R.r1 = *reinterpret_cast<const float4*>(grad_out + off + c1);
+                if (MASKCAT) {
+                    R.h0 = *reinterpret_cast<const float4*>(grad_out + off + C + c0);
+                    R.h1 = *reinterpret_cast<const float4*>(grad_out + off + C + c1);
+                    R.m = rr[1];
+                }
+            }
+        };
+        auto put = [&](const Regs& R, int buf) {
+            float4 a = R.r0, c = R.r1;
+            if (MASKCAT) {
+                a = make_float4(fmaf(R.m, R.h0.x, a.x), fmaf(R.m, R.h0.y, a.y), fmaf(R.m, R.h0.z, a.z), fmaf(R.m, R.h0.w, a.w));
+                c = make_float4(fmaf(R.m, R.h1.x, c.x), fmaf(R.m, R.h1.y, c.y), fmaf(R.m, R.h1.z, c.z), fmaf(R.m, R.h1.w, c.w));
+            }
+            float* sb = &stage[buf][le][lq * 4];
+            *reinterpret_cast<float4*>(sb) = a;
+            *reinterpret_cast<float4*>(sb + 4) = c;
+        };
+        auto consume = [&](int buf, int win) {
+            // entries of the window whose bin touches this wave's sub-block
+            const int e0 = win * RG_WIN;
+            int t = 0;
+            if (lane < RG_WIN && e0 + lane < n) t = reinterpret_cast<const int*>(erec + (e0 + lane) * RG_REC)[2];
+            const bool hit = ((t & my_touch & 0xffff) != 0) && (((t & my_touch) >> 16) != 0);
+            unsigned long long todo = __ballot(hit);
+            if (CIM_ROI_RG_EXP == 1) todo = 0;
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const float* rr = erec + (e0 + j) * RG_REC;
+                const float4 g = *reinterpret_cast<const float4*>(&stage[buf][j][lane * 4]);
+                const float4 wyq = *reinterpret_cast<const float4*>(rr + 4 + wr * 4);
+                const float4 wxq = *reinterpret_cast<const float4*>(rr + 20 + wc * 4);
+                const ga_f2 gl = ga_lo(g), gh = ga_hi(g);
+                const float wys[3] = {wyq.x, wyq.y, wyq.z};
+                const float wxs[4] = {wxq.x, wxq.y, wxq.z, wxq.w};
+                // (tried: skipping rows with a zero weight by a scalar branch, 0.227 vs 0.213 ms; reading the next entry's
+                // LDS operands one iteration ahead, 0.224 vs 0.207 ms - the phase is paced by the busiest wave of a window)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const ga_f2 tl = ga_f2{wys[i], wys[i]} * gl, th = ga_f2{wys[i], wys[i]} * gh;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        accl[i * 4 + jj] = ga_fma(wxs[jj], tl, accl[i * 4 + jj]);
+                        acch[i * 4 + jj] = ga_fma(wxs[jj], th, acch[i * 4 + jj]);
+                    }
+                }
+            }
+        };
+        Regs A;
+        gload(A, 0);
+        for (int win = 0; win < nwin; ++win) {
+            put(A, win & 1);
+            __syncthreads();                               // (also: every wave is done with the buffer the NEXT put overwrites)
+            if (win + 1 < nwin) gload(A, win + 1);         // in flight while this window is consumed
+            consume(win & 1, win);
+        }
+    }
+    // ---- flush this wave's 3 x 4 pixels
+    const int cs = slice * 256 + lane * 4;
+    if (cs < C && (total > 0 || !use_atomic || partial) && ((CIM_ROI_RG_EXP != 4 && CIM_ROI_RG_EXP != 5 && CIM_ROI_RG_EXP != 6) || accl[0].x == 123.456f)) {
+#pragma unroll
+        for (int i = 0; i < RG_SBH; ++i)
+#pragma unroll
+            for (int j = 0; j < RG_SBW; ++j)
+                if (sy0 + i < H && sx0 + j < W && sy0 + i < y0 + RG_RH) {
+                    const size_t o = (((size_t)b * H + sy0 + i) * W + sx0 + j) * C + cs;
+                    float* dst = grad_in + o;
+                    const float4 v = make_float4(accl[i * 4 + j].x, accl[i * 4 + j].y, acch[i * 4 + j].x, acch[i * 4 + j].y);
+                    if (partial) {      // the groups' partial maps are summed by roi_partial_reduce_kernel (no atomics)
+                        __builtin_nontemporal_store(v.x, partial + (size_t)kgroup * B * H * W * C + o);
+                        __builtin_nontemporal_store(v.y, partial + (size_t)kgroup * B * H * W * C + o + 1);
+                        __builtin_nontemporal_store(v.z, partial + (size_t)kgroup * B * H * W * C + o + 2);
+                        __builtin_nontemporal_store(v.w, partial + (size_t)kgroup * B * H * W * C + o + 3);
+                    } else if (use_atomic) {
+                        atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+                    } else {
+                        *reinterpret_cast<float4*>(dst) = v;
+                    }
+                }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward, pixel-owner form (default when the per-launch tables exist and the tile fits).
 // Same ownership idea as above - a workgroup owns 16 channels of the whole map as an LDS tile - but
 //   * a LANE owns one pixel of the ROI's bounding box with all 16 channels (16 accumulators), so the
@@ -1465,16 +1727,84 @@ static int launch_bwd_gather(const float* go, const float* rois, const float* ma
     return 0;
 }
 
+// Region order, centre first (the centre regions carry the most entries: longest jobs first), computed on the host
+// and passed by value.
+static RegionOrder region_order(int ry, int rx) {
+    RegionOrder ro;
+    const int n = ry * rx;
+    int idx[RG_MAXREG];
+    float d[RG_MAXREG];
+    for (int r = 0; r < n; ++r) {
+        const float dy = (r / rx) + 0.5f - 0.5f * ry, dx = (r % rx) + 0.5f - 0.5f * rx;
+        idx[r] = r;
+        d[r] = dy * dy * (float)(RG_RH * RG_RH) + dx * dx * (float)(RG_RW * RG_RW);
+    }
+    for (int i = 0; i < n; ++i) {
+        int best = i;
+        for (int j = i + 1; j < n; ++j)
+            if (d[idx[j]] < d[idx[best]]) best = j;
+        const int t = idx[i]; idx[i] = idx[best]; idx[best] = t;
+        ro.o[i] = (unsigned char)idx[i];
+    }
+    return ro;
+}
+
+// grad_in = sum over the ROI groups' partial maps: n4 float4 per map, groups maps `stride4` float4 apart.
+__global__ __launch_bounds__(256) void roi_partial_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ out,
+                                                                 size_t n4, int groups) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    typedef float rp_f4 __attribute__((ext_vector_type(4)));
+    const rp_f4* p = reinterpret_cast<const rp_f4*>(partial) + i;
+    rp_f4 acc = __builtin_nontemporal_load(p);
+    for (int g = 1; g < groups; ++g) acc += __builtin_nontemporal_load(p + (size_t)g * n4);
+    out[i] = make_float4(acc.x, acc.y, acc.z, acc.w);
+}
+
+template <bool MASKCAT>
+static int launch_bwd_region(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W,
+                             int K, int P, float scale, int sr, int aligned, float* ws, hipStream_t st, int tables_ready,
+                             float* scratch) {
+    if (!tables_ready)
+        hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), sizeof(float) * roi_rec_words(P, H, W), st, rois, ws, K, P, H, W, scale, sr, aligned);
+    const int ry = (H + RG_RH - 1) / RG_RH, rx = (W + RG_RW - 1) / RG_RW, n_regions = ry * rx;
+    const RegionOrder order = region_order(ry, rx);
+    const int GS = rg_group_size(K);
+    const int groups = (K + GS - 1) / GS, n_slices = (C + 255) / 256;
+    float* partial = (groups > 1) ? scratch : nullptr;      // without scratch the groups meet through atomicAdd (slow)
+    if (groups > 1 && !partial) {
+        hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * (size_t)B * H * W * C, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    auto kern = GS == 128 ? roi_align_bwd_region_kernel<MASKCAT, 128> : roi_align_bwd_region_kernel<MASKCAT, 64>;
+    const size_t lds = sizeof(float) * (2 * RG_WIN * 256 + RG_MAXE * RG_REC);
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return (int)ea;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_slices * B * groups * n_regions)), dim3(RG_NT), lds, st, go, masks, gin, C, H, W, K, P, B,
+                       groups > 1 ? 1 : 0, ws, order, n_regions, rx, n_slices, partial);
+    if (partial) {
+        const size_t n4 = (size_t)B * H * W * C / 4;
+        hipLaunchKernelGGL(roi_partial_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(gin), n4, groups);
+    }
+    return 0;
+}
+
 template <bool MASKCAT>
 int launch_bwd(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W, int K,
-               int P, float scale, int sr, int aligned, float* ws, hipStream_t st, int tables_ready = 0) {
+               int P, float scale, int sr, int aligned, float* ws, hipStream_t st, int tables_ready = 0, float* scratch = nullptr) {
     const size_t budget = 150 * 1024;
     // gather form: 256 lanes x 4 channels per workgroup (grid.z chunks of 1024 channels), 8-bit bin indices in the
     // packed ranges, 32-bit element offsets
     if (K > 0 && ws != nullptr && C % 4 == 0 && P <= 16 && H < 256 && W < 256 && (long long)B * ((K + GA_GS - 1) / GA_GS) <= 65535 &&
         (long long)K * P * P * (MASKCAT ? 2 : 1) * C < (1ll << 31) && getenv("CIM_ROI_BWD_TILE") == nullptr &&
-        getenv("CIM_ROI_BWD_PX16") == nullptr)
+        getenv("CIM_ROI_BWD_PX16") == nullptr) {
+        // region form needs the partial-map scratch (or a single ROI group); without it the gather form's fewer atomics win
+        if (getenv("CIM_ROI_BWD_GATHER") == nullptr && (scratch != nullptr || K <= rg_group_size(K)) && ((H + RG_RH - 1) / RG_RH) * ((W + RG_RW - 1) / RG_RW) <= RG_MAXREG &&
+            (long long)B * ((K + 63) / 64) * ((C + 255) / 256) * RG_MAXREG < (1ll << 31))
+            return launch_bwd_region<MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st, tables_ready, scratch);
         return launch_bwd_gather<MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st, tables_ready);
+    }
     if (K > 0 && ws != nullptr && C % 16 == 0 && P * P * 4 <= PX_THREADS && H < 256 && W < 256 &&
         (P + 1) * (H + W) + 6 <= PX_MAXTAB * PX_THREADS && bwd_px_lds(H, W, P) <= 160 * 1024 - 512 &&
         getenv("CIM_ROI_BWD_TILE") == nullptr)
@@ -1558,13 +1888,19 @@ extern "C" int cim_roi_align_bwd(const float* grad_out, const float* rois, float
     return 0;
 }
 
+extern "C" long long cim_roi_align_bwd_scratch(int K, int B, int C, int H, int W) {
+    const int GS = rg_group_size(K);
+    const long long groups = (K + GS - 1) / GS;
+    return groups > 1 ? (long long)sizeof(float) * groups * B * H * W * C : 0;
+}
+
 extern "C" int cim_roi_align_bwd_ws(const float* grad_out, const float* rois, float* grad_in, int B, int C, int H, int W,
                                     int K, int P, float spatial_scale, int sampling_ratio, int aligned, float* workspace,
-                                    int tables_ready, void* stream) {
+                                    int tables_ready, float* scratch, void* stream) {
     ROI_ARGS_OK();
     CIM_CHECK_ARG(grad_in && (grad_out || K == 0) && (workspace || !tables_ready));
     int rc = launch_bwd<false>(grad_out, rois, nullptr, grad_in, B, C, H, W, K, P, spatial_scale, sampling_ratio,
-                               aligned, workspace, cim::as_stream(stream), tables_ready);
+                               aligned, workspace, cim::as_stream(stream), tables_ready, scratch);
     if (rc) return rc;
     CIM_CHECK_LAUNCH();
     return 0;
@@ -1573,11 +1909,11 @@ extern "C" int cim_roi_align_bwd_ws(const float* grad_out, const float* rois, fl
 extern "C" int cim_roi_align_maskcat_bwd_ws(const float* grad_cat, const float* rois, const float* masks, float* grad_in,
                                             int B, int C, int H, int W, int K, int P, float spatial_scale,
                                             int sampling_ratio, int aligned, float* workspace, int tables_ready,
-                                            void* stream) {
+                                            float* scratch, void* stream) {
     ROI_ARGS_OK();
     CIM_CHECK_ARG(grad_in && ((grad_cat && masks) || K == 0) && (workspace || !tables_ready));
     int rc = launch_bwd<true>(grad_cat, rois, masks, grad_in, B, C, H, W, K, P, spatial_scale, sampling_ratio, aligned,
-                              workspace, cim::as_stream(stream), tables_ready);
+                              workspace, cim::as_stream(stream), tables_ready, scratch);
     if (rc) return rc;
     CIM_CHECK_LAUNCH();
     return 0;

@@ -40,6 +40,12 @@ def _workspace(k, p, h, w, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
+def _scratch(k, b, c, h, w, device):
+    """Per-ROI-group partial maps of the region-form backward (freed right after the call)."""
+    nbytes = _lib.call("cim_roi_align_bwd_scratch", k, b, c, h, w)
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device) if nbytes else None
+
+
 def _empty_nhwc(k, c, h, w, like):
     return torch.empty((k, h, w, c), dtype=like.dtype, device=like.device).permute(0, 3, 1, 2)
 
@@ -71,7 +77,8 @@ class RoIAlignFunction(Function):
         grad_in = _empty_nhwc(B, C, H, W, grad_out)
         ws = ctx.tables if ctx.tables is not None else _workspace(K, P, H, W, grad_out.device)
         _lib.call("cim_roi_align_bwd_ws", grad_out.data_ptr(), rois.data_ptr(), grad_in.data_ptr(), B, C, H, W, K, P,
-                  scale, sr, aligned, ws.data_ptr(), int(ctx.tables is not None), _lib.stream_ptr())
+                  scale, sr, aligned, ws.data_ptr(), int(ctx.tables is not None),
+                  _lib.ptr(_scratch(K, B, C, H, W, grad_out.device)), _lib.stream_ptr())
         return grad_in, None, None, None, None, None
 
 
@@ -108,7 +115,7 @@ class RoIAlignMaskCatFunction(Function):
         ws = ctx.tables if ctx.tables is not None else _workspace(K, P, H, W, grad_cat.device)
         _lib.call("cim_roi_align_maskcat_bwd_ws", grad_cat.data_ptr(), rois.data_ptr(), masks.data_ptr(),
                   grad_in.data_ptr(), B, C, H, W, K, P, scale, sr, aligned, ws.data_ptr(), int(ctx.tables is not None),
-                  _lib.stream_ptr())
+                  _lib.ptr(_scratch(K, B, C, H, W, grad_cat.device)), _lib.stream_ptr())
         return grad_in, None, None, None, None, None, None
 
 

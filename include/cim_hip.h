@@ -62,13 +62,19 @@ int cim_roi_align_maskcat_fwd_ws(const float* feat, const float* rois, const flo
                                  float spatial_scale, int sampling_ratio, int aligned, float* workspace, void* stream);
 
 /* Backward with tables_ready != 0: `workspace` still holds the tables a *_fwd_ws call on the SAME rois / geometry
- * built (the aggregated-weight forward and the gather backward share them); 0 rebuilds them. */
+ * built (the aggregated-weight forward and the backward share them); 0 rebuilds them.
+ * scratch: cim_roi_align_bwd_scratch(K,B,C,H,W) bytes (0: none needed) for the per-ROI-group partial maps of the
+ * region-form backward, which are then summed by one streaming pass; with scratch == NULL the groups meet in
+ * grad_in through float atomics (device-scope float atomics run at ~90 G/s on MI355X: 2-3x slower end to end). */
+long long cim_roi_align_bwd_scratch(int K, int B, int C, int H, int W);
 int cim_roi_align_bwd_ws(const float* grad_out, const float* rois, float* grad_in,
                          int B, int C, int H, int W, int K, int P,
-                         float spatial_scale, int sampling_ratio, int aligned, float* workspace, int tables_ready, void* stream);
+                         float spatial_scale, int sampling_ratio, int aligned, float* workspace, int tables_ready,
+                         float* scratch, void* stream);
 int cim_roi_align_maskcat_bwd_ws(const float* grad_cat, const float* rois, const float* masks, float* grad_in,
                                  int B, int C, int H, int W, int K, int P,
-                                 float spatial_scale, int sampling_ratio, int aligned, float* workspace, int tables_ready, void* stream);
+                                 float spatial_scale, int sampling_ratio, int aligned, float* workspace, int tables_ready,
+                                 float* scratch, void* stream);
 
 /* Fused ROIAlign + mask multiply + channel concat: the input of MaskFuse.mask_branch,
  * lib/modeling/resnet50.py:121-134 (vgg16.py:162-175, HRNet.py:615-628):
