@@ -22,6 +22,7 @@ SIGNATURES = {
     "cim_roi_align_bwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
     "cim_roi_align_maskcat_fwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
     "cim_roi_align_maskcat_bwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
+    "cim_image_prep": [_P, c_int, c_int, _P, c_int, c_int, c_longlong, c_int, ctypes.c_double, c_int, _P, _P],
     "cim_mask_pack": [_P, _P, c_int, c_int, _P],
     "cim_mask_iou_pair": [_P, c_int, c_int, _P, _P, _P, _P],
     "cim_asy_flag": [_P, c_int, c_float, _P, _P],

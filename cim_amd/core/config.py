@@ -26,7 +26,10 @@ def _defaults():
     c = AttrDict()
     c.TRAIN = AttrDict(FREEZE_CONV_BODY=False, SCALES=(600,), MAX_SIZE=1000, IMS_PER_BATCH=1,
                        BATCH_SIZE_PER_IM=4096)
-    c.TEST = AttrDict()
+    c.TEST = AttrDict(SCALE=600, MAX_SIZE=1000,           # lib/core/config.py:123-126,167-201
+                      BBOX_AUG=AttrDict(ENABLED=False, SCORE_HEUR="AVG", COORD_HEUR="ID", H_FLIP=False, SCALES=(),
+                                        MAX_SIZE=4000, SCALE_H_FLIP=False, SCALE_SIZE_DEP=False, ASPECT_RATIOS=(),
+                                        ASPECT_RATIO_H_FLIP=False))
     c.MODEL = AttrDict(TYPE="generalized_rcnn", CONV_BODY="", NUM_CLASSES=-1,
                        LOAD_IMAGENET_PRETRAINED_WEIGHTS=False, EXTRA=AttrDict())
     c.SOLVER = AttrDict(BASE_LR=0.0005, WEIGHT_DECAY=0.0005, MOMENTUM=0.9, TYPE="SGD",

@@ -36,6 +36,10 @@ def apply_preset(name):
     cfg.MODEL.CONV_BODY = p["CONV_BODY"]
     cfg.MODEL.NUM_CLASSES = p["NUM_CLASSES"]
     cfg.MODEL.LOAD_IMAGENET_PRETRAINED_WEIGHTS = False
+    # TEST section of the configs (configs/resnet50_voc.yaml:40-53): 5 scales x flip test-time augmentation
+    cfg.TEST.SCALE, cfg.TEST.MAX_SIZE = 480, 2000
+    cfg.TEST.BBOX_AUG.update(ENABLED=True, H_FLIP=True, SCALES=(576, 688, 864, 1200), SCALE_H_FLIP=True,
+                             SCORE_HEUR="AVG", COORD_HEUR="ID")
     for k, v in p["flags"].items():
         cfg[k] = v
     return cfg

@@ -176,6 +176,19 @@ typedef struct cim_mining_args {
 long long cim_mining_lds_bytes(int N, int K);
 int cim_mining_step(const cim_mining_args* args, void* stream);
 
+/* ------------------------------------------------------------------ network-input image (f-3: the data side of the step)
+ * Replaces prep_im_for_blob(flag="ToTensor"), lib/utils/blob.py:93-147, called from lib/roi_data/minibatch.py:109-150
+ * (training) and lib/core/test.py:464-473 via get_image_blob (inference):
+ *   src_bgr [h,w,3] uint8 as cv2.imread returns it (device memory) [-> horizontal flip, minibatch.py:121-122]
+ *   -> float32 -> cv2.resize(fx = fy = im_scale, INTER_LINEAR) -> np.uint8 -> BGR2RGB -> /255 -> (x - mean) / std
+ * dst: float32 planes [3][H][W] of an NCHW blob: element (c,y,x) at dst[c*plane_stride + y*row_stride + x]
+ * (H = round(h*im_scale), W = round(w*im_scale); strides let the caller write into a padded batch blob,
+ * lib/utils/blob.py:59-83).  inv_scale = 1 / im_scale (double, as cv::resize uses it).
+ * mean_std6_host: HOST pointer to {mean_r, mean_g, mean_b, std_r, std_g, std_b}.
+ * The resize arithmetic restates OpenCV 4.x's INTER_LINEAR float path; cv2 is not in the reference tree: unpinned. */
+int cim_image_prep(const uint8_t* src_bgr, int h, int w, float* dst, int H, int W, long long plane_stride, int row_stride,
+                   double inv_scale, int hflip, const float* mean_std6_host, void* stream);
+
 /* ------------------------------------------------------------------ backbone BatchNorm chains (a-11)
  * Frozen-statistics BatchNorm (+ residual) (+ ReLU) of the ResNet / HRNet bodies, lib/modeling/resnet50.py:17-44,53-77
  * (every BN in eval(): running statistics, trainable affine), one launch each way instead of 2-3 / 3-4 ATen passes.

@@ -357,6 +357,57 @@ def gen_e2e():
     print("e2e", {k: float(v) for k, v in store.items() if k.startswith("loss_")}, "params with grad:", len(names))
 
 
+def gen_e2e_eval():
+    """f-2: the reference's INFERENCE branch (model_builder.py:60-68,209-211; called per TTA pass by
+    lib/core/test.py:83-146) on the cfg1 case: eval-mode `refine_score` of the three refinement heads, same
+    procedural weights and inputs as gen_e2e, oracle ROIAlign plugged in for mmcv."""
+    from oracle import roi_align as ora
+
+    class RoIAlignStub(torch.nn.Module):          # constructor signature of mmcv.ops.RoIAlign
+        def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode="avg", aligned=True,
+                     use_torchvision=False):
+            super().__init__()
+            self.args = (output_size, spatial_scale, sampling_ratio)
+
+        def forward(self, x, rois):
+            P, scale, sr = self.args
+            return torch.from_numpy(ora.roi_align_fwd(x.detach().numpy(), rois.detach().numpy(), P, scale, sr, True))
+
+    sys.modules["mmcv.ops"].RoIAlign = RoIAlignStub
+    for m in [k for k in sys.modules if k == "ops" or k.startswith("ops.") or k.startswith("modeling")]:
+        del sys.modules[m]
+    cfgmod = importlib.import_module("core.config")
+    cfg = cfgmod.cfg
+    if cfg.is_immutable():
+        cfg.immutable(False)
+    cfg.MODEL.NUM_CLASSES = 20
+    cfgmod.cfg_from_file(_ref_shims.REF_ROOT + "/configs/vgg16_voc.yaml")
+    cfg.MODEL.LOAD_IMAGENET_PRETRAINED_WEIGHTS = False
+    mb = importlib.import_module("modeling.model_builder")
+    model = mb.Generalized_RCNN()
+    procedural_init(model)
+    model.eval()
+    inp = e2e_inputs()
+    store = {}
+    for tag, flip in (("", False), ("hflip_", True)):
+        data, rois, masks = inp["data"], inp["rois"].copy(), inp["masks"]
+        if flip:                                   # lib/core/test.py:244-262 on the network-input side
+            W = data.shape[3]
+            data = data[:, :, :, ::-1].copy()
+            x1 = rois[:, 1].copy()
+            rois[:, 1] = W - rois[:, 3] - 1
+            rois[:, 3] = W - x1 - 1
+            masks = np.flip(masks.copy(), 2).copy()
+        out = model(data=torch.from_numpy(data), rois=torch.from_numpy(rois), masks=torch.from_numpy(masks),
+                    labels=torch.zeros(1, 20), gtrois=torch.zeros(1, 5), mat=torch.zeros(1), path="/x/img.jpg")
+        assert set(out) == {"blob_conv", "refine_score"}
+        for i, r in enumerate(out["refine_score"]):
+            store["%srefine_score_%d" % (tag, i)] = r.detach().numpy().astype(np.float32)
+        store[tag + "blob_conv_absmean"] = np.array(float(out["blob_conv"].abs().mean()))
+    np.savez_compressed(os.path.join(HERE, "e2e_vgg16_voc_eval.npz"), **store)
+    print("e2e eval", {k: v.shape for k, v in store.items()})
+
+
 def gen_hrnet():
     """The reference's HRNet-W48 trunk (lib/modeling/HRNet.py) on procedural weights: state_dict keys
     and the fused 2048-channel stride-32 map for an image whose sides are not multiples of 32."""
@@ -442,6 +493,9 @@ def gen_lr():
 
 def main():
     _ref_shims.install()
+    if len(sys.argv) > 1 and sys.argv[1] == "e2e_eval":      # one fixture only
+        gen_e2e_eval()
+        return
     heads = importlib.import_module("modeling.heads")
     gen_mining(heads)
     gen_losses(heads)
@@ -449,6 +503,7 @@ def main():
     gen_mask_iou()
     gen_mask_iou_witness()
     gen_e2e()
+    gen_e2e_eval()
     gen_hrnet()
     gen_lr()
 

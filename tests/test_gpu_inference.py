@@ -1,0 +1,108 @@
+"""-m gpu: f-2 (inference branch + batched test-time augmentation) and f-3 (network-input image chain on the device)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cases import E2E, e2e_inputs, procedural_init
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("hw,scale,flip", [((37, 53), 1.0, False), ((375, 500), 480 / 500.0, False), ((375, 500), 688 / 500.0, True),
+                                            ((333, 500), 1200 / 500.0, False), ((500, 375), 576 / 500.0, True), ((64, 48), 0.37, False)])
+def test_image_prep_bit_identical_to_oracle(hw, scale, flip):
+    from cim_amd.utils import blob
+    from oracle import image_prep as ip
+    rng = np.random.RandomState(hw[0] + int(scale * 100))
+    im = rng.randint(0, 256, size=hw + (3,)).astype(np.uint8)
+    im[:8, :8] = 255
+    im[-8:, -8:] = 0
+    target = scale * max(hw)
+    ims, scales = blob.prep_im_for_blob(im, None, [target], 2000, "ToTensor", hflip=flip, device=DEV)
+    assert abs(scales[0] - scale) < 1e-12
+    ref = ip.prep_image(im, scales[0], hflip=flip)
+    assert tuple(ims[0].shape) == ref.shape
+    np.testing.assert_array_equal(ims[0].cpu().numpy(), ref)
+    # into a padded batch blob through strides
+    blobt = torch.zeros((3, ref.shape[1] + 5, ref.shape[2] + 9), device=DEV)
+    blob.prep_im_for_blob(im, None, [target], 2000, "ToTensor", hflip=flip, device=DEV, out=[blobt])
+    np.testing.assert_array_equal(blobt[:, :ref.shape[1], :ref.shape[2]].cpu().numpy(), ref)
+    assert float(blobt[:, ref.shape[1]:].abs().sum()) == 0 and float(blobt[:, :, ref.shape[2]:].abs().sum()) == 0
+    rois = blob.project_im_rois(np.array([[1, 2, 30, 40], [0, 0, 5, 5]], np.float32), scales[0], batch_index=1, device=DEV).cpu().numpy()
+    np.testing.assert_array_equal(rois[:, 0], [1, 1])
+    np.testing.assert_array_equal(rois[:, 1:], np.array([[1, 2, 30, 40], [0, 0, 5, 5]], np.float32) * np.float32(scales[0]))
+    with pytest.raises(NotImplementedError):
+        blob.prep_im_for_blob(im, None, [target], 2000, "org", device=DEV)
+
+
+def test_eval_branch_matches_reference(golden_dir):
+    """The reference's eval-mode refine_score (model_builder.py:60-68) on cfg1, plain and horizontally flipped views
+    (tests/golden/e2e_vgg16_voc_eval.npz, captured by running the reference)."""
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    g = np.load(os.path.join(golden_dir, "e2e_vgg16_voc_eval.npz"))
+    apply_preset(E2E["config"])
+    m = Generalized_RCNN()
+    procedural_init(m)
+    m = m.to(DEV).eval()
+    inp = e2e_inputs()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    W = inp["data"].shape[3]
+    rois_f = inp["rois"].copy()
+    rois_f[:, 1], rois_f[:, 3] = W - inp["rois"][:, 3] - 1, W - inp["rois"][:, 1] - 1
+    views = {"": (inp["data"], inp["rois"], inp["masks"]),
+             "hflip_": (inp["data"][:, :, :, ::-1], rois_f, np.flip(inp["masks"], 2))}
+    worst = 0.0
+    for tag, (data, rois, masks) in views.items():
+        out = m(data=t(data), rois=t(rois), masks=t(masks), labels=None, gtrois=None, mat=None)
+        assert set(out) == {"blob_conv", "refine_score"} and len(out["refine_score"]) == 3
+        np.testing.assert_allclose(float(out["blob_conv"].abs().mean()), float(g[tag + "blob_conv_absmean"]), rtol=1e-4)
+        for i, r in enumerate(out["refine_score"]):
+            ref = g["%srefine_score_%d" % (tag, i)]
+            got = r.cpu().numpy()
+            assert got.shape == ref.shape == (300, 20) and not r.requires_grad
+            worst = max(worst, float(np.abs(got - ref).max() / np.abs(ref).max()))
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=3e-5 * float(np.abs(ref).max()))      # measured 5.4e-6 of max|ref|
+    print("eval branch: worst |score - reference| / max|reference| = %.2e" % worst)
+    # both views in ONE forward (batch 2) give the same rows
+    b_rois = np.concatenate([inp["rois"], rois_f], 0)
+    b_rois[300:, 0] = 1
+    out = m(data=t(np.concatenate([views[""][0], views["hflip_"][0]], 0)), rois=t(b_rois),
+            masks=t(np.concatenate([inp["masks"], np.flip(inp["masks"], 2)], 0)), labels=None, gtrois=None, mat=None)
+    for i in range(3):
+        np.testing.assert_allclose(out["refine_score"][i][:300].cpu().numpy(), g["refine_score_%d" % i], rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(out["refine_score"][i][300:].cpu().numpy(), g["hflip_refine_score_%d" % i], rtol=2e-3, atol=1e-6)
+
+
+def test_tta_batched_equals_sequential():
+    """im_detect_all with the configs' 5 scales x flip augmentation: the batched schedule (5 forwards of batch 2) gives
+    the averages of the reference's 10 sequential passes (lib/core/test.py:149-241)."""
+    from cim_amd import synthetic
+    from cim_amd.core import test as ctest
+    from cim_amd.core.config import cfg
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    apply_preset("resnet50_voc")
+    assert cfg.TEST.BBOX_AUG.ENABLED and tuple(cfg.TEST.BBOX_AUG.SCALES) == (576, 688, 864, 1200) and cfg.TEST.SCALE == 480
+    cfg.TEST.SCALE, cfg.TEST.BBOX_AUG.SCALES = 160, (192, 224, 288, 400)        # same structure, small images
+    torch.manual_seed(0)
+    model = Generalized_RCNN().to(DEV).eval()
+    rng = np.random.RandomState(3)
+    h, w, n = 96, 128, 40
+    im = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+    full_masks, boxes = synthetic.make_masks(n, h, w, rng, min_side=8)
+    masks = synthetic.masks_7x7(full_masks, boxes)
+    boxes = boxes.astype(np.float32)
+    res = ctest.im_detect_all(model, im, boxes, masks)
+    assert set(res) == {"scores", "boxes"} and tuple(res["scores"].shape) == (n, 20)
+    seq, _, im_scale, blob_conv = ctest.im_detect_bbox_aug(model, im, boxes, masks, batched=False)
+    assert abs(im_scale - 160.0 / 128.0) < 1e-12 and blob_conv.shape[0] == 1
+    torch.testing.assert_close(res["scores"], seq, rtol=1e-4, atol=1e-7)
+    # the average really contains the flipped passes: it differs from the single identity pass
+    single, _, _, _ = ctest.im_detect_bbox(model, im, 160, 2000, boxes, masks)
+    assert float((single - seq).abs().max()) > 1e-6
+    hf, _, _ = ctest.im_detect_bbox_hflip(model, im, 160, 2000, boxes, masks)
+    assert tuple(hf.shape) == (n, 20)

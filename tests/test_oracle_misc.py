@@ -130,3 +130,33 @@ def test_roi_align_bwd_is_adjoint_of_fwd():
     # total gradient mass: every in-range sample spreads weight 1/count
     ones = roi_align.roi_align_bwd(np.ones_like(go), rois[:1], feat.shape, aligned=True)
     np.testing.assert_allclose(ones.sum(), 3 * 49, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ f-3: network-input image chain (oracle closed forms)
+def test_image_prep_oracle_closed_forms():
+    from oracle import image_prep as ip
+    rng = np.random.RandomState(0)
+    im = rng.randint(0, 256, size=(37, 53, 3)).astype(np.uint8)
+    # scale 1: the resize is the identity (f = 0 everywhere) -> plain BGR2RGB, /255, normalise
+    ref = ((im[:, :, ::-1].astype(np.float32) / np.float32(255) - ip.MEAN) / ip.STD).transpose(2, 0, 1)
+    np.testing.assert_array_equal(ip.prep_image(im, 1.0), ref)
+    # horizontal flip commutes with the identity resize
+    np.testing.assert_array_equal(ip.prep_image(im, 1.0, hflip=True), ref[:, :, ::-1])
+    # output size = round-half-even(h * scale), (w * scale): the training scales on a 375 x 500 VOC image
+    big = rng.randint(0, 256, size=(375, 500, 3)).astype(np.uint8)
+    for target, hw in ((480, (360, 480)), (576, (432, 576)), (688, (516, 688)), (864, (648, 864)), (1200, (900, 1200))):
+        assert ip.prep_image(big, target / 500.0).shape == (3,) + hw
+    # a constant image stays constant per channel; values are (k/255 - mean) / std for an integer k
+    c = np.full((20, 30, 3), 200, np.uint8)
+    out = ip.prep_image(c, 1.376)
+    for ch in range(3):
+        vals = np.unique(out[ch])
+        assert vals.size == 1
+        k = np.round((vals[0] * ip.STD[ch] + ip.MEAN[ch]) * 255)
+        assert k in (199, 200)                        # truncation after the float32 interpolation may lose one level
+    # exact 2x down-scale of a 2-periodic pattern: every output pixel is the mean of a 2 x 2 block
+    blk = np.zeros((8, 12, 3), np.uint8)
+    blk[0::2, 0::2], blk[0::2, 1::2], blk[1::2, 0::2], blk[1::2, 1::2] = 10, 20, 30, 40
+    out = ip.prep_image(blk, 0.5)
+    want = (np.float32(25) / np.float32(255) - ip.MEAN[0]) / ip.STD[0]
+    np.testing.assert_allclose(out[0], want, rtol=0, atol=1e-6)
