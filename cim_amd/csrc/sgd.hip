@@ -8,8 +8,8 @@
 // checkpoint code work unchanged.
 //
 // One launch for ALL tensors.  Two device tables: `chunks` (tensor index + element offset of every 16384-element chunk;
-// built once, it only depends on the tensor sizes) and `tensors` (pointers, element count, lr, wd per tensor: 40 bytes
-// each, refreshed per step - autograd hands out new gradient tensors every step, the chunk layout never changes).
+// built once, it only depends on the tensor sizes) and `tensors` (cim_sgd_tensor: pointers, element count, lr, wd, matrix shape and |max|
+// array pointers per tensor: 64 bytes each, refreshed per step - autograd hands out new gradient tensors every step, the chunk layout never changes).
 // A workgroup streams one chunk with 16 B accesses: 12 B read + 8 B written per parameter, HBM-bound.
 #include "common.h"
 #include "../../include/cim_hip.h"

@@ -7,11 +7,16 @@ load unchanged: `res1.0`=conv1, `res1.1`=bn1, `res2|res3|res4.<i>.{conv1,bn1,con
 bn3,downsample.0,downsample.1}`.  All BatchNorm layers stay in eval mode and res1-2 are frozen,
 as resnet50.py:53-77 does.
 """
+import os
+
 import torch.nn as nn
 
 from ..core.config import cfg
-from ..ops import bn_act
+from ..ops import bn_act, conv1x1_bn_act
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "resnet50.MaskFuse" by get_func)
+
+
+OWN_1X1 = os.environ.get("CIM_BACKBONE_1X1", "hip") != "aten"      # CIM_BACKBONE_1X1=aten: the MIOpen / rocBLAS path (A/B runs)
 
 
 class Bottleneck(nn.Module):
@@ -29,9 +34,17 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        # BatchNorm (eval statistics) + residual + ReLU chains as one HIP launch each way (cim_amd/csrc/bn_act.hip);
-        # bn_act falls back to the ATen ops for a BN in training mode or CPU tensors
+        # the 1 x 1 convolutions with their BatchNorm (eval statistics) (+ identity) (+ ReLU) are ONE HIP launch each
+        # (small-tile fp32-MFMA GEMM with the chain in its epilogue, cim_amd/csrc/conv1x1.hip); the 3 x 3 convolution
+        # stays on MIOpen's fp32 Winograd kernel with the fused BatchNorm + ReLU launch behind it (cim_amd/csrc/bn_act.hip).
+        # Both fall back to the ATen ops for a BN in training mode or CPU tensors.
         identity = x
+        if OWN_1X1:
+            out = conv1x1_bn_act(x, self.conv1, self.bn1)
+            out = bn_act(self.conv2(out), self.bn2)
+            if self.downsample is not None:
+                identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+            return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity)
         out = bn_act(self.conv1(x), self.bn1)
         out = bn_act(self.conv2(out), self.bn2)
         if self.downsample is not None:

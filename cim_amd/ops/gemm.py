@@ -7,6 +7,7 @@ the reference's layouts ([out,in] and [out,in,3,3]) so checkpoints and optimizer
 Forward and both backward contractions run on hand-written HIP; there is no CPU fallback.
 """
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -49,18 +50,31 @@ def amax(x, rows, cols, ld, want_rows=False, want_cols=False, batch=1, bs=0, out
 
 
 # |max| arrays of weight matrices handed in by a producer that already streamed over the weight (the fused SGD kernel):
-# data_ptr -> (version counter, rows, cols, row array, column array).  An entry is valid only for that exact version.
-_WEIGHT_SCALES = {}
+# keyed by the weight tensor's identity with a weak reference (an entry dies with its tensor; a recycled address or id can
+# never match) and holding (version counter, data_ptr, rows, cols, row array, column array).  An entry is valid only for that exact version of that storage: any
+# tracked in-place change (optimizer step, load_state_dict, init) bumps the counter and the ops make their own pass.
+# Writes through `w.data` are invisible to the counter - as for autograd itself - so code that edits weights that way
+# must call forget_weight_scales(w).
+_WEIGHT_SCALES = {}          # id(tensor) -> (weak reference, version, data_ptr, rows, cols, row array, column array)
 
 
 def register_weight_scales(w, rows, cols, row_amax, col_amax):
-    _WEIGHT_SCALES[w.data_ptr()] = (w._version, rows, cols, row_amax, col_amax)
+    key = id(w)
+    ref = weakref.ref(w, lambda _r, key=key: _WEIGHT_SCALES.pop(key, None))     # the entry dies with its tensor
+    _WEIGHT_SCALES[key] = (ref, w._version, w.data_ptr(), rows, cols, row_amax, col_amax)
+
+
+def forget_weight_scales(w=None):
+    if w is None:
+        _WEIGHT_SCALES.clear()
+    else:
+        _WEIGHT_SCALES.pop(id(w), None)
 
 
 def _registered_scales(w, rows, cols):
-    e = _WEIGHT_SCALES.get(w.data_ptr())
-    if e is not None and e[0] == w._version and e[1] == rows and e[2] == cols:
-        return e[3], e[4]
+    e = _WEIGHT_SCALES.get(id(w))
+    if e is not None and e[0]() is w and e[1] == w._version and e[2] == w.data_ptr() and e[3] == rows and e[4] == cols:
+        return e[5], e[6]
     return None
 
 

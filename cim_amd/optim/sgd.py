@@ -7,9 +7,11 @@ rule - but ONE kernel launch per step for all parameters instead of one multi-te
 Only what the reference uses is supported on the HIP path: fp32 CUDA/HIP parameters, dampening 0, no Nesterov,
 dense gradients, one momentum value; anything else raises (there is no silent fallback).
 
-Host cost per step: autograd hands out new gradient tensors every step, so the 64-byte record of every tensor is
-refreshed (one pass over the parameters, one 10 KB H2D copy); the chunk table only depends on the tensor sizes and is
-built once.
+Host cost per step: autograd hands out new gradient tensors every step and the row / column |max| arrays are fresh
+storage every step, so the 64-byte record of every tensor is rebuilt and copied (one pass over the parameters, one
+10 KB H2D copy; the copy is skipped only when the table happens to be byte-identical to the previous step's); the chunk
+table only depends on the tensor sizes and is built once.  Matrix mode and 16-byte accesses need 16-byte aligned
+parameter, gradient and history pointers: nn.DataParallel's flat gradient buffer aligns its views accordingly.
 
 Weights of >= 2^20 elements are updated in the kernel's matrix mode, which also emits max |w_new| per row and per column:
 exactly what the f16x2 contraction engine needs as operand scales of `nn.Linear` / conv weights.  They are registered with

@@ -189,6 +189,35 @@ int cim_mining_step(const cim_mining_args* args, void* stream);
 int cim_image_prep(const uint8_t* src_bgr, int h, int w, float* dst, int H, int W, long long plane_stride, int row_stride,
                    double inv_scale, int hflip, const float* mean_std6_host, void* stream);
 
+/* ------------------------------------------------------------------ backbone 1x1 convolutions (a-11)
+ * The 1 x 1 convolutions of the ResNet bottlenecks (torchvision Bottleneck conv1 / conv3 / downsample.0 as wrapped by
+ * lib/modeling/resnet50.py:17-91) and their backward products as small-tile fp32-MFMA GEMMs, C[M,N] = A . B:
+ *   A: a_mcontig == 0: element (m,k) at A[m*lda + k];  1: at A[k*lda + m]
+ *   B: b_kcontig == 0: element (k,n) at B[k*ldb + n];  1: at B[n*ldb + k]
+ *   forward (NCHW, one image): A = weight [Cout][Cin], B = x [Cin][HW];  dX: A = weight (a_mcontig), B = dy;
+ *   dW: A = dy [Cout][HW], B = x [Cin][HW] (b_kcontig).
+ * Epilogue (splits == 1): x_raw (optional) receives the plain product (the convolution output the BatchNorm backward
+ * needs); C = relu?(acc * a[m] + b[m] (+ residual)), a = gamma*rsqrt(var+eps), b = beta - mean*a per ROW m (= output
+ * channel) when gamma/beta/mean/var are given - the frozen-statistics BatchNorm (+ identity) (+ ReLU) that follows the
+ * convolution, lib/modeling/resnet50.py:53-77 - else C = relu?(acc (+ residual)).
+ * splits > 1 (cim_gemm_small_splits): split-K through `workspace` [splits][M][N] + a fixed-order reduce pass that applies
+ * the same epilogue. */
+int cim_gemm_small_splits(int M, int N, int K);
+int cim_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       int a_mcontig, int b_kcontig, float* x_raw, const float* gamma, const float* beta,
+                       const float* mean, const float* var, float eps, const float* residual, int relu, int splits,
+                       float* workspace, void* stream);
+
+/* Backward of conv1x1 -> frozen BatchNorm (+ residual) (+ ReLU) for B images in one call: BatchNorm / ReLU backward
+ * (cim_bn_act_bwd), dx [B,cin,hw] = W^T . dconv, dw [cout,cin] = sum_b dconv_b . x_b^T.  dy, y (post-activation output; may
+ * be NULL without relu), x_raw (convolution output) are [B,cout,hw]; x is the convolution input [B,cin,hw]; w [cout,cin].
+ * dres / dgamma+dbeta / dx / dw may be NULL when not needed.  workspace: cim_conv1x1_bwd_workspace(B,cin,cout,hw) bytes. */
+long long cim_conv1x1_bwd_workspace(int B, int cin, int cout, int hw);
+int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
+                           const float* gamma, const float* mean, const float* var, float eps, int relu,
+                           float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int hw,
+                           float* workspace, void* stream);
+
 /* ------------------------------------------------------------------ backbone BatchNorm chains (a-11)
  * Frozen-statistics BatchNorm (+ residual) (+ ReLU) of the ResNet / HRNet bodies, lib/modeling/resnet50.py:17-44,53-77
  * (every BN in eval(): running statistics, trainable affine), one launch each way instead of 2-3 / 3-4 ATen passes.

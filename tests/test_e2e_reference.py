@@ -19,19 +19,26 @@ def _model():
     return m
 
 
+# Stated tolerance against the REFERENCE's own run of this step (north_star "within stated fp tolerance"): each loss
+# 1e-5 relative, each parameter gradient's norm 3e-4 relative, its leading elements 5e-3 of the gradient's rms.  Measured on
+# MI355X (tests/test_gpu_tolerance.py, profiles/r2/parity_deviation.json): losses <= 1.3e-6, gradient norms <= 5.0e-5 for
+# every CIM_GEMM_ENGINE x CIM_CONV_ALGO combination.
+LOSS_RTOL, NORM_RTOL, HEAD_TOL = 1e-5, 3e-4, 5e-3
+
+
 def _check(g, losses, named_grads, probe):
     assert probe == float(g["rng_probe"]), "anti-noise sampling consumed a different NumPy RNG stream"
     for k in ("bag_loss", "pcl_loss", "cls_loss", "iou_loss"):
-        np.testing.assert_allclose(losses[k], float(g["loss_" + k]), rtol=2e-3, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(losses[k], float(g["loss_" + k]), rtol=LOSS_RTOL, atol=1e-7, err_msg=k)
     names = [str(n) for n in g["grad_names"]]
     assert names == [n for n, _ in named_grads], "parameter names / order differ from the reference"
     for (name, grad), norm, head in zip(named_grads, g["grad_norms"], g["grad_heads"]):
         n = grad.numel()
         floor = 1e-7 * n ** 0.5
-        assert abs(float(grad.double().norm()) - norm) <= 2e-2 * norm + floor, name
+        assert abs(float(grad.double().norm()) - norm) <= NORM_RTOL * norm + floor, name
         if n >= 8 and norm > 1e-6:      # (detector.bias: softmax over proposals -> exact gradient 0, pure rounding noise)
-            np.testing.assert_allclose(grad.reshape(-1)[:8].double().numpy(), head, rtol=5e-2,
-                                       atol=5e-2 * norm / n ** 0.5 + 1e-9, err_msg=name)
+            np.testing.assert_allclose(grad.reshape(-1)[:8].double().numpy(), head, rtol=HEAD_TOL,
+                                       atol=HEAD_TOL * norm / n ** 0.5 + 1e-9, err_msg=name)
 
 
 def test_cpu_oracle_step_matches_reference(golden_dir):

@@ -294,3 +294,45 @@ def test_conv3x3_flatten_chw(dev, Cout):
     y.backward(go.to(dev))
     for got, ref in ((y.detach(), yr.detach()), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
         assert _rel(got.cpu(), ref) < 3e-5
+
+
+# ------------------------------------------------------------------ backbone 1 x 1 convolutions (csrc/conv1x1.hip)
+@pytest.mark.parametrize("B,cin,cout,H,W,stride,relu,res", [(1, 64, 256, 33, 43, 1, True, True), (1, 256, 64, 65, 86, 1, True, False),
+                                                            (1, 512, 1024, 66, 86, 2, False, False), (2, 128, 128, 17, 23, 1, True, False),
+                                                            (1, 1024, 256, 33, 43, 1, True, False), (1, 64, 64, 129, 172, 1, True, False)])
+def test_conv1x1_bn_act_vs_aten(B, cin, cout, H, W, stride, relu, res):
+    """Forward and all five gradients (x, weight, residual, gamma, beta) against the ATen formulation in float64."""
+    from cim_amd.ops import conv1x1_bn_act
+    torch.manual_seed(cin + cout)
+    dev = torch.device("cuda:0")
+    conv = torch.nn.Conv2d(cin, cout, 1, stride=stride, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(cout).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5); bn.running_mean.uniform_(-0.3, 0.3); bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(B, cin, H, W, device=dev, requires_grad=True)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    r = torch.randn(B, cout, Ho, Wo, device=dev, requires_grad=True) if res else None
+    y = conv1x1_bn_act(x, conv, bn, residual=r, relu=relu)
+    up = torch.randn_like(y)
+    y.backward(up)
+    got = [y.detach(), x.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad] + ([r.grad] if res else [])
+    # float64 ATen reference
+    c64, b64 = torch.nn.Conv2d(cin, cout, 1, stride=stride, bias=False).to(dev).double(), torch.nn.BatchNorm2d(cout).to(dev).double().eval()
+    c64.weight.data.copy_(conv.weight.data); b64.load_state_dict({k: v.double() for k, v in bn.state_dict().items()})
+    x64 = x.detach().double().requires_grad_(True)
+    r64 = r.detach().double().requires_grad_(True) if res else None
+    ref = b64(c64(x64))
+    if res:
+        ref = ref + r64
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(up.double())
+    want = [ref.detach(), x64.grad, c64.weight.grad, b64.weight.grad, b64.bias.grad] + ([r64.grad] if res else [])
+    for name, g, w in zip(("y", "dx", "dw", "dgamma", "dbeta", "dres"), got, want):
+        assert g.shape == w.shape, name
+        err = float((g.double() - w).norm() / (w.norm() + 1e-30))
+        assert err < 2e-6, (name, err)       # fp32 products and accumulation
+    # frozen layer (no gradients requested): same values, nothing saved
+    with torch.no_grad():
+        y2 = conv1x1_bn_act(x.detach(), conv, bn, residual=(r.detach() if res else None), relu=relu)
+    assert torch.equal(y2, y.detach())

@@ -334,7 +334,7 @@ def test_training_step_matches_cpu_oracle(dev, config):
     sum(v.sum() for v in out["losses"].values()).backward()
     for k, v in ref.items():
         assert out["losses"][k].shape == (1,)
-        np.testing.assert_allclose(float(out["losses"][k]), v, rtol=2e-3, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(float(out["losses"][k]), v, rtol=1e-4, atol=1e-6, err_msg=k)
     cpu_p = dict(cpu_model.named_parameters())
     checked = 0
     for name, p in gpu_model.named_parameters():
@@ -348,7 +348,7 @@ def test_training_step_matches_cpu_oracle(dev, config):
         g = p.grad.cpu()
         # relative to the gradient's own norm, with an absolute floor for vanishing gradients
         # (the detector head: softmax over proposals, |g| ~ 1e-9)
-        tol = 2e-2 * float(g_ref.norm()) + 1e-7 * (g_ref.numel() ** 0.5)
+        tol = 6e-3 * float(g_ref.norm()) + 1e-6 * (g_ref.numel() ** 0.5)
         assert float((g - g_ref).norm()) < tol, "gradient mismatch at %s" % name
         checked += 1
     assert checked > 20
