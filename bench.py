@@ -133,7 +133,7 @@ def run(args):
     base_n = synthetic.CONFIGS[args.config]["n"]
     base_t = synthetic.CONFIGS[args.config]["target"]
     mix = [(base_n, base_t)] if args.fixed_image else \
-        [(int(round(n * base_n / 1000.0)), t) for n, t in (IMAGE_MIX * ((args.images + 7) // 8))[:args.images]]
+        [(int(round(n * base_n / 1000.0)), int(round(t * base_t / 688.0))) for n, t in (IMAGE_MIX * ((args.images + 7) // 8))[:args.images]]
     host_batches, dev_batches, infos = [], [], []
     for j, (n, target) in enumerate(mix):
         inp = synthetic.make_image_inputs(args.config, seed=cfg.RNG_SEED + 1000 * rank + j, n=n, target=target)

@@ -16,7 +16,12 @@ def pack_masks(masks):
     n = masks.shape[0]
     hw = int(masks[0].numel())
     m = masks.reshape(n, hw)
-    m = (m != 0).to(torch.uint8).contiguous() if m.dtype != torch.uint8 else m.contiguous()
+    if m.dtype == torch.bool:
+        m = m.contiguous().view(torch.uint8)                 # same bytes: no conversion pass over the 187 MB of cfg2's masks
+    elif m.dtype != torch.uint8:
+        m = (m != 0).to(torch.uint8).contiguous()
+    else:
+        m = m.contiguous()
     words = (hw + 63) // 64
     packed = torch.empty((words, n), dtype=torch.int64, device=masks.device)
     _lib.call("cim_mask_pack", m.data_ptr(), packed.data_ptr(), n, hw, _lib.stream_ptr())

@@ -1,46 +1,76 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into per-kernel HBM traffic.
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into per-kernel HBM traffic per launch.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_FETCH_SIZE -o r -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_WRITE_SIZE -o r -- python3 bench.py ...
-    python3 tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE [conv_algo] > profiles/r1/pmc_traffic.json
+    python3 tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE <conv_algo> <engine> <workload tag> \
+            [--calibrate /tmp/cal_FETCH_SIZE /tmp/cal_WRITE_SIZE]  > profiles/r2/pmc_traffic_<config>.json
 
-Counters are in KiB per dispatch.  MI355X_MICROARCH.md (HBM) warns that on gfx950 FETCH_SIZE can
-report half of the bytes of a wide streaming read and asks for a calibration on a known byte
-count in the kernel's own access pattern.  Calibration here: roi_align_bwd_tile_kernel reads
-grad_out exactly once (N*49*2C*4 B = 383 MiB at cfg2) and reports FETCH_SIZE = 384 MiB;
-roi_align_fwd / wino_input / wino_dy report WRITE_SIZE equal to their output size to the MiB.
-So for these 16 B/lane, 64 B-segment access patterns no correction applies:
-bytes = (FETCH_SIZE + WRITE_SIZE) * 1024."""
+Counters are in KiB per dispatch.  MI355X_MICROARCH.md (HBM) warns that on gfx950 FETCH_SIZE can report half of the
+bytes of a wide streaming read and prescribes a calibration on a known byte count with the kernel's own access width.
+--calibrate takes the two passes of tools/pmc_calibrate.py (1 GiB copied at 16 B per lane; 256 MiB of 4-byte strided
+accesses) and stores bytes_counted / bytes_moved for reads and writes; the per-kernel figures below are divided by the
+16-byte factors (all product kernels listed here read and write 16 B per lane)."""
 import collections
 import csv
 import json
 import sys
 
-OURS = ("gemm_f32_kernel", "gemm_bf16x3_kernel", "gemm_f16x2_kernel", "amax_rowcol", "roi_align", "mask_iou", "mask_pack", "mask_area", "splitk", "asy_flag", "seed_select",
-        "contain_argmax", "arbitrate", "assign_kernel", "wino")
+# product kernels -> the key bench.py looks up
+KEYS = (("gemm_f16x2_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_bf16x3_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_f32_kernel<0, 0>", "wino_gemm_fwd"),
+        ("roi_align_fwd_rowsum", "cim_roi_align_maskcat_fwd"), ("roi_align_fwd_agg", "cim_roi_align_maskcat_fwd"),
+        ("roi_align_bwd_region", "cim_roi_align_maskcat_bwd"), ("roi_align_bwd_gather", "cim_roi_align_maskcat_bwd"),
+        ("roi_partial_reduce", "roi_partial_reduce"), ("mask_iou_pair", "mask_iou_pair"), ("mask_pack", "mask_pack"),
+        ("sgd_multi", "sgd_multi"), ("gemm_small_kernel", "backbone_conv1x1"))
 
 
-def per_kernel(d, counter):
+def per_kernel(d, counter, names=None):
     rows = csv.DictReader(open(d + "/r_counter_collection.csv"))
     vals = collections.defaultdict(list)
     for r in rows:
-        if r["Counter_Name"] == counter and any(s in r["Kernel_Name"] for s in OURS):
+        if r["Counter_Name"] == counter:
             vals[r["Kernel_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     return vals
 
 
+def calibrate(fdir, wdir):
+    f, w = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
+    out = {}
+    for tag, needle, nbytes in (("copy16", "vectorized_elementwise_kernel", float(1 << 30)), ("copy4", "elementwise_kernel", None)):
+        pick = lambda k: needle in k and "FillFunctor" not in k and ("vectorized" in needle or "vectorized" not in k)
+        fk = [v for k, vs in f.items() if pick(k) for _, v in vs]
+        wk = [v for k, vs in w.items() if pick(k) for _, v in vs]
+        if not fk or not wk:
+            continue
+        big_f, big_w = max(fk), max(wk)
+        if nbytes is None:      # strided 4-byte copy: every 64-byte sector of 256 MiB x 2 is touched; bytes USED are 128 MiB
+            out[tag] = dict(fetch_kib=big_f, write_kib=big_w, note="2^25 4-byte elements at stride 8 B: 128 MiB used, 256 MiB of lines")
+        else:
+            out[tag] = dict(fetch_kib=big_f, write_kib=big_w, fetch_factor=big_f * 1024 / nbytes, write_factor=big_w * 1024 / nbytes)
+    return out
+
+
 def main():
-    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    # which conv algorithm the profiled run used (bench.py only attaches GEMM traffic when it matches)
-    out = {"_conv_algo": sys.argv[3] if len(sys.argv) > 3 else "winograd4"}
-    for k in fetch:
-        f = [v for _, v in sorted(fetch[k])]
-        w = [v for _, v in sorted(write.get(k, []))]
-        name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
-        out[name] = dict(dispatches=len(f), fetch_kib_mean=sum(f) / len(f), write_kib_mean=(sum(w) / len(w)) if w else None,
-                         fetch_kib_per_dispatch=f[:12], write_kib_per_dispatch=w[:12],
-                         hbm_bytes_mean=(sum(f) / len(f) + ((sum(w) / len(w)) if w else 0)) * 1024)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    fetch, write = per_kernel(args[0], "FETCH_SIZE"), per_kernel(args[1], "WRITE_SIZE")
+    out = {"_conv_algo": args[2] if len(args) > 2 else "winograd7", "_engine": args[3] if len(args) > 3 else "f16x2",
+           "_workload": args[4] if len(args) > 4 else "mix8"}
+    ff = wf = 1.0
+    if "--calibrate" in sys.argv:
+        i = sys.argv.index("--calibrate")
+        cal = calibrate(sys.argv[i + 1], sys.argv[i + 2])
+        out["_calibration"] = cal
+        if "copy16" in cal:
+            ff, wf = cal["copy16"]["fetch_factor"], cal["copy16"]["write_factor"]
+    out["_applied_factors"] = dict(fetch=ff, write=wf)
+    for needle, key in KEYS:
+        f = [v for k, vs in fetch.items() if needle in k for _, v in sorted(vs)]
+        w = [v for k, vs in write.items() if needle in k for _, v in sorted(vs)]
+        if not f or key in out:
+            continue
+        # (the first launches of a run belong to the warm-up: same kernels, same sizes)
+        out[key] = dict(kernel=needle, dispatches=len(f), fetch_kib_mean=sum(f) / len(f), write_kib_mean=(sum(w) / len(w)) if w else None,
+                        hbm_bytes_mean=(sum(f) / len(f) / ff + ((sum(w) / len(w) / wf) if w else 0)) * 1024)
     json.dump(out, sys.stdout, indent=1)
 
 
