@@ -5,8 +5,11 @@
 // (as an implicit GEMM: the im2col matrix is never materialised), Linear(49C->4096),
 // Linear(4096->4096), and their data / weight gradients.
 //
-// Arithmetic: exact fp32 - v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bitwise a k-ordered
-// fmaf chain), 157.3 TFLOP/s dense peak on MI355X.  No reduced-precision path.
+// Arithmetic: fp32 in, fp32 accumulate, fp32 out.  Three engines execute the multiplies:
+//   gemm_f32_kernel     v_mfma_f32_32x32x2_f32 (f32 products; bitwise a k-ordered fmaf chain), 157.3 TFLOP/s peak
+//   gemm_bf16x3_kernel  exact three-term bf16 split of both operands, 6 bf16 MFMA products per multiply-add
+//   gemm_f16x2_kernel   scaled two-term fp16 split (23 of 24 significand bits), 3 f16 MFMA products (default)
+// The split engines are in the error class of the f32-multiply engine (tests/test_gpu_gemm.py, tests/test_gpu_tolerance.py).
 //
 // Tiling (64-wide waves): workgroup tile BM x BN = 256 x 256, 8 waves as 2(M) x 4(N), each wave
 // 128 x 64 = 4 x 2 MFMA tiles of 32 x 32 (128 accumulator VGPRs).  K is consumed in slabs of

@@ -50,8 +50,9 @@ class SGD(torch.optim.Optimizer):
         self._layout = None         # tuple of element counts the chunk table on the device was built for
         self._chunks = None         # device chunk table
         self._n_chunks = 0
-        self._stage = None          # (pinned host array, device array, event of the last H2D copy) of the tensor records
-        self._last = None           # tensor records of the last step (skip the copy when nothing changed)
+        self._cache = None          # per-parameter records that do not change from step to step (see _scan)
+        self._check_every_step = True    # re-count the parameters with gradients every step (a parameter that starts to
+                                         # receive gradients must not be skipped silently; ~20 us)
 
     def _build_chunks(self, layout, dev):
         """layout: per tensor (numel, rows, cols) with rows = cols = 0 for flat tensors."""
@@ -71,21 +72,18 @@ class SGD(torch.optim.Optimizer):
         self._chunks = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(dev)
         self._n_chunks, self._layout = int(tab.shape[0]), tuple(layout)
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        recs, touched, momentum, dev = [], [], None, None
-        for group in self.param_groups:
+    def _scan(self):
+        """Slow path (first step, or when the set of parameters with gradients / a learning rate changed): validate every
+        tensor and cache what does not change from step to step - parameter and history pointers, sizes, matrix shapes,
+        the device chunk table.  Returns False when no parameter has a gradient."""
+        recs, momentum, dev = [], None, None
+        for gi, group in enumerate(self.param_groups):
             if group.get("dampening", 0.0) != 0.0 or group.get("nesterov", False):
                 raise NotImplementedError("cim_amd.optim.SGD: dampening / Nesterov")
             if momentum is None:
                 momentum = float(group["momentum"])
             elif float(group["momentum"]) != momentum:
                 raise NotImplementedError("cim_amd.optim.SGD: one momentum value for all groups")
-            lr, wd = float(group["lr"]), float(group["weight_decay"])
             for p in group["params"]:
                 g = p.grad
                 if g is None:
@@ -94,54 +92,103 @@ class SGD(torch.optim.Optimizer):
                     raise _lib.CimHipError("cim_amd.optim.SGD: CUDA/HIP parameters required (no CPU fallback)")
                 if p.dtype != torch.float32 or g.dtype != torch.float32 or g.is_sparse or not p.is_contiguous():
                     raise NotImplementedError("cim_amd.optim.SGD: dense contiguous fp32 parameters and gradients")
-                if not g.is_contiguous():
-                    g = g.contiguous()
                 st = self.state[p]
                 buf = st.get("momentum_buffer")
                 if buf is None:
                     buf = st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 dev = p.device
-                pp, gp, bp = p.data_ptr(), g.data_ptr(), buf.data_ptr()
-                ms = _matrix_shape(p) if ((pp | gp | bp) & 15) == 0 else None
-                recs.append((pp, gp, bp, p.numel(), lr, wd, ms[0] if ms else 0, ms[1] if ms else 0, g, p))
-                touched.append(p)
-                touched.append(buf)
+                recs.append((p, buf, gi))
         if not recs:
-            return loss
-        layout = tuple((r[3], r[6], r[7]) for r in recs)
-        if layout != self._layout:
+            self._cache = None
+            return False
+        n = len(recs)
+        tab = np.zeros(n, dtype=_TENSOR)
+        tab["p"] = [p.data_ptr() for p, _, _ in recs]
+        tab["buf"] = [b.data_ptr() for _, b, _ in recs]
+        tab["n"] = [p.numel() for p, _, _ in recs]
+        amax_off, off = [], 0
+        for i, (p, buf, _) in enumerate(recs):
+            ms = _matrix_shape(p) if ((p.data_ptr() | buf.data_ptr() | p.grad.data_ptr()) & 15) == 0 else None
+            if ms:
+                tab["rows"][i], tab["cols"][i] = ms
+                amax_off.append((i, off, ms[0], ms[1]))
+                off += ms[0] + ms[1]
+        layout = tuple((int(tab["n"][i]), int(tab["rows"][i]), int(tab["cols"][i])) for i in range(n))
+        if layout != self._layout or self._chunks is None or self._chunks.device != dev:
             self._build_chunks(layout, dev)
-            self._stage = self._last = None
+        touched = []
+        for p, buf, _ in recs:
+            touched += [p, buf]
+        self._cache = dict(recs=recs, tab=tab, amax_off=amax_off, n_amax=off, momentum=momentum, dev=dev, touched=touched,
+                           pinned=torch.empty(tab.nbytes, dtype=torch.uint8).pin_memory(),
+                           table=torch.empty(tab.nbytes, dtype=torch.uint8, device=dev), copied=None,
+                           group_of=np.array([gi for _, _, gi in recs]), sig=None)
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        c = self._cache
+        # fast path: the same parameters have gradients as last step (the usual case) - only the gradient pointers, the
+        # learning rates and the |max| arrays are refreshed; anything else re-scans
+        if c is not None:
+            grads = [p.grad for p, _, _ in c["recs"]]
+            n_with_grad = sum(1 for g in self.param_groups for p in g["params"] if p.grad is not None) if self._check_every_step else len(grads)
+            if any(g is None for g in grads) or n_with_grad != len(grads) or \
+                    any(float(g["momentum"]) != c["momentum"] for g in self.param_groups):
+                c = None
+        if c is None:
+            if not self._scan():
+                return loss
+            c = self._cache
+            grads = [p.grad for p, _, _ in c["recs"]]
+        tab, dev = c["tab"], c["dev"]
+        keep = []
+        gp = []
+        for g in grads:
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                if g.dtype != torch.float32 or g.is_sparse:
+                    raise NotImplementedError("cim_amd.optim.SGD: dense fp32 gradients")
+                g = g.contiguous()
+                keep.append(g)
+            gp.append(g.data_ptr())
+        tab["g"] = gp
+        lrs = np.array([float(g["lr"]) for g in self.param_groups], dtype=np.float32)
+        wds = np.array([float(g["weight_decay"]) for g in self.param_groups], dtype=np.float32)
+        tab["lr"], tab["wd"] = lrs[c["group_of"]], wds[c["group_of"]]
         # row / column |max| arrays of the matrix-mode tensors: fresh (zeroed) storage every step - consumers of the
-        # previous step's arrays (autograd graphs kept alive) never see them change
-        n_amax = sum(r[6] + r[7] for r in recs)
-        amax_buf = torch.zeros(max(n_amax, 1), dtype=torch.int32, device=dev)
-        base, off, slices = amax_buf.data_ptr(), 0, []
-        rows_list = []
-        for r in recs:
-            ra = ca = 0
-            if r[7] > 0:
-                ra, ca = base + 4 * off, base + 4 * (off + r[6])
-                slices.append((r[9], amax_buf[off:off + r[6]], amax_buf[off + r[6]:off + r[6] + r[7]], r[6], r[7]))
-                off += r[6] + r[7]
-            rows_list.append(r[:8] + (ra, ca))
-        tab = np.array(rows_list, dtype=_TENSOR)
-        if self._last is None or not np.array_equal(tab, self._last):
-            nbytes = tab.nbytes
-            if self._stage is None:
-                self._stage = [torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.empty(nbytes, dtype=torch.uint8, device=dev), None]
-            pinned, table, copied = self._stage
-            if copied is not None:
-                copied.synchronize()            # the previous H2D copy out of the staging buffer (long done in practice)
-            pinned.numpy()[:] = tab.view(np.uint8).reshape(-1)
-            table.copy_(pinned, non_blocking=True)
-            self._stage[2] = torch.cuda.Event()
-            self._stage[2].record()
-            self._last = tab
-        _lib.call("cim_sgd_multi", self._stage[1].data_ptr(), self._chunks.data_ptr(), self._n_chunks, momentum, _lib.stream_ptr())
+        # previous step's arrays (autograd graphs kept alive) never see them change.  A matrix-mode tensor whose gradient
+        # is not 16-byte aligned this step falls back to flat mode for the step.
+        amax_buf = torch.zeros(max(c["n_amax"], 1), dtype=torch.int32, device=dev)
+        base = amax_buf.data_ptr()
+        slices = []
+        for i, off, rows, cols in c["amax_off"]:
+            if gp[i] & 15:
+                tab["row_amax"][i] = tab["col_amax"][i] = 0
+                tab["rows"][i] = tab["cols"][i] = 0
+                c["sig"] = None
+                self._layout = None                      # chunk table no longer matches: rebuilt by the next scan
+                self._cache = None
+                return self.step()                       # rare (a gradient view at an odd offset): start over on the slow path
+            tab["row_amax"][i], tab["col_amax"][i] = base + 4 * off, base + 4 * (off + rows)
+            slices.append((c["recs"][i][0], amax_buf[off:off + rows], amax_buf[off + rows:off + rows + cols], rows, cols))
+        raw = tab.view(np.uint8).reshape(-1)
+        sig = raw.tobytes()
+        if sig != c["sig"]:
+            if c["copied"] is not None:
+                c["copied"].synchronize()               # the previous H2D copy out of the staging buffer (long done in practice)
+            c["pinned"].numpy()[:] = raw
+            c["table"].copy_(c["pinned"], non_blocking=True)
+            c["copied"] = torch.cuda.Event()
+            c["copied"].record()
+            c["sig"] = sig
+        _lib.call("cim_sgd_multi", c["table"].data_ptr(), self._chunks.data_ptr(), self._n_chunks, c["momentum"], _lib.stream_ptr())
         # the kernel wrote parameters and momentum buffers through raw pointers: tell autograd's version counters, so that
         # anything keyed by Tensor._version (saved-tensor checks, caches) sees the in-place update
-        torch.autograd.graph.increment_version(touched)
+        torch.autograd.graph.increment_version(c["touched"])
         if slices:      # hand the by-product scales to the contraction ops (valid for exactly this version of the weight)
             from ..ops import gemm
             for p, ra, ca, rows, cols in slices:
