@@ -127,6 +127,9 @@ def run(args):
     instrument(_lib, timer)
     dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True)
     opt = make_optimizer(model, torch)
+    if os.environ.get("CIM_EARLY_STEP", "0") == "1":
+        dp.attach_optimizer(opt)     # opt-in: MaskFuse / heads update overlapped with the ROIAlign + backbone backward
+                                     # (measured at 1 GPU: 17.36-17.47 ms with, 17.37 without - HBM time only moves)
     Cf = model.Conv_Body.dim_out
 
     # ---- the images of the cycle: host (pinned) copies + device-resident copies

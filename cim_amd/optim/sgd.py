@@ -41,20 +41,28 @@ def _matrix_shape(p):
     return (rows, cols) if cols % 4 == 0 else None
 
 
+class _Pass:
+    """Device tables and cached per-parameter records of ONE fused launch over a fixed subset of the parameters."""
+
+    def __init__(self):
+        self.layout = None          # tuple of (numel, rows, cols) the chunk table on the device was built for
+        self.chunks = None          # device chunk table
+        self.n_chunks = 0
+        self.cache = None           # records that do not change from step to step (see SGD._scan)
+
+
 class SGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
         if dampening != 0.0 or nesterov:
             raise NotImplementedError("cim_amd.optim.SGD: dampening / Nesterov are not used by the reference and not provided")
         defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
         super().__init__(params, defaults)
-        self._layout = None         # tuple of element counts the chunk table on the device was built for
-        self._chunks = None         # device chunk table
-        self._n_chunks = 0
-        self._cache = None          # per-parameter records that do not change from step to step (see _scan)
+        self._passes = {}           # "all" | "early" | "rest" -> _Pass
+        self._early = None          # (frozenset of parameter ids updated early in this optimizer step, stream, event)
         self._check_every_step = True    # re-count the parameters with gradients every step (a parameter that starts to
                                          # receive gradients must not be skipped silently; ~20 us)
 
-    def _build_chunks(self, layout, dev):
+    def _build_chunks(self, ps, layout, dev):
         """layout: per tensor (numel, rows, cols) with rows = cols = 0 for flat tensors."""
         parts = []
         for ti, (n, rows, cols) in enumerate(layout):
@@ -69,13 +77,13 @@ class SGD(torch.optim.Optimizer):
             tab["tensor"] = ti
             parts.append(tab)
         tab = np.concatenate(parts)
-        self._chunks = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(dev)
-        self._n_chunks, self._layout = int(tab.shape[0]), tuple(layout)
+        ps.chunks = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(dev)
+        ps.n_chunks, ps.layout = int(tab.shape[0]), tuple(layout)
 
-    def _scan(self):
-        """Slow path (first step, or when the set of parameters with gradients / a learning rate changed): validate every
-        tensor and cache what does not change from step to step - parameter and history pointers, sizes, matrix shapes,
-        the device chunk table.  Returns False when no parameter has a gradient."""
+    def _scan(self, ps, select):
+        """Slow path (first step, or when the set of parameters with gradients changed): validate every selected tensor and
+        cache what does not change from step to step - parameter and history pointers, sizes, matrix shapes, the device
+        chunk table.  Returns False when no selected parameter has a gradient."""
         recs, momentum, dev = [], None, None
         for gi, group in enumerate(self.param_groups):
             if group.get("dampening", 0.0) != 0.0 or group.get("nesterov", False):
@@ -86,7 +94,7 @@ class SGD(torch.optim.Optimizer):
                 raise NotImplementedError("cim_amd.optim.SGD: one momentum value for all groups")
             for p in group["params"]:
                 g = p.grad
-                if g is None:
+                if g is None or not select(p):
                     continue
                 if not p.is_cuda:
                     raise _lib.CimHipError("cim_amd.optim.SGD: CUDA/HIP parameters required (no CPU fallback)")
@@ -99,7 +107,7 @@ class SGD(torch.optim.Optimizer):
                 dev = p.device
                 recs.append((p, buf, gi))
         if not recs:
-            self._cache = None
+            ps.cache = None
             return False
         n = len(recs)
         tab = np.zeros(n, dtype=_TENSOR)
@@ -114,40 +122,38 @@ class SGD(torch.optim.Optimizer):
                 amax_off.append((i, off, ms[0], ms[1]))
                 off += ms[0] + ms[1]
         layout = tuple((int(tab["n"][i]), int(tab["rows"][i]), int(tab["cols"][i])) for i in range(n))
-        if layout != self._layout or self._chunks is None or self._chunks.device != dev:
-            self._build_chunks(layout, dev)
+        if layout != ps.layout or ps.chunks is None or ps.chunks.device != dev:
+            self._build_chunks(ps, layout, dev)
         touched = []
         for p, buf, _ in recs:
             touched += [p, buf]
-        self._cache = dict(recs=recs, tab=tab, amax_off=amax_off, n_amax=off, momentum=momentum, dev=dev, touched=touched,
-                           pinned=torch.empty(tab.nbytes, dtype=torch.uint8).pin_memory(),
-                           table=torch.empty(tab.nbytes, dtype=torch.uint8, device=dev), copied=None,
-                           group_of=np.array([gi for _, _, gi in recs]), sig=None)
+        ps.cache = dict(recs=recs, tab=tab, amax_off=amax_off, n_amax=off, momentum=momentum, dev=dev, touched=touched,
+                        pinned=torch.empty(tab.nbytes, dtype=torch.uint8).pin_memory(),
+                        table=torch.empty(tab.nbytes, dtype=torch.uint8, device=dev), copied=None,
+                        group_of=np.array([gi for _, _, gi in recs]), sig=None, ids=frozenset(id(p) for p, _, _ in recs))
         return True
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        c = self._cache
+    def _run(self, key, select, _retry=True):
+        """One fused launch over the parameters `select` accepts (on the current stream)."""
+        ps = self._passes.setdefault(key, _Pass())
+        c = ps.cache
         # fast path: the same parameters have gradients as last step (the usual case) - only the gradient pointers, the
         # learning rates and the |max| arrays are refreshed; anything else re-scans
         if c is not None:
             grads = [p.grad for p, _, _ in c["recs"]]
-            n_with_grad = sum(1 for g in self.param_groups for p in g["params"] if p.grad is not None) if self._check_every_step else len(grads)
-            if any(g is None for g in grads) or n_with_grad != len(grads) or \
-                    any(float(g["momentum"]) != c["momentum"] for g in self.param_groups):
+            stale = any(g is None for g in grads) or any(float(g["momentum"]) != c["momentum"] for g in self.param_groups)
+            if not stale and self._check_every_step:
+                n_sel = sum(1 for g in self.param_groups for p in g["params"] if p.grad is not None and select(p))
+                stale = n_sel != len(grads)
+            if stale:
                 c = None
         if c is None:
-            if not self._scan():
-                return loss
-            c = self._cache
+            if not self._scan(ps, select):
+                return
+            c = ps.cache
             grads = [p.grad for p, _, _ in c["recs"]]
         tab, dev = c["tab"], c["dev"]
-        keep = []
-        gp = []
+        keep, gp = [], []
         for g in grads:
             if g.dtype != torch.float32 or not g.is_contiguous():
                 if g.dtype != torch.float32 or g.is_sparse:
@@ -160,19 +166,16 @@ class SGD(torch.optim.Optimizer):
         wds = np.array([float(g["weight_decay"]) for g in self.param_groups], dtype=np.float32)
         tab["lr"], tab["wd"] = lrs[c["group_of"]], wds[c["group_of"]]
         # row / column |max| arrays of the matrix-mode tensors: fresh (zeroed) storage every step - consumers of the
-        # previous step's arrays (autograd graphs kept alive) never see them change.  A matrix-mode tensor whose gradient
-        # is not 16-byte aligned this step falls back to flat mode for the step.
+        # previous step's arrays (autograd graphs kept alive) never see them change
         amax_buf = torch.zeros(max(c["n_amax"], 1), dtype=torch.int32, device=dev)
         base = amax_buf.data_ptr()
         slices = []
         for i, off, rows, cols in c["amax_off"]:
-            if gp[i] & 15:
-                tab["row_amax"][i] = tab["col_amax"][i] = 0
-                tab["rows"][i] = tab["cols"][i] = 0
-                c["sig"] = None
-                self._layout = None                      # chunk table no longer matches: rebuilt by the next scan
-                self._cache = None
-                return self.step()                       # rare (a gradient view at an odd offset): start over on the slow path
+            if gp[i] & 15:          # a gradient view at an odd offset this step (rare): re-scan, the tensor takes flat mode
+                ps.cache = None
+                if not _retry:
+                    raise _lib.CimHipError("cim_amd.optim.SGD: inconsistent gradient alignment")
+                return self._run(key, select, _retry=False)
             tab["row_amax"][i], tab["col_amax"][i] = base + 4 * off, base + 4 * (off + rows)
             slices.append((c["recs"][i][0], amax_buf[off:off + rows], amax_buf[off + rows:off + rows + cols], rows, cols))
         raw = tab.view(np.uint8).reshape(-1)
@@ -185,7 +188,7 @@ class SGD(torch.optim.Optimizer):
             c["copied"] = torch.cuda.Event()
             c["copied"].record()
             c["sig"] = sig
-        _lib.call("cim_sgd_multi", c["table"].data_ptr(), self._chunks.data_ptr(), self._n_chunks, c["momentum"], _lib.stream_ptr())
+        _lib.call("cim_sgd_multi", c["table"].data_ptr(), ps.chunks.data_ptr(), ps.n_chunks, c["momentum"], _lib.stream_ptr())
         # the kernel wrote parameters and momentum buffers through raw pointers: tell autograd's version counters, so that
         # anything keyed by Tensor._version (saved-tensor checks, caches) sees the in-place update
         torch.autograd.graph.increment_version(c["touched"])
@@ -193,4 +196,37 @@ class SGD(torch.optim.Optimizer):
             from ..ops import gemm
             for p, ra, ca, rows, cols in slices:
                 gemm.register_weight_scales(p, rows, cols, ra, ca)
+        return c["ids"]
+
+    @torch.no_grad()
+    def step_early(self, params, stream):
+        """Update `params` NOW, on `stream`, ahead of `step()` - called from inside the backward pass once their gradients
+        are final (nn.DataParallel.attach_optimizer): the 1 GB of MaskFuse weights is updated while the backward of the
+        backbone - small latency-bound launches that leave HBM idle - is still running.  The following `step()` updates
+        only the remaining parameters and makes the caller's stream wait for this one."""
+        ids = frozenset(id(p) for p in params)
+        cur = torch.cuda.current_stream()
+        stream.wait_stream(cur)
+        with torch.cuda.stream(stream):
+            done = self._run("early", lambda p: id(p) in ids)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        for p in params:                                 # the side stream reads / writes these; keep the allocator informed
+            if p.grad is not None:
+                p.grad.record_stream(stream)
+        self._early = (done or frozenset(), stream, ev)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._early is not None:
+            done, stream, ev = self._early
+            self._early = None
+            self._run("rest", lambda p: id(p) not in done)
+            torch.cuda.current_stream().wait_event(ev)  # everything after the step sees the early update too
+        else:
+            self._run("all", lambda p: True)
         return loss
