@@ -483,6 +483,7 @@ def test_model_pickle_path_and_eval_branch(dev, tmp_path):
     heads.settle_rng()                                        # no backward here: settle the generator by hand
     np.random.seed(3)
     b = model(iou_map=torch.from_numpy(iou).to(dev), asy_iou_map=torch.from_numpy(asy).to(dev), **kw)
+    heads.settle_rng()
     for k in ("bag_loss", "pcl_loss", "cls_loss", "iou_loss"):
         assert a["losses"][k].shape == (1,)
         # (not bit-equal: MIOpen may pick a different backbone conv algorithm on the second call)
