@@ -486,32 +486,75 @@ __device__ __forceinline__ void a_load(const L& l, const GemmArgs& g, int k0, in
 }
 
 // grid = (tiles_n, tiles_m, splits); block = 512
+// XCD-aware work order (speed only).  Workgroups are dealt to the 8 XCDs round robin in dispatch order (x fastest, then y,
+// then z), and every XCD has its own 4 MB L2: an operand panel that several tiles share is fetched through the fabric once
+// per XCD that runs one of them.  The calibrated FETCH_SIZE of the Winograd-forward launch (121 positions x 4 x 4 tiles)
+// was 6.5 GB for 2.0 GB of operands: with each position's 16 tiles spread over all 8 XCDs its A panels crossed the fabric
+// twice and its B panels four times.
+//   * z >= 8 slices (batch entries = Winograd positions, or K-splits): each XCD takes WHOLE slices - slice z = 8 j + xcd -
+//     so all tiles of a slice share ONE L2 and run at the same time (the first T workgroups an XCD receives are the T
+//     tiles of its first slice); the z % 8 left-over slices are spread as before.
+//   * otherwise each XCD gets a contiguous run of tiles of the slice.
+//   * tile order inside a run: the index that walks the SMALLER operand's panels runs fastest, so the tiles that share a
+//     panel of the bigger operand are neighbours (N > M: B = [K,N] is the bigger one -> m fastest).
+#ifndef CIM_GEMM_XCD_MODE
+#define CIM_GEMM_XCD_MODE 1          // 0 = round 1's order (contiguous runs inside a slice, n fastest)
+#endif
+__device__ __forceinline__ void xcd_tile_map(const GemmArgs& g, int& tile_m, int& tile_n, int& z) {
+    const int tn = gridDim.x, tm = gridDim.y, T = tn * tm, Z = gridDim.z;
+    tile_m = blockIdx.y;
+    tile_n = blockIdx.x;
+    z = blockIdx.z;
+#ifdef CIM_GEMM_NO_XCD
+    return;
+#endif
+    int b = blockIdx.y * tn + blockIdx.x;                       // index inside the slice
+    bool remap_in_slice = true;
+#if CIM_GEMM_XCD_MODE == 1
+    const bool m_fast = g.N > g.M;
+    if (Z >= 8) {
+        const long long L = (long long)blockIdx.z * T + b;
+        const int zfull = Z & ~7;
+        if (L < (long long)zfull * T) {
+            const int xcd = (int)(L & 7);
+            const long long s = L >> 3;
+            z = (int)(s / T) * 8 + xcd;
+            b = (int)(s % T);
+            remap_in_slice = false;
+        }
+    }
+#else
+    const bool m_fast = false;
+#endif
+    int t = b;
+    if (remap_in_slice) {
+        const int q = T >> 3, r = T & 7, xcd = b & 7, i = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;   // bijective for any T
+    }
+    if (m_fast) {
+        tile_n = t / tm;
+        tile_m = t - tile_n * tm;
+    } else {
+        tile_m = t / tn;
+        tile_n = t - tile_m * tn;
+    }
+}
+
 template <int AL, int BL>
 __global__ __launch_bounds__(NT, CIM_GEMM_MINW) void gemm_f32_kernel(const GemmArgs g_in) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    // XCD-aware tile order (speed only): workgroup b runs on XCD b % 8; give each XCD a contiguous
-    // run of tiles (n fastest) so the tiles sharing an A row-panel hit the same 4 MB L2.
-    int tile_m = blockIdx.y, tile_n = blockIdx.x;
-#ifndef CIM_GEMM_NO_XCD
-    {
-        const int tn = gridDim.x, nt = gridDim.x * gridDim.y;
-        const int b = blockIdx.y * tn + blockIdx.x;
-        const int q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;   // bijective for any nt
-        tile_m = t / tn;
-        tile_n = t - tile_m * tn;
-    }
-#endif
+    int tile_m, tile_n, zidx;
+    xcd_tile_map(g_in, tile_m, tile_n, zidx);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     GemmArgs gb = g_in;
-    int zsplit = blockIdx.z;
+    int zsplit = zidx;
     if (gb.batch > 1) {          // batched: one independent GEMM per z (Winograd positions)
-        gb.A += (size_t)blockIdx.z * gb.a_bs;
-        gb.B += (size_t)blockIdx.z * gb.b_bs;
-        gb.C += (size_t)blockIdx.z * gb.c_bs;
+        gb.A += (size_t)zidx * gb.a_bs;
+        gb.B += (size_t)zidx * gb.b_bs;
+        gb.C += (size_t)zidx * gb.c_bs;
         zsplit = 0;
     }
     const GemmArgs& g = gb;
@@ -642,22 +685,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x3_kernel(const GemmArgs g_in)
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    int tile_m = blockIdx.y, tile_n = blockIdx.x;
-    {
-        const int tn = gridDim.x, nt = gridDim.x * gridDim.y;
-        const int b = blockIdx.y * tn + blockIdx.x;
-        const int q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-        tile_m = t / tn;
-        tile_n = t - tile_m * tn;
-    }
+    int tile_m, tile_n, zidx;
+    xcd_tile_map(g_in, tile_m, tile_n, zidx);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     GemmArgs gb = g_in;
-    int zsplit = blockIdx.z;
+    int zsplit = zidx;
     if (gb.batch > 1) {
-        gb.A += (size_t)blockIdx.z * gb.a_bs;
-        gb.B += (size_t)blockIdx.z * gb.b_bs;
-        gb.C += (size_t)blockIdx.z * gb.c_bs;
+        gb.A += (size_t)zidx * gb.a_bs;
+        gb.B += (size_t)zidx * gb.b_bs;
+        gb.C += (size_t)zidx * gb.c_bs;
         zsplit = 0;
     }
     const GemmArgs& g = gb;
@@ -804,24 +840,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_f16x2_kernel(const GemmArgs g_in) 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    int tile_m = blockIdx.y, tile_n = blockIdx.x;
-    {
-        const int tn = gridDim.x, nt = gridDim.x * gridDim.y;
-        const int b = blockIdx.y * tn + blockIdx.x;
-        const int q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-        tile_m = t / tn;
-        tile_n = t - tile_m * tn;
-    }
+    int tile_m, tile_n, zidx;
+    xcd_tile_map(g_in, tile_m, tile_n, zidx);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     GemmArgs gb = g_in;
-    int zsplit = blockIdx.z;
+    int zsplit = zidx;
     if (gb.batch > 1) {
-        gb.A += (size_t)blockIdx.z * gb.a_bs;
-        gb.B += (size_t)blockIdx.z * gb.b_bs;
-        gb.C += (size_t)blockIdx.z * gb.c_bs;
-        gb.a_amax += (size_t)blockIdx.z * gb.M;
-        gb.b_amax += (size_t)blockIdx.z * gb.N;
+        gb.A += (size_t)zidx * gb.a_bs;
+        gb.B += (size_t)zidx * gb.b_bs;
+        gb.C += (size_t)zidx * gb.c_bs;
+        gb.a_amax += (size_t)zidx * gb.M;
+        gb.b_amax += (size_t)zidx * gb.N;
         zsplit = 0;
     }
     const GemmArgs& g = gb;
@@ -1142,6 +1171,8 @@ static int pick_splits(int M, int N, int K, int engine) {
         const double t = flops / (rate * eff) + (s > 1 ? (2.0 * s + 1.0) * M * (double)N * 4.0 / 4e12 : 0.0);
         if (t < best_t) { best_t = t; best = s; }
     }
+    // (tried: forcing 8 K-splits where 2-7 were picked, so that every XCD takes whole splits in xcd_tile_map: 16.93-17.02
+    // vs 16.82-16.87 ms per step - the extra workspace round trip costs more than the saved fabric traffic)
     return best;
 }
 
