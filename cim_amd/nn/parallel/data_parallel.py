@@ -101,19 +101,35 @@ class DataParallel(nn.Module):
             p.grad = self.flat_grad[off:off + n].view_as(p)
             spans.append((p, off, off + n))
             off += (n + 3) & ~3      # 16-byte aligned views: float4 accesses / matrix mode of the fused SGD stay enabled
-        # buckets: contiguous spans of ~bucket_bytes of the flat buffer; a big tensor (seg_fc.0: 822 MB) is its own bucket
+        # buckets, in the order the collectives are issued: a big tensor (seg_fc.0: 822 MB) is its own bucket, issued where it
+        # stands in the backward order; the small parameters fill flat buckets of ~bucket_bytes that do NOT break at a big
+        # tensor - a flat bucket is issued where it is CLOSED (full, or right after the last big tensor, or at the end) -
+        # so the few biases between the big weights do not become collectives of their own:
+        # fc2 | fc1 | conv | heads + MaskFuse biases | backbone = 5 collectives per step (was 7)
         self.buckets = []
+        last_big = max([i for i, (p, a, b) in enumerate(spans) if a is None], default=-1)
         cur = None
-        for p, a, b in spans:
+
+        def close():
+            nonlocal cur
+            if cur is not None:
+                self.buckets.append(cur)
+                cur = None
+
+        for i, (p, a, b) in enumerate(spans):
             if a is None:
                 self.buckets.append(dict(tensor=p, params=[p], ready=0))
-                cur = None
-            elif cur is None or (cur["end"] - cur["start"]) * 4 >= bucket_bytes:
+                if i == last_big:
+                    close()
+                continue
+            if cur is None:
                 cur = dict(start=a, end=b, params=[p], ready=0)
-                self.buckets.append(cur)
             else:
                 cur["end"] = b
                 cur["params"].append(p)
+            if (cur["end"] - cur["start"]) * 4 >= bucket_bytes:
+                close()
+        close()
         self._bucket_of = {}
         for bi, bk in enumerate(self.buckets):
             for p in bk["params"]:
