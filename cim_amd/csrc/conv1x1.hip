@@ -83,7 +83,10 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, float4 v, int 
 }
 
 // WN = waves along N: 2 -> 64 x 64 tile, 256 threads; 1 -> 64 x 32 tile, 128 threads (twice the workgroups for the
-// smallest problems).
+// smallest problems).  Tried and measured slower (tools/bench_gemm_small.py, 7 layer shapes, us forward / dX / dW:
+// 158 / 137 / 183 with this kernel): 128- and 256-row tiles (4 waves of 1 x 2 / 2 x 2 MFMA tiles, 134-170 VGPRs) to re-read
+// the activation operand less often: 251 / 207 / 290 - these products are bound by the latency chain of a tile's few
+// slabs and by how many tiles are in flight, not by operand traffic.
 template <bool AM, bool BKc, int WN>
 __global__ __launch_bounds__(128 * WN) void gemm_small_kernel(const SmallArgs g) {
     constexpr int NT = 128 * WN, BNT = 32 * WN;
