@@ -1174,6 +1174,9 @@ __global__ __launch_bounds__(256, CIM_ROI_GOCC) void roi_align_bwd_gather_kernel
 // Regions are dispatched centre first (they carry the most entries); groups meet in grad_in through atomicAdd.
 // ROIs per workgroup (template parameter GS): 64 up to 1535 ROIs, 128 from there on (measured at cfg2 / cfg4, ms:
 // 1000 ROIs 0.207 / 0.312, 2000 ROIs 0.407 / 0.352; 32: 0.66, 96: 0.26, 160: 0.38, 256: 0.56 at 1000 ROIs)
+#ifndef CIM_ROI_RG_DIRECT
+#define CIM_ROI_RG_DIRECT 0         // 1 = no LDS staging: every wave loads its entries itself (L1 / L2 serve the re-reads)
+#endif
 #ifndef CIM_ROI_RG_EXP
 #define CIM_ROI_RG_EXP 0            // ablations: 1 = no consume phase, 2 = no gradient loads, 3 = records only
 #endif
@@ -1386,6 +1389,69 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
                 }
             }
         };
+#if CIM_ROI_RG_DIRECT
+        // DIRECT variant: no LDS staging and no per-window barrier - every wave loads the gradient slices of the entries
+        // that touch its sub-block itself, four entries (8 x 16 B loads) in flight; the ~2.5 waves of the workgroup that
+        // share an entry re-read it from this CU's L1 / this XCD's L2 (all consumers of a region sit on one CU), so the
+        // fabric still sees each slice once per region.
+        (void)gload; (void)put; (void)consume; (void)nwin;
+        const float* __restrict__ gc = grad_out + min(cbase + lane * 4, C - 4);
+#define RD_LOAD(G, J)                                                                                  \
+        const float* rr##G = erec + (J) * RG_REC;                                                      \
+        const int off##G = reinterpret_cast<const int*>(rr##G)[0];                                     \
+        float4 G = *reinterpret_cast<const float4*>(gc + off##G);                                      \
+        float4 G##h;                                                                                   \
+        if (MASKCAT) G##h = *reinterpret_cast<const float4*>(gc + off##G + C);
+#define RD_ACC(G)                                                                                      \
+        {                                                                                              \
+            ga_f2 gl_ = ga_lo(G), gh_ = ga_hi(G);                                                      \
+            if (MASKCAT) {                                                                             \
+                const float m_ = rr##G[1];                                                             \
+                gl_ = ga_fma(m_, ga_lo(G##h), gl_);                                                    \
+                gh_ = ga_fma(m_, ga_hi(G##h), gh_);                                                    \
+            }                                                                                          \
+            const float4 wyq = *reinterpret_cast<const float4*>(rr##G + 4 + wr * 4);                   \
+            const float4 wxq = *reinterpret_cast<const float4*>(rr##G + 20 + wc * 4);                  \
+            const float wys[3] = {wyq.x, wyq.y, wyq.z};                                                \
+            const float wxs[4] = {wxq.x, wxq.y, wxq.z, wxq.w};                                         \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                            \
+                const ga_f2 tl = ga_f2{wys[i], wys[i]} * gl_, th = ga_f2{wys[i], wys[i]} * gh_;        \
+                _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                     \
+                    accl[i * 4 + jj] = ga_fma(wxs[jj], tl, accl[i * 4 + jj]);                          \
+                    acch[i * 4 + jj] = ga_fma(wxs[jj], th, acch[i * 4 + jj]);                          \
+                }                                                                                      \
+            }                                                                                          \
+        }
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            int t = 0;
+            if (e0 + lane < n) t = reinterpret_cast<const int*>(erec + (e0 + lane) * RG_REC)[2];
+            const bool hit = ((t & my_touch & 0xffff) != 0) && (((t & my_touch) >> 16) != 0);
+            unsigned long long todo = __ballot(hit);
+            while (todo) {
+                const int cnt = __popcll(todo);
+                if (cnt >= 4) {
+                    const int j0 = __ffsll((long long)todo) - 1; todo &= todo - 1;
+                    const int j1 = __ffsll((long long)todo) - 1; todo &= todo - 1;
+                    const int j2 = __ffsll((long long)todo) - 1; todo &= todo - 1;
+                    const int j3 = __ffsll((long long)todo) - 1; todo &= todo - 1;
+                    RD_LOAD(g0, e0 + j0)
+                    RD_LOAD(g1, e0 + j1)
+                    RD_LOAD(g2, e0 + j2)
+                    RD_LOAD(g3, e0 + j3)
+                    RD_ACC(g0)
+                    RD_ACC(g1)
+                    RD_ACC(g2)
+                    RD_ACC(g3)
+                } else {
+                    const int j0 = __ffsll((long long)todo) - 1; todo &= todo - 1;
+                    RD_LOAD(g0, e0 + j0)
+                    RD_ACC(g0)
+                }
+            }
+        }
+#undef RD_LOAD
+#undef RD_ACC
+#else
         Regs A;
         gload(A, 0);
         for (int win = 0; win < nwin; ++win) {
@@ -1394,6 +1460,7 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
             if (win + 1 < nwin) gload(A, win + 1);         // in flight while this window is consumed
             consume(win & 1, win);
         }
+#endif
     }
     // ---- flush this wave's 3 x 4 pixels
     const int cs = slice * 256 + lane * 4;
