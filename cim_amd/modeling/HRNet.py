@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..core.config import cfg
-from ..ops import bn_act
+from ..ops import bn_act, conv1x1_bn_act
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "HRNet.MaskFuse" by get_func)
 
 BN_MOMENTUM = 0.1
@@ -40,6 +40,8 @@ def _conv_bn(cin, cout, k, stride, relu, bias=False):
 def _downsample(ds, x):
     """conv -> BN projection shortcut (nn.Sequential of exactly those two)."""
     if len(ds) == 2 and isinstance(ds[1], nn.BatchNorm2d):
+        if ds[0].kernel_size == (1, 1):      # 1 x 1 projection: small-tile GEMM with the BatchNorm in its epilogue
+            return conv1x1_bn_act(x, ds[0], ds[1], relu=False)
         return bn_act(ds[0](x), ds[1], relu=False)
     return ds(x)
 
@@ -78,11 +80,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out = bn_act(self.conv1(x), self.bn1)
+    def forward(self, x):       # 1 x 1 convolutions + BatchNorm (+ identity) (+ ReLU): one HIP launch each (csrc/conv1x1.hip)
+        out = conv1x1_bn_act(x, self.conv1, self.bn1)
         out = bn_act(self.conv2(out), self.bn2)
         res = x if self.downsample is None else _downsample(self.downsample, x)
-        return bn_act(self.conv3(out), self.bn3, residual=res)
+        return conv1x1_bn_act(out, self.conv3, self.bn3, residual=res)
 
 
 BLOCKS = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
