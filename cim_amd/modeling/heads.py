@@ -545,7 +545,13 @@ def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None):
         views.update(gt_weight=f32[i, 0], gt_w=f32[i, 1], pre_keep=pre_keep[i], counts=meta[2 + 2 * i:4 + 2 * i],
                      asy_flag=flags[L.flag_slot] if using_CIM[i] else None, C=C, K=K)
         out.debug.append(views)
-    _lib.call("cim_mining_step", ctypes.byref(a), st)
+    try:
+        _lib.call("cim_mining_step", ctypes.byref(a), st)
+    except Exception:
+        if _rng.snapshot is not None:                   # nothing was launched: give the drawn uniforms back
+            np.random.set_state(_rng.snapshot[0])
+            _rng.snapshot = None
+        raise
     out.valid, out.status, out.meta, out.keep_alive = valid, meta[1:2], meta, keep
     return out
 

@@ -106,3 +106,48 @@ def test_tta_batched_equals_sequential():
     assert float((single - seq).abs().max()) > 1e-6
     hf, _, _ = ctest.im_detect_bbox_hflip(model, im, 160, 2000, boxes, masks)
     assert tuple(hf.shape) == (n, 20)
+
+
+def test_minibatch_on_device_feeds_the_model():
+    """cim_amd.roi_data.get_minibatch (lib/roi_data/minibatch.py:19-89 on the device): blobs have the reference's shapes and
+    conventions, the scale draw consumes the global NumPy generator exactly like the reference's, and the dictionary goes
+    straight into Generalized_RCNN.forward (with the batch dimensions DataLoader's collate adds)."""
+    from cim_amd import mask_iou, synthetic
+    from cim_amd.core.config import cfg
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    from cim_amd.roi_data import get_minibatch
+    from cim_amd.utils import blob
+    from oracle import image_prep as ip
+    apply_preset("resnet50_voc")
+    cfg.TRAIN.SCALES = (96, 128, 160)
+    rng = np.random.RandomState(7)
+    h, w, n = 75, 100, 36
+    im = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+    full_masks, boxes = synthetic.make_masks(n, h, w, rng, min_side=8)
+    labels = np.zeros(20, np.float32)
+    labels[[3, 11]] = 1
+    entry = dict(image=im, flipped=True, boxes=boxes.astype(np.float32), masks=synthetic.masks_7x7(full_masks, boxes),
+                 mat=synthetic.make_mat(full_masks, np.array([3, 11]), 20, rng), gt_classes=labels, path="/x/img.jpg")
+    np.random.seed(5)
+    blobs, ok = get_minibatch([entry], 20, "ToTensor", device=DEV)
+    probe = np.random.random_sample()
+    np.random.seed(5)
+    scale_ind = np.random.randint(0, high=3, size=1)[0]                      # the reference's draw (minibatch.py:115-116)
+    assert probe == np.random.random_sample()
+    target = cfg.TRAIN.SCALES[scale_ind]
+    s = target / 100.0
+    assert ok and set(blobs) == {"data", "rois", "masks", "labels", "gtrois", "mat", "index", "path"}
+    np.testing.assert_array_equal(blobs["data"][0].cpu().numpy(), ip.prep_image(im, s, hflip=True))
+    np.testing.assert_array_equal(blobs["rois"].cpu().numpy()[:, 1:], (boxes.astype(np.float32) * s).astype(np.float32))
+    assert tuple(blobs["rois"].shape) == (n, 5) and tuple(blobs["labels"].shape) == (1, 20) and tuple(blobs["masks"].shape) == (n, 7, 7)
+    np.testing.assert_array_equal(blobs["index"].cpu().numpy(), np.arange(n))
+    # DataLoader collate adds a leading dimension per image (lib/roi_data/loader.py:155-189); the model squeezes it
+    torch.manual_seed(0)
+    model = Generalized_RCNN().to(DEV).train()
+    iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(full_masks).to(DEV))
+    out = model(data=blobs["data"], rois=blobs["rois"].unsqueeze(0), masks=blobs["masks"].unsqueeze(0), labels=blobs["labels"].unsqueeze(0),
+                gtrois=blobs["gtrois"], mat=blobs["mat"].unsqueeze(0), index=blobs["index"].unsqueeze(0), iou_map=iou, asy_iou_map=asy)
+    total = sum(v.sum() for v in out["losses"].values())
+    total.backward()
+    assert torch.isfinite(total)
