@@ -1172,8 +1172,8 @@ __global__ __launch_bounds__(256, CIM_ROI_GOCC) void roi_align_bwd_gather_kernel
 // size (3.6 x 4.1 px): (15.6 / 12)(20.1 / 16) = 1.6 instead of 3.7; registers per lane as in the 3 x 4 gather.
 // Entry record in LDS: gradient offset, mask, separable weights wy[4 sub-rows][4] (3 used) and wx[4 sub-columns][4], touch mask.
 // Regions are dispatched centre first (they carry the most entries); groups meet in grad_in through atomicAdd.
-// ROIs per workgroup (template parameter GS): 64 up to 1535 ROIs, 128 from there on (measured at cfg2 / cfg4, ms:
-// 1000 ROIs 0.207 / 0.312, 2000 ROIs 0.407 / 0.352; 32: 0.66, 96: 0.26, 160: 0.38, 256: 0.56 at 1000 ROIs)
+// ROIs per workgroup (template parameter GS): rg_group_size() below (32: 0.66, 96: 0.26, 160: 0.38, 256: 0.56 ms at 1000 ROIs).
+// Entry order inside a group: interleaved over the ROIs (see the entry map below); sub-blocks spread over the SIMDs.
 #ifndef CIM_ROI_RG_DIRECT
 #define CIM_ROI_RG_DIRECT 0         // 1 = no LDS staging: every wave loads its entries itself (L1 / L2 serve the re-reads)
 #endif
@@ -1185,10 +1185,20 @@ constexpr int RG_RH = RG_SBH * RG_WR, RG_RW = RG_SBW * RG_WC;          // 12 x 1
 constexpr int RG_NT = 64 * RG_WR * RG_WC;                               // 1024 threads
 constexpr int RG_WIN = 32;                                              // entries per staging window
 constexpr int RG_MAXE = 256;                                            // entries per super-window (records in LDS)
-static inline int rg_group_size(int K) { return K >= 1536 ? 128 : 64; }
+// ROIs per workgroup: 64, or 128 when 64 would make more than ~3.5 workgroups per CU (measured, ms at 64 / 128:
+// 1000 ROIs on 33 x 43: 0.188 / 0.284, 800 on 27 x 36: 0.159 / 0.253, 1200 on 41 x 54: 0.288 / 0.261, 2000 on 33 x 43: 0.353 / 0.321)
+static inline int rg_group_size(int K, int B, int C, int H, int W) {
+    const char* e = getenv("CIM_ROI_RG_GS");                // 64 / 128: sweep switch (tools/bench_roi_bwd.py)
+    if (e && (atoi(e) == 64 || atoi(e) == 128)) return atoi(e);
+    const long long wgs = (long long)B * ((K + 63) / 64) * ((H + 11) / 12) * ((W + 15) / 16) * ((C + 255) / 256);
+    return wgs > 900 ? 128 : 64;
+}
 constexpr int RG_REC = 36;                                              // words per entry record: off, m, touch, pad, wy[16], wx[16]
 constexpr int RG_MAXREG = 256;
 struct RegionOrder { unsigned char o[RG_MAXREG]; };
+static inline size_t rg_lds_bytes(int GS, int P) {     // staging windows + entry records + entry map
+    return sizeof(float) * (2 * RG_WIN * 256 + RG_MAXE * RG_REC) + sizeof(unsigned short) * ((size_t)GS * P * P + 8);
+}
 
 template <bool MASKCAT, int RG_GS>
 __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float* __restrict__ grad_out,
@@ -1201,6 +1211,7 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
     extern __shared__ __attribute__((aligned(16))) float rg_smem[];
     float (*stage)[RG_WIN][256] = reinterpret_cast<float (*)[RG_WIN][256]>(rg_smem);   // [2][32][256]: 64 KB
     float* erec = rg_smem + 2 * RG_WIN * 256;                                         // [MAXE][REC]: 36 KB
+    unsigned short* emap = reinterpret_cast<unsigned short*>(erec + RG_MAXE * RG_REC);   // [GS * P * P]: entry -> ROI | ph << 7 | pw << 11
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // work order: region (centre first) slowest, then ROI group, then channel slice
@@ -1212,7 +1223,9 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
     const int region = region_order.o[lin / groups_total];
     const int b = by % B, kgroup = by / B;
     const int y0 = (region / regions_x) * RG_RH, x0 = (region % regions_x) * RG_RW;
-    const int wr = wave / RG_WC, wc = wave % RG_WC;
+    // wave w runs on SIMD w % 4: the sub-blocks of one SIMD are spread out (row t, column (s + 2 t) % 4: every 2 x 2
+    // neighbourhood of sub-blocks sits on four different SIMDs) - a bin hits ADJACENT sub-blocks together
+    const int wr = wave / RG_WC, wc = (wave + 2 * wr) % RG_WC;
     const int sy0 = y0 + wr * RG_SBH, sx0 = x0 + wc * RG_SBW;
     const int recw = roi_rec_words(P, H, W);
     const int OC = MASKCAT ? 2 * C : C, PP = P * P;
@@ -1225,6 +1238,7 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
     __shared__ int d_base[RG_GS + 1];          // first entry index of the ROI (exclusive prefix sum), [GS] = total
     __shared__ int d_bins[RG_GS];              // phl | pwl << 8 | npw << 16
     __shared__ float d_inv[RG_GS];             // 1 / count
+    __shared__ int d_cnt[RG_GS];               // entries of the ROI
     {
         const int k = kgroup * RG_GS + tid;
         int phl = 0, phh = -1, pwl = 0, pwh = -1;
@@ -1269,8 +1283,42 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
             d_base[tid] = wbase + incl - n_mine;
             d_bins[tid] = phl | (pwl << 8) | (max(npw, 1) << 16);
             d_inv[tid] = inv_count;
+            d_cnt[tid] = n_mine;
         }
         if (tid == RG_GS - 1) d_base[RG_GS] = wbase + incl;
+        __syncthreads();
+        // ---- entry order: INTERLEAVED over the group's ROIs (level l = the l-th touching bin of every ROI that has one):
+        // consecutive entries come from different ROIs, i.e. from all over the region, so every window spreads over all
+        // waves.  In ROI-major order a window holds the bins of one or two ROIs and costs the time of the 2-4 waves they
+        // hit (summed over the windows of cfg2 the busiest wave saw 32 k entries against 9 k on average).
+        // Level l starts at sum_r min(n_r, l); wave w writes the levels l = w (mod 16), rank inside a level by ballot.
+        {
+            constexpr int RPL = RG_GS / 64;                                  // ROIs per lane
+            int n[RPL], bins[RPL];
+#pragma unroll
+            for (int h = 0; h < RPL; ++h) { n[h] = d_cnt[lane + 64 * h]; bins[h] = d_bins[lane + 64 * h]; }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            for (int l = wave; l < PP; l += 16) {
+                int mins = 0, before = 0;
+                unsigned long long have[RPL];
+                bool any = false;
+#pragma unroll
+                for (int h = 0; h < RPL; ++h) { have[h] = __ballot(n[h] > l); mins += min(n[h], l); any |= have[h] != 0; }
+                if (!any) break;                                             // uniform: levels are nested
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mins += __shfl_xor(mins, o);
+#pragma unroll
+                for (int h = 0; h < RPL; ++h) {
+                    if (n[h] > l) {
+                        const int npw = bins[h] >> 16;
+                        const int dph = (int)(((float)l + 0.5f) / (float)npw);      // l / npw (exact for these sizes)
+                        const int ph = (bins[h] & 0xff) + dph, pw = ((bins[h] >> 8) & 0xff) + l - dph * npw;
+                        emap[mins + before + __popcll(have[h] & below)] = (unsigned short)((lane + 64 * h) | (ph << 7) | (pw << 11));
+                    }
+                    before += __popcll(have[h]);
+                }
+            }
+        }
         __syncthreads();
     }
     const int total = (CIM_ROI_RG_EXP == 6) ? 0 : d_base[RG_GS];
@@ -1289,13 +1337,8 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
             const int ge = w0 + e;
             int rm = 0, cm = 0;
             if (ge < total) {
-                int lo = 0, hi = RG_GS - 1;                // last ROI with d_base <= ge (ROIs without entries repeat a base)
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (d_base[mid] <= ge) lo = mid; else hi = mid - 1;
-                }
-                const int bins = d_bins[lo], local = ge - d_base[lo];
-                const int npw = bins >> 16, ph = (bins & 0xff) + local / npw, pw = ((bins >> 8) & 0xff) + local % npw;
+                const int code = emap[ge];
+                const int lo = code & 127, ph = (code >> 7) & 15, pw = code >> 11;
                 const int k = kgroup * RG_GS + lo;
                 const float* rec = rec_all + (size_t)k * recw;
                 const float* wy = rec + ph * H;
@@ -1485,6 +1528,438 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
                     }
                 }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, pipelined region form (opt-in: CIM_ROI_BWD_PIPE=1, P == 7): the region form above with the loading and the
+// accumulating decoupled - an experiment that measured NO faster (cfg2: 0.197 vs 0.195 ms; 800 ROIs 0.156 vs 0.165; 1200
+// ROIs 0.313 vs 0.307), kept for its instrumentation (CIM_ROI_PL_TRACE + tools/trace_roi_bwd.py) and for what it showed:
+//   * the 16 waves of the workgroup are specialised: 4 PRODUCER waves stream the gradient slices (wave p takes batch p of
+//     every round of 16 entries: entry map look-up, both mask-cat halves of the 4 entries' 256-channel slices - 8 x 16 B
+//     per lane, the NEXT round's loads issued before this round's are waited for - combined g_lo + m g_hi into a ring of
+//     4 rounds in LDS with a two-word descriptor, published through a byte counter in LDS); 12 CONSUMER waves own 4 x 4
+//     pixel sub-blocks (16 float4 accumulators per lane), poll the producers' counters (one word), pick the entries of the
+//     round that touch their sub-block by a ballot over the descriptors, accumulate from LDS with the next hit's operands
+//     in flight, and post their own counter, which the producers read before they overwrite a ring slot.  No workgroup
+//     barrier inside the stream.  The per-ROI separable weights are staged in LDS once per chunk of 64 ROIs (196 floats
+//     per ROI) instead of travelling in per-entry records.
+//   * per-workgroup time stamps: set-up 9 us (the first version 13-19 us: the prologue is INSTRUCTION bound - 16 waves
+//     share 4 SIMDs, index arithmetic with constant divisions cost ~1400 VALU slots per wave - not latency bound), then a
+//     constant 0.105 us per entry whatever the workgroup's size or the load of the chip, 2 us flush; producers alone
+//     0.058 us / entry, consumers alone 0.086.  The heaviest workgroup (1467 entries, centre region) alone takes
+//     144 of the kernel's 162 us; the CUs are busy 131 us on average.
+//   * what bounds both this and the region kernel is VALU issue: the FMAs are ~80 cycles per entry per SIMD when spread
+//     perfectly (34 us for the launch), the rest is per-round / per-window bookkeeping on 12-16 waves; HBM is not the limit
+//     (a CU streams 19 GB/s here against its 28 GB/s share).  Interleaving the entry order and spreading the sub-blocks over
+//     the SIMDs came out of this and moved into the region kernel (-6 %).
+#ifndef CIM_ROI_PL_EXP
+#define CIM_ROI_PL_EXP 0            // ablations: 1 = consumers skip the accumulation, 2 = producers skip the gradient loads, 3 = chunk set-up only
+#endif
+#ifndef CIM_ROI_PL_TRACE
+#define CIM_ROI_PL_TRACE 0          // 1 = (tools/trace_roi_bwd.py) per-workgroup time stamps behind the partial maps
+#endif
+#if CIM_ROI_PL_TRACE
+#define PL_TRACE_PTR (pl_trace + (size_t)blockIdx.x * 16)
+#define PL_STAMP(I) if (lane == 0 && (wave == 0 || wave == 15)) pl_trace[(size_t)blockIdx.x * 16 + (wave ? 8 : 0) + (I)] = wall_clock64()
+#else
+#define PL_TRACE_PTR nullptr
+#define PL_STAMP(I)
+#endif
+constexpr int PL_NPROD = 4, PL_NCONS = 12;
+constexpr int PL_BT = 4;                                     // entries per producer batch (16 lanes each)
+constexpr int PL_ROUND = PL_NPROD * PL_BT;                   // entries per round
+constexpr int PL_RING = 4;                                   // rounds in the LDS ring
+constexpr int PL_SLOTS = PL_RING * PL_ROUND;                 // 64 entries x 1 KB
+constexpr int PL_GS = 64;                                    // ROIs per chunk
+constexpr int PL_WR = 3, PL_WC = 4;                          // consumer sub-blocks: 3 x 4 of 4 x 4 pixels
+static_assert(PL_WR * 4 == RG_RH && PL_WC * 4 == RG_RW && PL_NPROD + PL_NCONS == 16, "region geometry");
+static inline int pl_chunks(int K, int B, int C, int H, int W) { return rg_group_size(K, B, C, H, W) / 64; }
+template <int P> constexpr int pl_tab_words() { return P * (RG_RH + RG_RW); }
+template <int P> constexpr size_t pl_lds_bytes() {
+    return sizeof(float) * (PL_SLOTS * 256 + PL_GS * pl_tab_words<P>() + PL_GS * P * P) + sizeof(int) * (PL_GS * 2 * P + 2 * PL_SLOTS) +
+           sizeof(unsigned short) * (PL_GS * P * P + 8);
+}
+
+// chunk prologue, executed by all 16 waves (two workgroup barriers): returns the chunk's entry count.
+// ONE global round trip: every thread first issues all its loads - its share of the ROIs' packed bin ranges (16 lanes
+// per ROI: 12 rows + 16 columns of the region), of the region's table segments (49 unaligned 16-byte segments per ROI:
+// 7 x 3 of wy, 7 x 4 of wx) and of the masks - then the ranges are reduced with shuffles, the tables go to LDS, and
+// after the first barrier the entry map and the touch masks are derived from LDS alone.  (The first version went
+// through three dependent global round trips of ~2 us each and scalar 4-byte gathers: 13 us per workgroup.)
+// Entry order: INTERLEAVED over the chunk's ROIs (level l = the l-th touching bin of every ROI that has one, ROIs in
+// order): consecutive entries come from different ROIs, i.e. from all over the region, so every round spreads over all
+// consumer waves / SIMDs.  ROI-major order kept the same 2-4 sub-blocks busy for a whole ROI (up to 49 entries in a
+// row, most of the 64-entry ring) while the other consumer waves starved.
+typedef float pl_f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <bool MASKCAT, int P>
+__device__ __forceinline__ int pl_chunk_setup(float* __restrict__ tab, float* __restrict__ mk, int* __restrict__ rcm,
+                                              unsigned short* __restrict__ emap, int* d_cnt, int* d_bins, int* f_ready, int* f_done,
+                                              const float* __restrict__ rec_all, const float* __restrict__ masks, int kb,
+                                              int K, int H, int W, int b, int y0, int x0, int tid, int lane, int wave,
+                                              unsigned long long* tr = nullptr) {
+    constexpr int TW = pl_tab_words<P>(), PP = P * P;
+    constexpr int SEG_Y = RG_RH / 4, SEG_X = RG_RW / 4, SEGS = P * (SEG_Y + SEG_X);       // 3, 4, 49 segments per ROI
+    constexpr int RPW = PL_GS / 16;                                                        // ROIs per wave
+    constexpr int NMK = (PL_GS * PP + RG_NT - 1) / RG_NT;
+    static_assert(SEGS <= 64 && PL_GS % 16 == 0, "one lane per table segment");
+    const int recw = roi_rec_words(P, H, W);
+    // The prologue is INSTRUCTION bound (16 waves share 4 SIMDs; the first version spent ~1400 VALU slots per wave on
+    // index arithmetic: 11 us), so everything per lane is computed once and each load costs an add.
+    // ---- tables: wave w stages ROIs 4 w ... 4 w + 3, lane = segment (49 of 64 lanes); all loads first
+    const bool seg_on = lane < SEGS;
+    const int sg = seg_on ? lane : 0;
+    const bool is_y = sg < P * SEG_Y;
+    const int s2 = sg - P * SEG_Y;
+    const int src_off = is_y ? (sg / SEG_Y) * H + y0 + 4 * (sg % SEG_Y) : P * H + (s2 / SEG_X) * W + x0 + 4 * (s2 % SEG_X);
+    const int dst_off = is_y ? (sg / SEG_Y) * RG_RH + 4 * (sg % SEG_Y) : P * RG_RH + (s2 / SEG_X) * RG_RW + 4 * (s2 % SEG_X);
+    const int pos = is_y ? y0 + 4 * (sg % SEG_Y) : x0 + 4 * (s2 % SEG_X), lim = is_y ? H : W;
+    pl_f4u seg[RPW];
+    float seg_cnt[RPW], mkv[NMK];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const float* rec2 = rec_all + (size_t)min(kb + wave * RPW + i, K - 1) * recw;
+        seg[i] = *reinterpret_cast<const pl_f4u*>(rec2 + src_off);     // may run past the row's end: masked below, inside the record
+        seg_cnt[i] = rec2[P * (H + W) + H + W + 4];
+    }
+    if (MASKCAT) {
+#pragma unroll
+        for (int i = 0; i < NMK; ++i) mkv[i] = masks[min((size_t)kb * PP + tid + i * RG_NT, (size_t)K * PP - 1)];
+    }
+    if (wave == 15) {
+        // ---- (a producer wave: registers to spare) lane t inspects ROI kb + t: the bins that touch the region, from the
+        // packed per-row / per-column ranges (28 clamped loads, in flight with the segment loads)
+        const float* rec = rec_all + (size_t)min(kb + lane, K - 1) * recw;
+        const int* yr = reinterpret_cast<const int*>(rec + P * (H + W));
+        const int* xr = yr + H;
+        int wy_[RG_RH], wx_[RG_RW];
+#pragma unroll
+        for (int i = 0; i < RG_RH; ++i) wy_[i] = yr[min(y0 + i, H - 1)];
+#pragma unroll
+        for (int jj = 0; jj < RG_RW; ++jj) wx_[jj] = xr[min(x0 + jj, W - 1)];
+        const int batch = yr[H + W + 5];
+        int ylo = P, yhi = -1, xlo = P, xhi = -1;
+#pragma unroll
+        for (int i = 0; i < RG_RH; ++i)
+            if (y0 + i < H && !(wy_[i] & 0x10000)) { ylo = min(ylo, wy_[i] & 0xff); yhi = max(yhi, (wy_[i] >> 8) & 0xff); }
+#pragma unroll
+        for (int jj = 0; jj < RG_RW; ++jj)
+            if (x0 + jj < W && !(wx_[jj] & 0x10000)) { xlo = min(xlo, wx_[jj] & 0xff); xhi = max(xhi, (wx_[jj] >> 8) & 0xff); }
+        const bool in = (kb + lane < K) && batch == b;
+        const int nph = max(yhi - ylo + 1, 0), npw = max(xhi - xlo + 1, 0);
+        d_cnt[lane] = (in && nph > 0 && npw > 0) ? nph * npw : 0;
+        d_bins[lane] = ylo | (xlo << 8) | (max(npw, 1) << 16);
+        if (lane == 0) f_ready[0] = 0;
+        if (lane < 16) f_done[lane] = 0;
+    }
+    if (seg_on) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const float sc = is_y ? 1.0f / seg_cnt[i] : 1.0f;          // 1 / count folded into wy
+            float4 v;
+            v.x = (pos + 0 < lim) ? seg[i].x * sc : 0.0f;
+            v.y = (pos + 1 < lim) ? seg[i].y * sc : 0.0f;
+            v.z = (pos + 2 < lim) ? seg[i].z * sc : 0.0f;
+            v.w = (pos + 3 < lim) ? seg[i].w * sc : 0.0f;
+            *reinterpret_cast<float4*>(tab + (wave * RPW + i) * TW + dst_off) = v;
+        }
+    }
+    if (MASKCAT) {
+#pragma unroll
+        for (int i = 0; i < NMK; ++i)
+            if (tid + i * RG_NT < PL_GS * PP) mk[tid + i * RG_NT] = mkv[i];
+    }
+    __syncthreads();
+    if (CIM_ROI_PL_TRACE && tr && tid == 0) tr[4] = wall_clock64();
+    // ---- entry map: level l of the interleaved order holds the l-th bin of every ROI with more than l bins; it starts
+    // at sum_r min(n_r, l).  Wave w writes the levels l = w (mod 16): lanes = ROIs, rank inside the level by a ballot.
+    const int n = d_cnt[lane], bins = d_bins[lane];
+    auto wave_sum = [&](int v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    const int total = wave_sum(n);
+    {
+        const int npw = bins >> 16;
+        const float inv_npw = 1.0f / (float)npw;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (int l = wave; l < PP; l += 16) {
+            const unsigned long long have = __ballot(n > l);
+            if (have == 0) break;                                      // uniform: levels are nested
+            const int base = wave_sum(min(n, l));
+            if (n > l) {
+                const int dph = (int)(((float)l + 0.5f) * inv_npw);   // l / npw (exact: npw <= P)
+                const int ph = (bins & 0xff) + dph, pw = ((bins >> 8) & 0xff) + l - dph * npw;
+                emap[base + __popcll(have & below)] = (unsigned short)(lane | (ph << 6) | (pw << 9));
+            }
+        }
+    }
+    // ---- per (ROI, bin row) / (ROI, bin column) touch masks over the region's rows / columns
+    if (tid < PL_GS * 2 * P) {
+        const int r3 = tid / (2 * P), q = tid % (2 * P);
+        int m = 0;
+        if (q < P) {
+#pragma unroll
+            for (int i = 0; i < RG_RH; ++i) m |= (tab[r3 * TW + q * RG_RH + i] != 0.0f) << i;
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < RG_RW; ++jj) m |= (tab[r3 * TW + P * RG_RH + (q - P) * RG_RW + jj] != 0.0f) << jj;
+        }
+        rcm[tid] = m;
+    }
+    __syncthreads();
+    if (CIM_ROI_PL_TRACE && tr && tid == 0) tr[5] = wall_clock64();
+    return total;
+}
+
+template <bool MASKCAT, int P>
+__global__ __launch_bounds__(RG_NT) void roi_align_bwd_pipe_kernel(const float* __restrict__ grad_out,
+                                                                   const float* __restrict__ masks,
+                                                                   float* __restrict__ grad_in, int C, int H, int W, int K,
+                                                                   int B, int chunks, const float* __restrict__ rec_all,
+                                                                   const RegionOrder region_order, int n_regions,
+                                                                   int regions_x, int n_slices, float* __restrict__ partial) {
+    constexpr int TW = pl_tab_words<P>(), PP = P * P;
+    extern __shared__ __attribute__((aligned(16))) float pl_smem[];
+    float* ring = pl_smem;                                            // [SLOTS][256]
+    float* tab = ring + PL_SLOTS * 256;                               // [GS][P * 12 | P * 16]
+    float* mk = tab + PL_GS * TW;                                     // [GS][P * P]
+    int* rcm = reinterpret_cast<int*>(mk + PL_GS * PP);               // [GS][P row masks | P column masks]
+    int* desc = rcm + PL_GS * 2 * P;                                  // [SLOTS][touch, weight offsets]
+    unsigned short* emap = reinterpret_cast<unsigned short*>(desc + 2 * PL_SLOTS);   // [GS * P * P]
+    __shared__ int d_cnt[PL_GS];
+    __shared__ int d_bins[PL_GS];
+    __shared__ int f_ready[1];                                        // byte p: rounds published by producer p (mod 256)
+    __shared__ int f_done[16];                                        // rounds consumed by consumer c
+    // LDS-qualified volatile views (a generic volatile pointer makes the polls flat loads, which count on vmcnt too).
+    // The four producers' counters share ONE word (byte stores): a consumer's poll is a single ds_read_b32 - with a word per
+    // producer the polls of 12 spinning consumers alone kept the LDS pipeline busy.
+    typedef volatile int __attribute__((address_space(3))) pl_flag;
+    typedef volatile unsigned char __attribute__((address_space(3))) pl_flag8;
+    pl_flag* const ready = (pl_flag*)f_ready;
+    pl_flag8* const ready8 = (pl_flag8*)f_ready;
+    pl_flag* const done = (pl_flag*)f_done;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lin = blockIdx.x;
+    const int slice = lin % n_slices;
+    lin /= n_slices;
+    const int groups_total = gridDim.x / (n_slices * n_regions);      // B * groups
+    const int by = lin % groups_total;
+    const int region = region_order.o[lin / groups_total];
+    const int b = by % B, kgroup = by / B;
+    const int y0 = (region / regions_x) * RG_RH, x0 = (region % regions_x) * RG_RW;
+    const int OC = MASKCAT ? 2 * C : C;
+    const int cbase = slice * 256;
+#if CIM_ROI_PL_TRACE
+    unsigned long long* pl_trace = reinterpret_cast<unsigned long long*>(partial + (size_t)(gridDim.x / (n_slices * n_regions * B)) * B * H * W * C);
+    PL_STAMP(0);
+    if (tid == 0) pl_trace[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF804) << 32) | __builtin_amdgcn_s_getreg(0xF814);
+#endif
+
+#define PL_CHUNK_PROLOGUE()                                                                                                \
+        const int kb = (kgroup * chunks + ch) * PL_GS;                                                                   \
+        if (kb >= K) break;                                            /* uniform */                                      \
+        if (ch > 0) __syncthreads();                                   /* every wave is done with the previous chunk */   \
+        const int total = pl_chunk_setup<MASKCAT, P>(tab, mk, rcm, emap, d_cnt, d_bins, f_ready, f_done, rec_all, masks, \
+                                                     kb, K, H, W, b, y0, x0, tid, lane, wave, PL_TRACE_PTR);              \
+        PL_STAMP(1 + 3 * ch);                                                                                            \
+        if (lane == 0 && wave == 0 && CIM_ROI_PL_TRACE) reinterpret_cast<unsigned long long*>(partial + (size_t)(gridDim.x / (n_slices * n_regions * B)) * B * H * W * C)[(size_t)blockIdx.x * 16 + 6] = total; \
+        if (total == 0) continue;                                      /* uniform */                                      \
+        const int nrounds = (CIM_ROI_PL_EXP == 3) ? 0 : (total + PL_ROUND - 1) / PL_ROUND;
+
+    if (wave >= PL_NCONS) {
+        // ================= producer waves (no accumulators live here) =================
+        const int p = wave - PL_NCONS;
+        const int e = lane >> 4;
+        const float* __restrict__ gc = grad_out + min(cbase + lane * 4, C - 4);
+        for (int ch = 0; ch < chunks; ++ch) {
+            PL_CHUNK_PROLOGUE()
+            struct Batch { float4 lo[PL_BT], hi[PL_BT]; float m; int touch, woff; };
+            auto prepare = [&](Batch& Bt, int round) {
+                const int ge = round * PL_ROUND + p * PL_BT + e;
+                int off = 0;
+                Bt.m = 0.0f; Bt.touch = 0; Bt.woff = 0;
+                if (ge < total) {
+                    const int code = emap[ge];
+                    const int lo = code & 63, ph = (code >> 6) & 7, pw = code >> 9;
+                    off = (((kb + lo) * P + ph) * P + pw) * OC;        // < 2^31: checked by the launcher
+                    if (MASKCAT) Bt.m = mk[lo * PP + ph * P + pw];
+                    Bt.touch = rcm[lo * 2 * P + ph] | (rcm[lo * 2 * P + P + pw] << 16);
+                    Bt.woff = (lo * TW + ph * RG_RH) | ((lo * TW + P * RG_RH + pw * RG_RW) << 16);
+                }
+#pragma unroll
+                for (int i = 0; i < PL_BT; ++i) {                      // unconditional: entries past the end read offset 0
+                    const int off_i = __builtin_amdgcn_readlane(off, i * 16);
+                    if (CIM_ROI_PL_EXP == 2) { Bt.lo[i] = Bt.hi[i] = make_float4(0.f, 0.f, 0.f, (float)off_i); continue; }
+                    Bt.lo[i] = *reinterpret_cast<const float4*>(gc + off_i);
+                    if (MASKCAT) Bt.hi[i] = *reinterpret_cast<const float4*>(gc + off_i + C);
+                }
+            };
+            auto finish = [&](Batch& Bt, int round) {
+                if (round >= PL_RING) {                                // the slots' previous round consumed by every consumer?
+                    const int need = round - PL_RING + 1;
+                    while (true) {
+                        const int d = (lane < PL_NCONS) ? done[lane] : need;
+                        if (__ballot(d < need) == 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                asm volatile("" ::: "memory");
+                const int sbase = (round % PL_RING) * PL_ROUND + p * PL_BT;
+#pragma unroll
+                for (int i = 0; i < PL_BT; ++i) {
+                    float4 a = Bt.lo[i];
+                    if (MASKCAT) {
+                        const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Bt.m), i * 16));
+                        a = make_float4(fmaf(m, Bt.hi[i].x, a.x), fmaf(m, Bt.hi[i].y, a.y), fmaf(m, Bt.hi[i].z, a.z), fmaf(m, Bt.hi[i].w, a.w));
+                    }
+                    *reinterpret_cast<float4*>(ring + (sbase + i) * 256 + lane * 4) = a;
+                }
+                if ((lane & 15) == 0) {
+                    desc[2 * (sbase + e)] = Bt.touch;
+                    desc[2 * (sbase + e) + 1] = Bt.woff;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) ready8[p] = (unsigned char)(round + 1);
+            };
+            Batch A, Bb;
+            prepare(A, 0);
+            for (int r = 0; r < nrounds; r += 2) {
+                prepare(Bb, r + 1);                                    // in flight while round r is finished
+                finish(A, r);
+                prepare(A, r + 2);
+                if (r + 1 < nrounds) finish(Bb, r + 1);
+            }
+            PL_STAMP(2 + 3 * ch);
+        }
+        return;
+    }
+
+    // ================= consumer waves =================
+    // wave w runs on SIMD w % 4: the sub-blocks of one SIMD are spread out ((row t, column (s + 2 t) % 4): every 2 x 2
+    // neighbourhood of sub-blocks sits on four different SIMDs), because a bin hits ADJACENT sub-blocks together - with
+    // column = w % 4 a whole column of sub-blocks shared one SIMD's VALU while the other three idled
+    const int wr = wave / PL_WC, wc = (wave + 2 * wr) % PL_WC;
+    const int my_touch = (15 << (4 * wr)) | ((15 << (4 * wc)) << 16);
+    ga_f2 accl[16], acch[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accl[q] = acch[q] = ga_f2{0.f, 0.f};
+    for (int ch = 0; ch < chunks; ++ch) {
+        PL_CHUNK_PROLOGUE()
+        // Steady state of a round: nothing waits.  `known` (rounds every producer has published) is refreshed by a poll
+        // issued one round earlier, the descriptors of round r + 1 are read while round r is accumulated, and inside a
+        // round the LDS operands of the next hit are in flight while the current hit's 40 packed FMAs run.
+        struct Ops { float4 g, wy, wx; };
+        auto load_ops = [&](Ops& o, int slot0, int j, int wo) {
+            const int woj = __builtin_amdgcn_readlane(wo, j);
+            o.g = *reinterpret_cast<const float4*>(ring + (slot0 + j) * 256 + lane * 4);
+            o.wy = *reinterpret_cast<const float4*>(tab + (woj & 0xffff) + wr * 4);
+            o.wx = *reinterpret_cast<const float4*>(tab + (woj >> 16) + wc * 4);
+        };
+        auto accumulate = [&](const Ops& o) {
+            const ga_f2 gl = ga_lo(o.g), gh = ga_hi(o.g);
+            const float wys[4] = {o.wy.x, o.wy.y, o.wy.z, o.wy.w};
+            const float wxs[4] = {o.wx.x, o.wx.y, o.wx.z, o.wx.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const ga_f2 tl = ga_f2{wys[i], wys[i]} * gl, th = ga_f2{wys[i], wys[i]} * gh;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    accl[i * 4 + jj] = ga_fma(wxs[jj], tl, accl[i * 4 + jj]);
+                    acch[i * 4 + jj] = ga_fma(wxs[jj], th, acch[i * 4 + jj]);
+                }
+            }
+        };
+        auto published = [&](unsigned r4) {                            // min over the four producers' bytes (< 256 rounds per chunk)
+            return (int)min(min(r4 & 0xff, (r4 >> 8) & 0xff), min((r4 >> 16) & 0xff, r4 >> 24));
+        };
+        auto read_desc = [&](int round, int& t, int& wo) {
+            const int slot0 = (round % PL_RING) * PL_ROUND;
+            const int n_here = min(PL_ROUND, total - round * PL_ROUND);
+            t = 0; wo = 0;
+            if (lane < n_here) {
+                t = desc[2 * (slot0 + lane)];
+                wo = desc[2 * (slot0 + lane) + 1];
+            }
+        };
+        int known = 0, t_nx = 0, wo_nx = 0;
+        bool have_nx = false;
+        for (int round = 0; round < nrounds; ++round) {
+            int t, wo;
+            if (have_nx) {
+                t = t_nx; wo = wo_nx;
+            } else {
+                while (known <= round) {
+                    known = published((unsigned)ready[0]);
+                    if (known <= round) __builtin_amdgcn_s_sleep(2);
+                }
+                asm volatile("" ::: "memory");
+                read_desc(round, t, wo);
+            }
+            const unsigned poll = (unsigned)ready[0];                  // consumed at the end of the round
+            have_nx = (round + 1 < nrounds) && (known > round + 1);
+            if (have_nx) read_desc(round + 1, t_nx, wo_nx);
+            const int slot0 = (round % PL_RING) * PL_ROUND;
+            const bool hit = ((t & my_touch & 0xffff) != 0) && (((t & my_touch) >> 16) != 0);
+            unsigned long long todo = __ballot(hit);
+            if (CIM_ROI_PL_EXP == 1) todo = 0;
+            if (todo) {
+                // two operand sets, loads unconditional (past the last hit the current one is read again): straight-line
+                // code, so that the next set's ds_reads stay ABOVE the current set's FMAs and their uses below
+                Ops A, Bo;
+                int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                load_ops(A, slot0, j, wo);
+                while (true) {
+                    const bool more_b = todo != 0;
+                    j = more_b ? __ffsll((long long)todo) - 1 : j;
+                    todo &= todo - 1;
+                    load_ops(Bo, slot0, j, wo);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accumulate(A);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!more_b) break;
+                    const bool more_a = todo != 0;
+                    j = more_a ? __ffsll((long long)todo) - 1 : j;
+                    todo &= todo - 1;
+                    load_ops(A, slot0, j, wo);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accumulate(Bo);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!more_a) break;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this round's LDS reads have returned
+            if (lane == 0) done[wave] = round + 1;
+            known = max(known, published(poll));
+        }
+        PL_STAMP(2 + 3 * ch);
+    }
+#undef PL_CHUNK_PROLOGUE
+    // ---- flush this wave's 4 x 4 pixels (zeros included: the partial maps are not cleared)
+    const int cs = slice * 256 + lane * 4;
+    const int sy0 = y0 + wr * 4, sx0 = x0 + wc * 4;
+    if (cs < C) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sy0 + i < H && sx0 + j < W) {
+                    const size_t o = (((size_t)b * H + sy0 + i) * W + sx0 + j) * C + cs;
+                    const float4 v = make_float4(accl[i * 4 + j].x, accl[i * 4 + j].y, acch[i * 4 + j].x, acch[i * 4 + j].y);
+                    if (partial) {
+                        float* dst = partial + (size_t)kgroup * B * H * W * C + o;
+                        __builtin_nontemporal_store(v.x, dst);
+                        __builtin_nontemporal_store(v.y, dst + 1);
+                        __builtin_nontemporal_store(v.z, dst + 2);
+                        __builtin_nontemporal_store(v.w, dst + 3);
+                    } else {
+                        *reinterpret_cast<float4*>(grad_in + o) = v;
+                    }
+                }
+    }
+    PL_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1836,7 +2311,7 @@ static int launch_bwd_region(const float* go, const float* rois, const float* ma
         hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), sizeof(float) * roi_rec_words(P, H, W), st, rois, ws, K, P, H, W, scale, sr, aligned);
     const int ry = (H + RG_RH - 1) / RG_RH, rx = (W + RG_RW - 1) / RG_RW, n_regions = ry * rx;
     const RegionOrder order = region_order(ry, rx);
-    const int GS = rg_group_size(K);
+    const int GS = rg_group_size(K, B, C, H, W);
     const int groups = (K + GS - 1) / GS, n_slices = (C + 255) / 256;
     float* partial = (groups > 1) ? scratch : nullptr;      // without scratch the groups meet through atomicAdd (slow)
     if (groups > 1 && !partial) {
@@ -1844,11 +2319,37 @@ static int launch_bwd_region(const float* go, const float* rois, const float* ma
         if (e != hipSuccess) return (int)e;
     }
     auto kern = GS == 128 ? roi_align_bwd_region_kernel<MASKCAT, 128> : roi_align_bwd_region_kernel<MASKCAT, 64>;
-    const size_t lds = sizeof(float) * (2 * RG_WIN * 256 + RG_MAXE * RG_REC);
+    const size_t lds = rg_lds_bytes(GS, P);
     hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) return (int)ea;
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_slices * B * groups * n_regions)), dim3(RG_NT), lds, st, go, masks, gin, C, H, W, K, P, B,
                        groups > 1 ? 1 : 0, ws, order, n_regions, rx, n_slices, partial);
+    if (partial) {
+        const size_t n4 = (size_t)B * H * W * C / 4;
+        hipLaunchKernelGGL(roi_partial_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(gin), n4, groups);
+    }
+    return 0;
+}
+
+// pipelined region form: same grid, scratch and reduce as launch_bwd_region
+template <bool MASKCAT>
+static int launch_bwd_pipe(const float* go, const float* rois, const float* masks, float* gin, int B, int C, int H, int W,
+                           int K, float scale, int sr, int aligned, float* ws, hipStream_t st, int tables_ready, float* scratch) {
+    constexpr int P = 7;
+    if (!tables_ready)
+        hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), sizeof(float) * roi_rec_words(P, H, W), st, rois, ws, K, P, H, W, scale, sr, aligned);
+    const int ry = (H + RG_RH - 1) / RG_RH, rx = (W + RG_RW - 1) / RG_RW, n_regions = ry * rx;
+    const RegionOrder order = region_order(ry, rx);
+    const int chunks = pl_chunks(K, B, C, H, W);
+    const int groups = (K + PL_GS * chunks - 1) / (PL_GS * chunks), n_slices = (C + 255) / 256;
+    float* partial = (groups > 1) ? scratch : nullptr;
+    auto kern = roi_align_bwd_pipe_kernel<MASKCAT, P>;
+    const size_t lds = pl_lds_bytes<P>();
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return (int)ea;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_slices * B * groups * n_regions)), dim3(RG_NT), lds, st, go, masks, gin, C, H, W, K, B,
+                       chunks, ws, order, n_regions, rx, n_slices, partial);
     if (partial) {
         const size_t n4 = (size_t)B * H * W * C / 4;
         hipLaunchKernelGGL(roi_partial_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
@@ -1867,9 +2368,13 @@ int launch_bwd(const float* go, const float* rois, const float* masks, float* gi
         (long long)K * P * P * (MASKCAT ? 2 : 1) * C < (1ll << 31) && getenv("CIM_ROI_BWD_TILE") == nullptr &&
         getenv("CIM_ROI_BWD_PX16") == nullptr) {
         // region form needs the partial-map scratch (or a single ROI group); without it the gather form's fewer atomics win
-        if (getenv("CIM_ROI_BWD_GATHER") == nullptr && (scratch != nullptr || K <= rg_group_size(K)) && ((H + RG_RH - 1) / RG_RH) * ((W + RG_RW - 1) / RG_RW) <= RG_MAXREG &&
-            (long long)B * ((K + 63) / 64) * ((C + 255) / 256) * RG_MAXREG < (1ll << 31))
+        if (getenv("CIM_ROI_BWD_GATHER") == nullptr && (scratch != nullptr || K <= rg_group_size(K, B, C, H, W)) && rg_lds_bytes(rg_group_size(K, B, C, H, W), P) <= 158 * 1024 && ((H + RG_RH - 1) / RG_RH) * ((W + RG_RW - 1) / RG_RW) <= RG_MAXREG &&
+            (long long)B * ((K + 63) / 64) * ((C + 255) / 256) * RG_MAXREG < (1ll << 31)) {
+            // pipelined form (opt-in, CIM_ROI_BWD_PIPE=1: measured no faster, see its header): P = 7, partial maps (or one group)
+            if (P == 7 && (scratch != nullptr || K <= PL_GS * pl_chunks(K, B, C, H, W)) && getenv("CIM_ROI_BWD_PIPE") != nullptr)
+                return launch_bwd_pipe<MASKCAT>(go, rois, masks, gin, B, C, H, W, K, scale, sr, aligned, ws, st, tables_ready, scratch);
             return launch_bwd_region<MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st, tables_ready, scratch);
+        }
         return launch_bwd_gather<MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st, tables_ready);
     }
     if (K > 0 && ws != nullptr && C % 16 == 0 && P * P * 4 <= PX_THREADS && H < 256 && W < 256 &&
@@ -1956,7 +2461,7 @@ extern "C" int cim_roi_align_bwd(const float* grad_out, const float* rois, float
 }
 
 extern "C" long long cim_roi_align_bwd_scratch(int K, int B, int C, int H, int W) {
-    const int GS = rg_group_size(K);
+    const int GS = rg_group_size(K, B, C, H, W);
     const long long groups = (K + GS - 1) / GS;
     return groups > 1 ? (long long)sizeof(float) * groups * B * H * W * C : 0;
 }

@@ -123,6 +123,38 @@ def test_roi_align_batches_groups_and_channel_chunks(dev, B, C, H, W, K):
     np.testing.assert_allclose(x.grad.cpu().numpy(), gref, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("B,C,H,W,K,gs", [(2, 8, 13, 17, 300, None), (1, 516, 33, 43, 200, None), (1, 256, 25, 30, 700, "128")])
+def test_roi_align_backward_forms_agree_with_oracle(dev, B, C, H, W, K, gs, monkeypatch):
+    """The three backward forms behind cim_roi_align(_maskcat)_bwd_ws - region (default: partial maps, interleaved entry
+    order), its producer / consumer variant (CIM_ROI_BWD_PIPE=1) and the gather form (CIM_ROI_BWD_GATHER=1) - against
+    the fp64 oracle, with several images, several ROI groups (128-ROI groups / two 64-ROI chunks in the last case: the size
+    the launcher picks when 64 would make too many workgroups) and a channel count that is not a multiple of the slice."""
+    from cim_amd.ops import roi_align_maskcat
+    if gs:
+        monkeypatch.setenv("CIM_ROI_RG_GS", gs)
+    from oracle import roi_align as oracle
+    _, rois = _roi_case(B * 31 + K, C, H, W, K)
+    rng = np.random.RandomState(K)
+    feat = rng.randn(B, C, H, W).astype(np.float32)
+    rois[:, 0] = rng.randint(0, B, K)
+    masks = (rng.rand(K, 7, 7) > 0.4).astype(np.float32)
+    g = rng.randn(K, 2 * C, 7, 7).astype(np.float32)
+    gref = oracle.roi_align_bwd(g[:, :C] + g[:, C:] * masks[:, None], rois, feat.shape)
+    grads = {}
+    for form, env in (("region", None), ("pipe", "CIM_ROI_BWD_PIPE"), ("gather", "CIM_ROI_BWD_GATHER")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        x = _cl(feat, dev).requires_grad_(True)
+        cat = roi_align_maskcat(x, torch.from_numpy(rois).to(dev), torch.from_numpy(masks).to(dev), 7, 1 / 16.0, 0, True)
+        cat.backward(torch.from_numpy(g).to(dev))
+        grads[form] = x.grad.cpu().numpy()
+        if env:
+            monkeypatch.delenv(env)
+        np.testing.assert_allclose(grads[form], gref, rtol=1e-4, atol=2e-4 * max(1.0, K / 300.0), err_msg=form)
+    # same entries, same order, same arithmetic per element: the two region forms are bit-identical
+    np.testing.assert_array_equal(grads["region"], grads["pipe"])
+
+
 def test_roi_align_empty_and_bad_args(dev):
     from cim_amd import _lib
     from cim_amd.ops import roi_align
