@@ -182,6 +182,10 @@ __device__ __forceinline__ float x2_scale(unsigned amax_bits) {
 __device__ __forceinline__ float x2_inv(float s) { return __uint_as_float((254u << 23) - __float_as_uint(s)); }
 
 // (a, b) already scaled -> packed f16 pairs (a in the low half) of the two terms
+// (tried: l = f16(a * s - h) as ONE v_fma_mixlo_f16 / v_fma_mixhi_f16 per element - scaling, f16 -> f32 of h, the exact
+// subtraction and the rounding fused, 4 VALU per pair instead of 8, bit-identical: 1.807 vs 1.801 ms on the Winograd
+// forward GEMM, no change on the others - the split arithmetic is not what co-limits these kernels; with only the MFMAs
+// left (CIM_X2_EXP=7) the same launch takes 1.204 ms)
 __device__ __forceinline__ void x2_split(float a, float b, unsigned& h, unsigned& l) {
 #if CIM_X2_EXP == 6
     h = l = __float_as_uint(a) ^ __float_as_uint(b);
