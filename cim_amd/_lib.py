@@ -31,7 +31,11 @@ SIGNATURES = {
     "cim_gemm_small_splits": [c_int, c_int, c_int],
     "cim_gemm_small_f32": [_P, _P, _P] + [c_int] * 8 + [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P, _P],
     "cim_conv1x1_bwd_workspace": [c_int, c_int, c_int, c_int],
-    "cim_conv1x1_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 4 + [_P, _P],
+    "cim_conv1x1_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 4 + [_P, _P, _P, c_int],
+    "cim_conv3x3_nchw_splits": [c_int] * 5,
+    "cim_conv3x3_nchw_f32": [_P, _P, _P] + [c_int] * 5 + [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P, _P],
+    "cim_conv3x3_nchw_bwd_workspace": [c_int] * 6,
+    "cim_conv3x3_nchw_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 6 + [_P, _P, _P, c_int],
     "cim_bn_act_fwd": [_P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, _P],
     "cim_bn_act_bwd_chunks": [c_int, c_int, c_int],
     "cim_bn_act_bwd": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
@@ -63,7 +67,7 @@ SIGNATURES = {
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }
 
-ABI_VERSION = 3          # cim_abi_version() of include/cim_hip.h this binding was written against
+ABI_VERSION = 4          # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 
@@ -93,7 +97,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = c_longlong if name in ("cim_conv1x1_bwd_workspace", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_mining_lds_bytes") else c_int
+        fn.restype = c_longlong if name in ("cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_mining_lds_bytes") else c_int
     # CIM_GEMM_ENGINE = f16x2 (default; own entry points, chosen in cim_amd/ops/gemm.py) | bf16x3 | fp32.
     # cim_gemm_f32 / cim_conv3x3_f32 (operands without scales) run bf16x3 unless fp32 is asked for.
     lib.cim_gemm_set_engine(0 if os.environ.get("CIM_GEMM_ENGINE", "f16x2") == "fp32" else 1)
@@ -101,7 +105,7 @@ def load():
     return lib
 
 
-VALUE_RETURNING = {"cim_conv1x1_bwd_workspace", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_gemm_get_engine"}      # return a count, not a status
+VALUE_RETURNING = {"cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_gemm_get_engine"}      # return a count, not a status
 
 
 def call(name, *args):

@@ -19,10 +19,14 @@
 // a = gamma * rsqrt(var + eps), b = beta - mean * a: the BatchNorm (+ identity) (+ ReLU) of the bottleneck costs no pass.
 #include "common.h"
 #include "../../include/cim_hip.h"
+#include <mutex>
 
 namespace {
 
-constexpr int SBM = 64, SBN = 64, SBK = 32, SNT = 256;
+#ifndef CIM_SMALL_BK
+#define CIM_SMALL_BK 32
+#endif
+constexpr int SBM = 64, SBN = 64, SBK = CIM_SMALL_BK, SNT = 256;
 constexpr int SLD = 68;                      // padded row stride of a k-major slab (floats); % 4 == 0 for b128 stores
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 16-byte global loads from 4-byte aligned addresses: rows of an NCHW activation [C][HW] start wherever HW puts them
@@ -189,6 +193,209 @@ __global__ __launch_bounds__(256) void small_splitk_reduce_kernel(const SmallArg
     g.C[o] = y;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 3 x 3 convolutions (padding 1, stride 1 or 2) of the bottlenecks as IMPLICIT GEMMs on the same tile, MFMA loop and
+// epilogue: the im2col matrix is never built, the B loader (and, for the data gradient, the A loader) computes the
+// shifted / strided address and the zero-padding predicate per element.  In NCHW, one image, X [Cin][H][W] -> Y
+// [Cout][Ho][Wo], W [Cout][Cin][3][3] (the module's own tensor, no repacking), k-order (channel, tap):
+//   forward          M = Cout, N = Ho Wo, K = 9 Cin   A = W as [Cout][9 Cin] (K-contiguous)    B(k, n) = X[ci][s yo + dy][s xo + dx]
+//   data gradient    M = Cin,  N = H W,   K = 9 Cout  A(m, k) = W[co][m][tap], from a transposed copy  B(k, n) = dY[co][(yi - dy) / s][(xi - dx) / s]
+//   weight gradient  M = Cout, N = 9 Cin, K = Ho Wo   A = dY as [Cout][Ho Wo] (K-contiguous)   B(k, n) = X[ci][s yo + dy][s xo + dx]
+// (tap = 3 (dy + 1) + (dx + 1); the weight gradient's C is the weight tensor's own layout).  Gathered elements are 4-byte
+// loads, 8 per thread and slab, issued together; interior float4 pieces of stride-1 convolutions take one 16-byte load.
+enum { CONV_FWD = 0, CONV_DX = 1, CONV_DW = 2 };
+struct ConvGeom { int H, W, Ho, Wo, stride, cin, cout; float inv_w; };
+
+// element (k, n) of the implicit B operand; `src` = X (forward, weight gradient) or dY (data gradient)
+template <int MODE>
+__device__ __forceinline__ bool conv_src(const ConvGeom& c, int ch, int tap, int y, int x, int& off) {
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    if (MODE == CONV_DX) {                 // (y, x) = input pixel; the output pixel that reads it through this tap
+        const int ty = y - dy, tx = x - dx;
+        if (c.stride == 2 && ((ty | tx) & 1)) return false;
+        const int yo = c.stride == 2 ? ty >> 1 : ty, xo = c.stride == 2 ? tx >> 1 : tx;
+        off = (ch * c.Ho + yo) * c.Wo + xo;
+        return ty >= 0 && tx >= 0 && yo < c.Ho && xo < c.Wo;
+    }
+    const int yi = y * c.stride + dy, xi = x * c.stride + dx;   // (y, x) = output pixel
+    off = (ch * c.H + yi) * c.W + xi;
+    return (unsigned)yi < (unsigned)c.H && (unsigned)xi < (unsigned)c.W;
+}
+
+#ifndef CIM_CONV3_BK
+#define CIM_CONV3_BK 32            // slab depth of the 3 x 3 kernel (K = 9 C is long: 64 halves the barriers and load round trips per k)
+#endif
+constexpr int CBK = CIM_CONV3_BK;
+template <int MODE>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, const ConvGeom c) {
+    constexpr int NT = 256, PA = SBM * (CBK / 4) / NT, PB = SBN * (CBK / 4) / NT;        // sixteen-byte pieces per thread and slab
+    extern __shared__ __attribute__((aligned(16))) float c3_smem[];
+    float (*As)[CBK * SLD] = reinterpret_cast<float (*)[CBK * SLD]>(c3_smem);
+    float (*Bs)[CBK * SLD] = reinterpret_cast<float (*)[CBK * SLD]>(c3_smem + 2 * CBK * SLD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (g.N + SBN - 1) / SBN;
+    const int m0 = (blockIdx.x / tiles_n) * SBM, n0 = (blockIdx.x % tiles_n) * SBN;
+    const int split = blockIdx.y;
+    const int kper = ((g.K + g.splits - 1) / g.splits + CBK - 1) / CBK * CBK;
+    const int kbeg = split * kper, kend = min(g.K, kbeg + kper);
+    const int wsrc = (MODE == CONV_DX) ? c.Wo : c.W;                     // row length of the gathered tensor
+    (void)wsrc;
+
+    // ---- per-thread constants of the B pieces
+    // forward / data gradient: B is row-contiguous in n (pixels): piece p -> k = k0 + p / 16, n = n0 + (p % 16) * 4: the
+    // four pixels are fixed for the whole K loop, (channel, tap) changes per slab.
+    // weight gradient: B is K-contiguous: piece p -> n = n0 + p % 64 (a (channel, tap) pair, fixed), k = k0 + (p / 64) * 4 pixels.
+    int py[PB][4], px[PB][4];            // forward / dX: pixel coordinates of the piece's 4 columns (-1: column >= N)
+    int bch[PB], btap[PB];               // dW: (channel, tap) of the piece's row (-1: row >= N)
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int p = tid + i * NT;
+        if (MODE == CONV_DW) {
+            const int n = n0 + p % SBN;
+            bch[i] = n < g.N ? n / 9 : -1;
+            btap[i] = n - (n / 9) * 9;
+        } else {
+            const int wrow = (MODE == CONV_DX) ? c.W : c.Wo;             // n runs over input pixels (dX) / output pixels (forward)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + (p % 16) * 4 + j;
+                const int y = (int)(((float)n + 0.5f) * c.inv_w);       // n / wrow (exact: see the launcher)
+                py[i][j] = n < g.N ? y : -1;
+                px[i][j] = n - y * wrow;
+            }
+        }
+    }
+
+    auto load_b = [&](int k0, float4 (&rb)[PB]) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int p = tid + i * NT;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == CONV_DW) {
+                const int k = k0 + (p / SBN) * 4;                        // 4 consecutive output pixels
+                if (bch[i] >= 0) {
+                    int off[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int po = k + j;
+                        const int yo = (int)(((float)po + 0.5f) * c.inv_w), xo = po - yo * c.Wo;
+                        ok[j] = po < kend && conv_src<MODE>(c, bch[i], btap[i], yo, xo, off[j]);
+                    }
+                    if (c.stride == 1 && ok[0] && ok[1] && ok[2] && ok[3] && off[3] == off[0] + 3) {     // all inside: 16-byte load
+                        const float4 t = ld4(g.B + off[0]);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ok[j]) v[j] = g.B[off[j]];
+                    }
+                }
+            } else {
+                const int k = k0 + p / 16;
+                if (k < kend) {
+                    const int ch = k / 9, tap = k - ch * 9;
+                    int off[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ok[j] = py[i][j] >= 0 && conv_src<MODE>(c, ch, tap, py[i][j], px[i][j], off[j]);
+                    if (c.stride == 1 && ok[0] && ok[1] && ok[2] && ok[3] && off[3] == off[0] + 3) {     // all inside: 16-byte load
+                        const float4 t = ld4(g.B + off[0]);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ok[j]) v[j] = g.B[off[j]];
+                    }
+                }
+            }
+            rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto load_a = [&](int k0, float4 (&ra)[PA]) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int p = tid + i * NT;
+            if (MODE == CONV_DX) {       // A = the weight transposed to [(co, tap)][ci] by conv3x3_wt_kernel: M-contiguous rows
+                ra[i] = tile_load<true, SBM>(g.A, g.lda, g.M, kend, m0, k0, p);
+            } else {
+                ra[i] = tile_load<false, SBM>(g.A, g.lda, g.M, kend, m0, k0, p);
+            }
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    float4 ra0[PA], rb0[PB];
+#define C3_PUT(BUF)                                                                                                 \
+    {                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i) tile_store<MODE == CONV_DX, SBM>(As[BUF], ra0[i], tid + i * NT); \
+        _Pragma("unroll") for (int i = 0; i < PB; ++i) tile_store<MODE != CONV_DW, SBN>(Bs[BUF], rb0[i], tid + i * NT); \
+    }
+#define C3_MMA(BUF)                                                                                                 \
+    {                                                                                                               \
+        const float* __restrict__ a = As[BUF] + (lane >> 5) * SLD + wm * 32 + (lane & 31);                          \
+        const float* __restrict__ b = Bs[BUF] + (lane >> 5) * SLD + wn * 32 + (lane & 31);                          \
+        _Pragma("unroll") for (int kk = 0; kk < CBK; kk += 2)                                                       \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk * SLD], b[kk * SLD], acc, 0, 0, 0);                     \
+    }
+    if (kbeg < kend) {
+        const int nslab = (kend - kbeg + CBK - 1) / CBK;
+        load_a(kbeg, ra0);
+        load_b(kbeg, rb0);
+        C3_PUT(0)
+        __syncthreads();
+        for (int s = 0; s < nslab; ++s) {
+            const int more = s + 1 < nslab;
+            if (more) { load_a(kbeg + (s + 1) * CBK, ra0); load_b(kbeg + (s + 1) * CBK, rb0); }
+            if (s & 1) { C3_MMA(1) } else { C3_MMA(0) }
+            if (more) { if (s & 1) { C3_PUT(0) } else { C3_PUT(1) } }
+            __syncthreads();
+        }
+    }
+#undef C3_PUT
+#undef C3_MMA
+    // ---- epilogue (as gemm_small_kernel)
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= g.N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        if (row >= g.M) continue;
+        const float v = acc[r];
+        if (g.splits > 1) {
+            g.ws[((size_t)split * g.M + row) * g.N + col] = v;
+            continue;
+        }
+        const size_t o = (size_t)row * g.ldc + col;
+        if (g.Xraw) g.Xraw[o] = v;
+        float y = v;
+        if (g.bn) {
+            const float a = g.gamma[row] * rsqrtf(g.var[row] + g.eps);
+            y = fmaf(v, a, g.beta[row] - g.mean[row] * a);
+        }
+        if (g.res) y += g.res[o];
+        if (g.relu) y = fmaxf(y, 0.0f);
+        g.C[o] = y;
+    }
+}
+
+// w [Cout][Cin][9] -> wt [Cout][9][Cin] (the data gradient's A operand, M-contiguous): one workgroup per output channel,
+// through LDS so that both sides are coalesced.  (Gathering W[co][ci][tap] in the GEMM's loader - 36-byte strides between
+// lanes - made the data gradient 1.7x slower than the forward: 69 vs 40 us.)
+__global__ __launch_bounds__(256) void conv3x3_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin) {
+    extern __shared__ float wt_s[];
+    const int co = blockIdx.x, n = cin * 9;
+    for (int i = threadIdx.x; i < n; i += 256) wt_s[i] = w[(size_t)co * n + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int tap = i / cin, ci = i - tap * cin;
+        wt[(size_t)co * n + i] = wt_s[ci * 9 + tap];
+    }
+}
+
 template <bool AM, bool BKc>
 static void launch_small(const SmallArgs& g, int splits, hipStream_t st, bool narrow) {
     const long long tm = (g.M + SBM - 1) / SBM;
@@ -249,10 +456,46 @@ extern "C" long long cim_conv1x1_bwd_workspace(int B, int cin, int cout, int hw)
     const long long dx = (long long)cim_gemm_small_splits(cin, hw, cout) * cin * hw;
     const long long dw = (long long)cim_gemm_small_splits(cout, cin, hw) * cout * cin + (B > 1 ? (long long)cout * cin : 0);
     const long long dconv = (long long)B * cout * hw;
-    return (long long)sizeof(float) * (dconv + (dx > dw ? dx : dw));
+    return (long long)sizeof(float) * (dconv + dx + dw);      // (dX and dW run side by side: separate split-K areas)
 }
 
 namespace {
+// Fork / join between the caller's stream and a side stream inside one host call: the weight-gradient GEMM of a layer
+// runs on the side stream next to the data-gradient GEMM (both only read the BatchNorm backward's output; each fills a
+// fraction of the chip - they are latency bound).  Events come from a small round-robin pool (recorded and waited on at
+// once, so reuse is safe).
+struct ForkJoin {
+    hipStream_t main, side;
+    hipEvent_t ev[2];
+    bool on;
+    ForkJoin(hipStream_t m, hipStream_t s, bool want) : main(m), side(s), on(want && s != nullptr && s != m) {
+        static std::mutex mu;
+        static hipEvent_t pool[64];
+        static int next = -1;            // -1: pool not created yet
+        if (!on) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (next < 0) {
+            for (int i = 0; i < 64; ++i)
+                if (hipEventCreateWithFlags(&pool[i], hipEventDisableTiming) != hipSuccess) { on = false; return; }
+            next = 0;
+        }
+        ev[0] = pool[next];
+        ev[1] = pool[next + 1];
+        next = (next + 2) % 64;
+    }
+    hipStream_t fork() {                 // side stream, ordered after everything enqueued on main so far
+        if (!on) return main;
+        (void)hipEventRecord(ev[0], main);
+        (void)hipStreamWaitEvent(side, ev[0], 0);
+        return side;
+    }
+    void join() {                        // main waits for the side stream's work
+        if (!on) return;
+        (void)hipEventRecord(ev[1], side);
+        (void)hipStreamWaitEvent(main, ev[1], 0);
+    }
+};
+
 __global__ __launch_bounds__(256) void small_axpy_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] += x[i];
@@ -262,29 +505,140 @@ __global__ __launch_bounds__(256) void small_axpy_kernel(float* __restrict__ y, 
 extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                                       const float* gamma, const float* mean, const float* var, float eps, int relu,
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
-                                      int hw, float* workspace, void* stream) {
+                                      int hw, float* workspace, void* stream, void* side_stream, int join) {
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0 && cin > 0 && cout > 0 && hw > 0);
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)));
     float* dconv = workspace;                                  // [B][cout][hw]: dz * a, the gradient of the convolution output
-    float* ws = workspace + (size_t)B * cout * hw;
+    float* ws_dx = workspace + (size_t)B * cout * hw;
+    float* ws_dw = ws_dx + (size_t)cim_gemm_small_splits(cin, hw, cout) * cin * hw;
     int rc = cim_bn_act_bwd(dy, y, x_raw, gamma, mean, var, eps, dconv, dres, dgamma, dbeta, B, cout, hw, relu, stream);
     if (rc) return rc;
-    for (int b = 0; b < B && dx; ++b) {                        // dX[cin, hw] = W^T . dconv
-        rc = cim_gemm_small_f32(w, dconv + (size_t)b * cout * hw, dx + (size_t)b * cin * hw, cin, hw, cout, cin, hw, hw, 1, 0,
-                                nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, cout), ws, stream);
-        if (rc) return rc;
-    }
+    ForkJoin fj(cim::as_stream(stream), cim::as_stream(side_stream), dx && dw);
+    void* st_dw = fj.fork();                                   // the weight gradient next to the data gradient
     for (int b = 0; b < B && dw; ++b) {                        // dW[cout, cin] = dconv . X^T  (K = hw)
         const int sp = cim_gemm_small_splits(cout, cin, hw);
-        float* out = b == 0 ? dw : ws + (size_t)sp * cout * cin;
+        float* out = b == 0 ? dw : ws_dw + (size_t)sp * cout * cin;
         rc = cim_gemm_small_f32(dconv + (size_t)b * cout * hw, x + (size_t)b * cin * hw, out, cout, cin, hw, hw, hw, cin, 0, 1,
-                                nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, sp, ws, stream);
+                                nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, sp, ws_dw, st_dw);
         if (rc) return rc;
         if (b) {
             const size_t n = (size_t)cout * cin;
-            hipLaunchKernelGGL(small_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dw, out, n);
+            hipLaunchKernelGGL(small_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(st_dw), dw, out, n);
         }
     }
+    for (int b = 0; b < B && dx; ++b) {                        // dX[cin, hw] = W^T . dconv
+        rc = cim_gemm_small_f32(w, dconv + (size_t)b * cout * hw, dx + (size_t)b * cin * hw, cin, hw, cout, cin, hw, hw, 1, 0,
+                                nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, cout), ws_dx, stream);
+        if (rc) return rc;
+    }
+    if (join) fj.join();                                       // else the caller joins the side stream before the weight gradient is used
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3 x 3 convolution (padding 1, stride 1 / 2, no bias) + BatchNorm (eval statistics) (+ residual) (+ ReLU), one image per
+// launch; see conv3x3_small_kernel.
+namespace {
+int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldc, const ConvGeom& c,
+                   float* x_raw, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                   const float* residual, int relu, int splits, float* ws, hipStream_t st) {
+    SmallArgs g;
+    g.A = A; g.B = B; g.C = C; g.Xraw = x_raw;
+    g.gamma = gamma; g.beta = beta; g.mean = mean; g.var = var; g.res = residual; g.eps = eps;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = 0; g.ldc = ldc;
+    g.a_mcontig = 0; g.b_kcontig = mode == CONV_DW; g.relu = relu; g.bn = gamma != nullptr;
+    g.splits = splits; g.ws = ws;
+    const dim3 grid((unsigned)(((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN)), (unsigned)splits);
+    const size_t lds = sizeof(float) * 4 * CBK * SLD;
+    auto kern = mode == CONV_FWD ? conv3x3_small_kernel<CONV_FWD> : mode == CONV_DX ? conv3x3_small_kernel<CONV_DX> : conv3x3_small_kernel<CONV_DW>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, c);
+    if (splits > 1) {
+        const size_t n = (size_t)M * N;
+        hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
+    }
+    return 0;
+}
+ConvGeom conv_geom(int cin, int cout, int H, int W, int stride, int mode) {
+    ConvGeom c;
+    c.H = H; c.W = W; c.stride = stride; c.cin = cin; c.cout = cout;
+    c.Ho = (H - 1) / stride + 1; c.Wo = (W - 1) / stride + 1;            // kernel 3, padding 1
+    c.inv_w = 1.0f / (float)(mode == CONV_DX ? W : c.Wo);
+    return c;
+}
+}  // namespace
+
+#define CONV3_ARGS_OK()                                                                                              \
+    CIM_CHECK_ARG(cin > 0 && cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && W <= 4096 &&               \
+                  (long long)H * W < (1ll << 20) && (long long)cin * H * W < (1ll << 31) && (long long)cout * H * W < (1ll << 31) && \
+                  (long long)cin * cout * 9 < (1ll << 31) && cin % 4 == 0)
+
+extern "C" int cim_conv3x3_nchw_splits(int cin, int cout, int H, int W, int stride) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    return cim_gemm_small_splits(cout, Ho * Wo, 9 * cin);
+}
+
+extern "C" int cim_conv3x3_nchw_f32(const float* x, const float* w, float* y, int cin, int cout, int H, int W, int stride,
+                               float* x_raw, const float* gamma, const float* beta, const float* mean, const float* var,
+                               float eps, const float* residual, int relu, int splits, float* workspace, void* stream) {
+    CIM_CHECK_ARG(x && w && y && splits >= 1 && splits <= 65535 && (splits == 1 || workspace));
+    CONV3_ARGS_OK();
+    CIM_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (gamma == nullptr) == (mean == nullptr) && (gamma == nullptr) == (var == nullptr));
+    const ConvGeom c = conv_geom(cin, cout, H, W, stride, CONV_FWD);
+    conv3x3_launch(CONV_FWD, w, x, y, cout, c.Ho * c.Wo, 9 * cin, 9 * cin, c.Ho * c.Wo, c, x_raw, gamma, beta, mean, var, eps,
+                   residual, relu, splits, workspace, cim::as_stream(stream));
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" long long cim_conv3x3_nchw_bwd_workspace(int B, int cin, int cout, int H, int W, int stride) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long long dx = (long long)cim_gemm_small_splits(cin, H * W, 9 * cout) * cin * H * W;
+    const long long dw = (long long)cim_gemm_small_splits(cout, 9 * cin, Ho * Wo) * cout * cin * 9 + (B > 1 ? (long long)cout * cin * 9 : 0);
+    const long long dconv = (long long)B * cout * Ho * Wo;
+    return (long long)sizeof(float) * (dconv + (long long)cout * cin * 9 + dx + dw);
+}
+
+// The whole backward of conv3x3 -> BatchNorm (+ residual) (+ ReLU): BatchNorm / ReLU backward (bn_act.hip), data gradient
+// and weight gradient implicit GEMMs with their split-K reduces, enqueued by one host call (as cim_conv1x1_bn_act_bwd).
+extern "C" int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
+                                      const float* gamma, const float* mean, const float* var, float eps, int relu,
+                                      float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
+                                      int H, int W, int stride, float* workspace, void* stream, void* side_stream, int join) {
+    CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0);
+    CONV3_ARGS_OK();
+    CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)) && cout % 4 == 0);
+    const ConvGeom cx = conv_geom(cin, cout, H, W, stride, CONV_DX), cw = conv_geom(cin, cout, H, W, stride, CONV_DW);
+    const int hwo = cx.Ho * cx.Wo, hw = H * W;
+    hipStream_t st = cim::as_stream(stream);
+    float* dconv = workspace;                                  // [B][cout][Ho Wo]: the gradient of the convolution output
+    float* wt = workspace + (size_t)B * cout * hwo;            // [cout][9][cin]
+    float* ws_dx = wt + (size_t)cout * cin * 9;
+    float* ws_dw = ws_dx + (size_t)cim_gemm_small_splits(cin, hw, 9 * cout) * cin * hw;
+    CIM_CHECK_ARG((size_t)cin * 9 * sizeof(float) <= 64 * 1024);
+    int rc = cim_bn_act_bwd(dy, y, x_raw, gamma, mean, var, eps, dconv, dres, dgamma, dbeta, B, cout, hwo, relu, stream);
+    if (rc) return rc;
+    ForkJoin fj(st, cim::as_stream(side_stream), dx && dw);
+    hipStream_t st_dw = fj.fork();                             // the weight gradient next to the data gradient
+    for (int b = 0; b < B && dw; ++b) {                        // dW[cout][cin 9] = dconv . im2col(X)^T  (K = Ho Wo)
+        const int sp = cim_gemm_small_splits(cout, 9 * cin, hwo);
+        float* out = b == 0 ? dw : ws_dw + (size_t)sp * cout * cin * 9;
+        conv3x3_launch(CONV_DW, dconv + (size_t)b * cout * hwo, x + (size_t)b * cin * hw, out, cout, 9 * cin, hwo, hwo, 9 * cin, cw,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, sp, ws_dw, st_dw);
+        if (b) {
+            const size_t n = (size_t)cout * cin * 9;
+            hipLaunchKernelGGL(small_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_dw, dw, out, n);
+        }
+    }
+    if (dx) hipLaunchKernelGGL(conv3x3_wt_kernel, dim3(cout), dim3(256), sizeof(float) * cin * 9, st, w, wt, cin);
+    for (int b = 0; b < B && dx; ++b)                          // dX[cin][H W] = sum over (co, tap) W[co][ci][tap] dconv[co][shifted]
+        conv3x3_launch(CONV_DX, wt, dconv + (size_t)b * cout * hwo, dx + (size_t)b * cin * hw, cin, hw, 9 * cout, cin, hw, cx, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, 9 * cout), ws_dx, st);
+    if (join) fj.join();                                       // else the caller joins the side stream before the weight gradient is used
     CIM_CHECK_LAUNCH();
     return 0;
 }

@@ -12,10 +12,11 @@ import os
 import torch.nn as nn
 
 from ..core.config import cfg
-from ..ops import bn_act, conv1x1_bn_act
+from ..ops import bn_act, conv1x1_bn_act, conv3x3_bn_act
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "resnet50.MaskFuse" by get_func)
 
 
+OWN_3X3 = os.environ.get("CIM_BACKBONE_3X3", "hip") != "aten"      # CIM_BACKBONE_3X3=aten: MIOpen's 3 x 3 kernels + the bn_act launch (A/B runs)
 OWN_1X1 = os.environ.get("CIM_BACKBONE_1X1", "hip") != "aten"      # CIM_BACKBONE_1X1=aten: the MIOpen / rocBLAS path (A/B runs)
 
 
@@ -34,14 +35,13 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        # the 1 x 1 convolutions with their BatchNorm (eval statistics) (+ identity) (+ ReLU) are ONE HIP launch each
-        # (small-tile fp32-MFMA GEMM with the chain in its epilogue, cim_amd/csrc/conv1x1.hip); the 3 x 3 convolution
-        # stays on MIOpen's fp32 Winograd kernel with the fused BatchNorm + ReLU launch behind it (cim_amd/csrc/bn_act.hip).
-        # Both fall back to the ATen ops for a BN in training mode or CPU tensors.
+        # every convolution of the block with its BatchNorm (eval statistics) (+ identity) (+ ReLU) is ONE HIP launch
+        # (small-tile fp32-MFMA GEMM - implicit for the 3 x 3 - with the chain in its epilogue, cim_amd/csrc/conv1x1.hip).
+        # They fall back to the ATen ops for a BN in training mode or CPU tensors.
         identity = x
         if OWN_1X1:
             out = conv1x1_bn_act(x, self.conv1, self.bn1)
-            out = bn_act(self.conv2(out), self.bn2)
+            out = conv3x3_bn_act(out, self.conv2, self.bn2) if OWN_3X3 else bn_act(self.conv2(out), self.bn2)
             if self.downsample is not None:
                 identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
             return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity)

@@ -31,6 +31,8 @@ import contextlib
 
 import torch
 import torch.distributed as dist
+
+from ...ops.gemm import join_side as _join_side
 from torch import nn
 
 
@@ -210,6 +212,7 @@ class DataParallel(nn.Module):
         """Buckets are reduced STRICTLY in index order, so every rank issues the same sequence of
         collectives even if a rank's autograd produced gradients in a different order or skipped
         a parameter (e.g. a refinement head whose CIM layer returned None on that image)."""
+        _join_side()        # (weight gradients deferred to the side stream, cim_amd/ops/gemm.py: no-op with the flat gradient views)
         while self._next_bucket < len(self.buckets):
             bk = self.buckets[self._next_bucket]
             if not force and bk["ready"] < len(bk["params"]):

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from . import gemm as _gemm_mod
 
 
 def _gemm(a, b, c, m, n, k, lda, ldb, ldc, a_mcontig, b_kcontig, x_raw=None, bn=None, eps=0.0, res=None, relu=False):
@@ -41,6 +42,7 @@ class Conv1x1BnActFunction(Function):
                   bn=(gamma, beta, mean, var), eps=eps, res=(res[b] if res is not None else None), relu=relu)
         if need_grad:
             ctx.save_for_backward(x, w2, xr, y if relu else None, gamma, mean, var)
+        ctx.param = w if isinstance(w, torch.nn.Parameter) else None      # (its .grad tells the backward whether it may defer the join)
         ctx.cfg = (B, cin, cout, H, W, float(eps), bool(relu), res is not None)
         return y
 
@@ -63,9 +65,13 @@ class Conv1x1BnActFunction(Function):
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=dev) if need_w else None
         ws = torch.empty(_lib.call("cim_conv1x1_bwd_workspace", B, cin, cout, hw) // 4, dtype=torch.float32, device=dev)
+        side, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
         _lib.call("cim_conv1x1_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w2.data_ptr(),
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres), _lib.ptr(dgamma),
-                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr())
+                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, join)
+        if not join:                       # the weight gradient is still running on the side stream: installed as .grad at the join
+            _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x)
+            dw = None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
             None, None, None, None
 

@@ -1,0 +1,89 @@
+"""3 x 3 convolution + frozen-statistics BatchNorm (+ residual) (+ ReLU) of the ResNet bottlenecks as ONE HIP launch
+(implicit GEMM, cim_amd/csrc/conv1x1.hip: conv3x3_small_kernel), with autograd.
+
+`conv3x3_bn_act(x, conv, bn, residual=None, relu=True)` == F.relu(bn(conv(x)) + residual) for an nn.Conv2d with a
+3 x 3 kernel, padding 1, stride 1 or 2, no bias, and an nn.BatchNorm2d in eval() mode -
+/root/reference/lib/modeling/resnet50.py:17-44 (torchvision Bottleneck conv2 / bn2) with every BatchNorm frozen as
+:53-77 does.  The parameters stay the modules' own tensors (checkpoint surface unchanged; the kernel reads the
+[Cout, Cin, 3, 3] weight as it is).  Forward, data gradient and weight gradient are three loaders of the same kernel; the
+BatchNorm backward stays the fused `bn_act` kernel.  CPU tensors, a BatchNorm in training mode or other convolution
+shapes take the ATen ops."""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from .. import _lib
+from . import gemm as _gemm_mod
+
+
+class Conv3x3BnActFunction(Function):
+    @staticmethod
+    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, stride):
+        x = x.contiguous()
+        w = w.contiguous()
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        need_grad = any(ctx.needs_input_grad[:5])
+        y = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=x.device)
+        xr = torch.empty_like(y) if need_grad else None            # convolution output: the BatchNorm backward's x
+        if res is not None:
+            res = res.contiguous()
+        splits = _lib.call("cim_conv3x3_nchw_splits", cin, cout, H, W, stride)
+        ws = torch.empty(splits * cout * ho * wo, dtype=torch.float32, device=x.device) if splits > 1 else None
+        st = _lib.stream_ptr()
+        for b in range(B):
+            _lib.call("cim_conv3x3_nchw_f32", x[b].data_ptr(), w.data_ptr(), y[b].data_ptr(), cin, cout, H, W, stride,
+                      _lib.ptr(xr[b] if xr is not None else None), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                      float(eps), _lib.ptr(res[b] if res is not None else None), int(relu), splits, _lib.ptr(ws), st)
+        if need_grad:
+            ctx.save_for_backward(x, w, xr, y if relu else None, gamma, mean, var)
+        ctx.param = w if isinstance(w, torch.nn.Parameter) else None      # (its .grad tells the backward whether it may defer the join)
+        ctx.cfg = (B, cin, cout, H, W, float(eps), bool(relu), res is not None, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, xr, y, gamma, mean, var = ctx.saved_tensors
+        B, cin, cout, H, W, eps, relu, has_res, stride = ctx.cfg
+        dy = dy.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_res = has_res and ctx.needs_input_grad[2]
+        need_affine = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        dev = dy.device
+        hwo = dy.shape[2] * dy.shape[3]
+        dres = torch.empty_like(dy) if need_res else None
+        dgamma = dbeta = None
+        if need_affine:
+            alloc = torch.zeros if _lib.call("cim_bn_act_bwd_chunks", B, cout, hwo) > 1 else torch.empty
+            dgamma, dbeta = alloc(2, cout, dtype=torch.float32, device=dev).unbind(0)
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(w) if need_w else None
+        ws = torch.empty(_lib.call("cim_conv3x3_nchw_bwd_workspace", B, cin, cout, H, W, stride) // 4, dtype=torch.float32, device=dev)
+        side, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
+        _lib.call("cim_conv3x3_nchw_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w.data_ptr(),
+                  gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres), _lib.ptr(dgamma),
+                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, H, W, stride, ws.data_ptr(), _lib.stream_ptr(), side, join)
+        if not join:                       # the weight gradient is still running on the side stream: installed as .grad at the join
+            _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x)
+            dw = None
+        return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
+            None, None, None, None, None
+
+
+def conv3x3_bn_act(x, conv, bn, residual=None, relu=True):
+    """relu?(bn(conv(x)) + residual) for a 3 x 3 nn.Conv2d `conv` (padding 1, stride 1 / 2) and an nn.BatchNorm2d `bn`."""
+    fused = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.bias is None
+             and conv.padding == (1, 1) and conv.stride in ((1, 1), (2, 2)) and conv.dilation == (1, 1) and conv.groups == 1
+             and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0 and x.shape[3] <= 4096 and x.shape[2] * x.shape[3] < (1 << 20)
+             and (not bn.training) and bn.affine and bn.track_running_stats)
+    if not fused:
+        out = bn(conv(x))
+        if residual is not None:
+            out = out + residual
+        return F.relu(out) if relu else out
+    args = (x, conv.weight, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu, conv.stride[0])
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:5])):
+        with torch.no_grad():
+            return Conv3x3BnActFunction.apply(*args)
+    return Conv3x3BnActFunction.apply(*args)

@@ -117,6 +117,59 @@ def _side_stream(dev):
     return s
 
 
+# ---- weight gradients that run BESIDE the rest of the backward pass (backbone convolutions) ---------------------------
+# A backbone layer's weight-gradient GEMM is only needed by the optimizer.  Joined layer by layer (as the MaskFuse layers
+# above do) it cannot overlap much: the main stream waits for it before the next layer's BatchNorm backward.  Deferred, the
+# ~30 weight-gradient GEMMs of the body form their own chain on the side stream and the main stream's data-gradient chain
+# never waits: the join happens ONCE, in an autograd-engine callback at the end of the backward pass (and defensively
+# at the start of SGD.step / before DataParallel reduces a bucket).  Buffers the side work reads or writes (saved
+# activations, workspaces) are kept referenced here until that join, so the caching allocator cannot hand them out.
+# Only when the weight's .grad is still None (the first backward after zero_grad(set_to_none=True)): accumulation into an
+# existing .grad - iter_size > 1, DataParallel's flat gradient views - runs on the main stream right after the layer's
+# backward returns and needs the gradient complete, so those cases join at once.  (Consequence: torch.autograd.grad() with
+# such a weight among its inputs does not see the gradient - use .backward(), or CIM_DEFER_DW=0.)
+DEFER_DW = OVERLAP and os.environ.get("CIM_DEFER_DW", "1") == "1"
+_DEFERRED = {}        # device -> [main stream, [(param, dw)], [tensors kept alive]]
+
+
+def side_stream_for_backward(dev, param):
+    """(side stream pointer or None, join flag) for a layer's backward whose weight is `param`."""
+    if not OVERLAP:
+        return None, 1
+    defer = DEFER_DW and param is not None and param.grad is None
+    return _side_stream(dev).cuda_stream, 0 if defer else 1
+
+
+def defer_side_join(dev, param, dw, *keep):
+    """The layer's weight gradient `dw` was enqueued on the side stream without a join.  It does NOT travel through
+    autograd (the layer's backward returns None for the weight: AccumulateGrad may copy a gradient it cannot steal, on the
+    main stream, before the side stream has written it): it is installed as param.grad by join_side(), after the join."""
+    ent = _DEFERRED.get(dev)
+    if ent is None or not (ent[1] or ent[2]):
+        ent = _DEFERRED[dev] = [torch.cuda.current_stream(dev), [], []]
+        torch.autograd.Variable._execution_engine.queue_callback(join_side)
+    ent[1].append((param, dw))
+    ent[2].extend(keep)
+
+
+def join_side():
+    """Make the stream the backward ran on wait for the deferred side-stream work, install the weight gradients, release
+    the kept buffers.  Runs as an autograd-engine callback at the end of the backward pass."""
+    for dev, ent in list(_DEFERRED.items()):
+        if ent[1] or ent[2]:
+            ent[0].wait_stream(_side_stream(dev))
+            cur = torch.cuda.current_stream(dev)
+            if cur != ent[0]:
+                cur.wait_stream(_side_stream(dev))
+            with torch.no_grad():
+                for param, dw in ent[1]:
+                    if param.grad is None:
+                        param.grad = dw
+                    else:
+                        param.grad += dw
+            ent[1], ent[2] = [], []
+
+
 class LinearFunction(Function):
     """y = relu?(x @ w.T + b); x [M,K], w [N,K] (nn.Linear layout)."""
 

@@ -22,6 +22,8 @@ version and the ops fall back to their own pass.
 import numpy as np
 import torch
 
+from ..ops.gemm import join_side as _join_side
+
 from .. import _lib
 
 CHUNK = 16384          # elements per workgroup
@@ -222,6 +224,7 @@ class SGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        _join_side()            # weight gradients deferred to the side stream (cim_amd/ops/gemm.py; normally joined at the end of backward)
         if self._early is not None:
             done, stream, ev = self._early
             self._early = None

@@ -211,12 +211,36 @@ int cim_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, i
 /* Backward of conv1x1 -> frozen BatchNorm (+ residual) (+ ReLU) for B images in one call: BatchNorm / ReLU backward
  * (cim_bn_act_bwd), dx [B,cin,hw] = W^T . dconv, dw [cout,cin] = sum_b dconv_b . x_b^T.  dy, y (post-activation output; may
  * be NULL without relu), x_raw (convolution output) are [B,cout,hw]; x is the convolution input [B,cin,hw]; w [cout,cin].
- * dres / dgamma+dbeta / dx / dw may be NULL when not needed.  workspace: cim_conv1x1_bwd_workspace(B,cin,cout,hw) bytes. */
+ * dres / dgamma+dbeta / dx / dw may be NULL when not needed.  workspace: cim_conv1x1_bwd_workspace(B,cin,cout,hw) bytes.
+ * side_stream (may be NULL): a second HIP stream the weight-gradient GEMM is enqueued on, next to the data-gradient GEMM on
+ * `stream`, forked after the BatchNorm backward.  join != 0: `stream` waits for it before the call returns (stream order is all the
+ * caller needs); join == 0: the CALLER makes `stream` wait for side_stream before dw (and the buffers x, workspace) are used or
+ * reused - the weight gradients of a whole backward pass then run beside the data-gradient chain. */
 long long cim_conv1x1_bwd_workspace(int B, int cin, int cout, int hw);
 int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                            const float* gamma, const float* mean, const float* var, float eps, int relu,
                            float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int hw,
-                           float* workspace, void* stream);
+                           float* workspace, void* stream, void* side_stream, int join);
+
+/* 3 x 3 convolution (padding 1, stride 1 or 2, no bias, groups 1) -> frozen BatchNorm (+ residual) (+ ReLU) of the
+ * bottlenecks (torchvision Bottleneck.conv2 / bn2, lib/modeling/resnet50.py:17-44,53-77), NCHW fp32, ONE image per call, as an
+ * implicit GEMM on the small-tile fp32-MFMA kernel above (the im2col matrix is never built): x [cin][H][W], w [cout][cin][3][3]
+ * (the nn.Conv2d weight as it is), y / x_raw / residual [cout][Ho][Wo], Ho = (H-1)/stride + 1.  Epilogue and split-K as
+ * cim_gemm_small_f32 (workspace [splits][cout][Ho Wo] floats when cim_conv3x3_nchw_splits(...) > 1).  cin % 4 == 0.
+ * Replaces ATen -> MIOpen (miopenSp3AsmConv / Im2d2Col + rocBLAS) for those layers. */
+int cim_conv3x3_nchw_splits(int cin, int cout, int H, int W, int stride);
+int cim_conv3x3_nchw_f32(const float* x, const float* w, float* y, int cin, int cout, int H, int W, int stride, float* x_raw,
+                         const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                         const float* residual, int relu, int splits, float* workspace, void* stream);
+/* Backward of the above for B images in one call: BatchNorm / ReLU backward (cim_bn_act_bwd), dx [B,cin,H,W] (transposed
+ * convolution as an implicit GEMM over (cout, tap)), dw [cout,cin,3,3] = sum over images and output pixels (split-K).
+ * dy, y (may be NULL without relu), x_raw are [B,cout,Ho,Wo]; dres / dgamma+dbeta / dx / dw may be NULL when not needed.
+ * workspace: cim_conv3x3_nchw_bwd_workspace(...) bytes.  cin % 4 == 0, cout % 4 == 0.  side_stream as in cim_conv1x1_bn_act_bwd. */
+long long cim_conv3x3_nchw_bwd_workspace(int B, int cin, int cout, int H, int W, int stride);
+int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
+                                const float* gamma, const float* mean, const float* var, float eps, int relu, float* dres,
+                                float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int H, int W,
+                                int stride, float* workspace, void* stream, void* side_stream, int join);
 
 /* ------------------------------------------------------------------ backbone BatchNorm chains (a-11)
  * Frozen-statistics BatchNorm (+ residual) (+ ReLU) of the ResNet / HRNet bodies, lib/modeling/resnet50.py:17-44,53-77

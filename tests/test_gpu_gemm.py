@@ -1,6 +1,8 @@
 """-m gpu: the exact-fp32 MFMA contractions (cim_amd/csrc/gemm_f32.hip) through the C ABI against
 fp64 references: every operand layout, ragged M/N/K, split-K, the implicit 3x3 conv and its
 data / weight gradients, and the autograd wrappers used by MaskFuse."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -336,3 +338,77 @@ def test_conv1x1_bn_act_vs_aten(B, cin, cout, H, W, stride, relu, res):
     with torch.no_grad():
         y2 = conv1x1_bn_act(x.detach(), conv, bn, residual=(r.detach() if res else None), relu=relu)
     assert torch.equal(y2, y.detach())
+
+
+@pytest.mark.parametrize("cin,cout,H,W,stride,res,relu,B", [(64, 64, 20, 27, 1, False, True, 1), (128, 128, 33, 43, 2, False, True, 1),
+                                                            (256, 256, 17, 22, 1, True, True, 2), (32, 48, 9, 5, 2, False, False, 1),
+                                                            (128, 128, 66, 86, 1, False, True, 1), (4, 8, 1, 7, 1, True, False, 1)])
+def test_conv3x3_bn_act_matches_aten(dev, cin, cout, H, W, stride, res, relu, B):
+    """Implicit-GEMM 3 x 3 convolution + frozen BatchNorm (+ residual) (+ ReLU), forward and all gradients, against the ATen
+    ops in float64 (torchvision Bottleneck.conv2 / bn2 shapes of the C4 body, both strides, ragged tiles, a one-row map)."""
+    from cim_amd.ops import conv3x3_bn_act
+    torch.manual_seed(cin + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(cout).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(B, cin, H, W, device=dev, requires_grad=True)
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(B, cout, ho, wo, device=dev, requires_grad=True) if res else None
+    y = conv3x3_bn_act(x, conv, bn, residual=r, relu=relu)
+    g = torch.randn_like(y)
+    y.backward(g)
+    got = [y.detach(), x.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad] + ([r.grad] if res else [])
+    conv64, bn64 = copy.deepcopy(conv).double(), copy.deepcopy(bn).double()
+    for m in (conv64, bn64):
+        for p_ in m.parameters():
+            p_.grad = None
+    x64 = x.detach().double().requires_grad_(True)
+    r64 = r.detach().double().requires_grad_(True) if res else None
+    o = bn64(conv64(x64))
+    if res:
+        o = o + r64
+    if relu:
+        o = torch.relu(o)
+    o.backward(g.double())
+    ref = [o.detach(), x64.grad, conv64.weight.grad, bn64.weight.grad, bn64.bias.grad] + ([r64.grad] if res else [])
+    for name, a, b_ in zip(("y", "dx", "dw", "dgamma", "dbeta", "dres"), got, ref):
+        scale = float(b_.abs().max()) + 1e-30
+        err = float((a.double() - b_).abs().max()) / scale
+        assert err < 2e-5, (name, err)
+
+
+def test_backbone_weight_gradients_deferred_to_the_side_stream(dev, monkeypatch):
+    """The body's weight-gradient GEMMs run on the side stream and are joined once, at the end of the backward pass
+    (cim_amd/ops/gemm.py: defer_side_join): same gradients as with the join inside every layer, nothing left pending after
+    backward(), and accumulation into an existing .grad (second backward without zero_grad) still exact."""
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling import resnet50
+    from cim_amd.ops import gemm
+    apply_preset("resnet50_voc")
+    torch.manual_seed(0)
+    body = resnet50.resnet().to(dev).train()
+    x = torch.randn(1, 3, 200, 264, device=dev)
+    g = None
+
+    def grads(defer, passes):
+        monkeypatch.setattr(gemm, "DEFER_DW", defer)
+        body.zero_grad(set_to_none=True)
+        nonlocal g
+        for _ in range(passes):
+            y = body(x)
+            if g is None:
+                g = torch.randn_like(y)
+            y.backward(g)
+            assert all(not (ent[1] or ent[2]) for ent in gemm._DEFERRED.values())          # joined by the engine callback
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in body.parameters() if p.grad is not None]
+
+    ref1, ref2 = grads(False, 1), grads(False, 2)
+    for trial in range(3):                                                       # (a race would show as run-to-run differences)
+        for a, b in zip(ref1, grads(True, 1)):
+            assert torch.equal(a, b)
+    for a, b in zip(ref2, grads(True, 2)):
+        assert torch.equal(a, b)
+    for a, b in zip(ref1, ref2):
+        torch.testing.assert_close(2 * a, b, rtol=1e-5, atol=1e-7)
