@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..core.config import cfg
-from ..ops import bn_act, conv1x1_bn_act
+from ..ops import bn_act, conv1x1_bn_act, conv3x3_bn_act
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "HRNet.MaskFuse" by get_func)
 
 BN_MOMENTUM = 0.1
@@ -42,8 +42,22 @@ def _downsample(ds, x):
     if len(ds) == 2 and isinstance(ds[1], nn.BatchNorm2d):
         if ds[0].kernel_size == (1, 1):      # 1 x 1 projection: small-tile GEMM with the BatchNorm in its epilogue
             return conv1x1_bn_act(x, ds[0], ds[1], relu=False)
-        return bn_act(ds[0](x), ds[1], relu=False)
+        return conv3x3_bn_act(x, ds[0], ds[1], relu=False)      # (falls back to ATen + bn_act for other shapes)
     return ds(x)
+
+
+def _is_conv_bn(m):
+    return isinstance(m, nn.Sequential) and len(m) in (2, 3) and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.BatchNorm2d) \
+        and m[0].kernel_size == (3, 3) and m[0].bias is None and (len(m) == 2 or isinstance(m[2], nn.ReLU))
+
+
+def _conv_bn_steps(seq, x):
+    """A fuse / transition path: one `_conv_bn` (conv -> BN [-> ReLU]) or an nn.Sequential of them, each as one fused launch."""
+    if _is_conv_bn(seq):
+        return conv3x3_bn_act(x, seq[0], seq[1], relu=len(seq) == 3)
+    for step in seq:
+        x = conv3x3_bn_act(x, step[0], step[1], relu=len(step) == 3) if _is_conv_bn(step) else step(x)
+    return x
 
 
 class BasicBlock(nn.Module):
@@ -59,10 +73,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):       # BN (+ residual) + ReLU chains fused (cim_amd/csrc/bn_act.hip) when the BN is in eval()
-        out = bn_act(self.conv1(x), self.bn1)
+    def forward(self, x):       # 3 x 3 convolution + BN (+ residual) + ReLU: one HIP launch each (csrc/conv1x1.hip) when the BN is in eval()
+        out = conv3x3_bn_act(x, self.conv1, self.bn1)
         res = x if self.downsample is None else _downsample(self.downsample, x)
-        return bn_act(self.conv2(out), self.bn2, residual=res)
+        return conv3x3_bn_act(out, self.conv2, self.bn2, residual=res)
 
 
 class Bottleneck(nn.Module):
@@ -82,7 +96,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):       # 1 x 1 convolutions + BatchNorm (+ identity) (+ ReLU): one HIP launch each (csrc/conv1x1.hip)
         out = conv1x1_bn_act(x, self.conv1, self.bn1)
-        out = bn_act(self.conv2(out), self.bn2)
+        out = conv3x3_bn_act(out, self.conv2, self.bn2)
         res = x if self.downsample is None else _downsample(self.downsample, x)
         return conv1x1_bn_act(out, self.conv3, self.bn3, residual=res)
 
@@ -139,9 +153,9 @@ class HighResolutionModule(nn.Module):
         x = [self.branches[i](x[i]) for i in range(self.num_branches)]
         fused = []
         for i, row in enumerate(self.fuse_layers):
-            y = x[0] if i == 0 else row[0](x[0])
+            y = x[0] if i == 0 else _conv_bn_steps(row[0], x[0])
             for j in range(1, self.num_branches):
-                y = y + (x[j] if i == j else row[j](x[j]))
+                y = y + (x[j] if i == j else (_conv_bn_steps(row[j], x[j]) if j < i else row[j](x[j])))
             fused.append(self.relu(y))
         return fused
 
@@ -227,7 +241,7 @@ class HighResolutionNet(nn.Module):
 
     def _stem(self, x):
         x = bn_act(self.conv1(x), self.bn1)
-        x = bn_act(self.conv2(x), self.bn2)
+        x = conv3x3_bn_act(x, self.conv2, self.bn2)
         return self.layer1(x)
 
     def _stage(self, idx, ys):
@@ -236,7 +250,7 @@ class HighResolutionNet(nn.Module):
         xs = []
         for i in range(sc["NUM_BRANCHES"]):
             if tr[i] is not None:
-                xs.append(tr[i](ys[-1] if idx > 2 else ys[0]))
+                xs.append(_conv_bn_steps(tr[i], ys[-1] if idx > 2 else ys[0]))
             else:
                 xs.append(ys[i])
         return getattr(self, "stage%d" % idx)(xs)
