@@ -211,12 +211,16 @@ class Generalized_RCNN(nn.Module):
             if n < GRAPH_AFTER or len(state["graphs"]) >= GRAPH_SHAPES:
                 return self.Conv_Body(im_data)
             wrapper = _BodyWrapper(self.Conv_Body)
+            from ..ops import gemm as _gemm
+            defer, _gemm.DEFER_DW = _gemm.DEFER_DW, False       # (make_graphed_callables differentiates with torch.autograd.grad and on one stream)
             try:
                 g = torch.cuda.make_graphed_callables(wrapper, (im_data.detach().clone(),))
             except Exception as e:      # capture not possible (e.g. a library kernel that allocates): stay eager
+                _gemm.DEFER_DW = defer
                 print("cim_amd: backbone graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e))
                 state["graphs"][key] = False
                 return self.Conv_Body(im_data)
+            _gemm.DEFER_DW = defer
             state["graphs"][key] = g
         if g is False:
             return self.Conv_Body(im_data)

@@ -136,7 +136,7 @@ _DEFERRED = {}        # device -> [main stream, [(param, dw)], [tensors kept ali
 
 def side_stream_for_backward(dev, param):
     """(side stream pointer or None, join flag) for a layer's backward whose weight is `param`."""
-    if not OVERLAP:
+    if not OVERLAP or torch.cuda.is_current_stream_capturing():      # (a HIP-graph capture of the body stays on one stream)
         return None, 1
     defer = DEFER_DW and param is not None and param.grad is None
     return _side_stream(dev).cuda_stream, 0 if defer else 1

@@ -151,8 +151,8 @@ def test_roi_align_backward_forms_agree_with_oracle(dev, B, C, H, W, K, gs, monk
         if env:
             monkeypatch.delenv(env)
         np.testing.assert_allclose(grads[form], gref, rtol=1e-4, atol=2e-4 * max(1.0, K / 300.0), err_msg=form)
-    # same entries, same order, same arithmetic per element: the two region forms are bit-identical
-    np.testing.assert_array_equal(grads["region"], grads["pipe"])
+    if gs is None:      # same entries, same order, same arithmetic per element: the two region forms are bit-identical
+        np.testing.assert_array_equal(grads["region"], grads["pipe"])        # (128-ROI groups interleave 128 ROIs, the chunks 64)
 
 
 def test_roi_align_empty_and_bad_args(dev):
