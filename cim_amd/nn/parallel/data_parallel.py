@@ -66,6 +66,12 @@ class DataParallel(nn.Module):
         if self.world_size > 1:
             self._broadcast_module_state()
         self._build_flat_grads(bucket_bytes)
+        if self.world_size > 1 or self._force_flat:
+            # the buckets count ready gradients through per-parameter autograd hooks, and the gradients accumulate into flat
+            # views right after a layer's backward returns: the backbone's weight gradients must come through autograd, on
+            # the caller's stream (cim_amd/ops/gemm.py: the side-stream deferral bypasses both)
+            from ...ops import gemm as _gemm
+            _gemm.DEFER_DW = False
 
     def _broadcast_module_state(self):
         tensors = [p.data for p in self.module.parameters()] + [b.data for b in self.module.buffers()]

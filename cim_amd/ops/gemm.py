@@ -124,10 +124,11 @@ def _side_stream(dev):
 # never waits: the join happens ONCE, in an autograd-engine callback at the end of the backward pass (and defensively
 # at the start of SGD.step / before DataParallel reduces a bucket).  Buffers the side work reads or writes (saved
 # activations, workspaces) are kept referenced here until that join, so the caching allocator cannot hand them out.
-# Only when the weight's .grad is still None (the first backward after zero_grad(set_to_none=True)): accumulation into an
-# existing .grad - iter_size > 1, DataParallel's flat gradient views - runs on the main stream right after the layer's
-# backward returns and needs the gradient complete, so those cases join at once.  (Consequence: torch.autograd.grad() with
-# such a weight among its inputs does not see the gradient - use .backward(), or CIM_DEFER_DW=0.)
+# The deferred gradients do not travel through autograd (see defer_side_join): join_side() installs them as param.grad, or
+# adds them to an existing one (iter_size > 1) after the join.  Consequences: per-parameter autograd hooks do not fire for
+# these weights - DataParallel (which counts ready gradients per bucket through such hooks) switches the deferral off for
+# the process - and torch.autograd.grad() with such a weight among its inputs does not see the gradient (use .backward(),
+# or CIM_DEFER_DW=0).
 # Measured at cfg2: 17.33 -> 16.62 ms per step.  Deferring the MaskFuse layers' weight gradients as well (fc1, fc2, the
 # Winograd convolution: they already run beside their layer's data gradient) changed nothing: 16.71 ms.
 DEFER_DW = OVERLAP and os.environ.get("CIM_DEFER_DW", "1") == "1"
@@ -135,11 +136,12 @@ _DEFERRED = {}        # device -> [main stream, [(param, dw)], [tensors kept ali
 
 
 def side_stream_for_backward(dev, param):
-    """(side stream pointer or None, join flag) for a layer's backward whose weight is `param`."""
-    if not OVERLAP or torch.cuda.is_current_stream_capturing():      # (a HIP-graph capture of the body stays on one stream)
+    """(side stream pointer or None, join flag) for a backbone layer's backward whose weight is `param`: deferred to the
+    side stream, or - DataParallel, HIP-graph capture, CIM_DEFER_DW=0, a weight that is not a Parameter - everything on the
+    caller's stream (a fork / join inside every layer measured SLOWER than that: 17.0-17.1 vs 16.8 ms per step)."""
+    if not DEFER_DW or param is None or torch.cuda.is_current_stream_capturing():
         return None, 1
-    defer = DEFER_DW and param is not None and param.grad is None
-    return _side_stream(dev).cuda_stream, 0 if defer else 1
+    return _side_stream(dev).cuda_stream, 0
 
 
 def defer_side_join(dev, param, dw, *keep):

@@ -11,6 +11,7 @@ python3 "$ROOT/bench.py" > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o r -- python3 "$ROOT/bench.py" --steps 8 --warmup 8 --no-cpu-baseline --no-extra > "$OUT/trace_bench.log" 2>&1
 python3 "$ROOT/tools/trace_steps.py" /tmp/kt/r_kernel_trace.csv 8 > "$OUT/bench_kernel_stats.csv"
 python3 "$ROOT/tools/trace_phase.py" /tmp/kt/r_kernel_trace.csv > "$OUT/backbone_phases.txt"
+python3 "$ROOT/tools/trace_tail.py" /tmp/kt/r_kernel_trace.csv > "$OUT/step_tail.txt"
 cp /tmp/kt/r_kernel_stats.csv "$OUT/rocprofv3_kernel_stats_uncut.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o r -- python3 "$ROOT/bench.py" --steps 8 --warmup 8 --no-cpu-baseline --no-extra > "$OUT/pmc_$c.log" 2>&1
@@ -23,4 +24,5 @@ done > "$OUT/bench_other_configs.json"
 python3 "$ROOT/bench.py" --fixed-image --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > "$OUT/bench_fixed_image.json"
 python3 "$ROOT/tools/bench_roi_bwd.py" 2>/dev/null | grep "^{" > "$OUT/bench_roi_bwd.json"
 python3 "$ROOT/tools/bench_roi.py" 2>/dev/null | tail -1 > "$OUT/bench_roi.json"
+python3 "$ROOT/tools/bench_conv3x3.py" 2>/dev/null | grep "^{" > "$OUT/bench_conv3x3.json"
 ls -la "$OUT"
