@@ -32,7 +32,7 @@ import contextlib
 import torch
 import torch.distributed as dist
 
-from ...ops.gemm import join_side as _join_side
+from ...ops.gemm import join_side as _join_side, gradient_is_deferred as _gradient_is_deferred
 from torch import nn
 
 
@@ -66,12 +66,6 @@ class DataParallel(nn.Module):
         if self.world_size > 1:
             self._broadcast_module_state()
         self._build_flat_grads(bucket_bytes)
-        if self.world_size > 1 or self._force_flat:
-            # the buckets count ready gradients through per-parameter autograd hooks, and the gradients accumulate into flat
-            # views right after a layer's backward returns: the backbone's weight gradients must come through autograd, on
-            # the caller's stream (cim_amd/ops/gemm.py: the side-stream deferral bypasses both)
-            from ...ops import gemm as _gemm
-            _gemm.DEFER_DW = False
 
     def _broadcast_module_state(self):
         tensors = [p.data for p in self.module.parameters()] + [b.data for b in self.module.buffers()]
@@ -205,6 +199,8 @@ class DataParallel(nn.Module):
             return
         if not self._sync_this_backward():
             return
+        if _gradient_is_deferred(p):      # its gradient is still on the side stream (cim_amd/ops/gemm.py): the hook fires at the layer's
+            return                        # backward, the gradient arrives at the join - the bucket goes out at the end of backward
         bk = self.buckets[self._bucket_of[p]]
         bk["ready"] += 1
         if "tensor" not in bk and (p.grad.data_ptr() < self.flat_grad.data_ptr() or
@@ -218,7 +214,11 @@ class DataParallel(nn.Module):
         """Buckets are reduced STRICTLY in index order, so every rank issues the same sequence of
         collectives even if a rank's autograd produced gradients in a different order or skipped
         a parameter (e.g. a refinement head whose CIM layer returned None on that image)."""
-        _join_side()        # (weight gradients deferred to the side stream, cim_amd/ops/gemm.py: no-op with the flat gradient views)
+        if force:
+            # the backbone's weight gradients run on the side stream and do not come through autograd (cim_amd/ops/gemm.py):
+            # their hooks never fire, so the bucket that holds them is only ever launched here, at the end of the backward
+            # pass - after the join that adds them into the flat gradient views
+            _join_side()
         while self._next_bucket < len(self.buckets):
             bk = self.buckets[self._next_bucket]
             if not force and bk["ready"] < len(bk["params"]):

@@ -125,19 +125,26 @@ def _side_stream(dev):
 # at the start of SGD.step / before DataParallel reduces a bucket).  Buffers the side work reads or writes (saved
 # activations, workspaces) are kept referenced here until that join, so the caching allocator cannot hand them out.
 # The deferred gradients do not travel through autograd (see defer_side_join): join_side() installs them as param.grad, or
-# adds them to an existing one (iter_size > 1) after the join.  Consequences: per-parameter autograd hooks do not fire for
-# these weights - DataParallel (which counts ready gradients per bucket through such hooks) switches the deferral off for
-# the process - and torch.autograd.grad() with such a weight among its inputs does not see the gradient (use .backward(),
-# or CIM_DEFER_DW=0).
+# adds them to an existing one (iter_size > 1, DataParallel's flat views) after the join.  Consequences: per-parameter
+# autograd hooks do not fire for these weights - DataParallel, which counts ready gradients per bucket through such hooks,
+# launches the bucket that holds them at the end of the backward pass, after calling join_side() itself - and
+# torch.autograd.grad() with such a weight among its inputs does not see the gradient (use .backward(), or CIM_DEFER_DW=0).
 # Measured at cfg2: 17.33 -> 16.62 ms per step.  Deferring the MaskFuse layers' weight gradients as well (fc1, fc2, the
 # Winograd convolution: they already run beside their layer's data gradient) changed nothing: 16.71 ms.
 DEFER_DW = OVERLAP and os.environ.get("CIM_DEFER_DW", "1") == "1"
 _DEFERRED = {}        # device -> [main stream, [(param, dw)], [tensors kept alive]]
+_PENDING_IDS = set()  # id(param) of the weights whose gradient is still on the side stream
+
+
+def gradient_is_deferred(param):
+    """True between a layer's backward and join_side() for a weight whose gradient runs on the side stream (its
+    post-accumulate-grad hooks fire at the layer's backward although nothing was accumulated yet)."""
+    return id(param) in _PENDING_IDS
 
 
 def side_stream_for_backward(dev, param):
     """(side stream pointer or None, join flag) for a backbone layer's backward whose weight is `param`: deferred to the
-    side stream, or - DataParallel, HIP-graph capture, CIM_DEFER_DW=0, a weight that is not a Parameter - everything on the
+    side stream, or - HIP-graph capture, CIM_DEFER_DW=0, a weight that is not a Parameter - everything on the
     caller's stream (a fork / join inside every layer measured SLOWER than that: 17.0-17.1 vs 16.8 ms per step)."""
     if not DEFER_DW or param is None or torch.cuda.is_current_stream_capturing():
         return None, 1
@@ -154,6 +161,7 @@ def defer_side_join(dev, param, dw, *keep):
         torch.autograd.Variable._execution_engine.queue_callback(join_side)
     ent[1].append((param, dw))
     ent[2].extend(keep)
+    _PENDING_IDS.add(id(param))
 
 
 def join_side():
@@ -171,6 +179,7 @@ def join_side():
                         param.grad = dw
                     else:
                         param.grad += dw
+                    _PENDING_IDS.discard(id(param))
             ent[1], ent[2] = [], []
 
 
