@@ -31,6 +31,10 @@ class MaskFuse(nn.Module):
     def detectron_weight_mapping(self):
         return {name: name for name, _ in self.named_parameters()}, []
 
+    def prefetch(self):
+        """Weight-only work of the forward, launched ahead on the side stream (called before the backbone forward)."""
+        gemm.prefetch_filter_transform(self.mask_branch[0].weight, cfg.FAST_RCNN.ROI_XFORM_RESOLUTION)
+
     def forward(self, x, rois, masks):
         method = cfg.FAST_RCNN.ROI_XFORM_METHOD
         if method != "RoIAlign":

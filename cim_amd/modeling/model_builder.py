@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from ..core.config import cfg
 from ..ops import RoIAlign, RoIPool
+from ..ops import gemm as _gemm_ops
 from . import heads
 
 logger = logging.getLogger(__name__)
@@ -136,6 +137,11 @@ class Generalized_RCNN(nn.Module):
         with torch.set_grad_enabled(self.training):
             im_data = data
             if self.training:
+                # (weight gradients a previous backward pass left on the side stream - only if that pass was interrupted
+                # before its end-of-backward callback: normally nothing is pending here)
+                _gemm_ops.join_side()
+                if hasattr(self.Box_Head, "prefetch"):
+                    self.Box_Head.prefetch()        # the MaskFuse filter transform runs under the backbone forward
                 dev, dt = im_data.device, im_data.dtype
                 rois = rois.squeeze(dim=0).to(device=dev, dtype=dt)
                 masks = masks.squeeze(dim=0).to(device=dev, dtype=dt)

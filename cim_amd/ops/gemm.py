@@ -268,6 +268,7 @@ def _bounds(amax_in, n, group, kind, npos, dev):
 # "winograd7" (default: a 4-wide + a 3-wide tile per axis of the 7 x 7 map, 121 positions; other map sizes take winograd4)
 # | "winograd4" (F(4x4,3x3), 2 x 2 tiles of 36 positions) | "winograd" (F(2x2,3x3)) | "direct"
 CONV_ALGO = os.environ.get("CIM_CONV_ALGO", "winograd7")
+PREFETCH_U = os.environ.get("CIM_PREFETCH_U", "1") == "1"     # filter transform on the side stream, under the backbone forward
 
 
 def _wino_geometry(algo, p, r):
@@ -277,6 +278,33 @@ def _wino_geometry(algo, p, r):
     tile = 4 if algo == "winograd4" else 2
     t = (p + tile - 1) // tile
     return tile, (tile + 2) ** 2, r * t * t
+
+
+_U_PREFETCH = {}     # id(weight) -> (tile, U, event): filter transforms launched ahead on the side stream
+
+
+def prefetch_filter_transform(w, p):
+    """Launch the Winograd filter transform of the conv weight `w` (maps of p x p) on the SIDE stream now: it only depends on the
+    weight, so it can run under the backbone forward (small latency-bound kernels that leave most of the chip idle) instead
+    of between the ROIAlign and the convolution's GEMM.  Conv3x3Function.forward picks it up (and waits for its event)."""
+    if not (OVERLAP and PREFETCH_U and w.is_cuda and w.dim() == 4) or torch.cuda.is_current_stream_capturing():
+        return
+    cout, cin = w.shape[0], w.shape[1]
+    algo = CONV_ALGO if (cin % 4 == 0 and cout % 4 == 0) else "direct"
+    if algo == "winograd7" and p != 7:
+        algo = "winograd4"
+    if not algo.startswith("winograd") or not w.is_contiguous():
+        return
+    tile, npos, _ = _wino_geometry(algo, p, 1)
+    dev = w.device
+    cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    side.wait_stream(cur)                    # (the optimizer's update of w was enqueued on `cur`)
+    with torch.cuda.stream(side), torch.no_grad():
+        U = torch.empty((npos, cin, cout), dtype=torch.float32, device=dev)
+        _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), cout, cin, 0, tile, _lib.stream_ptr())
+        ev = torch.cuda.Event()
+        ev.record(side)
+    _U_PREFETCH[id(w)] = (tile, U, ev)
 
 
 class Conv3x3Function(Function):
@@ -330,7 +358,13 @@ class Conv3x3Function(Function):
                 _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), r, p, cin, tile, st)
                 if ENGINE == "f16x2":    # one pass over V: row scales for this product, column scales for the weight gradient
                     vr, ctx.v_cols = amax(V, mt, cin, cin, True, ctx.needs_input_grad[1], batch=npos, bs=mt * cin)
-            _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), cout, cin, 0, tile, st)
+            pre = _U_PREFETCH.pop(id(w), None)
+            if pre is not None and pre[0] == tile and pre[1].shape == U.shape:
+                U = pre[1]                                             # transformed ahead, on the side stream
+                torch.cuda.current_stream(dev).wait_event(pre[2])
+                U.record_stream(torch.cuda.current_stream(dev))
+            else:
+                _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), cout, cin, 0, tile, st)
             _bgemm(V, U, M, mt, cout, cin, cin, cout, False, npos, mt * cin, cin * cout, mt * cout, a_amax=vr, b_amax=uc)
             _lib.call("cim_wino_output_transform", M.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cout, int(relu), tile, st)
         else:
