@@ -207,9 +207,9 @@ enum { CONV_FWD = 0, CONV_DX = 1, CONV_DW = 2 };
 struct ConvGeom { int H, W, Ho, Wo, stride, cin, cout; float inv_w; };
 
 // element (k, n) of the implicit B operand; `src` = X (forward, weight gradient) or dY (data gradient)
-template <int MODE>
+template <int MODE, int KS>
 __device__ __forceinline__ bool conv_src(const ConvGeom& c, int ch, int tap, int y, int x, int& off) {
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int dy = tap / KS - KS / 2, dx = tap - (tap / KS) * KS - KS / 2;      // padding KS / 2
     if (MODE == CONV_DX) {                 // (y, x) = input pixel; the output pixel that reads it through this tap
         const int ty = y - dy, tx = x - dx;
         if (c.stride == 2 && ((ty | tx) & 1)) return false;
@@ -226,8 +226,9 @@ __device__ __forceinline__ bool conv_src(const ConvGeom& c, int ch, int tap, int
 #define CIM_CONV3_BK 32            // slab depth of the 3 x 3 kernel (K = 9 C is long: 64 halves the barriers and load round trips per k)
 #endif
 constexpr int CBK = CIM_CONV3_BK;
-template <int MODE>
+template <int MODE, int KS = 3>
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, const ConvGeom c) {
+    constexpr int TAPS = KS * KS;
     constexpr int NT = 256, PA = SBM * (CBK / 4) / NT, PB = SBN * (CBK / 4) / NT;        // sixteen-byte pieces per thread and slab
     extern __shared__ __attribute__((aligned(16))) float c3_smem[];
     float (*As)[CBK * SLD] = reinterpret_cast<float (*)[CBK * SLD]>(c3_smem);
@@ -253,8 +254,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
         const int p = tid + i * NT;
         if (MODE == CONV_DW) {
             const int n = n0 + p % SBN;
-            bch[i] = n < g.N ? n / 9 : -1;
-            btap[i] = n - (n / 9) * 9;
+            bch[i] = n < g.N ? n / TAPS : -1;
+            btap[i] = n - (n / TAPS) * TAPS;
         } else {
             const int wrow = (MODE == CONV_DX) ? c.W : c.Wo;             // n runs over input pixels (dX) / output pixels (forward)
 #pragma unroll
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
                     for (int j = 0; j < 4; ++j) {
                         const int po = k + j;
                         const int yo = (int)(((float)po + 0.5f) * c.inv_w), xo = po - yo * c.Wo;
-                        ok[j] = po < kend && conv_src<MODE>(c, bch[i], btap[i], yo, xo, off[j]);
+                        ok[j] = po < kend && conv_src<MODE, KS>(c, bch[i], btap[i], yo, xo, off[j]);
                     }
                     if (c.stride == 1 && ok[0] && ok[1] && ok[2] && ok[3] && off[3] == off[0] + 3) {     // all inside: 16-byte load
                         const float4 t = ld4(g.B + off[0]);
@@ -295,11 +296,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
             } else {
                 const int k = k0 + p / 16;
                 if (k < kend) {
-                    const int ch = k / 9, tap = k - ch * 9;
+                    const int ch = k / TAPS, tap = k - ch * TAPS;
                     int off[4];
                     bool ok[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ok[j] = py[i][j] >= 0 && conv_src<MODE>(c, ch, tap, py[i][j], px[i][j], off[j]);
+                    for (int j = 0; j < 4; ++j) ok[j] = py[i][j] >= 0 && conv_src<MODE, KS>(c, ch, tap, py[i][j], px[i][j], off[j]);
                     if (c.stride == 1 && ok[0] && ok[1] && ok[2] && ok[3] && off[3] == off[0] + 3) {     // all inside: 16-byte load
                         const float4 t = ld4(g.B + off[0]);
                         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -542,7 +543,7 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
 namespace {
 int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldc, const ConvGeom& c,
                    float* x_raw, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
-                   const float* residual, int relu, int splits, float* ws, hipStream_t st) {
+                   const float* residual, int relu, int splits, float* ws, hipStream_t st, int ksize = 3) {
     SmallArgs g;
     g.A = A; g.B = B; g.C = C; g.Xraw = x_raw;
     g.gamma = gamma; g.beta = beta; g.mean = mean; g.var = var; g.res = residual; g.eps = eps;
@@ -551,7 +552,8 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
     g.splits = splits; g.ws = ws;
     const dim3 grid((unsigned)(((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN)), (unsigned)splits);
     const size_t lds = sizeof(float) * 4 * CBK * SLD;
-    auto kern = mode == CONV_FWD ? conv3x3_small_kernel<CONV_FWD> : mode == CONV_DX ? conv3x3_small_kernel<CONV_DX> : conv3x3_small_kernel<CONV_DW>;
+    auto kern = ksize == 7 ? conv3x3_small_kernel<CONV_FWD, 7>
+                : mode == CONV_FWD ? conv3x3_small_kernel<CONV_FWD> : mode == CONV_DX ? conv3x3_small_kernel<CONV_DX> : conv3x3_small_kernel<CONV_DW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -566,7 +568,7 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
 ConvGeom conv_geom(int cin, int cout, int H, int W, int stride, int mode) {
     ConvGeom c;
     c.H = H; c.W = W; c.stride = stride; c.cin = cin; c.cout = cout;
-    c.Ho = (H - 1) / stride + 1; c.Wo = (W - 1) / stride + 1;            // kernel 3, padding 1
+    c.Ho = (H - 1) / stride + 1; c.Wo = (W - 1) / stride + 1;            // odd kernel k, padding k / 2
     c.inv_w = 1.0f / (float)(mode == CONV_DX ? W : c.Wo);
     return c;
 }
@@ -591,6 +593,21 @@ extern "C" int cim_conv3x3_nchw_f32(const float* x, const float* w, float* y, in
     const ConvGeom c = conv_geom(cin, cout, H, W, stride, CONV_FWD);
     conv3x3_launch(CONV_FWD, w, x, y, cout, c.Ho * c.Wo, 9 * cin, 9 * cin, c.Ho * c.Wo, c, x_raw, gamma, beta, mean, var, eps,
                    residual, relu, splits, workspace, cim::as_stream(stream));
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+// The stem: 7 x 7 convolution (padding 3, stride 1 / 2, no bias, any cin) -> frozen BatchNorm (+ ReLU), forward only (the
+// reference freezes it: FREEZE_AT >= 1); the same implicit GEMM with 49 taps (K = 49 cin; A = the weight as it is).
+extern "C" int cim_conv7x7_nchw_f32(const float* x, const float* w, float* y, int cin, int cout, int H, int W, int stride,
+                                    const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                                    int relu, void* stream) {
+    CIM_CHECK_ARG(x && w && y && cin > 0 && cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && W <= 4096);
+    CIM_CHECK_ARG((long long)H * W < (1ll << 20) && (long long)cin * H * W < (1ll << 31) && (long long)cout * H * W < (1ll << 31));
+    CIM_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (gamma == nullptr) == (mean == nullptr) && (gamma == nullptr) == (var == nullptr));
+    const ConvGeom c = conv_geom(cin, cout, H, W, stride, CONV_FWD);
+    conv3x3_launch(CONV_FWD, w, x, y, cout, c.Ho * c.Wo, 49 * cin, 49 * cin, c.Ho * c.Wo, c, nullptr, gamma, beta, mean, var, eps,
+                   nullptr, relu, 1, nullptr, cim::as_stream(stream), 7);
     CIM_CHECK_LAUNCH();
     return 0;
 }

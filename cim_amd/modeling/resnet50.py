@@ -12,7 +12,7 @@ import os
 import torch.nn as nn
 
 from ..core.config import cfg
-from ..ops import bn_act, conv1x1_bn_act, conv3x3_bn_act
+from ..ops import bn_act, conv1x1_bn_act, conv3x3_bn_act, conv7x7_bn_act
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "resnet50.MaskFuse" by get_func)
 
 
@@ -125,7 +125,11 @@ class resnet(nn.Module):
 
     def forward(self, x):
         for i in range(self.block_counts):
-            x = getattr(self, "res%d" % (i + 1))(x)
+            m = getattr(self, "res%d" % (i + 1))
+            if i == 0 and OWN_3X3:      # the stem: 7 x 7 convolution + BatchNorm + ReLU in one launch (frozen: forward only), then the max-pool
+                x = m[3](conv7x7_bn_act(x, m[0], m[1], relu=True))
+            else:
+                x = m(x)
         return x
 
 

@@ -87,3 +87,27 @@ def conv3x3_bn_act(x, conv, bn, residual=None, relu=True):
         with torch.no_grad():
             return Conv3x3BnActFunction.apply(*args)
     return Conv3x3BnActFunction.apply(*args)
+
+
+def conv7x7_bn_act(x, conv, bn, relu=True):
+    """relu?(bn(conv(x))) for the FROZEN 7 x 7 stem convolution (padding 3, stride 1 / 2, no bias) and its eval-mode BatchNorm:
+    one launch of the implicit-GEMM kernel with 49 taps.  A stem that still trains takes the ATen ops."""
+    frozen = not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad))
+    fused = (frozen and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (7, 7) and conv.bias is None
+             and conv.padding == (3, 3) and conv.stride in ((1, 1), (2, 2)) and conv.dilation == (1, 1) and conv.groups == 1
+             and x.shape[3] <= 4096 and x.shape[2] * x.shape[3] < (1 << 20)
+             and (not bn.training) and bn.affine and bn.track_running_stats)
+    if not fused:
+        out = bn(conv(x))
+        return F.relu(out) if relu else out
+    with torch.no_grad():
+        x = x.contiguous()
+        w = conv.weight.contiguous()
+        B, cin, H, W = x.shape
+        stride, cout = conv.stride[0], w.shape[0]
+        y = torch.empty((B, cout, (H - 1) // stride + 1, (W - 1) // stride + 1), dtype=torch.float32, device=x.device)
+        for b in range(B):
+            _lib.call("cim_conv7x7_nchw_f32", x[b].data_ptr(), w.data_ptr(), y[b].data_ptr(), cin, cout, H, W, stride,
+                      bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps),
+                      int(relu), _lib.stream_ptr())
+    return y

@@ -232,7 +232,13 @@ int cim_conv3x3_nchw_splits(int cin, int cout, int H, int W, int stride);
 int cim_conv3x3_nchw_f32(const float* x, const float* w, float* y, int cin, int cout, int H, int W, int stride, float* x_raw,
                          const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                          const float* residual, int relu, int splits, float* workspace, void* stream);
-/* Backward of the above for B images in one call: BatchNorm / ReLU backward (cim_bn_act_bwd), dx [B,cin,H,W] (transposed
+/* The stem of the ResNet body: 7 x 7 convolution (padding 3, stride 1 or 2, no bias, any cin) -> frozen BatchNorm (+ ReLU),
+ * forward only (torchvision ResNet conv1 / bn1 / relu, lib/modeling/resnet50.py:20,53-77, frozen by FREEZE_AT): the same
+ * implicit GEMM with 49 taps.  x [cin][H][W], w [cout][cin][7][7], y [cout][Ho][Wo].  Replaces ATen -> MIOpen + 2 launches. */
+int cim_conv7x7_nchw_f32(const float* x, const float* w, float* y, int cin, int cout, int H, int W, int stride,
+                         const float* gamma, const float* beta, const float* mean, const float* var, float eps, int relu,
+                         void* stream);
+/* Backward of cim_conv3x3_nchw_f32 for B images in one call: BatchNorm / ReLU backward (cim_bn_act_bwd), dx [B,cin,H,W] (transposed
  * convolution as an implicit GEMM over (cout, tap)), dw [cout,cin,3,3] = sum over images and output pixels (split-K).
  * dy, y (may be NULL without relu), x_raw are [B,cout,Ho,Wo]; dres / dgamma+dbeta / dx / dw may be NULL when not needed.
  * workspace: cim_conv3x3_nchw_bwd_workspace(...) bytes.  cin % 4 == 0, cout % 4 == 0.  side_stream as in cim_conv1x1_bn_act_bwd. */

@@ -412,3 +412,25 @@ def test_backbone_weight_gradients_deferred_to_the_side_stream(dev, monkeypatch)
         assert torch.equal(a, b)
     for a, b in zip(ref1, ref2):
         torch.testing.assert_close(2 * a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("H,W,stride", [(75, 100, 2), (516, 688, 2), (31, 45, 1)])
+def test_conv7x7_stem_matches_aten(dev, H, W, stride):
+    """The frozen ResNet stem (7 x 7, 3 -> 64 channels, padding 3) + BatchNorm + ReLU as one implicit-GEMM launch."""
+    from cim_amd.ops import conv7x7_bn_act
+    torch.manual_seed(H)
+    conv = torch.nn.Conv2d(3, 64, 7, stride=stride, padding=3, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(64).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    for p_ in list(conv.parameters()) + list(bn.parameters()):
+        p_.requires_grad = False
+    x = torch.randn(2, 3, H, W, device=dev)
+    y = conv7x7_bn_act(x, conv, bn)
+    ref = torch.relu(copy.deepcopy(bn).double()(copy.deepcopy(conv).double()(x.double())))
+    assert y.shape == ref.shape
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err < 5e-6, err
+    conv.weight.requires_grad = True                     # a stem that trains: the ATen path (autograd)
+    y2 = conv7x7_bn_act(x, conv, bn)
+    assert y2.requires_grad and float((y2.detach().double() - ref).abs().max() / ref.abs().max()) < 1e-4
