@@ -12,6 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o r -- python3 
 python3 "$ROOT/tools/trace_steps.py" /tmp/kt/r_kernel_trace.csv 8 > "$OUT/bench_kernel_stats.csv"
 python3 "$ROOT/tools/trace_phase.py" /tmp/kt/r_kernel_trace.csv > "$OUT/backbone_phases.txt"
 python3 "$ROOT/tools/trace_tail.py" /tmp/kt/r_kernel_trace.csv > "$OUT/step_tail.txt"
+python3 "$ROOT/tools/trace_phases_step.py" /tmp/kt/r_kernel_trace.csv > "$OUT/step_phases.txt"
 cp /tmp/kt/r_kernel_stats.csv "$OUT/rocprofv3_kernel_stats_uncut.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o r -- python3 "$ROOT/bench.py" --steps 8 --warmup 8 --no-cpu-baseline --no-extra > "$OUT/pmc_$c.log" 2>&1
