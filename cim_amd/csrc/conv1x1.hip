@@ -413,8 +413,12 @@ extern "C" int cim_gemm_small_splits(int M, int N, int K) {
     // long-K products with few output tiles (res4 conv1: 92 tiles x 32 slabs = 41 us) are cut until there are ~2
     // workgroups per CU, never below 4 slabs per workgroup.
     const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
+    // (sweep, tools/bench_gemm_small.py, us over 7 layer shapes forward / dX / dW: 157 / 136 / 182 with these limits; 2 slabs
+    // per workgroup or up to 768-1024 workgroups: 188 / 178 / 219 - more partial products than the latency chain gains)
+    static const int min_k = getenv("CIM_SMALL_MINK") ? atoi(getenv("CIM_SMALL_MINK")) : 4 * SBK;      // sweep switches
+    static const int want = getenv("CIM_SMALL_WGS") ? atoi(getenv("CIM_SMALL_WGS")) : 512;
     int s = 1;
-    while (tiles * s < 512 && K / (s * 2) >= 4 * SBK && s < 64) s *= 2;
+    while (tiles * s < want && K / (s * 2) >= min_k && s < 64) s *= 2;
     return s;
 }
 
