@@ -334,7 +334,7 @@ def instrument(_lib, timer):
             state["conv"] += 1
             with timer.span("maskfuse_conv_fwd" if state["conv"] == 1 else "maskfuse_conv_dgrad"):
                 return orig_call(name, *args)
-        if name in ("cim_gemm_f32_batched", "cim_gemm_f16x2_batched"):  # Winograd-domain GEMMs, per image: forward, data grad, weight grad
+        if name in ("cim_gemm_f32_batched", "cim_gemm_f16x2_batched", "cim_gemm_pair_batched"):  # Winograd-domain GEMMs, per image: forward, data grad, weight grad
             state["bg"] += 1
             with timer.span(("wino_gemm_fwd", "wino_gemm_dgrad", "wino_gemm_wgrad")[min(state["bg"], 3) - 1]):
                 return orig_call(name, *args)
@@ -389,9 +389,9 @@ def make_optimizer(model, torch):
 
 
 def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, np):
-    engine = gemm_mod.ENGINE
-    products = {"f16x2": 3.0, "bf16x3": 6.0, "fp32": 1.0}[engine]
-    kern = {"f16x2": "gemm_f16x2_kernel", "bf16x3": "gemm_bf16x3_kernel", "fp32": "gemm_f32_kernel"}[engine]
+    engine = "f16x2p" if getattr(gemm_mod, "PAIR", False) else gemm_mod.ENGINE
+    products = {"f16x2p": 3.0, "f16x2": 3.0, "bf16x3": 6.0, "fp32": 1.0}[engine]
+    kern = {"f16x2p": "gemm_pair_kernel", "f16x2": "gemm_f16x2_kernel", "bf16x3": "gemm_bf16x3_kernel", "fp32": "gemm_f32_kernel"}[engine]
     # dominant kernel: the MFMA GEMM of the MaskFuse 3x3 conv forward (a-2).  Algorithmic flops of ONE launch on image j:
     #   Winograd 4+3 mixed tiling (CIM_CONV_ALGO=winograd7, default): 121 batched GEMMs [N_j x 2Cf] x [2Cf x Cf]
     #   Winograd F(4x4,3x3) / F(2x2,3x3): 36 x [4N x 2Cf] / 16 x [16N x 2Cf];  direct: 2 * 49N * 18Cf * Cf   
@@ -403,7 +403,8 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
             _, npos, rows = gemm_mod._wino_geometry(gemm_mod.CONV_ALGO, 7, infos[j]["n"])
             flops.append(2.0 * npos * rows * (2 * Cf) * Cf)
         what = {"winograd7": "Winograd 4+3 mixed tiling", "winograd4": "Winograd F(4x4,3x3)", "winograd": "Winograd F(2x2,3x3)"}
-        kname = "%s<A_KCONTIG,B_NCONTIG> x%d (MaskFuse conv3x3 fwd, %s domain)" % (kern, npos, what.get(gemm_mod.CONV_ALGO, gemm_mod.CONV_ALGO))
+        kname = "%s<%s> x%d (MaskFuse conv3x3 fwd, %s domain)" % (kern, "L_KC,L_KC" if engine == "f16x2p" else "A_KCONTIG,B_NCONTIG", npos,
+                                                                   what.get(gemm_mod.CONV_ALGO, gemm_mod.CONV_ALGO))
     else:
         direct = timer.launches("maskfuse_conv_fwd")
         ms = [m for m, _ in direct]
@@ -417,7 +418,8 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
     roofline = dict(bound="mfma", kernel=kname, achieved=products * alg_tf,
                     peak=FP32_MFMA_PEAK_TF if engine == "fp32" else BF16_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None,
                     ms=conv_ms, launches=len(ms), algorithmic_flops_per_launch=float(np.mean(flops)),
-                    engine={"f16x2": "f16x2: 3 f16 MFMA products per fp32 multiply-add (scaled two-term split), fp32 accumulate",
+                    engine={"f16x2p": "f16x2p: 3 f16 MFMA products per fp32 multiply-add on operands pre-split by their producers (two fp16 terms, one power-of-two scale per matrix), LDS-DMA staging, fp32 accumulate",
+                            "f16x2": "f16x2: 3 f16 MFMA products per fp32 multiply-add (scaled two-term split), fp32 accumulate",
                             "bf16x3": "bf16x3: 6 bf16 MFMA products per fp32 multiply-add, fp32 accumulate",
                             "fp32": "fp32: v_mfma_f32_32x32x2_f32"}[engine],
                     algorithmic_tflops=alg_tf, fp32_mfma_peak=FP32_MFMA_PEAK_TF)
@@ -473,7 +475,11 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
     return dict(metric=metric, value=images / elapsed, unit="images/s", n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
                 scaling="weak", vs_baseline=None, dtype="fp32", data="synthetic",
-                dtype_note={"f16x2": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
+                dtype_note={"f16x2p": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
+                                      "two-term fp16 operand split written by the operands' producers (3 MFMA products, dropped "
+                                      "term <= 2^-22, one power-of-two scale per matrix) - measured deviation of losses / "
+                                      "gradients from the reference in tests/test_gpu_tolerance.py (profiles/r3/parity_deviation.json)",
+                            "f16x2": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
                                      "two-term fp16 operand split (3 MFMA products, dropped term <= 2^-22, rms 2^-25.6) - "
                                      "measured error vs fp64 in the class of the f32-multiply engine (CIM_GEMM_ENGINE=fp32)",
                             "bf16x3": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated as an exact "

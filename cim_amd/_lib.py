@@ -53,6 +53,19 @@ SIGNATURES = {
     "cim_gemm_f16x2": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "cim_gemm_f16x2_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
                                _P, _P, _P],
+    "cim_gemm_pair_splits": [c_int, c_int, c_int],
+    "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P],
+    "cim_gemm_pair_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
+                              _P, _P, _P],
+    "cim_pair_scales": [_P, c_int, _P, _P, c_int, _P],
+    "cim_pair_split": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, _P, _P, _P],
+    "cim_pair_amax": [_P, c_longlong, _P, _P],
+    "cim_wino7_pair_scales": [_P, c_int, _P, _P],
+    "cim_wino7_input_pair": [_P, _P, _P, c_int, c_int, c_int, _P],
+    "cim_wino7_filter_pair": [_P, _P, _P, c_int, c_int, _P],
+    "cim_wino7_dy_pair": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "cim_wino7_output_amax": [_P, _P, _P, c_int, c_int, c_int, _P, _P],
+    "cim_flatten_chw_pair": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_input_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_flatten_chw": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_input_transform_amax": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
@@ -68,7 +81,7 @@ SIGNATURES = {
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }
 
-ABI_VERSION = 4          # cim_abi_version() of include/cim_hip.h this binding was written against
+ABI_VERSION = 5          # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 
@@ -99,14 +112,14 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = c_longlong if name in ("cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_mining_lds_bytes") else c_int
-    # CIM_GEMM_ENGINE = f16x2 (default; own entry points, chosen in cim_amd/ops/gemm.py) | bf16x3 | fp32.
+    # CIM_GEMM_ENGINE = f16x2p (default) | f16x2 (both: own entry points, chosen in cim_amd/ops/gemm.py) | bf16x3 | fp32.
     # cim_gemm_f32 / cim_conv3x3_f32 (operands without scales) run bf16x3 unless fp32 is asked for.
-    lib.cim_gemm_set_engine(0 if os.environ.get("CIM_GEMM_ENGINE", "f16x2") == "fp32" else 1)
+    lib.cim_gemm_set_engine(0 if os.environ.get("CIM_GEMM_ENGINE", "f16x2p") == "fp32" else 1)
     _lib = lib
     return lib
 
 
-VALUE_RETURNING = {"cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_gemm_get_engine"}      # return a count, not a status
+VALUE_RETURNING = {"cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_gemm_get_engine"}      # return a count, not a status
 
 
 def call(name, *args):

@@ -41,6 +41,26 @@ static inline float round_to_f16(float thr) { return (float)(_Float16)thr; }
         }                                                                       \
     } while (0)
 
+// ---- pair images (f16x2p GEMM engine, gemm_pair.hip): x * s = h + l, two fp16 terms ------------------------------------
+typedef _Float16 pair_f16x2 __attribute__((ext_vector_type(2)));
+typedef float pair_f32x2 __attribute__((ext_vector_type(2)));
+// (a, b) already scaled -> packed f16 pairs (a in the low half) of the two terms
+__device__ __forceinline__ void pair_split2(float a, float b, unsigned& h, unsigned& l) {
+    const pair_f32x2 v = {a, b};
+    const pair_f16x2 hv = __builtin_convertvector(v, pair_f16x2);          // v_cvt_pk_f16_f32 (RNE)
+    const pair_f32x2 r = {a - (float)hv.x, b - (float)hv.y};               // exact
+    h = __builtin_bit_cast(unsigned, hv);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, pair_f16x2));
+}
+// |max| bit pattern -> power-of-two scale 2^(14 - e): |x| s < 2^15 (biased exponent clamped so that s and 1 / s are normal)
+__device__ __forceinline__ float pair_scale_of(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);
+    int b = 268 - e;
+    if (b > 253) b = 253;
+    if (e == 0 || e == 255) b = 127;
+    return __uint_as_float((unsigned)b << 23);
+}
+
 __device__ __forceinline__ float h2f(uint16_t bits) {
     return __half2float(__ushort_as_half(bits));
 }

@@ -1,0 +1,573 @@
+// f16x2p engine: the MaskFuse contractions on operands that their PRODUCERS already split.
+//
+// Replaces the dense contractions of MaskFuse.forward / backward, /root/reference/lib/modeling/resnet50.py:104-110,135-136
+// (Conv2d(2C, C, 3, pad = 1) in the Winograd domain, Linear(49C, 4096), Linear(4096, 4096), data and weight gradients).
+//
+// Arithmetic: the scaled two-term fp16 split of the f16x2 engine (gemm_f32.hip) - x * s = h + l, h = rne_f16(x s),
+// l = rne_f16(x s - h), a * b evaluated as l*h + h*l + h*h on v_mfma_f32_32x32x16_f16 with fp32 accumulation - with two
+// differences that take every non-MFMA instruction out of the main loop:
+//   * ONE power-of-two scale per stored matrix (per batch entry), not per row / column: an operand is then the same
+//     bytes for the product that contracts over its columns and for the one that contracts over its rows (V is the A
+//     operand of the forward product AND of the weight gradient; a weight is the B operand of the forward product AND
+//     of the data gradient), so the kernel that PRODUCES a tensor can write the split image once;
+//   * the split image lives in HBM: "pair" layout [row][col / 8][h: 8 x f16 | l: 8 x f16] = 4 bytes per element, the
+//     bytes of the fp32 tensor it replaces.  The GEMM brings 16-byte chunks straight into LDS with
+//     global_load_lds_dwordx4 (no VGPR round trip, no conversion, no ds_write) and its loop is MFMA + ds_read only.
+// Error: every element carries 22 significant bits relative to ITSELF while |x| >= 2^-13 max|X|, and an absolute error of
+// 2^-39 max|X| below that (fp16 subnormals; MFMA does not flush them): the bound of an fp32 GEMM relative to
+// max|A| max|B| instead of |a_row| |b_col| (tests/test_gpu_gemm.py::test_pair_engine_*).
+//
+// Tiling: workgroup 256 x 256 x 32, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA tiles (128 accumulator
+// registers), 48 MFMAs per wave and slab.  Two LDS buffers of 64 KB; ONE barrier per slab, placed between the slab's two
+// 16-k steps: the loads of slab t+1 were issued one slab earlier, the fragments of the second step are in registers, so
+// behind the barrier the wave issues the loads of slab t+2 into the buffer it just finished and multiplies while the first
+// fragments of slab t+1 arrive.
+// Operand layouts (template parameters):
+//   KC  rows of the stored matrix = tile rows, k contiguous   (A: activations [M,K];  B: nn.Linear weight [N,K])
+//       LDS [256 rows][128 B], 16-byte chunks XOR-swizzled inside 256-byte double rows -> conflict-free ds_read_b128
+//   MC  rows of the stored matrix = k, tile rows contiguous     (A: X^T for weight gradients;  B: [K,N])
+//       LDS [32 k][1024 B] chunks XOR-swizzled by k -> ds_read_b64_tr_b16 (hardware 4 x 4 transpose) delivers 4 consecutive
+//       k per lane: two reads = one MFMA operand
+// The swizzles are applied on the SOURCE address of the LDS-DMA (its destination is lane-linear) and on the reads.
+#include "common.h"
+#include "../../include/cim_hip.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+
+#ifndef CIM_PAIR_EXP
+#define CIM_PAIR_EXP 0          // ablation switches (tools/bench_gemm_pair.py); 0 = product
+#endif
+
+constexpr int BM = 256, BN = 256, BK = 32;
+constexpr int NT = 512;
+constexpr int WM = 128, WN = 64, MI = 4, NI = 2;
+constexpr int OPER = 256 * BK * 4;        // 32768 B per operand and slab
+constexpr int SLAB = 2 * OPER;
+constexpr int LDS_BYTES = 2 * SLAB;       // 131072
+
+enum { L_KC = 0, L_MC = 1 };
+
+struct PairArgs {
+    const char* A;          // pair images
+    const char* B;
+    float* C;
+    const float* bias;      // [N] or null
+    int M, N, K;
+    int lda, ldb, ldc;      // logical elements per stored row (multiples of 8 for A / B)
+    int relu;
+    int k_per_split;        // multiple of BK
+    long long c_split_stride;
+    int batch;
+    long long a_bs, b_bs, c_bs;     // elements between batch entries
+    const float* a_scale;   // [batch] power-of-two scales the images were written with
+    const float* b_scale;
+    unsigned* c_amax;       // optional: max |C| bit pattern (atomicMax; caller zeroes), final outputs only
+};
+
+typedef __attribute__((address_space(3))) char* lds_ptr_t;
+
+// Four LDS-DMA loads (global_load_lds_dwordx4: 16 B per lane, destination = M0 + 16 * lane) of one wave into four consecutive
+// 1 KiB pieces of LDS starting at byte address lds_dst (wave-uniform), sources sbase (SGPR pair) + 32-bit lane offsets.
+// Inline asm on purpose: through __builtin_amdgcn_global_load_lds hipcc treats every later ds_read as a possible reader of
+// the DMA's destination and puts s_waitcnt vmcnt(0) in front of it - the loads of slab t+2 would be waited for right
+// after their issue.  As an asm statement the DMA is invisible to that bookkeeping; the kernel waits with its own
+// s_waitcnt vmcnt(0) in front of the one barrier per slab.  M0 is saved and restored (compiler-reserved).
+__device__ __forceinline__ void glds16x4(const char* sbase, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_addk_i32 m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_addk_i32 m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %5\n\t"
+        "s_addk_i32 m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+
+// ---- staging ---------------------------------------------------------------------------------------
+// KC: instruction i (0..31) covers tile rows 8i .. 8i+7 = double rows 4i .. 4i+3; a wave issues i = 4w .. 4w+3.
+// LDS position (double row d, slot s) holds global (row 2d + (s >> 3), chunk (s & 7) ^ (d & 7)); chunk p = 2 * kgroup + plane.
+struct StageKC {
+    unsigned off[4];      // byte offsets of this lane's four source chunks relative to (base + k0 * 4)
+    __device__ __forceinline__ void init(int row0, int rows, int ld, int wave, int lane) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int d = 4 * (wave * 4 + ii) + (lane >> 4);
+            const int s = lane & 15;
+            const int r = min(row0 + 2 * d + (s >> 3), rows - 1);
+            const int p = (s & 7) ^ (d & 7);
+            off[ii] = (unsigned)r * (unsigned)ld * 4u + (unsigned)p * 16u;
+        }
+    }
+    __device__ __forceinline__ void issue(const char* base_k, const char* lds_oper, int wave) const {
+        glds16x4(base_k, off[0], off[1], off[2], off[3], lds_addr(lds_oper) + wave * 4096);
+    }
+    static __device__ __forceinline__ size_t k_step_bytes(int) { return (size_t)BK * 4; }
+};
+// MC: instruction i = k row i of the slab (1024 B = the 256 tile columns); lane q loads chunk q ^ swz(k),
+// swz(k) = (k & 1) | ((k >> 1) & 1) << 3 (k & 3 = ii for k = 4w + ii).
+struct StageMC {
+    unsigned off[4];
+    __device__ __forceinline__ void init(int col0, int cols, int ld, int wave, int lane) {
+        const int maxchunk = ((cols - col0) * 4 - 16) / 16;       // last whole chunk of the row that belongs to the matrix
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int swz = (ii & 1) | ((ii >> 1) << 3);
+            const int c = min(lane ^ swz, maxchunk);
+            off[ii] = (unsigned)(wave * 4 + ii) * (unsigned)ld * 4u + (unsigned)col0 * 4u + (unsigned)c * 16u;
+        }
+    }
+    __device__ __forceinline__ void issue(const char* base_k, const char* lds_oper, int wave) const {
+        glds16x4(base_k, off[0], off[1], off[2], off[3], lds_addr(lds_oper) + wave * 4096);
+    }
+    static __device__ __forceinline__ size_t k_step_bytes(int ld) { return (size_t)BK * ld * 4; }
+};
+
+// ---- fragment reads ----------------------------------------------------------------------------------
+// KC: tile row r = wbase + 32 i + (lane & 31), k group kg = 2 ks + (lane >> 5):
+//   byte = (r >> 1) * 256 + (((r & 1) << 3 | (2 kg + plane)) ^ ((r >> 1) & 7)) * 16
+template <int CNT>
+struct FragKC {
+    unsigned o[2][2];       // [ks][plane], tile 0
+    __device__ __forceinline__ void init(int wbase, int lane) {
+        const int l31 = lane & 31, lk = lane >> 5;
+        const int x = (l31 >> 1) & 7;
+        const unsigned base = (unsigned)((wbase >> 1) + (l31 >> 1)) * 256u + (unsigned)((l31 & 1) << 7);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) o[ks][pl] = base + (unsigned)(((4 * ks + 2 * lk + pl) ^ x) * 16);
+    }
+    __device__ __forceinline__ f16x8 read(const char* oper, int i, int ks, int pl) const {
+        return *reinterpret_cast<const f16x8*>(oper + o[ks][pl] + i * 4096);
+    }
+};
+// MC: lane supplies k row kb + (i16 >> 2) and 4 consecutive tile columns wbase + 32 i + 16 mg + 4 (i16 & 3); two reads
+// (k rows +0, +4) make the 8 k values of column wbase + 32 i + (lane & 31).
+template <int CNT>
+struct FragMC {
+    unsigned o[2][2];       // [i & 1][plane]
+    __device__ __forceinline__ void init(int wbase, int lane) {
+        const int i16 = lane & 15, mg = (lane >> 4) & 1, lk = lane >> 5;
+        const int s = ((i16 >> 2) & 1) | (((i16 >> 3) & 1) << 3);
+        const unsigned base = (unsigned)(8 * lk + (i16 >> 2)) * 1024u + (unsigned)wbase * 4u + (unsigned)(i16 & 1) * 8u;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                o[ip][pl] = base + (unsigned)(((8 * ip + 4 * mg + 2 * ((i16 >> 1) & 1) + pl) ^ s) * 16);
+    }
+    __device__ __forceinline__ f16x8 read(const char* oper, int i, int ks, int pl) const {
+        const char* p = oper + o[i & 1][pl] + ks * 16384 + (i >> 1) * 256;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4096));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(f16x8, v);
+    }
+};
+
+template <int L> struct StageSel { using type = StageKC; };
+template <> struct StageSel<L_MC> { using type = StageMC; };
+template <int L, int CNT> struct FragSel { using type = FragKC<CNT>; };
+template <int CNT> struct FragSel<L_MC, CNT> { using type = FragMC<CNT>; };
+
+// XCD-aware work order (same policy as gemm_f32.hip: xcd_tile_map): >= 8 z slices -> whole slices per XCD; otherwise a
+// contiguous run of tiles per XCD; inside a run the index walking the smaller operand's panels runs fastest.
+__device__ __forceinline__ void pair_tile_map(int M, int N, int& tile_m, int& tile_n, int& z) {
+    const int tn = gridDim.x, tm = gridDim.y, T = tn * tm, Z = gridDim.z;
+    int b = blockIdx.y * tn + blockIdx.x;
+    z = blockIdx.z;
+    bool remap_in_slice = true;
+    const bool m_fast = N > M;
+    if (Z >= 8) {
+        const long long L = (long long)blockIdx.z * T + b;
+        const int zfull = Z & ~7;
+        if (L < (long long)zfull * T) {
+            const int xcd = (int)(L & 7);
+            const long long s = L >> 3;
+            z = (int)(s / T) * 8 + xcd;
+            b = (int)(s % T);
+            remap_in_slice = false;
+        }
+    }
+    int t = b;
+    if (remap_in_slice) {
+        const int q = T >> 3, r = T & 7, xcd = b & 7, i = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    if (m_fast) {
+        tile_n = t / tm;
+        tile_m = t - tile_n * tm;
+    } else {
+        tile_m = t / tn;
+        tile_n = t - tile_m * tn;
+    }
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+
+template <int AL, int BL>
+__global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 2, wn = wave & 3;
+    int tile_m, tile_n, zidx;
+    pair_tile_map(g.M, g.N, tile_m, tile_n, zidx);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const char* Ab = g.A;
+    const char* Bb = g.B;
+    float* Cb = g.C;
+    int zsplit = zidx, zb = 0;
+    if (g.batch > 1) {
+        Ab += (size_t)zidx * g.a_bs * 4;
+        Bb += (size_t)zidx * g.b_bs * 4;
+        Cb += (size_t)zidx * g.c_bs;
+        zsplit = 0;
+        zb = zidx;
+    }
+    const int kbeg = zsplit * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nslab = (kend - kbeg) / BK;
+
+    typename StageSel<AL>::type sa;
+    typename StageSel<BL>::type sb;
+    sa.init(m0, g.M, g.lda, wave, lane);
+    sb.init(n0, g.N, g.ldb, wave, lane);
+    const char* ak = Ab + (AL == L_KC ? (size_t)kbeg * 4 : (size_t)kbeg * g.lda * 4);
+    const char* bk = Bb + (BL == L_KC ? (size_t)kbeg * 4 : (size_t)kbeg * g.ldb * 4);
+    const size_t a_adv = StageSel<AL>::type::k_step_bytes(g.lda), b_adv = StageSel<BL>::type::k_step_bytes(g.ldb);
+
+    typename FragSel<AL, MI>::type fa;
+    typename FragSel<BL, NI>::type fb;
+    fa.init(wm * WM, lane);
+    fb.init(wn * WN, lane);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // prologue: slab 0 -> buffer 0 (waited for), slab 1 -> buffer 1 (in flight), first fragments of slab 0
+    sa.issue(ak, smem, wave);
+    sb.issue(bk, smem + OPER, wave);
+    ak += a_adv;
+    bk += b_adv;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nslab > 1) {
+        sa.issue(ak, smem + SLAB, wave);
+        sb.issue(bk, smem + SLAB + OPER, wave);
+        ak += a_adv;
+        bk += b_adv;
+    }
+
+    f16x8 ah0[MI], al0[MI], bh0[NI], bl0[NI];
+    f16x8 ah1[MI], al1[MI], bh1[NI], bl1[NI];
+#define PAIR_READ(AH, AL_, BH, BL_, BUF, KS)                                                   \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                           \
+        BH[j] = fb.read((BUF) + OPER, j, KS, 0);                                               \
+        BL_[j] = fb.read((BUF) + OPER, j, KS, 1);                                              \
+    }                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                           \
+        AL_[i] = fa.read((BUF), i, KS, 1);                                                     \
+        AH[i] = fa.read((BUF), i, KS, 0);                                                      \
+    }
+#define PAIR_MMA(AF, BF)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i], BF[j], acc[i][j], 0, 0, 0)
+
+    PAIR_READ(ah0, al0, bh0, bl0, smem, 0)
+    for (int t = 0; t < nslab; ++t) {
+        const char* cur = smem + (t & 1) * SLAB;
+        char* nxt = smem + ((t + 1) & 1) * SLAB;
+        // first 16-k step of slab t; its second step's fragments arrive meanwhile
+        PAIR_READ(ah1, al1, bh1, bl1, cur, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        PAIR_MMA(al0, bh0);
+        PAIR_MMA(ah0, bl0);
+        PAIR_MMA(ah0, bh0);
+        __builtin_amdgcn_sched_barrier(0);
+        // every wave holds its fragments of slab t and its share of slab t+1 has landed: slab t+1 is complete and
+        // buffer t & 1 is free behind this barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < nslab) {
+            sa.issue(ak, cur, wave);
+            sb.issue(bk, cur + OPER, wave);
+            ak += a_adv;
+            bk += b_adv;
+        }
+        if (t + 1 < nslab) {
+            PAIR_READ(ah0, al0, bh0, bl0, nxt, 0)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PAIR_MMA(al1, bh1);
+        PAIR_MMA(ah1, bl1);
+        PAIR_MMA(ah1, bh1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef PAIR_READ
+#undef PAIR_MMA
+
+    // epilogue: undo the two scales (powers of two: exact), bias, ReLU
+    const float inv = 1.0f / (g.a_scale[zb] * g.b_scale[zb]);
+    float* C = Cb + (size_t)zsplit * g.c_split_stride;
+    const int lk = lane >> 5, l31 = lane & 31;
+    unsigned amax = 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n >= g.N) continue;
+        const float bv = (g.bias != nullptr) ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] * inv + bv;
+                if (g.relu) v = fmaxf(v, 0.0f);
+                amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
+                C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+    }
+    if (g.c_amax != nullptr && g.c_split_stride == 0) {
+        amax = wave_max_u32(amax);
+        if (lane == 0 && amax != 0) atomicMax(g.c_amax, amax);
+    }
+}
+
+// split-K reduce: fixed order, bias, ReLU, optional max |C|
+__global__ __launch_bounds__(256) void pair_splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
+                                                                 const float* __restrict__ bias, int M, int N, int ldc,
+                                                                 int splits, long long stride, int relu,
+                                                                 unsigned* __restrict__ c_amax) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned am = 0;
+    if (i < (long long)M * N) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float4 s = *reinterpret_cast<const float4*>(ws + i);
+        for (int k = 1; k < splits; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + k * stride + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + n);
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        }
+        if (relu) {
+            s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = s;
+        am = max(max(__float_as_uint(s.x) & 0x7fffffffu, __float_as_uint(s.y) & 0x7fffffffu),
+                 max(__float_as_uint(s.z) & 0x7fffffffu, __float_as_uint(s.w) & 0x7fffffffu));
+    }
+    if (c_amax != nullptr) {
+        am = wave_max_u32(am);
+        if ((threadIdx.x & 63) == 0 && am != 0) atomicMax(c_amax, am);
+    }
+}
+
+// ---- producers of pair images ---------------------------------------------------------------------------
+using cim::pair_split2;
+using cim::pair_scale_of;
+
+// scale[i] = pair_scale_of(amax[min(i, n_amax - 1)] * factor[i])   (factor may be null = 1; amax entries are bit patterns)
+__global__ void pair_scales_kernel(const unsigned* __restrict__ amax, int n_amax, const float* __restrict__ factor,
+                                   float* __restrict__ scale, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = __uint_as_float(amax[min(i, n_amax - 1)]);
+    if (factor != nullptr) a *= factor[i];
+    scale[i] = pair_scale_of(__float_as_uint(a));
+}
+
+// X [batch][rows][ld] fp32 (cols used, cols % 8 == 0) -> pair image [batch][rows_pad][ldp]; rows >= rows are written as zeros.
+// One lane = one 8-element chunk (32 B in, 32 B out).
+__global__ __launch_bounds__(256) void pair_split_kernel(const float* __restrict__ X, char* __restrict__ P, int rows,
+                                                         int rows_pad, int cols, int ld, int ldp, long long x_bs,
+                                                         long long p_bs, const float* __restrict__ scale,
+                                                         const float* __restrict__ relu_y) {
+    const int chunks = cols >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)rows_pad * chunks) return;
+    const int r = (int)(idx / chunks), c = (int)(idx % chunks);
+    const int z = blockIdx.y;
+    uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
+    if (r < rows) {
+        const float s = scale[z];
+        const float* src = X + (size_t)z * x_bs + (size_t)r * ld + c * 8;
+        float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        if (relu_y != nullptr) {        // x * (y > 0): the ReLU mask of the layer that produced y, fused into the split
+            const float* ys = relu_y + (size_t)z * x_bs + (size_t)r * ld + c * 8;
+            const float4 ya = *reinterpret_cast<const float4*>(ys), yb = *reinterpret_cast<const float4*>(ys + 4);
+            a = make_float4(ya.x > 0.f ? a.x : 0.f, ya.y > 0.f ? a.y : 0.f, ya.z > 0.f ? a.z : 0.f, ya.w > 0.f ? a.w : 0.f);
+            b = make_float4(yb.x > 0.f ? b.x : 0.f, yb.y > 0.f ? b.y : 0.f, yb.z > 0.f ? b.z : 0.f, yb.w > 0.f ? b.w : 0.f);
+        }
+        pair_split2(a.x * s, a.y * s, h.x, l.x);
+        pair_split2(a.z * s, a.w * s, h.y, l.y);
+        pair_split2(b.x * s, b.y * s, h.z, l.z);
+        pair_split2(b.z * s, b.w * s, h.w, l.w);
+    }
+    char* dst = P + ((size_t)z * p_bs + (size_t)r * ldp + c * 8) * 4;
+    *reinterpret_cast<uint4*>(dst) = h;
+    *reinterpret_cast<uint4*>(dst + 16) = l;
+}
+
+// max |x| of a dense fp32 array as a bit pattern (atomicMax into a caller-zeroed word)
+__global__ __launch_bounds__(256) void pair_amax_kernel(const float* __restrict__ X, long long n4, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(X + i * 4);
+        m = max(m, max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(out, m);
+}
+
+template <int AL, int BL>
+int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st) {
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    auto kern = gemm_pair_kernel<AL, BL>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    const int slabs = g.K / BK;
+    if (splits < 1) splits = 1;
+    if (splits > slabs) splits = slabs;
+    g.k_per_split = ((slabs + splits - 1) / splits) * BK;
+    splits = (g.K + g.k_per_split - 1) / g.k_per_split;
+    float* out = g.C;
+    const float* bias = g.bias;
+    const int relu = g.relu, ldc = g.ldc;
+    if (splits > 1) {
+        if (g.batch > 1) return -1;
+        g.C = workspace;
+        g.ldc = g.N;
+        g.c_split_stride = (long long)g.M * g.N;
+        g.bias = nullptr;
+        g.relu = 0;
+    } else {
+        g.c_split_stride = 0;
+    }
+    hipLaunchKernelGGL(kern, dim3(tn, tm, g.batch > 1 ? g.batch : splits), dim3(NT), LDS_BYTES, st, g);
+    if (splits > 1) {
+        const long long quads = ((long long)g.M * g.N + 3) / 4;
+        hipLaunchKernelGGL(pair_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, workspace,
+                           out, bias, g.M, g.N, ldc, splits, g.c_split_stride, relu, g.c_amax);
+    }
+    return 0;
+}
+
+int dispatch_pair(const PairArgs& g, int a_mcontig, int b_kcontig, int splits, float* workspace, hipStream_t st) {
+    if (!a_mcontig && !b_kcontig) return launch_pair<L_KC, L_MC>(g, splits, workspace, st);
+    if (!a_mcontig && b_kcontig) return launch_pair<L_KC, L_KC>(g, splits, workspace, st);
+    if (a_mcontig && !b_kcontig) return launch_pair<L_MC, L_MC>(g, splits, workspace, st);
+    return launch_pair<L_MC, L_KC>(g, splits, workspace, st);
+}
+
+}  // namespace
+
+static bool pair_dims_ok(int M, int N, int K, int lda, int ldb, int ldc, int a_mcontig, int b_kcontig) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || N % 4 != 0 || ldc % 4 != 0 || ldc < N) return false;
+    if (lda % 8 != 0 || ldb % 8 != 0) return false;
+    if (a_mcontig ? (M % 8 != 0 || lda < M) : (lda < K)) return false;
+    if (b_kcontig ? (ldb < K) : (N % 8 != 0 || ldb < N)) return false;
+    return true;
+}
+
+extern "C" int cim_gemm_pair_splits(int M, int N, int K) {
+    // same model as pick_splits() of gemm_f32.hip at this engine's rate and slab depth
+    const double CUS = 256.0;
+    const double tiles = (double)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int slabs = K / BK;
+    const double flops = 2.0 * M * (double)N * K;
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= 16; ++s) {
+        if (s > 1 && slabs / s < 8) break;
+        const double units = tiles * s;
+        const double rounds = (double)(long long)((units + CUS - 1) / CUS);
+        const double eff = units / (rounds * CUS);
+        const double t = flops / (420e12 * eff) + (s > 1 ? (2.0 * s + 1.0) * M * (double)N * 4.0 / 4e12 : 0.0);
+        if (t < best_t) { best_t = t; best = s; }
+    }
+    return best;
+}
+
+extern "C" int cim_gemm_pair(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda,
+                             int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
+                             const float* a_scale, const float* b_scale, uint32_t* c_amax, void* stream) {
+    CIM_CHECK_ARG(A && B && C && a_scale && b_scale);
+    CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
+    CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
+    PairArgs g{(const char*)A, (const char*)B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 1, 0, 0, 0, a_scale, b_scale, c_amax};
+    int rc = dispatch_pair(g, a_mcontig, b_kcontig, splits, workspace, cim::as_stream(stream));
+    if (rc) { cim::set_error("cim_gemm_pair: launch setup failed (%d)", rc); return rc; }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_gemm_pair_batched(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb,
+                                     int ldc, int a_mcontig, int b_kcontig, int batch, long long a_bs, long long b_bs,
+                                     long long c_bs, const float* a_scale, const float* b_scale, void* stream) {
+    CIM_CHECK_ARG(A && B && C && a_scale && b_scale && batch > 0 && batch <= 65535);
+    CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
+    CIM_CHECK_ARG(a_bs % 8 == 0 && b_bs % 8 == 0 && c_bs % 4 == 0);
+    PairArgs g{(const char*)A, (const char*)B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, batch, a_bs, b_bs, c_bs, a_scale, b_scale, nullptr};
+    int rc = dispatch_pair(g, a_mcontig, b_kcontig, 1, nullptr, cim::as_stream(stream));
+    if (rc) { cim::set_error("cim_gemm_pair_batched: launch setup failed (%d)", rc); return rc; }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float* scale, int n, void* stream) {
+    CIM_CHECK_ARG(amax && scale && n > 0 && n_amax > 0);
+    hipLaunchKernelGGL(pair_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax, n_amax, factor, scale, n);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_pair_split(const float* X, void* P, int rows, int rows_pad, int cols, int ld, int ldp, int batch,
+                              long long x_bs, long long p_bs, const float* scale, const float* relu_y, void* stream) {
+    CIM_CHECK_ARG(X && P && scale && rows > 0 && rows_pad >= rows && cols > 0 && batch > 0 && batch <= 65535);
+    CIM_CHECK_ARG(cols % 8 == 0 && ld % 4 == 0 && ld >= cols && ldp % 8 == 0 && ldp >= cols && x_bs % 4 == 0 && p_bs % 8 == 0);
+    const long long chunks = (long long)rows_pad * (cols / 8);
+    hipLaunchKernelGGL(pair_split_kernel, dim3((unsigned)((chunks + 255) / 256), batch), dim3(256), 0, cim::as_stream(stream), X,
+                       (char*)P, rows, rows_pad, cols, ld, ldp, x_bs, p_bs, scale, relu_y);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_pair_amax(const float* X, long long n, uint32_t* amax, void* stream) {
+    CIM_CHECK_ARG(X && amax && n > 0 && n % 4 == 0);
+    const long long n4 = n / 4;
+    const unsigned blocks = (unsigned)((n4 + 256 * 8 - 1) / (256 * 8) < 2048 ? (n4 + 256 * 8 - 1) / (256 * 8) : 2048);
+    hipLaunchKernelGGL(pair_amax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, cim::as_stream(stream), X, n4, amax);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}

@@ -478,6 +478,27 @@ __device__ __forceinline__ void w7_store(float* p, float4 v) {
 #endif
 }
 
+// ---- pair-image output (f16x2p GEMM engine, gemm_pair.hip) ------------------------------------------------------------
+// A lane holds 4 consecutive channels c .. c+3 (c = 4 x its index along C), its neighbour (lane ^ 1) the other half of the
+// 8-channel chunk [h: 8 x f16 | l: 8 x f16].  The even lane hands its two l words to the odd lane and receives the odd lane's
+// two h words (one quad_perm DPP move each way), so both store 16 contiguous bytes - the even lane the h half, the odd lane
+// the l half - at the byte offset the fp32 float4 would have gone to: pair images keep the fp32 tensor's addressing.
+typedef unsigned w7_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned w7_swap1(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ void w7_store_pair(float* p, const float4& v, float s) {
+    unsigned h0, l0, h1, l1;
+    cim::pair_split2(v.x * s, v.y * s, h0, l0);
+    cim::pair_split2(v.z * s, v.w * s, h1, l1);
+    const bool odd = (threadIdx.x & 1) != 0;
+    const unsigned r0 = w7_swap1(odd ? h0 : l0), r1 = w7_swap1(odd ? h1 : l1);
+    const w7_u4 o = odd ? w7_u4{r0, r1, l0, l1} : w7_u4{h0, h1, r0, r1};
+    __builtin_nontemporal_store(o, reinterpret_cast<w7_u4*>(p));
+}
+__device__ __forceinline__ void w7_store_pair(float*, const float2&, float) {}      // (only 4-channel lanes write pair images)
+__device__ __forceinline__ void w7_store_pair(float*, float, float) {}
+
 // lane vector width of the transform kernels (channels per lane): 16-byte accesses stream at 6.6-6.8 TB/s where the
 // 4- / 8-byte ones reach 4.3-5.0 (tools/bench_wino.py), as long as the tile still fits the register file
 #ifndef CIM_W7_VIN
@@ -538,9 +559,10 @@ __host__ __device__ constexpr float w7_abs_row_sum(const float (&M)[6], int n) {
     return s;
 }
 
-template <int KA, int KB, bool AMAX, int VW>
+template <int KA, int KB, bool AMAX, int VW, bool PAIR = false>
 __device__ __forceinline__ void w7_input_tile(const float* __restrict__ x, float* __restrict__ V, int r, int R, int C,
-                                              unsigned* __restrict__ row_amax) {
+                                              unsigned* __restrict__ row_amax, const float* __restrict__ scale = nullptr) {
+    // PAIR: V is a pair image [121][R (position stride, padded)][C], scale [121]; x rows are indexed by r as before
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
     typedef typename w7_vec<VW>::T VT;
     const size_t MC = (size_t)R * C;
@@ -575,7 +597,8 @@ __device__ __forceinline__ void w7_input_tile(const float* __restrict__ x, float
 #pragma unroll
                 for (int k = 0; k < NB; ++k)
                     if (W7_BT[KB][j][k] != 0.0f) vfma(v, W7_BT[KB][j][k], trow[k]);
-                w7_store(V + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c, v);
+                if constexpr (PAIR) w7_store_pair(V + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c, v, scale[Q0 + i * NB + j]);
+                else w7_store(V + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c, v);
             }
         }
     }
@@ -610,6 +633,81 @@ __global__ __launch_bounds__(256) void wino7_input_kernel(const float* __restric
         case 2: w7_input_tile<1, 0, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
         default: w7_input_tile<1, 1, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
     }
+}
+
+// zero rows of a pair image: positions [q0, q0 + nq) of row r (the rows that pad R up to a multiple of 32)
+__device__ __forceinline__ void w7_zero_rows(float* __restrict__ V, int q0, int nq, int r, int Rs, int C) {
+    for (int q = q0; q < q0 + nq; ++q)
+        for (int c = threadIdx.x * 4; c < C; c += 1024)
+            *reinterpret_cast<float4*>(V + ((size_t)q * Rs + r) * C + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// x [R][7][7][C] fp32 -> pair image V [121][Rs][C] (Rs = R padded to 32 rows, pad rows zeroed); grid = (Rs, 4)
+__global__ __launch_bounds__(256) void wino7_input_pair_kernel(const float* __restrict__ x, float* __restrict__ V, int R, int Rs,
+                                                               int C, const float* __restrict__ scale) {
+    const int r = blockIdx.x;
+    if (r >= R) {
+        w7_zero_rows(V, W7::QOFF[blockIdx.y], W7::NP[blockIdx.y >> 1] * W7::NP[blockIdx.y & 1], r, Rs, C);
+        return;
+    }
+    switch (blockIdx.y) {
+        case 0: w7_input_tile<0, 0, false, 4, true>(x, V, r, Rs, C, nullptr, scale); break;
+        case 1: w7_input_tile<0, 1, false, 4, true>(x, V, r, Rs, C, nullptr, scale); break;
+        case 2: w7_input_tile<1, 0, false, 4, true>(x, V, r, Rs, C, nullptr, scale); break;
+        default: w7_input_tile<1, 1, false, 4, true>(x, V, r, Rs, C, nullptr, scale); break;
+    }
+}
+
+// Filter transform into a pair image U' [121][Cout][Cin] (ci contiguous: the B operand of the forward product read
+// K-contiguously, of the data gradient read N-contiguously).  One thread = (co, 8 consecutive ci): 72 contiguous floats in,
+// one 32-byte chunk out per position.
+template <int KA, int KB>
+__device__ __forceinline__ void w7_filter_pair_tile(const float (&w)[8][3][3], float* __restrict__ U, size_t KN, size_t idx8,
+                                                    const float* __restrict__ scale) {
+    constexpr int NA = W7::NP[KA], NB = W7::NP[KB], Q0 = W7::QOFF[KA * 2 + KB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        float t[8][3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) t[e][b] = W7_G[KA][i][0] * w[e][0][b] + W7_G[KA][i][1] * w[e][1][b] + W7_G[KA][i][2] * w[e][2][b];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float s = scale[Q0 + i * NB + j];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (t[e][0] * W7_G[KB][j][0] + t[e][1] * W7_G[KB][j][1] + t[e][2] * W7_G[KB][j][2]) * s;
+            unsigned hh[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cim::pair_split2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
+            const w7_u4 h = {hh[0], hh[1], hh[2], hh[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+            float* d = U + (size_t)(Q0 + i * NB + j) * KN + idx8;
+            __builtin_nontemporal_store(h, reinterpret_cast<w7_u4*>(d));
+            __builtin_nontemporal_store(l, reinterpret_cast<w7_u4*>(d + 4));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino7_filter_pair_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
+                                                                int Cin, const float* __restrict__ scale) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // (co, ci / 8)
+    const size_t KN = (size_t)Cout * Cin;
+    if (idx * 8 >= KN) return;
+    const float* g = W + idx * 72;
+    float w[8][3][3];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(g + q * 4);
+        (&w[0][0][0])[q * 4 + 0] = v.x;
+        (&w[0][0][0])[q * 4 + 1] = v.y;
+        (&w[0][0][0])[q * 4 + 2] = v.z;
+        (&w[0][0][0])[q * 4 + 3] = v.w;
+    }
+    w7_filter_pair_tile<0, 0>(w, U, KN, idx * 8, scale);
+    w7_filter_pair_tile<0, 1>(w, U, KN, idx * 8, scale);
+    w7_filter_pair_tile<1, 0>(w, U, KN, idx * 8, scale);
+    w7_filter_pair_tile<1, 1>(w, U, KN, idx * 8, scale);
 }
 
 template <int KA, int KB>
@@ -649,7 +747,7 @@ __global__ __launch_bounds__(256) void wino7_filter_kernel(const float* __restri
 
 template <int KA, int KB, int VW>
 __device__ __forceinline__ void w7_output_tile(const float* __restrict__ M, const float* __restrict__ bias,
-                                               float* __restrict__ y, int r, int R, int C, int relu) {
+                                               float* __restrict__ y, int r, int R, int C, int relu, float& ymax) {
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], OA = W7::OUT[KA], OB = W7::OUT[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
     typedef typename w7_vec<VW>::T VT;
     const size_t MC = (size_t)R * C;
@@ -680,19 +778,29 @@ __device__ __forceinline__ void w7_output_tile(const float* __restrict__ M, cons
                 for (int j = 0; j < NB; ++j)
                     if (W7_AT[KB][b][j] != 0.0f) vfma(v, W7_AT[KB][b][j], s[a][j]);
                 if (relu) vrelu(v);
+                ymax = fmaxf(ymax, vamax(v));
                 w7_store(y + (((size_t)r * P + W7::OUT0[KA] + a) * P + W7::OUT0[KB] + b) * C + c, v);
             }
     }
 }
 
+// y_amax (optional): max |y| as a bit pattern, atomicMax into a caller-zeroed word - the scale source of the pair image
+// the flatten kernel writes next
 __global__ __launch_bounds__(256) void wino7_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
-                                                           float* __restrict__ y, int R, int C, int relu) {
+                                                           float* __restrict__ y, int R, int C, int relu,
+                                                           unsigned* __restrict__ y_amax) {
     const int r = blockIdx.x;
+    float ymax = 0.0f;
     switch (blockIdx.y) {
-        case 0: w7_output_tile<0, 0, CIM_W7_VOUT>(M, bias, y, r, R, C, relu); break;
-        case 1: w7_output_tile<0, 1, CIM_W7_VOUT>(M, bias, y, r, R, C, relu); break;
-        case 2: w7_output_tile<1, 0, CIM_W7_VOUT>(M, bias, y, r, R, C, relu); break;
-        default: w7_output_tile<1, 1, CIM_W7_VOUT>(M, bias, y, r, R, C, relu); break;
+        case 0: w7_output_tile<0, 0, CIM_W7_VOUT>(M, bias, y, r, R, C, relu, ymax); break;
+        case 1: w7_output_tile<0, 1, CIM_W7_VOUT>(M, bias, y, r, R, C, relu, ymax); break;
+        case 2: w7_output_tile<1, 0, CIM_W7_VOUT>(M, bias, y, r, R, C, relu, ymax); break;
+        default: w7_output_tile<1, 1, CIM_W7_VOUT>(M, bias, y, r, R, C, relu, ymax); break;
+    }
+    if (y_amax != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+        if ((threadIdx.x & 63) == 0 && ymax > 0.0f) atomicMax(y_amax, __float_as_uint(ymax));
     }
 }
 
@@ -701,9 +809,9 @@ __global__ __launch_bounds__(256) void wino7_output_kernel(const float* __restri
 //   y = A^T [U . (B^T d B)] A   =>   dx (+)= B [U^T . (A dy A^T)] B^T      (overlap-add over the tiles' patches),
 // which reuses the forward's U (contracted over the other channel index) instead of transforming a rotated filter;
 // with AMAX it also stores the row-scale bounds of E (column abs sums of A^T times the tile's max |dy|).
-template <int KA, int KB, bool ADJ, bool AMAX>
+template <int KA, int KB, bool ADJ, bool AMAX, bool PAIR = false>
 __device__ __forceinline__ void w7_dy_tile(const float* __restrict__ dy, float* __restrict__ D, int r, int R, int C,
-                                           unsigned* __restrict__ row_amax) {
+                                           unsigned* __restrict__ row_amax, const float* __restrict__ scale = nullptr) {
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], OA = W7::OUT[KA], OB = W7::OUT[KB], P = 7, Q0 = W7::QOFF[KA * 2 + KB];
     const size_t MC = (size_t)R * C;
     float dmax = 0.0f;
@@ -737,7 +845,8 @@ __device__ __forceinline__ void w7_dy_tile(const float* __restrict__ dy, float* 
                     const float m = ADJ ? W7_AT[KB][b][j] : W7_GD[KB][j][b];
                     if (m != 0.0f) fma4(v, m, trow[b]);
                 }
-                w7_store(D + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c, v);
+                if constexpr (PAIR) w7_store_pair(D + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c, v, scale[Q0 + i * NB + j]);
+                else w7_store(D + (size_t)(Q0 + i * NB + j) * MC + (size_t)r * C + c, v);
             }
         }
     }
@@ -777,6 +886,44 @@ __global__ __launch_bounds__(256) void wino7_dy_kernel(const float* __restrict__
         case 2: w7_dy_tile<1, 0, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
         default: w7_dy_tile<1, 1, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
     }
+}
+
+// dy [R][7][7][C] fp32 -> pair image D / E [121][Rs][C]; grid = (Rs, 4)
+template <bool ADJ>
+__global__ __launch_bounds__(256) void wino7_dy_pair_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int Rs,
+                                                            int C, const float* __restrict__ scale) {
+    const int r = blockIdx.x;
+    if (r >= R) {
+        w7_zero_rows(D, W7::QOFF[blockIdx.y], W7::NP[blockIdx.y >> 1] * W7::NP[blockIdx.y & 1], r, Rs, C);
+        return;
+    }
+    switch (blockIdx.y) {
+        case 0: w7_dy_tile<0, 0, ADJ, false, true>(dy, D, r, Rs, C, nullptr, scale); break;
+        case 1: w7_dy_tile<0, 1, ADJ, false, true>(dy, D, r, Rs, C, nullptr, scale); break;
+        case 2: w7_dy_tile<1, 0, ADJ, false, true>(dy, D, r, Rs, C, nullptr, scale); break;
+        default: w7_dy_tile<1, 1, ADJ, false, true>(dy, D, r, Rs, C, nullptr, scale); break;
+    }
+}
+
+// scale[q] = 2^(14 - exponent(bound_q)), bound_q = (abs row sum)_i (abs row sum)_j max|d| 1.0001 >= max |transformed value| at
+// position q.  kind 0: B^T (input), 1: G (filter), 2: GD (dy, weight gradient), 3: A (dy, adjoint data gradient).
+__global__ void wino7_pair_scales_kernel(const unsigned* __restrict__ amax, int kind, float* __restrict__ scale) {
+    const int q = threadIdx.x;
+    if (q >= 121) return;
+    const int type = q < 36 ? 0 : q < 66 ? 1 : q < 96 ? 2 : 3;
+    const int ka = type >> 1, kb = type & 1, nb = kb ? 5 : 6, pl = q - W7::QOFF[type];
+    const int pi = pl / nb, pj = pl % nb;
+    float fa = 0.0f, fb = 0.0f;
+    if (kind == 0) {
+        for (int t = 0; t < 6; ++t) { fa += fabsf(W7_BT[ka][pi][t]); fb += fabsf(W7_BT[kb][pj][t]); }
+    } else if (kind == 1) {
+        for (int t = 0; t < 3; ++t) { fa += fabsf(W7_G[ka][pi][t]); fb += fabsf(W7_G[kb][pj][t]); }
+    } else if (kind == 2) {
+        for (int t = 0; t < 4; ++t) { fa += fabsf(W7_GD[ka][pi][t]); fb += fabsf(W7_GD[kb][pj][t]); }
+    } else {
+        for (int t = 0; t < 4; ++t) { fa += fabsf(W7_AT[ka][t][pi]); fb += fabsf(W7_AT[kb][t][pj]); }
+    }
+    scale[q] = cim::pair_scale_of(__float_as_uint(fa * fb * __uint_as_float(amax[0]) * 1.0001f));
 }
 
 // Last stage of the adjoint data gradient: dx[r, y, x, c] = sum over the four tile types of (B M B^T)[y - y0][x - x0]
@@ -950,6 +1097,42 @@ __global__ __launch_bounds__(256) void flatten_chw_kernel(const float* __restric
     }
 }
 
+// Forward flatten straight into a pair image: src [R][PP][C] fp32 -> dst [Rs][C * PP] pair image in (c, p) order (seg_fc.0's
+// A operand and, contracted over its rows, the weight gradient's B operand).  A thread packs 8 consecutive (c, p) elements
+// = one 32-byte chunk.  Rows R .. Rs are zeroed.  grid = (Rs, C / 64)
+__global__ __launch_bounds__(256) void flatten_chw_pair_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
+                                                               int PP, int C, const float* __restrict__ scale) {
+    __shared__ float t[64][65];
+    const int r = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    float* out = dst + (size_t)r * PP * C + (size_t)c0 * PP;
+    const int chunks = PP * 8;                  // 64 * PP / 8
+    if (r >= R) {
+        for (int q = tid; q < chunks * 2; q += 256) *reinterpret_cast<float4*>(out + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const size_t base = (size_t)r * PP * C;
+    for (int e = tid; e < PP * 64; e += 256) {
+        const int p = e >> 6, c = e & 63;
+        t[p][c] = src[base + (size_t)p * C + c0 + c];
+    }
+    __syncthreads();
+    const float s = scale[0];
+    for (int q = tid; q < chunks; q += 256) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = q * 8 + k, c = e / PP, p = e - c * PP;
+            v[k] = t[p][c] * s;
+        }
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cim::pair_split2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
+        const w7_u4 h = {hh[0], hh[1], hh[2], hh[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+        *reinterpret_cast<w7_u4*>(out + q * 8) = h;
+        *reinterpret_cast<w7_u4*>(out + q * 8 + 4) = l;
+    }
+}
+
 }  // namespace
 
 #define WINO_GEOM_OK() CIM_CHECK_ARG(R > 0 && P > 0 && P <= 64 && C > 0 && C % 4 == 0)
@@ -1007,7 +1190,7 @@ extern "C" int cim_wino_output_transform(const float* M, const float* bias, floa
     WINO_TILE_OK();
     CIM_CHECK_ARG(M && y);
     const int T = (P + tile - 1) / tile;
-    if (tile == 7) hipLaunchKernelGGL(wino7_output_kernel, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, C, relu);
+    if (tile == 7) hipLaunchKernelGGL(wino7_output_kernel, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, C, relu, (unsigned*)nullptr);
     else if (tile == 4) hipLaunchKernelGGL(wino43_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C, relu);
     else hipLaunchKernelGGL(wino_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C,
                        relu);
@@ -1067,6 +1250,53 @@ extern "C" int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int 
     int chunks = (C + 256 * CIM_W7_VDX - 1) / (256 * CIM_W7_VDX);
     if (chunks > 4) chunks = 4;
     hipLaunchKernelGGL(wino7_dx_kernel, dim3(R, chunks), dim3(256), 0, cim::as_stream(stream), M, dx, R, C);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- pair-image producers of the f16x2p engine (tile = 7 geometry: 121 positions) ---------------------------------------
+extern "C" int cim_wino7_pair_scales(const uint32_t* amax, int kind, float* scale, void* stream) {
+    CIM_CHECK_ARG(amax && scale && kind >= 0 && kind <= 3);
+    hipLaunchKernelGGL(wino7_pair_scales_kernel, dim3(1), dim3(128), 0, cim::as_stream(stream), amax, kind, scale);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino7_input_pair(const float* x, void* V, const float* scale, int R, int Rs, int C, void* stream) {
+    CIM_CHECK_ARG(x && V && scale && R > 0 && Rs >= R && C > 0 && C % 8 == 0);
+    hipLaunchKernelGGL(wino7_input_pair_kernel, dim3(Rs, 4), dim3(256), 0, cim::as_stream(stream), x, (float*)V, R, Rs, C, scale);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino7_filter_pair(const float* W, void* U, const float* scale, int Cout, int Cin, void* stream) {
+    CIM_CHECK_ARG(W && U && scale && Cout > 0 && Cin > 0 && Cin % 8 == 0);
+    const size_t n = (size_t)Cout * (Cin / 8);
+    hipLaunchKernelGGL(wino7_filter_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W,
+                       (float*)U, Cout, Cin, scale);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino7_dy_pair(const float* dy, void* D, const float* scale, int R, int Rs, int C, int adjoint, void* stream) {
+    CIM_CHECK_ARG(dy && D && scale && R > 0 && Rs >= R && C > 0 && C % 8 == 0);
+    if (adjoint) hipLaunchKernelGGL(wino7_dy_pair_kernel<true>, dim3(Rs, 4), dim3(256), 0, cim::as_stream(stream), dy, (float*)D, R, Rs, C, scale);
+    else hipLaunchKernelGGL(wino7_dy_pair_kernel<false>, dim3(Rs, 4), dim3(256), 0, cim::as_stream(stream), dy, (float*)D, R, Rs, C, scale);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino7_output_amax(const float* M, const float* bias, float* y, int R, int C, int relu, uint32_t* y_amax,
+                                     void* stream) {
+    CIM_CHECK_ARG(M && y && R > 0 && C > 0 && C % 4 == 0);
+    hipLaunchKernelGGL(wino7_output_kernel, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, C, relu, y_amax);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_flatten_chw_pair(const float* src, void* dst, const float* scale, int R, int Rs, int PP, int C, void* stream) {
+    CIM_CHECK_ARG(src && dst && scale && R > 0 && Rs >= R && PP > 0 && PP <= 64 && C > 0 && C % 64 == 0 && C / 64 <= 65535);
+    hipLaunchKernelGGL(flatten_chw_pair_kernel, dim3(Rs, C / 64), dim3(256), 0, cim::as_stream(stream), src, (float*)dst, R, PP, C, scale);
     CIM_CHECK_LAUNCH();
     return 0;
 }

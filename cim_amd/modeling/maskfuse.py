@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from ..core.config import cfg
-from ..ops import conv3x3, gemm, linear, roi_align_maskcat
+from ..ops import conv3x3, gemm, linear, maskfuse_pair, pair, roi_align_maskcat
 
 
 class MaskFuse(nn.Module):
@@ -33,7 +33,10 @@ class MaskFuse(nn.Module):
 
     def prefetch(self):
         """Weight-only work of the forward, launched ahead on the side stream (called before the backbone forward)."""
-        gemm.prefetch_filter_transform(self.mask_branch[0].weight, cfg.FAST_RCNN.ROI_XFORM_RESOLUTION)
+        if gemm.PAIR and cfg.FAST_RCNN.ROI_XFORM_RESOLUTION == 7 and gemm.CONV_ALGO == "winograd7":
+            maskfuse_pair.prefetch_weight_images(self.mask_branch[0].weight, self.seg_fc[0].weight, self.seg_fc[2].weight)
+        else:
+            gemm.prefetch_filter_transform(self.mask_branch[0].weight, cfg.FAST_RCNN.ROI_XFORM_RESOLUTION)
 
     def forward(self, x, rois, masks):
         method = cfg.FAST_RCNN.ROI_XFORM_METHOD
@@ -44,6 +47,15 @@ class MaskFuse(nn.Module):
         # exact-fp32 MFMA contractions (cim_amd/csrc/gemm_f32.hip); the nn.Conv2d / nn.Linear
         # modules only hold the parameters (reference names and layouts)
         conv = self.mask_branch[0]
+        fc1, fc2 = self.seg_fc[0], self.seg_fc[2]
+        if gemm.PAIR and maskfuse_pair.supported(cat, conv.weight, fc1.weight, fc2.weight):
+            # f16x2p engine: conv -> flatten -> fc1 -> fc2 on pair images (one scale per matrix).  ROIAlign averages feature
+            # pixels and the masks are {0, 1}: max |cat| <= max |x| max(1, max |mask|) - a 6 MB pass instead of one over cat
+            xd = x.detach()
+            if not (xd.is_contiguous() or xd.is_contiguous(memory_format=torch.channels_last)):
+                xd = xd.contiguous()
+            fa = (pair.amax_of(xd).view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
+            return maskfuse_pair.maskfuse_head(cat, conv, fc1, fc2, fa)
         # ROIAlign averages feature pixels, so per channel max |box_x| <= max |x| over the map and
         # max |box_x * mask| <= that times max |mask| ({0,1} masks: 1): a 6 MB pass instead of one over the
         # 400 MB cat tensor for the conv's weight-gradient operand scales (f16x2 engine)
@@ -55,5 +67,4 @@ class MaskFuse(nn.Module):
             xc = torch.cat([fa, fm])
         # (c, h, w) flatten order of the reference's `.view(batch, -1)` on an NCHW tensor, fused into the conv op
         y = conv3x3(cat, conv.weight, conv.bias, relu=True, x_col_amax=xc, flatten_chw=True)
-        fc1, fc2 = self.seg_fc[0], self.seg_fc[2]
         return linear(linear(y, fc1.weight, fc1.bias, relu=True), fc2.weight, fc2.bias, relu=True)

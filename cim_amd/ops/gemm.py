@@ -21,9 +21,15 @@ def _ws(m, n, splits, like):
 
 # Arithmetic engine of the contractions: "f16x2" (default: scaled two-term fp16 split,
 # 3 MFMA products), "bf16x3" (exact three-term bf16 split, 6 products), "fp32" (f32 MFMA multiplies).
-ENGINE = os.environ.get("CIM_GEMM_ENGINE", "f16x2")
-if ENGINE not in ("f16x2", "bf16x3", "fp32"):
-    raise _lib.CimHipError("CIM_GEMM_ENGINE must be f16x2, bf16x3 or fp32, got %r" % ENGINE)
+# "f16x2p" (default): the f16x2 arithmetic with ONE scale per matrix on operands pre-split by their producers ("pair images",
+# cim_amd/csrc/gemm_pair.hip) - used by MaskFuse's fused head Function (cim_amd/ops/maskfuse_pair.py) wherever its shapes
+# qualify; everything else (and the per-layer Functions below) then runs "f16x2".
+ENGINE = os.environ.get("CIM_GEMM_ENGINE", "f16x2p")
+if ENGINE not in ("f16x2p", "f16x2", "bf16x3", "fp32"):
+    raise _lib.CimHipError("CIM_GEMM_ENGINE must be f16x2p, f16x2, bf16x3 or fp32, got %r" % ENGINE)
+PAIR = ENGINE == "f16x2p"
+if PAIR:
+    ENGINE = "f16x2"
 
 
 def _zeros_i32(dev, *sizes):

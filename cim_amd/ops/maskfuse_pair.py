@@ -1,0 +1,223 @@
+"""MaskFuse's contractions on the f16x2p engine: conv3x3 (mixed 4 + 3 Winograd tiling) -> (c, h, w) flatten -> fc1 -> fc2 as
+ONE autograd Function whose intermediate operands are pair images written by their producers.
+
+Replaces the `mask_branch` / `seg_fc` part of MaskFuse.forward, /root/reference/lib/modeling/resnet50.py:104-110,131-137,
+and its autograd backward.  Same values as cim_amd.ops.gemm's per-layer Functions (which stay for the other engines /
+shapes); what changes is who splits the operands (cim_amd/csrc/gemm_pair.hip header):
+
+  forward   cat --wino7_input_pair--> V'   (scale per position from max |feature map|)
+            w   --wino7_filter_pair--> U'  (side stream, under the backbone forward; scale from max |w|)
+            M = V' . U'^T  ->  wino7_output (+bias, ReLU, max |y|)  ->  y fp32 (kept: ReLU mask of the backward)
+            y --flatten_chw_pair--> X'     (never exists in fp32)
+            Y1 = relu(X' . W1'^T + b1) (max |Y1| from the split-K reduce) -> Y1' ;  Y2 = relu(Y1' . W2'^T + b2)
+  backward  dY2 -> dY2' (mask fused into the split);  dW2 = dY2'^T . Y1' | dY1 = dY2' . W2'
+            dY1 -> dY1' ;  dW1 = dY1'^T . X' | dX = dY1' . W1'  (max |dX|)
+            dX --flatten backward (ReLU mask)--> dy --wino7_dy_pair--> E', D'
+            dU = V'^T . D' -> dW  |  Md = E' . U' -> dcat      (weight gradients on the side stream)
+Every image is written once and read by two products (contracted over its columns by one, over its rows by the other).
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from . import gemm as G
+from . import pair
+
+NPOS = 121
+
+
+def supported(cat, wc, w1, w2):
+    r, cin, p, q = cat.shape
+    cout = wc.shape[0]
+    return (cat.is_cuda and p == 7 and q == 7 and cin % 32 == 0 and cout % 64 == 0 and wc.shape[1] == cin
+            and w1.shape[1] == cout * 49 and w1.shape[0] % 32 == 0 and w2.shape[1] == w1.shape[0] and w2.shape[0] % 32 == 0
+            and G.CONV_ALGO == "winograd7")
+
+
+def _weight_amax(w, rows, cols):
+    """int32[1] bit pattern of max |w|: from the arrays the fused SGD kernel registered for this version of w, else one pass."""
+    reg = G._registered_scales(w, rows, cols)
+    if reg is not None and reg[0] is not None:
+        return reg[0].max().reshape(1)
+    return pair.amax_of(w.detach())
+
+
+_IMAGES = {}      # id(weight) -> (version, data_ptr, Pair, event or None)
+
+
+def _cached(w):
+    e = _IMAGES.get(id(w))
+    if e is not None and e[0] == w._version and e[1] == w.data_ptr():
+        return e
+    return None
+
+
+def _conv_image(w):
+    cout, cin = w.shape[0], w.shape[1]
+    sc = torch.empty(NPOS, dtype=torch.float32, device=w.device)
+    st = _lib.stream_ptr()
+    _lib.call("cim_wino7_pair_scales", _weight_amax(w, cout, cin * 9).data_ptr(), 1, sc.data_ptr(), st)
+    U = pair.Pair(torch.empty((NPOS, cout, cin), dtype=torch.int32, device=w.device), cout, cin, NPOS, sc)
+    _lib.call("cim_wino7_filter_pair", w.data_ptr(), U.buf.data_ptr(), sc.data_ptr(), cout, cin, st)
+    return U
+
+
+def _fc_image(w):
+    n, k = w.shape
+    return pair.split(w.detach(), n, k, k, scale=pair.scales_from(_weight_amax(w, n, k), 1))
+
+
+def weight_image(w, conv=False):
+    """Pair image of a weight for its CURRENT version: the prefetched one (the caller's stream waits for its event), else
+    built now on the caller's stream."""
+    e = _cached(w)
+    if e is not None:
+        if e[3] is not None:
+            torch.cuda.current_stream(w.device).wait_event(e[3])
+            e[2].record_stream(torch.cuda.current_stream(w.device))
+        return e[2]
+    with torch.no_grad():
+        img = _conv_image(w.contiguous()) if conv else _fc_image(w.contiguous())
+    _IMAGES[id(w)] = (w._version, w.data_ptr(), img, None)
+    return img
+
+
+def prefetch_weight_images(wc, w1, w2):
+    """Build the three weights' pair images on the SIDE stream now (they depend on the weights only): called before the
+    backbone forward, whose small latency-bound kernels leave most of the chip idle."""
+    if not (G.OVERLAP and G.PREFETCH_U and wc.is_cuda) or torch.cuda.is_current_stream_capturing():
+        return
+    todo = [(w, c) for w, c in ((wc, True), (w1, False), (w2, False)) if _cached(w) is None and w.is_contiguous()]
+    if not todo:
+        return
+    dev = wc.device
+    cur, side = torch.cuda.current_stream(dev), G._side_stream(dev)
+    side.wait_stream(cur)                       # (the optimizer's update of the weights was enqueued on `cur`)
+    with torch.cuda.stream(side), torch.no_grad():
+        for w, conv in todo:
+            img = _conv_image(w) if conv else _fc_image(w)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            _IMAGES[id(w)] = (w._version, w.data_ptr(), img, ev)
+
+
+def _i32(dev):
+    return torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+class MaskFusePairFunction(Function):
+    @staticmethod
+    def forward(ctx, cat, wc, bc, w1, b1, w2, b2, feat_amax):
+        cat = cat.contiguous(memory_format=torch.channels_last)
+        r, cin, p, _ = cat.shape
+        cout, h1, h2 = wc.shape[0], w1.shape[0], w2.shape[0]
+        dev, rp = cat.device, pair.pad32(r)
+        st = _lib.stream_ptr()
+        Up, W1p, W2p = weight_image(wc, conv=True), weight_image(w1), weight_image(w2)
+        # conv: V' -> M -> y (+bias, ReLU, max |y|)
+        sV = torch.empty(NPOS, dtype=torch.float32, device=dev)
+        _lib.call("cim_wino7_pair_scales", feat_amax.data_ptr(), 0, sV.data_ptr(), st)
+        V = pair.Pair(torch.empty((NPOS, rp, cin), dtype=torch.int32, device=dev), r, cin, NPOS, sV)
+        _lib.call("cim_wino7_input_pair", cat.data_ptr(), V.buf.data_ptr(), sV.data_ptr(), r, rp, cin, st)
+        M = pair.gemm(V, Up, r, cout, cin, False, True)
+        y = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
+        am = torch.zeros(2, dtype=torch.int32, device=dev)
+        _lib.call("cim_wino7_output_amax", M.data_ptr(), _lib.ptr(bc), y.data_ptr(), r, cout, 1, am[0:1].data_ptr(), st)
+        del M
+        # flatten -> X' ; fc1 ; fc2
+        Xp = pair.Pair(torch.empty((1, rp, cout * p * p), dtype=torch.int32, device=dev), r, cout * p * p, 1,
+                       pair.scales_from(am[0:1], 1))
+        _lib.call("cim_flatten_chw_pair", y.data_ptr(), Xp.buf.data_ptr(), Xp.scale.data_ptr(), r, rp, p * p, cout, st)
+        Y1 = pair.gemm(Xp, W1p, r, h1, cout * p * p, False, True, bias=b1, relu=True, c_amax=am[1:2])
+        Y1p = pair.split(Y1, r, h1, h1, scale=pair.scales_from(am[1:2], 1))
+        Y2 = pair.gemm(Y1p, W2p, r, h2, h1, False, True, bias=b2, relu=True)
+        ctx.save_for_backward(y, Y1, Y2, V.buf, V.scale, Up.buf, Up.scale, W1p.buf, W1p.scale, W2p.buf, W2p.scale,
+                              Xp.buf, Xp.scale, Y1p.buf, Y1p.scale)
+        ctx.dims = (r, cin, cout, h1, h2, p)
+        ctx.has_bias = (bc is not None, b1 is not None, b2 is not None)
+        return Y2
+
+    @staticmethod
+    def backward(ctx, dY2):
+        (y, Y1, Y2, Vb, Vs, Ub, Us, W1b, W1s, W2b, W2s, Xb, Xs, Y1b, Y1s) = ctx.saved_tensors
+        r, cin, cout, h1, h2, p = ctx.dims
+        dev, rp = y.device, pair.pad32(r)
+        V = pair.Pair(Vb, r, cin, NPOS, Vs)
+        Up = pair.Pair(Ub, cout, cin, NPOS, Us)
+        W1p, W2p = pair.Pair(W1b, h1, cout * p * p, 1, W1s), pair.Pair(W2b, h2, h1, 1, W2s)
+        Xp, Y1p = pair.Pair(Xb, r, cout * p * p, 1, Xs), pair.Pair(Y1b, r, h1, 1, Y1s)
+        need_x, need_wc, need_w1, need_w2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[3], ctx.needs_input_grad[5]
+        cur, side = torch.cuda.current_stream(dev), G._side_stream(dev)
+        overlap = G.OVERLAP and not torch.cuda.is_current_stream_capturing()
+
+        def on_side(fn):
+            """Weight gradients run beside the data-gradient chain (second HIP stream)."""
+            if not overlap:
+                return fn()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                out = fn()
+            return out
+
+        dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = None
+        am = torch.zeros(3, dtype=torch.int32, device=dev)
+        # ---- fc2
+        dY2 = dY2.contiguous()
+        dY2m = dY2 * (Y2 > 0)
+        if ctx.has_bias[2] and ctx.needs_input_grad[6]:
+            db2 = dY2m.sum(dim=0)
+        pair.amax_of(dY2m, am[0:1])
+        dY2p = pair.split(dY2m, r, h2, h2, scale=pair.scales_from(am[0:1], 1))
+        if need_w2:
+            dw2 = on_side(lambda: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False))
+        dY1 = pair.gemm(dY2p, W2p, r, h1, h2, False, False)
+        # ---- fc1
+        dY1m = dY1 * (Y1 > 0)
+        if ctx.has_bias[1] and ctx.needs_input_grad[4]:
+            db1 = dY1m.sum(dim=0)
+        pair.amax_of(dY1m, am[1:2])
+        dY1p = pair.split(dY1m, r, h1, h1, scale=pair.scales_from(am[1:2], 1))
+        if need_w1:
+            dw1 = on_side(lambda: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False))
+        if need_x or need_wc or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
+            dX = pair.gemm(dY1p, W1p, r, cout * p * p, h1, False, False, c_amax=am[2:3])
+            # ---- flatten backward + ReLU mask of the conv; conv gradients
+            st = _lib.stream_ptr()
+            dy = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
+            _lib.call("cim_flatten_chw", dX.data_ptr(), y.data_ptr(), dy.data_ptr(), r, p * p, cout, 1, st)
+            del dX
+            if ctx.has_bias[0] and ctx.needs_input_grad[2]:
+                dbc = dy.sum(dim=(0, 1, 2))
+            if need_wc:
+                def wgrad():
+                    st2 = _lib.stream_ptr()
+                    sD = torch.empty(NPOS, dtype=torch.float32, device=dev)
+                    _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 2, sD.data_ptr(), st2)
+                    D = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sD)
+                    _lib.call("cim_wino7_dy_pair", dy.data_ptr(), D.buf.data_ptr(), sD.data_ptr(), r, rp, cout, 0, st2)
+                    dU = pair.gemm(V, D, cin, cout, rp, True, False)
+                    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+                    _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, 7, st2)
+                    return dw
+                dwc = on_side(wgrad)
+            if need_x:
+                sE = torch.empty(NPOS, dtype=torch.float32, device=dev)
+                _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 3, sE.data_ptr(), st)
+                E = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sE)
+                _lib.call("cim_wino7_dy_pair", dy.data_ptr(), E.buf.data_ptr(), sE.data_ptr(), r, rp, cout, 1, st)
+                M2 = pair.gemm(E, Up, r, cin, cout, False, False)
+                dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
+                _lib.call("cim_wino_dx_adjoint_output", M2.data_ptr(), dxp.data_ptr(), r, p, cin, 7, st)
+                dcat = dxp.permute(0, 3, 1, 2)
+            if overlap:
+                dy.record_stream(side)
+        if overlap:
+            cur.wait_stream(side)
+            for t in (dw2, dw1, dwc):
+                if t is not None:
+                    t.record_stream(cur)
+        return dcat, dwc, dbc, dw1, db1, dw2, db2, None
+
+
+def maskfuse_head(cat, conv, fc1, fc2, feat_amax):
+    return MaskFusePairFunction.apply(cat, conv.weight, conv.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, feat_amax)

@@ -1,0 +1,94 @@
+"""Pair images: fp32 matrices stored pre-split for the f16x2p GEMM engine (cim_amd/csrc/gemm_pair.hip).
+
+A pair image of a logical matrix [rows][cols] is an int32 tensor [batch][rows_pad][ld] (4 bytes per logical element: the
+bytes hold [col / 8][h: 8 x f16 | l: 8 x f16]) plus ONE power-of-two scale per batch entry with x * scale = h + l.  Rows
+>= rows are zero (so the image can be contracted over its rows in slabs of 32).  The contractions of MaskFuse
+(/root/reference/lib/modeling/resnet50.py:104-110,135-136) consume such images directly; the kernels that produce the
+tensors write them (winograd.hip transforms, flatten, SGD), `split()` is the generic producer.
+"""
+import torch
+
+from .. import _lib
+
+
+def pad32(n):
+    return (n + 31) & ~31
+
+
+class Pair:
+    __slots__ = ("buf", "rows", "cols", "batch", "scale")
+
+    def __init__(self, buf, rows, cols, batch, scale):
+        self.buf, self.rows, self.cols, self.batch, self.scale = buf, rows, cols, batch, scale
+
+    @property
+    def rows_pad(self):
+        return self.buf.shape[-2]
+
+    @property
+    def ld(self):
+        return self.buf.shape[-1]
+
+    @property
+    def bs(self):
+        return self.buf.shape[-2] * self.buf.shape[-1]
+
+    def record_stream(self, s):
+        self.buf.record_stream(s)
+        self.scale.record_stream(s)
+
+
+def amax_of(x, out=None):
+    """max |x| of a dense fp32 tensor as an int32[1] bit pattern (device)."""
+    if out is None:
+        out = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _lib.call("cim_pair_amax", x.data_ptr(), x.numel(), out.data_ptr(), _lib.stream_ptr())
+    return out
+
+
+def scales_from(amax, n=1, factor=None):
+    """float32[n] power-of-two scales 2^(14 - exponent(amax * factor[i])) (amax: int32 bit patterns, [1] or [n])."""
+    s = torch.empty(n, dtype=torch.float32, device=amax.device)
+    _lib.call("cim_pair_scales", amax.data_ptr(), amax.numel(), _lib.ptr(factor), s.data_ptr(), n, _lib.stream_ptr())
+    return s
+
+
+def empty(rows, cols, batch, dev, scale=None, zero_pad=True):
+    """Uninitialised image whose pad rows (rows .. pad32(rows)) are zeroed."""
+    rp = pad32(rows)
+    buf = torch.empty((batch, rp, cols), dtype=torch.int32, device=dev)
+    if zero_pad and rp != rows:
+        buf[:, rows:, :].zero_()
+    return Pair(buf, rows, cols, batch, scale)
+
+
+def split(x, rows=None, cols=None, ld=None, batch=1, x_bs=0, scale=None, relu_y=None):
+    """Generic producer: fp32 x ([batch][rows][ld], cols used) -> Pair.  scale: float32[batch] or None (from max |x|)."""
+    if rows is None:
+        rows, cols = x.shape[-2], x.shape[-1]
+        ld = cols
+    if scale is None:
+        scale = scales_from(amax_of(x), batch)
+    p = empty(rows, cols, batch, x.device, scale, zero_pad=False)
+    _lib.call("cim_pair_split", x.data_ptr(), p.buf.data_ptr(), rows, p.rows_pad, cols, ld, cols, batch, x_bs, p.bs,
+              scale.data_ptr(), _lib.ptr(relu_y), _lib.stream_ptr())
+    return p
+
+
+def gemm(a, b, m, n, k, a_mcontig=False, b_kcontig=False, bias=None, relu=False, out=None, c_amax=None):
+    """C[m,n] = A . B (+ bias)(ReLU) on pair images; k must be a multiple of 32 (the images' zero rows / columns pad it).
+    Batched when a.batch > 1 (then no bias / ReLU / split-K)."""
+    dev = a.buf.device
+    if a.batch > 1:
+        c = out if out is not None else torch.empty((a.batch, m, n), dtype=torch.float32, device=dev)
+        _lib.call("cim_gemm_pair_batched", a.buf.data_ptr(), b.buf.data_ptr(), c.data_ptr(), m, n, k, a.ld, b.ld, n,
+                  int(a_mcontig), int(b_kcontig), a.batch, a.bs, b.bs, m * n, a.scale.data_ptr(), b.scale.data_ptr(),
+                  _lib.stream_ptr())
+        return c
+    c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=dev)
+    splits = _lib.call("cim_gemm_pair_splits", m, n, k)
+    ws = torch.empty(splits * m * n, dtype=torch.float32, device=dev) if splits > 1 else None
+    _lib.call("cim_gemm_pair", a.buf.data_ptr(), b.buf.data_ptr(), c.data_ptr(), _lib.ptr(bias), m, n, k, a.ld, b.ld, n,
+              int(a_mcontig), int(b_kcontig), int(relu), splits, _lib.ptr(ws), a.scale.data_ptr(), b.scale.data_ptr(),
+              _lib.ptr(c_amax), _lib.stream_ptr())
+    return c

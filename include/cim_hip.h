@@ -325,6 +325,51 @@ int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int 
                            int batch, long long a_bs, long long b_bs, long long c_bs,
                            const uint32_t* a_amax, const uint32_t* b_amax, void* stream);
 
+/* f16x2p engine (CIM_GEMM_ENGINE=f16x2p, the host's default): the f16x2 arithmetic on operands that were split by
+ * their PRODUCERS.  A "pair image" of a logical fp32 matrix [rows][cols] is [rows][ld / 8][h: 8 x f16 | l: 8 x f16]
+ * (ld logical elements per row, a multiple of 8; 4 bytes per element) with x * s = h + l for ONE power-of-two scale s per
+ * matrix (per batch entry).  The same image serves the product that contracts over its columns (K-contiguous use) and the
+ * one that contracts over its rows (through the hardware transpose read of LDS), so it is written once.  The GEMM moves
+ * 16-byte chunks HBM -> LDS by LDS-DMA; its loop holds MFMAs and LDS reads only.
+ *   cim_gemm_pair[_batched]: C[M,N] = A . B * 1 / (a_scale * b_scale) (+ bias)(ReLU), fp32 C.  Layout flags as cim_gemm_f32;
+ *     K % 32 == 0 (zero-filled rows / columns pad the images), lda / ldb % 8 == 0, an M-contiguous A needs M % 8 == 0, an
+ *     N-contiguous B needs N % 8 == 0.  a_scale / b_scale: [batch] device floats, the scales the images were written with.
+ *     c_amax (optional): receives max |C| as an IEEE bit pattern through atomicMax (caller zeroes) - the scale source
+ *     of the next split.
+ *   cim_pair_scales: scale[i] = 2^(14 - exponent(amax[min(i, n_amax - 1)] * factor[i]))  (factor may be NULL)
+ *   cim_pair_split : fp32 X [batch][rows][ld] -> pair image [batch][rows_pad][ldp], rows >= `rows` zero-filled; relu_y
+ *                    (optional, laid out as X): elements with relu_y <= 0 are written as 0 (a fused ReLU backward mask)
+ *   cim_pair_amax  : max |x| bit pattern of n floats (atomicMax into a caller-zeroed word) */
+int cim_gemm_pair_splits(int M, int N, int K);
+int cim_gemm_pair(const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
+                  int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
+                  const float* a_scale, const float* b_scale, uint32_t* c_amax, void* stream);
+int cim_gemm_pair_batched(const void* A, const void* B, float* C, int M, int N, int K,
+                          int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
+                          int batch, long long a_bs, long long b_bs, long long c_bs,
+                          const float* a_scale, const float* b_scale, void* stream);
+int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float* scale, int n, void* stream);
+int cim_pair_split(const float* X, void* P, int rows, int rows_pad, int cols, int ld, int ldp, int batch,
+                   long long x_bs, long long p_bs, const float* scale, const float* relu_y, void* stream);
+int cim_pair_amax(const float* X, long long n, uint32_t* amax, void* stream);
+
+/* Producers of pair images for the MaskFuse convolution in the mixed 4 + 3 Winograd tiling (121 positions, P = 7; the
+ * fp32 stages are cim_wino_* with tile = 7 below) and for seg_fc.0's input:
+ *   cim_wino7_pair_scales: scale[121] from ONE max |d| bit pattern of the untransformed tensor: per position the bound
+ *        (abs row sum)_i (abs row sum)_j max|d| of the transform.  kind 0: input (B^T), 1: filter (G), 2: dy for the weight
+ *        gradient (GD), 3: dy for the adjoint data gradient (A)
+ *   cim_wino7_input_pair : x [R,7,7,C] fp32 -> V [121][Rs][C] pair image (Rs >= R rows per position, rows >= R zeroed)
+ *   cim_wino7_filter_pair: W [Cout,Cin,3,3] -> U' [121][Cout][Cin] pair image (ci contiguous)
+ *   cim_wino7_dy_pair    : dy [R,7,7,C] -> D (adjoint = 0: GD dy GD^T) or E (adjoint = 1: A dy A^T) [121][Rs][C]
+ *   cim_wino7_output_amax: cim_wino_output_transform(tile = 7) that also reports max |y| (atomicMax, caller zeroes)
+ *   cim_flatten_chw_pair : cim_flatten_chw forward into a pair image [Rs][C*PP] (lib/modeling/resnet50.py:135) */
+int cim_wino7_pair_scales(const uint32_t* amax, int kind, float* scale, void* stream);
+int cim_wino7_input_pair(const float* x, void* V, const float* scale, int R, int Rs, int C, void* stream);
+int cim_wino7_filter_pair(const float* W, void* U, const float* scale, int Cout, int Cin, void* stream);
+int cim_wino7_dy_pair(const float* dy, void* D, const float* scale, int R, int Rs, int C, int adjoint, void* stream);
+int cim_wino7_output_amax(const float* M, const float* bias, float* y, int R, int C, int relu, uint32_t* y_amax, void* stream);
+int cim_flatten_chw_pair(const float* src, void* dst, const float* scale, int R, int Rs, int PP, int C, void* stream);
+
 /* Winograd F(2x2,3x3) evaluation of the same 3x3 / stride 1 / pad 1 convolution (fp32 throughout,
  * 1.72x fewer multiplies at P = 7): T = ceil(P/2) tiles per side, 16 transform positions.
  *   cim_wino_input_transform : x [R,P,P,C]            -> V [16][R*T*T][C]       (B^T d B)

@@ -32,12 +32,14 @@ class _engine:
     def __enter__(self):
         from cim_amd import _lib
         from cim_amd.ops import gemm as G
-        self.G, self.lib, self.saved = G, _lib, (G.ENGINE, _lib.call("cim_gemm_get_engine"))
-        G.ENGINE = self.name
+        self.G, self.lib, self.saved = G, _lib, (G.ENGINE, _lib.call("cim_gemm_get_engine"), G.PAIR)
+        G.ENGINE = "f16x2" if self.name == "f16x2p" else self.name
+        G.PAIR = self.name == "f16x2p"
         _lib.call("cim_gemm_set_engine", 0 if self.name == "fp32" else 1)
 
     def __exit__(self, *exc):
         self.G.ENGINE = self.saved[0]
+        self.G.PAIR = self.saved[2]
         self.lib.call("cim_gemm_set_engine", self.saved[1])
 
 
@@ -80,10 +82,12 @@ def test_gemm_is_asymmetric_and_deterministic(dev):
     assert _rel(y1.cpu(), A.cpu().double() @ W.cpu().double().t()) < 3e-5   # K = 50176: fp32 accumulation error grows with K
 
 
-def test_default_engine_is_f16x2():
+def test_default_engine_is_f16x2p():
+    """Default: pair images for MaskFuse's fused head (PAIR), the f16x2 engine for every other contraction."""
     from cim_amd.ops import gemm as G
     import os
-    assert G.ENGINE == os.environ.get("CIM_GEMM_ENGINE", "f16x2")
+    want = os.environ.get("CIM_GEMM_ENGINE", "f16x2p")
+    assert (G.ENGINE, G.PAIR) == (("f16x2", True) if want == "f16x2p" else (want, False))
 
 
 @pytest.mark.parametrize("K", [2048, 50176])

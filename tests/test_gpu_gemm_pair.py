@@ -1,0 +1,281 @@
+"""-m gpu: the f16x2p contraction engine (cim_amd/csrc/gemm_pair.hip: pre-split fp16 pair images, LDS-DMA staging,
+hardware-transposed LDS reads) through the C ABI against fp64: the split producer, every operand layout, ragged M / N,
+batched and split-K launches, and its error class next to the f32-multiply engine."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from cim_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _decode(p):
+    """Pair image -> float64 [batch][rows_pad][ld] (h + l) / scale."""
+    raw = p.buf.cpu().numpy().view(np.float16).reshape(p.batch, p.rows_pad, p.ld // 8, 2, 8).astype(np.float64)
+    v = (raw[:, :, :, 0, :] + raw[:, :, :, 1, :]).reshape(p.batch, p.rows_pad, p.ld)
+    return v / p.scale.cpu().numpy().astype(np.float64)[:, None, None]
+
+
+def test_split_image_layout_and_precision(dev):
+    from cim_amd.ops import pair
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 70, 64, generator=g) * torch.exp2(8.0 * (torch.rand(3, 70, 64, generator=g) - 0.5))
+    p = pair.split(x.to(dev), 70, 64, 64, batch=3, x_bs=70 * 64)
+    assert p.rows_pad == 96 and p.ld == 64
+    s = p.scale.cpu().numpy()
+    assert np.all(np.log2(s) == np.round(np.log2(s)))                    # powers of two
+    assert float((x.abs().max() * float(s[0]))) < 2.0 ** 15               # one scale for the whole call's maximum
+    d = _decode(p)
+    assert np.all(d[:, 70:, :] == 0.0)                                    # zero pad rows
+    err = np.abs(d[:, :70, :] - x.double().numpy())
+    # 22 significant bits relative to the element (|x| >= 2^-13 max), absolute 2^-39 max below
+    bound = np.maximum(np.abs(x.double().numpy()) * 2.0 ** -22, float(x.abs().max()) * 2.0 ** -38)
+    assert np.all(err <= bound)
+
+
+def _operands(M, N, K, a_m, b_k, g, spread=0.0):
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    if spread:
+        A = A * torch.exp2(spread * (torch.rand(M, K, generator=g) - 0.5))
+        B = B * torch.exp2(spread * (torch.rand(K, N, generator=g) - 0.5))
+    return A, B
+
+
+def _pair_gemm(dev, A, B, a_m, b_k, bias=None, relu=False, c_amax=None):
+    from cim_amd.ops import pair
+    M, K = A.shape
+    N = B.shape[1]
+    pa = pair.split((A.t().contiguous() if a_m else A).to(dev))
+    pb = pair.split((B.t().contiguous() if b_k else B).to(dev))
+    kk = pair.pad32(K)
+    return pair.gemm(pa, pb, M, N, kk, bool(a_m), bool(b_k), bias=None if bias is None else bias.to(dev), relu=relu,
+                     c_amax=c_amax)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1024, 2048), (304, 264, 992), (40, 8, 32), (520, 520, 64), (256, 256, 32)])
+@pytest.mark.parametrize("a_m,b_k", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_pair_gemm_layouts_vs_fp64(dev, M, N, K, a_m, b_k):
+    # K-contiguous operands contract over their columns: K itself must be a multiple of 32 there; an operand
+    # contracted over its rows is padded with zero rows by the image
+    if (not a_m or b_k) and K % 32:
+        pytest.skip("a K-contiguous operand needs K % 32 == 0")
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A, B = _operands(M, N, K, a_m, b_k, g)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double() + bias.double()
+    c = _pair_gemm(dev, A, B, a_m, b_k, bias)
+    scale = A.double().abs() @ B.double().abs()
+    assert float(((c.cpu().double() - ref).abs() / scale).max()) < 2e-6
+    am = torch.zeros(1, dtype=torch.int32, device=dev)
+    c2 = _pair_gemm(dev, A, B, a_m, b_k, bias, relu=True, c_amax=am)
+    assert float(((c2.cpu().double() - ref.clamp(min=0)).abs() / scale).max()) < 2e-6
+    assert float(am.view(torch.float32)) == float(c2.abs().max())
+
+
+def test_pair_gemm_is_asymmetric_and_deterministic(dev):
+    """A = I with an asymmetric B catches a transposed operand read or C write in every layout; split-K is fixed-order."""
+    n = 320
+    B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 1000.0
+    for a_m in (0, 1):
+        for b_k in (0, 1):
+            c = _pair_gemm(dev, torch.eye(n), B, a_m, b_k)
+            assert float(((c.cpu() - B).abs() / B.clamp(min=1e-30)).max()) <= 2.0 ** -21, (a_m, b_k)
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(200, 50176, generator=g)
+    W = torch.randn(50176, 256, generator=g)
+    y1 = _pair_gemm(dev, A, W, 0, 1)
+    y2 = _pair_gemm(dev, A, W, 0, 1)
+    assert torch.equal(y1, y2)
+    ref = A.double() @ W.double()
+    assert float((y1.cpu().double() - ref).abs().max() / ref.abs().max()) < 3e-5
+
+
+def test_pair_gemm_batched(dev):
+    from cim_amd.ops import pair
+    g = torch.Generator().manual_seed(5)
+    nb, M, N, K = 11, 300, 264, 96
+    A = torch.randn(nb, M, K, generator=g) * torch.exp2(torch.arange(nb).float() - 5)[:, None, None]
+    B = torch.randn(nb, K, N, generator=g)
+    ref = A.double() @ B.double()
+    amax = torch.stack([a.abs().max() for a in A]).to(dev).view(torch.int32)
+    sa = pair.scales_from(amax, nb)                                              # one scale per batch entry
+    pa = pair.split(A.to(dev), M, K, K, batch=nb, x_bs=M * K, scale=sa)
+    pb = pair.split(B.to(dev), K, N, N, batch=nb, x_bs=K * N)
+    c = pair.gemm(pa, pb, M, N, K, False, False)
+    scale = A.double().abs() @ B.double().abs()
+    assert float(((c.cpu().double() - ref).abs() / scale).max()) < 2e-6
+    # the same images contracted the other way: C2[b] = A[b]^T . A[b]  (A as the M-contiguous AND the N-contiguous operand)
+    c2 = pair.gemm(pa, pa, K, K, pair.pad32(M), True, False)
+    ref2 = A.double().transpose(1, 2) @ A.double()
+    scale2 = A.double().abs().transpose(1, 2) @ A.double().abs()
+    assert float(((c2.cpu().double() - ref2).abs() / scale2).max()) < 2e-6
+
+
+@pytest.mark.parametrize("K", [2048, 50176])
+def test_pair_engine_error_class(dev, K):
+    """One scale per matrix: on unit-variance data and on data with exponents spread over 2^+-10 the engine sits in the
+    error class of the f32-multiply MFMA engine (componentwise scale sum |a||b|)."""
+    from cim_amd.ops import gemm as G
+    from cim_amd import _lib
+    g = torch.Generator().manual_seed(K)
+    M = N = 256
+    for spread in (0.0, 10.0):
+        A, B = _operands(M, N, K, 0, 0, g, spread)
+        ref = A.double() @ B.double()
+        scale = A.double().abs() @ B.double().abs()
+        c = _pair_gemm(dev, A, B, 0, 0)
+        err_pair = float(((c.cpu().double() - ref).abs() / scale).max())
+        saved = _lib.call("cim_gemm_get_engine")
+        _lib.call("cim_gemm_set_engine", 0)
+        c32 = torch.empty(M, N, device=dev)
+        splits = _lib.call("cim_gemm_f32_splits", M, N, K)
+        ws = torch.empty(splits * M * N, device=dev)
+        _lib.call("cim_gemm_f32", A.to(dev).data_ptr(), B.to(dev).data_ptr(), c32.data_ptr(), None, M, N, K, K, N, N, 0, 0, 0,
+                  splits, ws.data_ptr(), _lib.stream_ptr())
+        _lib.call("cim_gemm_set_engine", saved)
+        err_f32 = float(((c32.cpu().double() - ref).abs() / scale).max())
+        assert err_pair < 2e-6 and err_pair < 2.0 * err_f32 + 1e-7, (spread, err_pair, err_f32)
+
+
+def test_pair_small_elements_keep_absolute_accuracy(dev):
+    """Elements far below the matrix maximum fall into fp16's subnormal range: absolute accuracy 2^-39 of the maximum."""
+    g = torch.Generator().manual_seed(3)
+    M = N = 256
+    K = 64
+    A = torch.randn(M, K, generator=g)
+    A[:, 1:] *= 2.0 ** -20
+    B = torch.randn(K, N, generator=g)
+    ref = A.double() @ B.double()
+    c = _pair_gemm(dev, A, B, 0, 0)
+    # the large products carry the split's relative error (dropped l*l term <= 2^-22 |a b|), the 2^-20-scaled elements an
+    # ABSOLUTE error of 2^-38 max |A| each - not a relative one
+    big = float((A[:, :1].double().abs() @ B[:1].double().abs()).max())
+    bound = 2.0 ** -21 * big + K * float(A.abs().max()) * 2.0 ** -38 * float(B.abs().max())
+    assert float((c.cpu().double() - ref).abs().max()) < bound
+    small = (A[:, 1:].double() @ B[1:].double())                     # the small elements' own contribution survives
+    got_small = c.cpu().double() - A[:, :1].double() @ B[:1].double()
+    assert float((got_small - small).abs().max()) < bound
+
+
+# ---- producers that write pair images directly (winograd.hip) against the fp32 transforms -----------------------------
+def _close_to(d, ref, floor):
+    """decoded image vs the fp32 kernel's output: 22 bits relative to the element, `floor` (2^-38 of the position's scale
+    bound) below that, plus the fp32 rounding of the transform itself (the two kernels may contract FMAs differently:
+    relative to the position's largest value, not to a cancelled element)."""
+    ref = ref.astype(np.float64)
+    big = np.abs(ref).reshape(ref.shape[0], -1).max(axis=1).reshape((-1,) + (1,) * (ref.ndim - 1))
+    bad = np.abs(d - ref) > np.abs(ref) * 2.0 ** -21 + floor + 1e-6 * big
+    assert not bad.any(), (int(bad.sum()), float(np.abs(d - ref).max()))
+
+
+def test_wino7_pair_producers_match_fp32_transforms(dev):
+    from cim_amd import _lib
+    from cim_amd.ops import pair
+    st = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(11)
+    R, C, Co = 37, 64, 128
+    Rs = pair.pad32(R)
+    x = torch.randn(R, 7, 7, C, generator=g).to(dev)
+    amax = x.abs().max().reshape(1).view(torch.int32)
+    # input transform
+    V = torch.empty(121, R, C, device=dev)
+    _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), R, 7, C, 7, st)
+    sc = torch.empty(121, device=dev)
+    _lib.call("cim_wino7_pair_scales", amax.data_ptr(), 0, sc.data_ptr(), st)
+    Vp = pair.Pair(torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev), R, C, 121, sc)
+    _lib.call("cim_wino7_input_pair", x.data_ptr(), Vp.buf.data_ptr(), sc.data_ptr(), R, Rs, C, st)
+    d = _decode(Vp)
+    assert np.all(d[:, R:, :] == 0.0)
+    assert float((V.abs().amax(dim=(1, 2)) * sc).max()) < 2.0 ** 15          # the bound holds at every position
+    floor = (2.0 ** -38 * 2.0 ** 15 / sc.cpu().numpy().astype(np.float64))[:, None, None]
+    _close_to(d[:, :R, :], V.cpu().numpy(), floor)
+    # dy transforms (weight gradient and adjoint data gradient)
+    for adj, kind in ((0, 2), (1, 3)):
+        D = torch.empty(121, R, C, device=dev)
+        if adj:
+            _lib.call("cim_wino_dy_adjoint_transform", x.data_ptr(), D.data_ptr(), None, R, 7, C, 7, st)
+        else:
+            _lib.call("cim_wino_dy_transform", x.data_ptr(), D.data_ptr(), R, 7, C, 7, st)
+        _lib.call("cim_wino7_pair_scales", amax.data_ptr(), kind, sc.data_ptr(), st)
+        Dp = pair.Pair(torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev), R, C, 121, sc)
+        _lib.call("cim_wino7_dy_pair", x.data_ptr(), Dp.buf.data_ptr(), sc.data_ptr(), R, Rs, C, adj, st)
+        d = _decode(Dp)
+        assert np.all(d[:, R:, :] == 0.0)
+        assert float((D.abs().amax(dim=(1, 2)) * sc).max()) < 2.0 ** 15
+        floor = (2.0 ** -38 * 2.0 ** 15 / sc.cpu().numpy().astype(np.float64))[:, None, None]
+        _close_to(d[:, :R, :], D.cpu().numpy(), floor)
+    # filter transform: U' [121][Cout][Cin] = U [121][Cin][Cout] transposed
+    w = torch.randn(Co, C, 3, 3, generator=g).to(dev)
+    U = torch.empty(121, C, Co, device=dev)
+    _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), Co, C, 0, 7, st)
+    wamax = w.abs().max().reshape(1).view(torch.int32)
+    _lib.call("cim_wino7_pair_scales", wamax.data_ptr(), 1, sc.data_ptr(), st)
+    Up = pair.Pair(torch.empty((121, Co, C), dtype=torch.int32, device=dev), Co, C, 121, sc)
+    _lib.call("cim_wino7_filter_pair", w.data_ptr(), Up.buf.data_ptr(), sc.data_ptr(), Co, C, st)
+    assert float((U.abs().amax(dim=(1, 2)) * sc).max()) < 2.0 ** 15
+    floor = (2.0 ** -38 * 2.0 ** 15 / sc.cpu().numpy().astype(np.float64))[:, None, None]
+    _close_to(_decode(Up), U.transpose(1, 2).cpu().numpy(), floor)
+
+
+def test_output_amax_and_flatten_pair(dev):
+    from cim_amd import _lib
+    from cim_amd.ops import pair
+    st = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(12)
+    R, C = 21, 128
+    Rs = pair.pad32(R)
+    M = torch.randn(121, R, C, generator=g).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    y0 = torch.empty(R, 7, 7, C, device=dev)
+    y1 = torch.empty(R, 7, 7, C, device=dev)
+    am = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.call("cim_wino_output_transform", M.data_ptr(), bias.data_ptr(), y0.data_ptr(), R, 7, C, 1, 7, st)
+    _lib.call("cim_wino7_output_amax", M.data_ptr(), bias.data_ptr(), y1.data_ptr(), R, C, 1, am.data_ptr(), st)
+    assert torch.equal(y0, y1)
+    assert float(am.view(torch.float32)) == float(y0.max())
+    sc = pair.scales_from(am, 1)
+    Xp = pair.Pair(torch.full((1, Rs, C * 49), 0x7fff7fff, dtype=torch.int32, device=dev), R, C * 49, 1, sc)
+    _lib.call("cim_flatten_chw_pair", y0.data_ptr(), Xp.buf.data_ptr(), sc.data_ptr(), R, Rs, 49, C, st)
+    flat = y0.permute(0, 3, 1, 2).reshape(R, C * 49)                       # (c, h, w) order of `.view(R, -1)` on NCHW
+    d = _decode(Xp)[0]
+    assert np.all(d[R:] == 0.0)
+    _close_to(d[:R], flat.cpu().numpy(), float(y0.max()) * 2.0 ** -38)
+
+
+@pytest.mark.parametrize("r", [37, 64])
+def test_maskfuse_pair_function_vs_per_layer_path(dev, r):
+    """The fused head Function on pair images against the per-layer f16x2 Functions (same module parameters): forward
+    values and every gradient."""
+    from cim_amd.ops import conv3x3, linear, maskfuse_pair, pair
+    from cim_amd.ops import gemm as G
+    g = torch.Generator().manual_seed(r)
+    cin, cout, h = 128, 64, 256
+    cat = torch.randn(r, cin, 7, 7, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
+    fc1, fc2 = torch.nn.Linear(cout * 49, h).to(dev), torch.nn.Linear(h, h).to(dev)
+    assert maskfuse_pair.supported(cat, conv.weight, fc1.weight, fc2.weight)
+    dy = torch.randn(r, h, generator=g).to(dev)
+    params = [conv.weight, conv.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias]
+
+    def grads(out):
+        gs = torch.autograd.grad(out, [cat] + params, dy)
+        torch.cuda.synchronize()
+        return [t.double().cpu() for t in gs]
+
+    y = conv3x3(cat, conv.weight, conv.bias, relu=True, flatten_chw=True)
+    ref = linear(linear(y, fc1.weight, fc1.bias, relu=True), fc2.weight, fc2.bias, relu=True)
+    gref = grads(ref)
+    fa = pair.amax_of(cat.detach())
+    out = maskfuse_pair.maskfuse_head(cat, conv, fc1, fc2, fa)
+    gout = grads(out)
+    assert float((out - ref).abs().max() / ref.abs().max()) < 2e-5
+    for a, b, name in zip(gout, gref, ["cat", "wc", "bc", "w1", "b1", "w2", "b2"]):
+        assert float((a - b).norm() / b.norm()) < 2e-5, name

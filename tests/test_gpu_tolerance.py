@@ -18,7 +18,7 @@ from cases import E2E, e2e_inputs, procedural_init
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 COMBOS = [("fp32", "direct"), ("fp32", "winograd7"), ("bf16x3", "direct"), ("bf16x3", "winograd7"),
-          ("f16x2", "direct"), ("f16x2", "winograd7")]
+          ("f16x2", "direct"), ("f16x2", "winograd7"), ("f16x2p", "winograd7")]
 # bounds = ~3x the values measured on MI355X (see the printed table): (loss rel., gradient rel. vs reference / vs fp32-direct)
 LOSS_TOL = 1e-5
 GRAD_TOL = 6e-3
@@ -27,7 +27,8 @@ GRAD_TOL = 6e-3
 def _set(monkeypatch, engine, algo):
     from cim_amd import _lib
     from cim_amd.ops import gemm
-    monkeypatch.setattr(gemm, "ENGINE", engine)
+    monkeypatch.setattr(gemm, "PAIR", engine == "f16x2p")      # pre-split pair images (MaskFuse's fused head Function)
+    monkeypatch.setattr(gemm, "ENGINE", "f16x2" if engine == "f16x2p" else engine)
     monkeypatch.setattr(gemm, "CONV_ALGO", algo)
     gemm.forget_weight_scales()
     _lib.call("cim_gemm_set_engine", 0 if engine == "fp32" else 1)
