@@ -66,6 +66,7 @@ SIGNATURES = {
     "cim_wino7_dy_pair": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino7_output_amax": [_P, _P, _P, c_int, c_int, c_int, _P, _P],
     "cim_flatten_chw_pair": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "cim_flatten_chw_bwd_bias": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cim_wino_input_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_flatten_chw": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_input_transform_amax": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],

@@ -271,6 +271,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    float bvj[NI];          // bias of this lane's two output columns (consumed in the epilogue)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        bvj[j] = (g.bias != nullptr && n < g.N) ? g.bias[n] : 0.0f;
+    }
     // prologue: slab 0 -> buffer 0 (waited for), slab 1 -> buffer 1 (in flight), first fragments of slab 0
     sa.issue(ak, smem, wave);
     sb.issue(bk, smem + OPER, wave);
@@ -300,65 +306,115 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
     _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i], BF[j], acc[i][j], 0, 0, 0)
 
+#if CIM_PAIR_EXP == 1
+#define PAIR_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define PAIR_PRIO(x)
+#endif
+// scheduling fences around the MFMA clusters: they help the all-K-contiguous instantiation (+1 %) and cost the ones with a
+// transposed-read operand 1.5-6 % (tools/bench_gemm_pair.py, CIM_PAIR_EXP=2 removes them everywhere)
+#if CIM_PAIR_EXP == 2
+#define PAIR_FENCE()
+#else
+#define PAIR_FENCE() if constexpr (AL == L_KC && BL == L_KC) __builtin_amdgcn_sched_barrier(0)
+#endif
+#if CIM_PAIR_EXP == 3 || CIM_PAIR_EXP == 5       /* ablation: no LDS-DMA in the loop */
+#define PAIR_ISSUE(A, B)
+#else
+#define PAIR_ISSUE(A, B) { sa.issue(ak, A, wave); sb.issue(bk, B, wave); ak += a_adv; bk += b_adv; }
+#endif
+#if CIM_PAIR_EXP == 4 || CIM_PAIR_EXP == 5       /* ablation: fragments stay in registers (MFMA only) */
+#define PAIR_READ_L(AH, AL_, BH, BL_, BUF, KS) asm volatile("" : "+v"(AH[0]), "+v"(AL_[0]), "+v"(BH[0]), "+v"(BL_[0]));
+#else
+#define PAIR_READ_L(AH, AL_, BH, BL_, BUF, KS) PAIR_READ(AH, AL_, BH, BL_, BUF, KS)
+#endif
     PAIR_READ(ah0, al0, bh0, bl0, smem, 0)
+#if CIM_PAIR_EXP == 4 || CIM_PAIR_EXP == 5
+    PAIR_READ(ah1, al1, bh1, bl1, smem, 1)
+#endif
     for (int t = 0; t < nslab; ++t) {
         const char* cur = smem + (t & 1) * SLAB;
         char* nxt = smem + ((t + 1) & 1) * SLAB;
         // first 16-k step of slab t; its second step's fragments arrive meanwhile
-        PAIR_READ(ah1, al1, bh1, bl1, cur, 1)
-        __builtin_amdgcn_sched_barrier(0);
+        PAIR_READ_L(ah1, al1, bh1, bl1, cur, 1)
+        PAIR_FENCE();
+        PAIR_PRIO(1);
         PAIR_MMA(al0, bh0);
         PAIR_MMA(ah0, bl0);
         PAIR_MMA(ah0, bh0);
-        __builtin_amdgcn_sched_barrier(0);
+        PAIR_PRIO(0);
+        PAIR_FENCE();
         // every wave holds its fragments of slab t and its share of slab t+1 has landed: slab t+1 is complete and
         // buffer t & 1 is free behind this barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 2 < nslab) {
-            sa.issue(ak, cur, wave);
-            sb.issue(bk, cur + OPER, wave);
-            ak += a_adv;
-            bk += b_adv;
-        }
+        if (t + 2 < nslab) PAIR_ISSUE(cur, cur + OPER)
         if (t + 1 < nslab) {
-            PAIR_READ(ah0, al0, bh0, bl0, nxt, 0)
+            PAIR_READ_L(ah0, al0, bh0, bl0, nxt, 0)
         }
-        __builtin_amdgcn_sched_barrier(0);
+        PAIR_FENCE();
+        PAIR_PRIO(1);
         PAIR_MMA(al1, bh1);
         PAIR_MMA(ah1, bl1);
         PAIR_MMA(ah1, bh1);
-        __builtin_amdgcn_sched_barrier(0);
+        PAIR_PRIO(0);
+        PAIR_FENCE();
     }
+#undef PAIR_READ_L
+#undef PAIR_ISSUE
+#undef PAIR_FENCE
+#undef PAIR_PRIO
 #undef PAIR_READ
 #undef PAIR_MMA
 
-    // epilogue: undo the two scales (powers of two: exact), bias, ReLU
+    // epilogue: undo the two scales (powers of two: exact), bias, ReLU.  Nothing may be in flight on the vector-memory counter
+    // when the stores start: stores count on vmcnt as well, and a load whose completion the compiler cannot prove at a
+    // control-flow join draws an s_waitcnt vmcnt(0) in front of EVERY guarded store (128 per lane, each then waiting for
+    // the previous store's acknowledgement).  So the bias is loaded above the loop and consumed here once, and full tiles
+    // take a path without per-row guards.
     const float inv = 1.0f / (g.a_scale[zb] * g.b_scale[zb]);
+    asm volatile("" : "+v"(bvj[0]), "+v"(bvj[1]));
     float* C = Cb + (size_t)zsplit * g.c_split_stride;
     const int lk = lane >> 5, l31 = lane & 31;
     unsigned amax = 0;
+    const bool relu = g.relu != 0;
+    if (m0 + BM <= g.M && n0 + BN <= g.N) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * WN + j * 32 + l31;
-        if (n >= g.N) continue;
-        const float bv = (g.bias != nullptr) ? g.bias[n] : 0.0f;
+        for (int j = 0; j < NI; ++j) {
+            float* cj = C + (size_t)(m0 + wm * WM + 4 * lk) * g.ldc + n0 + wn * WN + j * 32 + l31;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m >= g.M) continue;
-                float v = acc[i][j][r] * inv + bv;
-                if (g.relu) v = fmaxf(v, 0.0f);
-                amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
-                C[(size_t)m * g.ldc + n] = v;
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * inv + bvj[j];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
+                    cj[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc] = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WN + j * 32 + l31;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (m >= g.M) continue;
+                    float v = acc[i][j][r] * inv + bvj[j];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
+                    C[(size_t)m * g.ldc + n] = v;
+                }
             }
         }
     }
     if (g.c_amax != nullptr && g.c_split_stride == 0) {
         amax = wave_max_u32(amax);
-        if (lane == 0 && amax != 0) atomicMax(g.c_amax, amax);
+        if (lane == 0) cim::amax_publish(g.c_amax, amax);
     }
 }
 
@@ -389,7 +445,7 @@ __global__ __launch_bounds__(256) void pair_splitk_reduce_kernel(const float* __
     }
     if (c_amax != nullptr) {
         am = wave_max_u32(am);
-        if ((threadIdx.x & 63) == 0 && am != 0) atomicMax(c_amax, am);
+        if ((threadIdx.x & 63) == 0) cim::amax_publish(c_amax, am);
     }
 }
 
@@ -447,7 +503,7 @@ __global__ __launch_bounds__(256) void pair_amax_kernel(const float* __restrict_
         m = max(m, max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
     }
     m = wave_max_u32(m);
-    if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) cim::amax_publish(out, m);
 }
 
 template <int AL, int BL>

@@ -659,55 +659,53 @@ __global__ __launch_bounds__(256) void wino7_input_pair_kernel(const float* __re
 }
 
 // Filter transform into a pair image U' [121][Cout][Cin] (ci contiguous: the B operand of the forward product read
-// K-contiguously, of the data gradient read N-contiguously).  One thread = (co, 8 consecutive ci): 72 contiguous floats in,
-// one 32-byte chunk out per position.
+// K-contiguously, of the data gradient read N-contiguously).  One lane = one (co, ci), lanes along ci (a wave reads 64 x 36
+// contiguous bytes of W); the 8 lanes of a chunk exchange their packed (h, l) halves through two ds_bpermute so that lane j
+// stores word j of the chunk [h0h1 h2h3 h4h5 h6h7 | l0l1 l2l3 l4l5 l6l7] - 4 bytes per lane at the fp32 tensor's byte offset,
+// 256 contiguous bytes per wave.  (The first version - one thread per chunk, 72 floats in, two 16-byte stores out per
+// position - ran 0.60 ms: its loads touched 64 cache lines per instruction.)
 template <int KA, int KB>
-__device__ __forceinline__ void w7_filter_pair_tile(const float (&w)[8][3][3], float* __restrict__ U, size_t KN, size_t idx8,
-                                                    const float* __restrict__ scale) {
+__device__ __forceinline__ void w7_filter_pair_tile(const float (&w)[3][3], float* __restrict__ U, size_t KN, size_t idx,
+                                                    const float* __restrict__ scale, int src_a, int src_b, bool lo_half) {
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], Q0 = W7::QOFF[KA * 2 + KB];
+    float t[NA][3];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        float t[8][3];
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+        for (int b = 0; b < 3; ++b) t[i][b] = W7_G[KA][i][0] * w[0][b] + W7_G[KA][i][1] * w[1][b] + W7_G[KA][i][2] * w[2][b];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) t[e][b] = W7_G[KA][i][0] * w[e][0][b] + W7_G[KA][i][1] * w[e][1][b] + W7_G[KA][i][2] * w[e][2][b];
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const float s = scale[Q0 + i * NB + j];
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (t[e][0] * W7_G[KB][j][0] + t[e][1] * W7_G[KB][j][1] + t[e][2] * W7_G[KB][j][2]) * s;
-            unsigned hh[4], ll[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cim::pair_split2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
-            const w7_u4 h = {hh[0], hh[1], hh[2], hh[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
-            float* d = U + (size_t)(Q0 + i * NB + j) * KN + idx8;
-            __builtin_nontemporal_store(h, reinterpret_cast<w7_u4*>(d));
-            __builtin_nontemporal_store(l, reinterpret_cast<w7_u4*>(d + 4));
+            const float v = (t[i][0] * W7_G[KB][j][0] + t[i][1] * W7_G[KB][j][1] + t[i][2] * W7_G[KB][j][2]) * scale[Q0 + i * NB + j];
+            unsigned h, l;
+            cim::pair_split2(v, 0.0f, h, l);
+            const unsigned mine = (h & 0xffffu) | (l << 16);                                  // (h, l) of this lane's element
+            const unsigned pa = (unsigned)__builtin_amdgcn_ds_bpermute(src_a, (int)mine);   // elements 2 (j & 3), 2 (j & 3) + 1
+            const unsigned pb = (unsigned)__builtin_amdgcn_ds_bpermute(src_b, (int)mine);
+            const unsigned word = lo_half ? ((pa & 0xffffu) | (pb << 16)) : ((pa >> 16) | (pb & 0xffff0000u));
+            __builtin_nontemporal_store(word, reinterpret_cast<unsigned*>(U + (size_t)(Q0 + i * NB + j) * KN + idx));
         }
-    }
 }
 
 __global__ __launch_bounds__(256) void wino7_filter_pair_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
                                                                 int Cin, const float* __restrict__ scale) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // (co, ci / 8)
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // (co, ci), ci fastest; Cin % 8 == 0: chunks never straddle rows
     const size_t KN = (size_t)Cout * Cin;
-    if (idx * 8 >= KN) return;
-    const float* g = W + idx * 72;
-    float w[8][3][3];
+    const bool live = idx < KN;
+    const float* g = W + (live ? idx : 0) * 9;
+    float w[3][3];
 #pragma unroll
-    for (int q = 0; q < 18; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(g + q * 4);
-        (&w[0][0][0])[q * 4 + 0] = v.x;
-        (&w[0][0][0])[q * 4 + 1] = v.y;
-        (&w[0][0][0])[q * 4 + 2] = v.z;
-        (&w[0][0][0])[q * 4 + 3] = v.w;
-    }
-    w7_filter_pair_tile<0, 0>(w, U, KN, idx * 8, scale);
-    w7_filter_pair_tile<0, 1>(w, U, KN, idx * 8, scale);
-    w7_filter_pair_tile<1, 0>(w, U, KN, idx * 8, scale);
-    w7_filter_pair_tile<1, 1>(w, U, KN, idx * 8, scale);
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) w[a][b] = live ? g[a * 3 + b] : 0.0f;
+    const int lane = threadIdx.x & 63, j = lane & 7;
+    const int src_a = ((lane & ~7) + 2 * (j & 3)) * 4, src_b = src_a + 4;
+    if (!live) return;               // (KN is a multiple of 8 and idx is chunk-aligned per 8 lanes: whole chunks leave together)
+    w7_filter_pair_tile<0, 0>(w, U, KN, idx, scale, src_a, src_b, j < 4);
+    w7_filter_pair_tile<0, 1>(w, U, KN, idx, scale, src_a, src_b, j < 4);
+    w7_filter_pair_tile<1, 0>(w, U, KN, idx, scale, src_a, src_b, j < 4);
+    w7_filter_pair_tile<1, 1>(w, U, KN, idx, scale, src_a, src_b, j < 4);
 }
 
 template <int KA, int KB>
@@ -800,7 +798,7 @@ __global__ __launch_bounds__(256) void wino7_output_kernel(const float* __restri
     if (y_amax != nullptr) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-        if ((threadIdx.x & 63) == 0 && ymax > 0.0f) atomicMax(y_amax, __float_as_uint(ymax));
+        if ((threadIdx.x & 63) == 0) cim::amax_publish(y_amax, __float_as_uint(ymax));
     }
 }
 
@@ -1066,9 +1064,11 @@ __global__ __launch_bounds__(256) void wino7_bound_kernel(const unsigned* __rest
 // (dy = dflat^T * (y > 0)): one pass each instead of a strided copy + compare + multiply.
 // Workgroup = (ROI, 64-channel chunk), staged through a [PP][65] LDS tile: both global sides are contiguous runs
 // (256 B along C, 64 * PP floats along (c, p)).
+// bsum (backward, optional): [R][C] per-ROI sums over the PP pixels of the masked gradient - the conv's bias gradient is
+// their sum over R (one small deterministic reduce instead of a pass over the 200 MB gradient).
 template <bool FWD>
 __global__ __launch_bounds__(256) void flatten_chw_kernel(const float* __restrict__ src, const float* __restrict__ y,
-                                                          float* __restrict__ dst, int PP, int C) {
+                                                          float* __restrict__ dst, int PP, int C, float* __restrict__ bsum) {
     __shared__ float t[64][65];
     const int r = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
     const size_t base = (size_t)r * PP * C;
@@ -1088,11 +1088,19 @@ __global__ __launch_bounds__(256) void flatten_chw_kernel(const float* __restric
             t[p][c] = src[base + (size_t)c0 * PP + e];
         }
         __syncthreads();
+        float part = 0.0f;
         for (int e = tid; e < PP * 64; e += 256) {
             const int p = e >> 6, c = e & 63;
             const size_t o = base + (size_t)p * C + c0 + c;
-            const float v = t[p][c];
-            dst[o] = (y == nullptr || y[o] > 0.0f) ? v : 0.0f;
+            const float v = (y == nullptr || y[o] > 0.0f) ? t[p][c] : 0.0f;
+            dst[o] = v;
+            part += v;                       // this thread's channel is tid & 63 in every iteration
+        }
+        if (bsum != nullptr) {
+            __syncthreads();
+            t[tid >> 6][tid & 63] = part;
+            __syncthreads();
+            if (tid < 64) bsum[(size_t)r * C + c0 + tid] = (t[0][tid] + t[1][tid]) + (t[2][tid] + t[3][tid]);
         }
     }
 }
@@ -1228,8 +1236,8 @@ extern "C" int cim_flatten_chw(const float* src, const float* relu_y, float* dst
                                void* stream) {
     CIM_CHECK_ARG(src && dst && R > 0 && PP > 0 && PP <= 64 && C > 0 && C % 64 == 0 && R <= 2147483647 / 1 && C / 64 <= 65535);
     CIM_CHECK_ARG(backward || relu_y == nullptr);
-    if (backward) hipLaunchKernelGGL(flatten_chw_kernel<false>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C);
-    else hipLaunchKernelGGL(flatten_chw_kernel<true>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C);
+    if (backward) hipLaunchKernelGGL(flatten_chw_kernel<false>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C, (float*)nullptr);
+    else hipLaunchKernelGGL(flatten_chw_kernel<true>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C, (float*)nullptr);
     CIM_CHECK_LAUNCH();
     return 0;
 }
@@ -1271,7 +1279,7 @@ extern "C" int cim_wino7_input_pair(const float* x, void* V, const float* scale,
 
 extern "C" int cim_wino7_filter_pair(const float* W, void* U, const float* scale, int Cout, int Cin, void* stream) {
     CIM_CHECK_ARG(W && U && scale && Cout > 0 && Cin > 0 && Cin % 8 == 0);
-    const size_t n = (size_t)Cout * (Cin / 8);
+    const size_t n = (size_t)Cout * Cin;
     hipLaunchKernelGGL(wino7_filter_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W,
                        (float*)U, Cout, Cin, scale);
     CIM_CHECK_LAUNCH();
@@ -1297,6 +1305,14 @@ extern "C" int cim_wino7_output_amax(const float* M, const float* bias, float* y
 extern "C" int cim_flatten_chw_pair(const float* src, void* dst, const float* scale, int R, int Rs, int PP, int C, void* stream) {
     CIM_CHECK_ARG(src && dst && scale && R > 0 && Rs >= R && PP > 0 && PP <= 64 && C > 0 && C % 64 == 0 && C / 64 <= 65535);
     hipLaunchKernelGGL(flatten_chw_pair_kernel, dim3(Rs, C / 64), dim3(256), 0, cim::as_stream(stream), src, (float*)dst, R, PP, C, scale);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_flatten_chw_bwd_bias(const float* src, const float* relu_y, float* dst, float* bias_partial, int R, int PP,
+                                        int C, void* stream) {
+    CIM_CHECK_ARG(src && dst && R > 0 && PP > 0 && PP <= 64 && C > 0 && C % 64 == 0 && C / 64 <= 65535);
+    hipLaunchKernelGGL(flatten_chw_kernel<false>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C, bias_partial);
     CIM_CHECK_LAUNCH();
     return 0;
 }

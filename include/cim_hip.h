@@ -369,6 +369,10 @@ int cim_wino7_filter_pair(const float* W, void* U, const float* scale, int Cout,
 int cim_wino7_dy_pair(const float* dy, void* D, const float* scale, int R, int Rs, int C, int adjoint, void* stream);
 int cim_wino7_output_amax(const float* M, const float* bias, float* y, int R, int C, int relu, uint32_t* y_amax, void* stream);
 int cim_flatten_chw_pair(const float* src, void* dst, const float* scale, int R, int Rs, int PP, int C, void* stream);
+/* cim_flatten_chw(backward = 1) that also writes bias_partial [R][C] = sum over the PP pixels of the masked gradient (the
+ * conv's bias gradient is its sum over R); bias_partial may be NULL */
+int cim_flatten_chw_bwd_bias(const float* src, const float* relu_y, float* dst, float* bias_partial, int R, int PP, int C,
+                             void* stream);
 
 /* Winograd F(2x2,3x3) evaluation of the same 3x3 / stride 1 / pad 1 convolution (fp32 throughout,
  * 1.72x fewer multiplies at P = 7): T = ceil(P/2) tiles per side, 16 transform positions.

@@ -25,6 +25,17 @@ args = ap.parse_args()
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
+# ablation / variant builds of the library next to the product one (python -m cim_amd.build --out=cim_amd/libcim_hip_alt<tag>.so
+# with CIM_HIPCC_FLAGS=-DCIM_PAIR_EXP=n): their pair GEMMs are timed in the same interleaved rounds
+import ctypes
+import glob
+alts = {}
+for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):
+    a = ctypes.CDLL(path)
+    for name, argt in _lib.SIGNATURES.items():
+        getattr(a, name).argtypes = argt
+        getattr(a, name).restype = ctypes.c_int
+    alts[os.path.basename(path)[len("libcim_hip_alt"):-3]] = a
 st = torch.cuda.current_stream().cuda_stream
 N, C, NPOS = args.n, 1024, 121
 NP = pair.pad32(N)
@@ -85,6 +96,11 @@ cases["pair fc1_fwd    (KC x KC)"] = (lambda: lib.cim_gemm_pair(P(pX.buf), P(pW.
 cases["pair fc1_dgrad  (KC x MC)"] = (lambda: lib.cim_gemm_pair(P(pY.buf), P(pW.buf), P(dx1), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, 1, None, P(pY.scale), P(pW.scale), None, st), fl_fc)
 cases["pair fc1_wgrad  (MC x MC)"] = (lambda: lib.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, st), fl_fc)
 cases["split V (generic producer)"] = (lambda: lib.cim_pair_split(P(V), P(pV.buf), NP, NP, 2 * C, 2 * C, 2 * C, NPOS, NP * 2 * C, pV.bs, P(pV.scale), None, st), 0.0)
+for tag, al in alts.items():
+    cases["%-4s wino_fwd" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pV.buf), P(pU.buf), P(M), N, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, pV.bs, pU.bs, N * C, P(pV.scale), P(pU.scale), st), fl_conv)
+    cases["%-4s wino_dgrad" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pD.buf), P(pU.buf), P(M2), N, 2 * C, C, C, C, 2 * C, 0, 1, NPOS, pD.bs, pU.bs, N * 2 * C, P(pD.scale), P(pU.scale), st), fl_conv)
+    cases["%-4s wino_wgrad" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pV.buf), P(pD.buf), P(dU), 2 * C, C, NP, 2 * C, C, C, 1, 0, NPOS, pV.bs, pD.bs, 2 * C * C, P(pV.scale), P(pD.scale), st), fl_conv)
+    cases["%-4s fc1_fwd" % tag] = (lambda al=al: al.cim_gemm_pair(P(pX.buf), P(pW.buf), P(y1), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), P(ws), P(pX.scale), P(pW.scale), None, st), fl_fc)
 if not args.no_old:
     Vr, Vc = _amax(V, NP, 2 * C, 2 * C, True, True, NPOS, NP * 2 * C)
     _, Uc = _amax(U, 2 * C, C, C, False, True, NPOS, 2 * C * C)
