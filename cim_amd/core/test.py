@@ -104,39 +104,61 @@ def im_detect_bbox_aug(model, im, box_proposals=None, masks=None, mat=None, path
     assert not _aug_cfg("SCALE_SIZE_DEP"), "Size dependent scaling not implemented"
     if len(_aug_cfg("ASPECT_RATIOS")):
         raise NotImplementedError("aspect-ratio augmentation (no shipped config uses it)")
-    heur = _aug_cfg("SCORE_HEUR")
-    if heur not in ("ID", "AVG", "UNION") or _aug_cfg("COORD_HEUR") != "ID":
-        raise NotImplementedError("SCORE_HEUR %s / COORD_HEUR %s" % (heur, _aug_cfg("COORD_HEUR")))
+    heur, coord = _aug_cfg("SCORE_HEUR"), _aug_cfg("COORD_HEUR")
+    # test.py:154-160: the two heuristics are UNION together or not at all
+    assert not heur == "UNION" or coord == "UNION", "Coord heuristic must be union whenever score heuristic is union"
+    assert not coord == "UNION" or heur == "UNION", "Score heuristic must be union whenever coord heuristic is union"
+    if heur not in ("ID", "AVG", "UNION"):
+        raise NotImplementedError("Score heur {} not supported".format(heur))
+    if coord not in ("ID", "AVG", "UNION"):
+        raise NotImplementedError("Coord heur {} not supported".format(coord))
     scale0, max0 = _test_cfg("SCALE"), _test_cfg("MAX_SIZE")
-    scores_ts = []
-    plan = []                                            # (scale, max_size, [flips]) in the reference's order
+    # views in the REFERENCE's order (test.py:171-216): flipped @ SCALE, then per scale (plain, flipped), identity LAST;
+    # `order` = position of a (scale slot, flip) view in that order
+    order, views = {}, []
+    if _aug_cfg("H_FLIP"):
+        order[(-1, True)] = len(order)
+    for si, _ in enumerate(_aug_cfg("SCALES")):
+        order[(si, False)] = len(order)
+        if _aug_cfg("SCALE_H_FLIP"):
+            order[(si, True)] = len(order)
+    order[(-1, False)] = len(order)
+    plan = []                                            # (scale slot, scale, max_size, [flips]): one forward each
     if batched:
-        plan.append((scale0, max0, [True, False] if _aug_cfg("H_FLIP") else [False]))
-        for scale in _aug_cfg("SCALES"):
-            plan.append((scale, _aug_cfg("MAX_SIZE"), [False, True] if _aug_cfg("SCALE_H_FLIP") else [False]))
+        plan.append((-1, scale0, max0, [True, False] if _aug_cfg("H_FLIP") else [False]))
+        for si, scale in enumerate(_aug_cfg("SCALES")):
+            plan.append((si, scale, _aug_cfg("MAX_SIZE"), [False, True] if _aug_cfg("SCALE_H_FLIP") else [False]))
     else:
         if _aug_cfg("H_FLIP"):
-            plan.append((scale0, max0, [True]))
-        for scale in _aug_cfg("SCALES"):
-            plan.append((scale, _aug_cfg("MAX_SIZE"), [False]))
+            plan.append((-1, scale0, max0, [True]))
+        for si, scale in enumerate(_aug_cfg("SCALES")):
+            plan.append((si, scale, _aug_cfg("MAX_SIZE"), [False]))
             if _aug_cfg("SCALE_H_FLIP"):
-                plan.append((scale, _aug_cfg("MAX_SIZE"), [True]))
-        plan.append((scale0, max0, [False]))
+                plan.append((si, scale, _aug_cfg("MAX_SIZE"), [True]))
+        plan.append((-1, scale0, max0, [False]))
     scores_i = im_scale_i = blob_conv_i = None
-    for scale, max_size, flips in plan:
+    for slot, scale, max_size, flips in plan:
         scores, im_scale, blob_conv = _forward(model, im, scale, max_size, box_proposals, masks, flips, flag)
-        scores_ts.extend(scores)
-        if scale == scale0 and False in flips:           # the identity view (test.py:211-216)
-            k = flips.index(False)
-            scores_i, im_scale_i = scores[k], im_scale
-            blob_conv_i = blob_conv[k:k + 1]
+        for k, f in enumerate(flips):
+            views.append((order[(slot, f)], scores[k]))
+            if slot == -1 and not f:                     # the identity view (test.py:211-216)
+                scores_i, im_scale_i = scores[k], im_scale
+                blob_conv_i = blob_conv[k:k + 1]
+    scores_ts = [sc for _, sc in sorted(views, key=lambda v: v[0])]
     if heur == "ID":
         scores_c = scores_i
     elif heur == "AVG":
         scores_c = torch.stack(scores_ts, 0).mean(0)
     else:
         scores_c = torch.cat(scores_ts, 0)
-    return scores_c, box_proposals, im_scale_i, blob_conv_i
+    # every view scores the SAME proposals (no box regression on this path: im_detect_bbox returns the proposals), so
+    # ID and AVG give the proposals themselves and UNION repeats them once per view (np.vstack(boxes_ts), test.py:236)
+    boxes_c = box_proposals
+    if coord == "UNION" and box_proposals is not None:
+        rep = len(scores_ts)
+        boxes_c = (box_proposals.repeat(rep, 1) if torch.is_tensor(box_proposals)
+                   else np.vstack([box_proposals] * rep))
+    return scores_c, boxes_c, im_scale_i, blob_conv_i
 
 
 def im_detect_all(model, im, box_proposals=None, masks=None, mat=None, timers=None, path=None, flag=None, labels=None):

@@ -277,6 +277,37 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
         const int n = n0 + wn * WN + j * 32 + (lane & 31);
         bvj[j] = (g.bias != nullptr && n < g.N) ? g.bias[n] : 0.0f;
     }
+    // Ragged last M-tile (800 ... 1200 proposals against 256-row tiles): when the tile's second 128 rows lie past M, the
+    // four waves that own them (wm = 1) only stage their share of the operands and keep the barrier sequence - the
+    // tile then costs its four working waves' MFMA time, about half a tile.
+#if CIM_PAIR_EXP != 6
+    if (wm == 1 && m0 + WM >= g.M) {
+        if constexpr (AL == L_MC) sa.issue(ak, smem, wave);
+        sb.issue(bk, smem + OPER, wave);
+        ak += a_adv;
+        bk += b_adv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nslab > 1) {
+            if constexpr (AL == L_MC) sa.issue(ak, smem + SLAB, wave);
+            sb.issue(bk, smem + SLAB + OPER, wave);
+            ak += a_adv;
+            bk += b_adv;
+        }
+        for (int t = 0; t < nslab; ++t) {
+            const char* cur = smem + (t & 1) * SLAB;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 2 < nslab) {
+                if constexpr (AL == L_MC) sa.issue(ak, cur, wave);
+                sb.issue(bk, cur + OPER, wave);
+                ak += a_adv;
+                bk += b_adv;
+            }
+        }
+        return;
+    }
+#endif
     // prologue: slab 0 -> buffer 0 (waited for), slab 1 -> buffer 1 (in flight), first fragments of slab 0
     sa.issue(ak, smem, wave);
     sb.issue(bk, smem + OPER, wave);

@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
+from ..utils import engine
 
 _EPS = 1e-6
 
@@ -209,7 +210,7 @@ class FusedLossFunction(torch.autograd.Function):
         # when the whole backward pass has been queued: bring the host's NumPy generator to the position the
         # mining consumed (no stall: the GPU finished the mining long before the host gets here)
         if _rng.pending is not None:
-            torch.autograd.Variable._execution_engine.queue_callback(settle_rng)
+            engine.queue_callback(settle_rng)
         g_bag, g_pcl, g_cls, g_iou = g[0], g[1], g[2], g[3]
         d_pc = g_bag * G[0] + g_pcl * G[1]
         d_pd = g_bag * G[2]
@@ -390,6 +391,10 @@ class _RngLedger:
                 if used > 0:
                     np.random.random_sample(used)
             else:       # the caller re-seeded / used the generator in between: its state wins, nothing to rewind
+                if STRICT_RNG:
+                    raise _lib.CimHipError("np.random was re-seeded or used between a training forward and the end of its "
+                                           "backward pass: the run has left the reference's NumPy stream (CIM_STRICT=1; call "
+                                           "cim_amd.modeling.heads.settle_rng() right after the forward)")
                 warnings.warn("np.random was re-seeded or used between a training forward and the end of its backward "
                               "pass: the anti-noise sampling's draws are not rewound (call "
                               "cim_amd.modeling.heads.settle_rng() right after the forward to avoid this)")
@@ -397,7 +402,9 @@ class _RngLedger:
 
 
 _rng = _RngLedger()
-MINING_SYNC = os.environ.get("CIM_MINING_SYNC", "0") == "1"
+MINING_SYNC = os.environ.get("CIM_MINING_SYNC", "0") == "1" or not engine.HAS_ENGINE_CALLBACK
+# CIM_STRICT=1 (the test suite sets it): leaving the reference's NumPy stream is an error, not a warning
+STRICT_RNG = os.environ.get("CIM_STRICT", "0") == "1"
 
 
 def settle_rng():

@@ -137,9 +137,10 @@ class Generalized_RCNN(nn.Module):
         with torch.set_grad_enabled(self.training):
             im_data = data
             if self.training:
-                # (weight gradients a previous backward pass left on the side stream - only if that pass was interrupted
-                # before its end-of-backward callback: normally nothing is pending here)
-                _gemm_ops.join_side()
+                # (weight gradients a previous backward pass left on the side stream - only if that pass was ABORTED before
+                # its end-of-backward callback: normally nothing is pending here.  They are dropped, not installed: the
+                # driver's zero_grad() for this step has already run)
+                _gemm_ops.join_side(discard=True)
                 if hasattr(self.Box_Head, "prefetch"):
                     self.Box_Head.prefetch()        # the MaskFuse filter transform runs under the backbone forward
                 dev, dt = im_data.device, im_data.dtype

@@ -33,6 +33,7 @@ import torch
 import torch.distributed as dist
 
 from ...ops.gemm import join_side as _join_side, gradient_is_deferred as _gradient_is_deferred
+from ...utils import engine
 from torch import nn
 
 
@@ -60,6 +61,8 @@ class DataParallel(nn.Module):
         self.iter_size = int(os.environ.get("CIM_ITER_SIZE", "1")) if iter_size is None else int(iter_size)
         self._backwards = 0          # backward passes since zero_grad()
         self._cb_queued = False
+        self._reduced_this_step = False     # this step's buckets are reduced: a second finish_gradient_sync() is a no-op
+        self._fwd_since_step = 0            # forward calls since the last optimizer step (fallback without the engine callback)
         self.comm_works = None       # optional (bench.py): list that receives every collective's Work object
         self._early = None           # attach_optimizer(): (optimizer, early parameters, their ids, trigger count, side stream)
         self._early_seen = 0
@@ -69,12 +72,7 @@ class DataParallel(nn.Module):
 
     def _broadcast_module_state(self):
         tensors = [p.data for p in self.module.parameters()] + [b.data for b in self.module.buffers()]
-        pg = self.process_group if self.process_group is not None else dist.group.WORLD
-        by_dtype = {}
-        for t in tensors:
-            by_dtype.setdefault(t.dtype, []).append(t)
-        for group in by_dtype.values():
-            dist._broadcast_coalesced(pg, group, 256 << 20, 0)
+        engine.broadcast_coalesced(tensors, 0, self.process_group)
 
     # ------------------------------------------------------------------ flat gradient storage
     def _build_flat_grads(self, bucket_bytes):
@@ -94,13 +92,14 @@ class DataParallel(nn.Module):
         # reverse registration order ~ order in which backward produces gradients
         off = 0
         spans = []
+        self._view_of = {}
         for p in reversed(params):
             if p in big:
                 p.grad = None
                 spans.append((p, None, None))
                 continue
             n = p.numel()
-            p.grad = self.flat_grad[off:off + n].view_as(p)
+            p.grad = self._view_of[p] = self.flat_grad[off:off + n].view_as(p)
             spans.append((p, off, off + n))
             off += (n + 3) & ~3      # 16-byte aligned views: float4 accesses / matrix mode of the fused SGD stay enabled
         # buckets, in the order the collectives are issued: a big tensor (seg_fc.0: 822 MB) is its own bucket, issued where it
@@ -139,6 +138,19 @@ class DataParallel(nn.Module):
         if self.world_size > 1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
+            if not engine.HAS_ENGINE_CALLBACK:
+                # no engine callback (see cim_amd/utils/engine.py): the public-API form of "finish the reduction" is a global
+                # optimizer-step pre-hook - whatever the gradient hooks have not reduced is reduced (and waited for) right
+                # before ANY optimizer.step(); backward passes are counted by the forward calls since the last step
+                from torch.optim.optimizer import register_optimizer_step_pre_hook
+                self._step_hook = register_optimizer_step_pre_hook(lambda opt, args, kwargs: self._before_optimizer_step())
+
+    def _before_optimizer_step(self):
+        self._cb_queued = False
+        if self.world_size > 1 and self._sync and not self._reduced_this_step:
+            self.finish_gradient_sync()
+        self._reduced_this_step = False
+        self._fwd_since_step = 0
 
     # ------------------------------------------------------------------ optimizer step overlapped with the backward pass
     def attach_optimizer(self, optimizer, early_modules=("Box_Head", "cls_iou_model")):
@@ -148,7 +160,7 @@ class DataParallel(nn.Module):
         cfg2) then runs on a side stream under the ROIAlign and backbone backward (latency-bound small launches).
         `optimizer.step()` stays where the driver calls it (tools/train.py:438) and updates the rest.
         Needs cim_amd.optim.SGD (step_early); any other optimizer is left alone."""
-        if not hasattr(optimizer, "step_early") or self.device.type != "cuda":
+        if not hasattr(optimizer, "step_early") or self.device.type != "cuda" or not engine.HAS_ENGINE_CALLBACK:
             return False
         params = []
         for name in early_modules:
@@ -187,13 +199,17 @@ class DataParallel(nn.Module):
         opt.step_early(params, side)
 
     def _sync_this_backward(self):
+        if not engine.HAS_ENGINE_CALLBACK:        # (backward passes cannot be counted without the engine callback)
+            return self._sync and self._fwd_since_step % max(self.iter_size, 1) == 0
         return self._sync and (self._backwards + 1) % max(self.iter_size, 1) == 0
 
     def _on_grad_ready(self, p):
         if not self._cb_queued:       # first gradient of this backward pass: finish the reduction when the pass ends
             self._cb_queued = True
             self._early_seen = 0
-            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            self._reduced_this_step = False
+            if engine.HAS_ENGINE_CALLBACK:
+                engine.queue_callback(self._end_of_backward)
         if self.world_size == 1:
             self._maybe_step_early(p)
             return
@@ -205,8 +221,13 @@ class DataParallel(nn.Module):
         bk["ready"] += 1
         if "tensor" not in bk and (p.grad.data_ptr() < self.flat_grad.data_ptr() or
                                    p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * 4):
-            raise RuntimeError("DataParallel: a .grad was replaced (use zero_grad(set_to_none=False) / "
-                               "DataParallel.zero_grad())")
+            # the driver dropped the flat view (optimizer.zero_grad() defaults to set_to_none=True - the reference loop,
+            # tools/train.py:418-438, calls exactly that): autograd produced a fresh tensor.  Move it into the view (it
+            # REPLACES the view's content: whatever the previous step left there) and bind the view again, so the bucket is
+            # reduced in place and later backward passes of an accumulation accumulate into the flat buffer.
+            view = self._view_of[p]
+            view.copy_(p.grad)
+            p.grad = view
         self._launch_ready_buckets()
         self._maybe_step_early(p)
 
@@ -219,6 +240,7 @@ class DataParallel(nn.Module):
             # their hooks never fire, so the bucket that holds them is only ever launched here, at the end of the backward
             # pass - after the join that adds them into the flat gradient views
             _join_side()
+            self._rebind_views()
         while self._next_bucket < len(self.buckets):
             bk = self.buckets[self._next_bucket]
             if not force and bk["ready"] < len(bk["params"]):
@@ -236,6 +258,18 @@ class DataParallel(nn.Module):
             self._all_reduce_mean(buf)
             self._next_bucket += 1
 
+    def _rebind_views(self):
+        """Gradients that arrived as fresh tensors instead of in the flat views - the driver dropped the views
+        (optimizer.zero_grad(set_to_none=True)) and either the backward passes so far did not communicate (iter_size > 1)
+        or the gradient was installed by join_side() - move into their views before the flat buckets are reduced."""
+        lo = self.flat_grad.data_ptr()
+        hi = lo + self.flat_grad.numel() * 4
+        for p, view in self._view_of.items():
+            g = p.grad
+            if g is not None and not (lo <= g.data_ptr() < hi):
+                view.copy_(g)
+                p.grad = view
+
     def _all_reduce_mean(self, buf):
         if self._avg_op is None:
             self._avg_op = dist.get_backend(self.process_group) == "nccl"
@@ -252,6 +286,7 @@ class DataParallel(nn.Module):
         self._cb_queued = False
         if self.world_size > 1 and self._sync_this_backward():
             self.finish_gradient_sync()
+            self._reduced_this_step = True
         self._backwards += 1
 
     def zero_grad(self, set_to_none=False):
@@ -261,6 +296,8 @@ class DataParallel(nn.Module):
             raise RuntimeError("DataParallel.zero_grad(): gradient all-reduces of the previous backward are still in "
                                "flight (a backward pass was interrupted?) - call finish_gradient_sync() first")
         self._backwards = 0
+        self._reduced_this_step = False
+        self._cb_queued = False             # (a backward pass that was aborted before the engine's callbacks ran leaves it set)
         if self.flat_grad is None:
             for p in self._params:
                 p.grad = None
@@ -282,8 +319,8 @@ class DataParallel(nn.Module):
         """Reduce whatever has not been reduced yet (in bucket order) and wait for the in-flight
         all-reduces.  Runs by itself at the end of every backward pass that
         communicates (`_end_of_backward`); calling it again is a no-op."""
-        if self.world_size > 1 and self._sync and (self._next_bucket or any(bk["ready"] for bk in self.buckets)
-                                                   or not self._cb_queued):
+        if self.world_size > 1 and self._sync and not self._reduced_this_step and (
+                self._next_bucket or any(bk["ready"] for bk in self.buckets) or not self._cb_queued):
             self._launch_ready_buckets(force=True)
         for w, buf in self._pending:
             w.wait()
@@ -306,6 +343,7 @@ class DataParallel(nn.Module):
         return v.to(self.device, non_blocking=True)
 
     def forward(self, *inputs, **kwargs):
+        self._fwd_since_step += 1
         if self.minibatch:
             # the reference passes one list entry per local GPU; this process owns exactly one
             inputs = [x[0] if isinstance(x, (list, tuple)) else x for x in inputs]

@@ -13,6 +13,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from ..utils import engine
 
 
 def _ws(m, n, splits, like):
@@ -131,13 +132,14 @@ def _side_stream(dev):
 # at the start of SGD.step / before DataParallel reduces a bucket).  Buffers the side work reads or writes (saved
 # activations, workspaces) are kept referenced here until that join, so the caching allocator cannot hand them out.
 # The deferred gradients do not travel through autograd (see defer_side_join): join_side() installs them as param.grad, or
-# adds them to an existing one (iter_size > 1, DataParallel's flat views) after the join.  Consequences: per-parameter
-# autograd hooks do not fire for these weights - DataParallel, which counts ready gradients per bucket through such hooks,
-# launches the bucket that holds them at the end of the backward pass, after calling join_side() itself - and
-# torch.autograd.grad() with such a weight among its inputs does not see the gradient (use .backward(), or CIM_DEFER_DW=0).
+# adds them to an existing one (iter_size > 1, DataParallel's flat views) after the join.  Consequences: a weight's
+# post-accumulate-grad hooks fire at the layer's backward although nothing was accumulated yet (gradient_is_deferred() tells) -
+# DataParallel, which counts ready gradients per bucket through such hooks, skips them and launches the bucket that holds
+# them at the end of the backward pass, after calling join_side() itself - and torch.autograd.grad() with such a weight
+# among its inputs does not see the gradient (use .backward(), or CIM_DEFER_DW=0).
 # Measured at cfg2: 17.33 -> 16.62 ms per step.  Deferring the MaskFuse layers' weight gradients as well (fc1, fc2, the
 # Winograd convolution: they already run beside their layer's data gradient) changed nothing: 16.71 ms.
-DEFER_DW = OVERLAP and os.environ.get("CIM_DEFER_DW", "1") == "1"
+DEFER_DW = OVERLAP and os.environ.get("CIM_DEFER_DW", "1") == "1" and engine.HAS_ENGINE_CALLBACK
 _DEFERRED = {}        # device -> [main stream, [(param, dw)], [tensors kept alive]]
 _PENDING_IDS = set()  # id(param) of the weights whose gradient is still on the side stream
 
@@ -164,15 +166,18 @@ def defer_side_join(dev, param, dw, *keep):
     ent = _DEFERRED.get(dev)
     if ent is None or not (ent[1] or ent[2]):
         ent = _DEFERRED[dev] = [torch.cuda.current_stream(dev), [], []]
-        torch.autograd.Variable._execution_engine.queue_callback(join_side)
+        engine.queue_callback(join_side)
     ent[1].append((param, dw))
     ent[2].extend(keep)
     _PENDING_IDS.add(id(param))
 
 
-def join_side():
+def join_side(discard=False):
     """Make the stream the backward ran on wait for the deferred side-stream work, install the weight gradients, release
-    the kept buffers.  Runs as an autograd-engine callback at the end of the backward pass."""
+    the kept buffers.  Runs as an autograd-engine callback at the end of the backward pass.
+    discard=True (the safety join at the start of a training forward): whatever is still pending belongs to a backward
+    pass that was ABORTED (an exception before the engine's callbacks ran) - the streams are joined, but its gradients
+    are dropped instead of being installed into the new step's `.grad`."""
     for dev, ent in list(_DEFERRED.items()):
         if ent[1] or ent[2]:
             ent[0].wait_stream(_side_stream(dev))
@@ -181,12 +186,15 @@ def join_side():
                 cur.wait_stream(_side_stream(dev))
             with torch.no_grad():
                 for param, dw in ent[1]:
-                    if param.grad is None:
-                        param.grad = dw
-                    else:
-                        param.grad += dw
+                    if not discard:
+                        if param.grad is None:
+                            param.grad = dw
+                        else:
+                            param.grad += dw
                     _PENDING_IDS.discard(id(param))
             ent[1], ent[2] = [], []
+    if discard:
+        _PENDING_IDS.clear()
 
 
 class LinearFunction(Function):

@@ -144,6 +144,14 @@ class SGD(torch.optim.Optimizer):
         if c is not None:
             grads = [p.grad for p, _, _ in c["recs"]]
             stale = any(g is None for g in grads) or any(float(g["momentum"]) != c["momentum"] for g in self.param_groups)
+            if not stale:
+                # the cached raw pointers must still be THE tensors: load_state_dict() replaces the momentum buffers,
+                # .to() / .half() / set_() the parameter storage (one int compare per tensor)
+                tabp, tabb, state = c["tab"]["p"], c["tab"]["buf"], self.state
+                for i, (p, buf, _) in enumerate(c["recs"]):
+                    if p.data_ptr() != tabp[i] or state[p].get("momentum_buffer") is not buf or buf.data_ptr() != tabb[i]:
+                        stale = True
+                        break
             if not stale and self._check_every_step:
                 n_sel = sum(1 for g in self.param_groups for p in g["params"] if p.grad is not None and select(p))
                 stale = n_sel != len(grads)
@@ -199,6 +207,26 @@ class SGD(torch.optim.Optimizer):
             for p, ra, ca, rows, cols in slices:
                 gemm.register_weight_scales(p, rows, cols, ra, ca)
         return c["ids"]
+
+    def _invalidate(self):
+        for ps in self._passes.values():
+            ps.cache = None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._invalidate()              # new momentum-buffer tensors: the cached pointers are dead
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault("_passes", {})
+        self.__dict__.setdefault("_early", None)
+        self.__dict__.setdefault("_check_every_step", True)
+        self._invalidate()
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_passes"):
+            self._invalidate()
 
     @torch.no_grad()
     def step_early(self, params, stream):

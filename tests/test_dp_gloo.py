@@ -142,3 +142,93 @@ def test_dp_single_process_passthrough():
     torch.testing.assert_close(got, _local_grad(_data(0), 1.0))
     dp2.zero_grad()
     assert all(p.grad is None for p in dp2.module.parameters())
+
+
+# ---- the reference driver's loop, literally (tools/train.py:418-438): optimizer.zero_grad() - torch's default drops the
+# gradients (set_to_none=True), i.e. DataParallel's flat views - then iter_size x (forward, loss.backward()), optimizer.step()
+def _loop_worker(rank, world, port, out, no_engine_callback):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if no_engine_callback:
+        os.environ["CIM_NO_ENGINE_CALLBACK"] = "1"      # public-API fallbacks of cim_amd/utils/engine.py
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cim_amd.nn import DataParallel
+    from cim_amd.utils import engine
+    assert engine.HAS_ENGINE_CALLBACK == (not no_engine_callback)
+    torch.manual_seed(rank)
+    results = {}
+    for iter_size in (1, 2):
+        torch.manual_seed(rank)
+        dp = DataParallel(Tiny(), minibatch=True, bucket_bytes=64, big_bytes=100, iter_size=iter_size)
+        optimizer = torch.optim.SGD([p for p in dp.parameters() if p.requires_grad], lr=0.1, momentum=0.9)
+        for step in range(3):
+            optimizer.zero_grad()
+            for inner in range(iter_size):
+                net_outputs = dp(data=[_data(rank + 10 * inner + 100 * step)], scale=[torch.tensor(1.0 + inner)])
+                loss = net_outputs["losses"]["l"].sum()
+                loss.backward(retain_graph=True)
+            optimizer.step()
+        results[iter_size] = torch.cat([p.detach().reshape(-1) for p in dp.module.parameters()]).clone()
+        if hasattr(dp, "_step_hook"):
+            dp._step_hook.remove()
+    if rank == 0:
+        torch.save(results, out)
+    dist.destroy_process_group()
+
+
+def _loop_reference(iter_size):
+    """The same three optimizer steps in one process on the mean of the two ranks' gradients."""
+    torch.manual_seed(0)
+    m = Tiny()
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.1, momentum=0.9)
+    for step in range(3):
+        opt.zero_grad()
+        total = [torch.zeros_like(p) for p in params]
+        for rank in range(2):
+            for inner in range(iter_size):
+                out = m(_data(rank + 10 * inner + 100 * step), torch.tensor(1.0 + inner))["losses"]["l"].sum()
+                gs = torch.autograd.grad(out, params)
+                for t, g in zip(total, gs):
+                    t += g / 2
+        for p, t in zip(params, total):
+            p.grad = t
+        opt.step()
+    return torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+
+
+@pytest.mark.parametrize("no_engine_callback", [False, True])
+def test_reference_driver_loop_world2(tmp_path, no_engine_callback):
+    out = str(tmp_path / "loop.pt")
+    mp.spawn(_loop_worker, args=(2, _free_port(), out, no_engine_callback), nprocs=2, join=True)
+    got = torch.load(out)
+    for iter_size in (1, 2):
+        torch.testing.assert_close(got[iter_size], _loop_reference(iter_size), rtol=1e-5, atol=1e-6)
+
+
+def test_finish_gradient_sync_twice_is_a_noop(tmp_path):
+    """a legacy driver calling finish_gradient_sync() after a backward that already reduced must not launch the
+    buckets again (a second all-reduce of an averaged buffer is value-neutral but costs a full round - and deadlocks when
+    only some ranks do it)."""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_twice_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert torch.load(out)["launched"] == 0
+
+
+def _twice_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cim_amd.nn import DataParallel
+    torch.manual_seed(0)
+    dp = DataParallel(Tiny(), minibatch=True, bucket_bytes=64)
+    dp.zero_grad()
+    dp(data=[_data(rank)], scale=[torch.tensor(1.0)])["losses"]["l"].sum().backward()
+    dp.comm_works = []
+    if rank == 0:                 # only ONE rank calls it: with a re-launch this would hang
+        dp.finish_gradient_sync()
+    n = len(dp.comm_works)
+    dist.barrier()
+    if rank == 0:
+        torch.save({"launched": n}, out)
+    dist.destroy_process_group()

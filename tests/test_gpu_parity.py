@@ -651,6 +651,46 @@ def test_fused_sgd_matches_torch_sgd(dev):
         SGD(hip_p, lr=0.1, momentum=0.9, nesterov=True)
 
 
+def test_fused_sgd_follows_replaced_state_and_storage(dev):
+    """the fast path caches raw pointers of parameters and momentum buffers.  load_state_dict() replaces the
+    buffer tensors and `p.data = ...` the parameter storage: the next step must use the NEW tensors (as torch.optim.SGD
+    does), and state_dict() must hold the momentum that was actually applied."""
+    from cim_amd.optim import SGD
+    g = torch.Generator().manual_seed(9)
+    base = [torch.randn(300, 40, generator=g), torch.randn(1234, generator=g)]
+    ref_p = [b.clone().requires_grad_(True) for b in base]
+    hip_p = [b.clone().to(dev).requires_grad_(True) for b in base]
+    ref, hip = torch.optim.SGD(ref_p, lr=0.1, momentum=0.9), SGD(hip_p, lr=0.1, momentum=0.9)
+
+    def step():
+        for rp, hp in zip(ref_p, hip_p):
+            gr = torch.randn(rp.shape, generator=g)
+            rp.grad, hp.grad = gr.clone(), gr.clone().to(dev)
+        ref.step()
+        hip.step()
+
+    step()
+    step()
+    # checkpoint round trip with a DIFFERENT momentum (as resuming from another run would)
+    sd_r, sd_h = ref.state_dict(), hip.state_dict()
+    for sd in (sd_r, sd_h):
+        for st in sd["state"].values():
+            st["momentum_buffer"] = st["momentum_buffer"] * 0.5 + 1.0
+    ref.load_state_dict(sd_r)
+    hip.load_state_dict(sd_h)
+    step()
+    # the parameter's storage is swapped (what .to() / .half().float() round trips do)
+    for rp, hp in zip(ref_p, hip_p):
+        rp.data = rp.data.clone()
+        hp.data = hp.data.clone()
+    step()
+    for rp, hp in zip(ref_p, hip_p):
+        torch.testing.assert_close(hp.detach().cpu(), rp.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(hip.state[hp]["momentum_buffer"].cpu(), ref.state[rp]["momentum_buffer"], rtol=1e-5, atol=1e-6)
+        got = hip.state_dict()["state"]
+    assert all(torch.equal(st["momentum_buffer"], hip.state[p]["momentum_buffer"]) for st, p in zip(got.values(), hip_p))
+
+
 def test_fused_sgd_matrix_mode_hands_scales_to_the_contractions(dev):
     """Weights of >= 2^20 elements take the SGD kernel's matrix mode: same update as torch.optim.SGD, and the row / column
     max |w_new| it registers are exactly what cim_amax_rowcol computes - valid for this version of the weight only."""
