@@ -200,9 +200,11 @@ def run(args):
         fence()
         el = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt)
+            mine = torch.tensor([el], device=dev, dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)                 # each rank's own clock; the line reports the MAX (the contract)
+            state["rank_seconds"] = [float(t) for t in every]
+            el = max(state["rank_seconds"])
         assert torch.isfinite(loss), "non-finite loss in the timed region"
         return el
 
@@ -225,6 +227,7 @@ def run(args):
         dp.comm_works = []
     elapsed = timed(args.steps, iter_size=args.iter_size)          # ---- THE timed region: exactly --steps steps
     timer.enabled = False
+    rank_seconds = state.get("rank_seconds", [elapsed])
     comm_works = getattr(dp, "comm_works", None)
     dp.comm_works = None
     images = world * args.steps * args.iter_size
@@ -278,6 +281,10 @@ def run(args):
     if rank == 0:
         line = report(args, world, elapsed, images, timer, infos, state["feat"], Cf, cfg, gemm_mod, np)
         line["extra"] = extra
+        # what the process group itself reports (a SCALE run is checkable: ranks, backend, every rank's own rate)
+        line["dist"] = dict(world_size=dist.get_world_size() if world > 1 else 1, backend=(dist.get_backend() if world > 1 else None),
+                            devices=torch.cuda.device_count(),
+                            per_rank_images_per_s=[args.steps * args.iter_size / t for t in rank_seconds])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
         print(json.dumps(line))

@@ -27,10 +27,9 @@ def _coeffs(dsize, ssize, scale):
     return s, f
 
 
-def prep_image(im_bgr_u8, im_scale, hflip=False):
-    """-> float32 [3,H,W] (RGB, normalised), H, W = round-half-even(h * scale), (w * scale)."""
-    im = im_bgr_u8[:, ::-1, :] if hflip else im_bgr_u8                      # minibatch.py:121-122 / test.py:249
-    im = im.astype(f32)
+def resize_linear(im, im_scale):
+    """cv2.resize(im, None, None, fx = fy = im_scale, interpolation = INTER_LINEAR) for a float32 [h, w, c] image."""
+    im = np.asarray(im, dtype=f32)
     h, w = im.shape[:2]
     H, W = int(np.round(h * im_scale)), int(np.round(w * im_scale))         # saturate_cast<int>(ssize * inv_scale)
     scale = 1.0 / float(im_scale)                                           # scale_x = 1. / inv_scale_x
@@ -48,7 +47,13 @@ def prep_image(im_bgr_u8, im_scale, hflip=False):
     y0 = np.clip(sy, 0, h - 1)                                              # row indices clipped, weights kept
     y1 = np.clip(sy + 1, 0, h - 1)
     b0, b1 = (f32(1) - fy)[:, None, None], fy[:, None, None]
-    ver = ((hor[y0] * b0).astype(f32) + (hor[y1] * b1).astype(f32)).astype(f32)   # VResizeLinear
+    return ((hor[y0] * b0).astype(f32) + (hor[y1] * b1).astype(f32)).astype(f32)   # VResizeLinear
+
+
+def prep_image(im_bgr_u8, im_scale, hflip=False):
+    """-> float32 [3,H,W] (RGB, normalised), H, W = round-half-even(h * scale), (w * scale)."""
+    im = im_bgr_u8[:, ::-1, :] if hflip else im_bgr_u8                      # minibatch.py:121-122 / test.py:249
+    ver = resize_linear(im.astype(f32), im_scale)
     u8 = np.clip(ver, 0, 255).astype(np.uint8)                              # np.uint8(): truncation
     rgb = u8[:, :, ::-1].astype(f32)                                        # cv2.COLOR_BGR2RGB
     unit = (rgb / f32(255)).astype(f32)                                     # ToTensor

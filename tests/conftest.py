@@ -9,6 +9,9 @@ for p in (REPO, os.path.join(REPO, "tests", "golden")):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
+# strict mode of the product under test: leaving the reference's NumPy stream (np.random touched between a training forward
+# and the end of its backward) and silent library fallbacks are errors, not warnings
+os.environ.setdefault("CIM_STRICT", "1")
 
 
 def pytest_configure(config):

@@ -99,3 +99,22 @@ def lr_toy_model():
 def lr_toy_grads(m, step):
     for k, p in enumerate(m.parameters()):
         p.grad = torch.cos(torch.arange(p.numel(), dtype=torch.float32) * 0.11 + 0.5 * step + k).view_as(p).to(p.device)
+
+
+# ---- test-time augmentation case (tests/golden/tta_vgg16_voc.npz): a small BGR image, proposals, 7 x 7 masks; the TEST
+# scales are shrunk (the aggregation - view order, flip mapping, averaging - is what the fixture pins, not the image size)
+TTA = dict(config="vgg16_voc", h=72, w=100, n=24, seed=21, SCALE=96, SCALES=(80, 112, 136), MAX_SIZE=2000)
+
+
+def tta_inputs():
+    rs = np.random.RandomState(TTA["seed"])
+    h, w, n = TTA["h"], TTA["w"], TTA["n"]
+    yy, xx = np.mgrid[0:h, 0:w]
+    im = np.stack([(xx * 2 + yy) % 256, (xx + 3 * yy) % 256, (5 * xx + 7 * yy) % 251], -1).astype(np.uint8)   # smooth: resize-robust
+    x1 = rs.randint(0, w - 20, n)
+    y1 = rs.randint(0, h - 20, n)
+    bw = rs.randint(12, 60, n)
+    bh = rs.randint(12, 50, n)
+    boxes = np.stack([x1, y1, np.minimum(x1 + bw, w - 1), np.minimum(y1 + bh, h - 1)], 1).astype(np.float32)
+    masks = (rs.rand(n, 7, 7) > 0.4).astype(np.float32)
+    return im, boxes, masks

@@ -408,6 +408,92 @@ def gen_e2e_eval():
     print("e2e eval", {k: v.shape for k, v in store.items()})
 
 
+def gen_tta():
+    """f-2: the reference's test-time augmentation, lib/core/test.py:149-241 `im_detect_bbox_aug` (flipped view, every
+    TEST.BBOX_AUG scale plain + flipped, identity view last; AVG / ID and UNION / UNION aggregation), run through the
+    reference's own `im_detect_bbox*`, `_get_blobs` and `utils.blob.prep_im_for_blob`.  Third-party packages the image lacks are
+    stood in for as elsewhere in this file: mmcv's RoIAlign by oracle/roi_align, cv2.resize / cvtColor and torchvision's
+    ToTensor / Normalize by the pieces of oracle/image_prep.py (the oracle of f-3)."""
+    from oracle import image_prep as oip
+    from oracle import roi_align as ora
+    from cases import TTA, tta_inputs
+
+    class RoIAlignStub(torch.nn.Module):
+        def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode="avg", aligned=True,
+                     use_torchvision=False):
+            super().__init__()
+            self.args = (output_size, spatial_scale, sampling_ratio)
+
+        def forward(self, x, rois):
+            P, scale, sr = self.args
+            return torch.from_numpy(ora.roi_align_fwd(x.detach().numpy(), rois.detach().numpy(), P, scale, sr, True))
+
+    sys.modules["mmcv.ops"].RoIAlign = RoIAlignStub
+    np.float, np.int = float, int                      # removed NumPy aliases the reference still uses (test.py:448-449)
+
+    def cv2_resize(im, dsize, dst=None, fx=None, fy=None, interpolation=None):
+        assert dsize is None and fx == fy
+        return oip.resize_linear(im, fx)
+
+    _ref_shims._module("cv2", resize=cv2_resize, cvtColor=lambda im, code: np.ascontiguousarray(im[:, :, ::-1]),
+                       COLOR_BGR2RGB=4, INTER_LINEAR=1)
+    _ref_shims._module("pycocotools")
+    _ref_shims._module("pycocotools.mask")
+    def _compiled_ext(*a, **k):
+        raise RuntimeError("compiled box-overlap / NMS extension: not on the test-time augmentation path")
+
+    _ref_shims._module("utils.cython_bbox", bbox_overlaps=_compiled_ext)
+    _ref_shims._module("utils.cython_nms", nms=_compiled_ext, soft_nms=_compiled_ext)
+    tvt = sys.modules["torchvision.transforms"]
+    tvt.Compose = lambda fs: (lambda x: [x := f(x) for f in fs][-1])
+    tvt.ToTensor = lambda: (lambda a: torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div(255))
+    tvt.Normalize = lambda mean, std: (lambda t: (t - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1))
+    for m in [k for k in sys.modules if k in ("ops", "utils.blob", "utils.boxes", "core.test") or k.startswith("ops.") or k.startswith("modeling")]:
+        del sys.modules[m]
+    cfgmod = importlib.import_module("core.config")
+    cfg = cfgmod.cfg
+    if cfg.is_immutable():
+        cfg.immutable(False)
+    cfg.MODEL.NUM_CLASSES = 20
+    cfgmod.cfg_from_file(_ref_shims.REF_ROOT + "/configs/vgg16_voc.yaml")
+    cfg.MODEL.LOAD_IMAGENET_PRETRAINED_WEIGHTS = False
+    cfg.TEST.SCALE, cfg.TEST.MAX_SIZE = TTA["SCALE"], TTA["MAX_SIZE"]
+    cfg.TEST.BBOX_AUG.SCALES, cfg.TEST.BBOX_AUG.MAX_SIZE = TTA["SCALES"], TTA["MAX_SIZE"]
+    mb = importlib.import_module("modeling.model_builder")
+    ref_test = importlib.import_module("core.test")
+    model = mb.Generalized_RCNN()
+    procedural_init(model)
+    model.eval()
+
+    class OneDevice(torch.nn.Module):
+        """What the reference's nn.DataParallel(minibatch=True) does with one device (data_parallel.py:77-84,107-108): every
+        keyword is a list with one entry per device; entry 0 goes to the module.  (On a host without CUDA the reference's
+        wrapper passes the lists through unchanged, data_parallel.py:56-59,75-76, and the model cannot run.)"""
+
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, **kwargs):
+            return self.module(**{k: v[0] for k, v in kwargs.items()})
+
+    model = OneDevice(model)
+    im, boxes, masks = tta_inputs()
+    store = dict(h_flip=np.array(cfg.TEST.BBOX_AUG.H_FLIP), scale_h_flip=np.array(cfg.TEST.BBOX_AUG.SCALE_H_FLIP))
+    labels = np.zeros((1, 20), dtype=np.float32)
+    for heur, coord in (("AVG", "ID"), ("ID", "ID"), ("UNION", "UNION")):
+        cfg.TEST.BBOX_AUG.SCORE_HEUR, cfg.TEST.BBOX_AUG.COORD_HEUR = heur, coord
+        with torch.no_grad():
+            scores, bx, im_scale, blob_conv = ref_test.im_detect_bbox_aug(model, im.copy(), boxes.copy(), masks.copy(), np.array([0]),
+                                                                          path="/x/img.jpg", flag="ToTensor", labels=labels)
+        store["scores_" + heur] = np.asarray(scores, dtype=np.float32)
+        store["boxes_" + heur] = np.asarray(bx, dtype=np.float32)
+        store["im_scale"] = np.array(float(np.asarray(im_scale).reshape(-1)[0]))
+        store["blob_conv_absmean"] = np.array(float(blob_conv.abs().mean()))
+    np.savez_compressed(os.path.join(HERE, "tta_vgg16_voc.npz"), **store)
+    print("tta", {k: v.shape for k, v in store.items()})
+
+
 def gen_hrnet():
     """The reference's HRNet-W48 trunk (lib/modeling/HRNet.py) on procedural weights: state_dict keys
     and the fused 2048-channel stride-32 map for an image whose sides are not multiples of 32."""
@@ -496,6 +582,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "e2e_eval":      # one fixture only
         gen_e2e_eval()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "tta":
+        gen_tta()
+        return
     heads = importlib.import_module("modeling.heads")
     gen_mining(heads)
     gen_losses(heads)
@@ -506,6 +595,7 @@ def main():
     gen_e2e_eval()
     gen_hrnet()
     gen_lr()
+    gen_tta()
 
 
 if __name__ == "__main__":

@@ -178,3 +178,31 @@ def test_early_optimizer_step_is_identical():
         torch.testing.assert_close(p1[n], p0[n], rtol=1e-4, atol=1e-6, msg=n)
     for n in m0:
         torch.testing.assert_close(m1[n], m0[n], rtol=2e-3, atol=1e-6, msg=n)
+
+
+def test_bench_two_ranks_launch_path():
+    """`python bench.py --gpus 2` from a bare shell - the exact command the driver's SCALE run issues -
+    must start its ranks as children before touching the GPU, run the step with real collectives and print ONE JSON line
+    with n_gpus = 2, the process group's own world size and the communication figures.  gloo on a 1-GPU box (both ranks
+    share cuda:0), nccl = RCCL when two devices are visible."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--backend", backend, "--steps", "2", "--warmup", "1",
+           "--images", "2", "--no-cpu-baseline", "--sustained", "0"]
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["dist"]["world_size"] == 2 and line["dist"]["backend"] == backend and len(line["dist"]["per_rank_images_per_s"]) == 2
+    assert abs(line["value"] - 2 * min(line["dist"]["per_rank_images_per_s"])) < 1e-6 * line["value"]     # MAX over ranks
+    comm = line["extra"]["comm"]
+    assert comm["buckets"] >= 3 and comm["gradient_bytes"] > 9e8 and comm["ms_per_step_no_sync"] > 0
+    assert "roofline" in line and "cpu_baseline" not in line

@@ -108,6 +108,48 @@ def test_tta_batched_equals_sequential():
     assert tuple(hf.shape) == (n, 20)
 
 
+def test_tta_aggregation_matches_reference(golden_dir):
+    """`im_detect_bbox_aug` against the REFERENCE's own run of lib/core/test.py:149-241
+    (tests/golden/tta_vgg16_voc.npz: flipped view, three scales plain + flipped, identity view last; AVG / ID, ID / ID and
+    UNION / UNION; cv2 / torchvision / mmcv stood in for by the oracles when the fixture was captured) - view order, flip
+    mapping of boxes and masks, and the averaging, batched and sequential."""
+    from cases import TTA, tta_inputs
+    from cim_amd.core import test as ctest
+    from cim_amd.core.config import cfg
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    g = np.load(os.path.join(golden_dir, "tta_vgg16_voc.npz"))
+    apply_preset(TTA["config"])
+    cfg.TEST.SCALE, cfg.TEST.MAX_SIZE = TTA["SCALE"], TTA["MAX_SIZE"]
+    cfg.TEST.BBOX_AUG.SCALES, cfg.TEST.BBOX_AUG.MAX_SIZE = TTA["SCALES"], TTA["MAX_SIZE"]
+    assert bool(cfg.TEST.BBOX_AUG.H_FLIP) == bool(g["h_flip"]) and bool(cfg.TEST.BBOX_AUG.SCALE_H_FLIP) == bool(g["scale_h_flip"])
+    m = Generalized_RCNN()
+    procedural_init(m)
+    m = m.to(DEV).eval()
+    im, boxes, masks = tta_inputs()
+    n = boxes.shape[0]
+    worst = 0.0
+    for heur, coord in (("AVG", "ID"), ("ID", "ID"), ("UNION", "UNION")):
+        cfg.TEST.BBOX_AUG.SCORE_HEUR, cfg.TEST.BBOX_AUG.COORD_HEUR = heur, coord
+        ref, ref_boxes = g["scores_" + heur], g["boxes_" + heur]
+        for batched in (True, False):
+            scores, bx, im_scale, blob_conv = ctest.im_detect_bbox_aug(m, im, boxes, masks, flag="ToTensor", batched=batched)
+            got = scores.cpu().numpy()
+            assert got.shape == ref.shape and abs(im_scale - float(g["im_scale"])) < 1e-9
+            worst = max(worst, float(np.abs(got - ref).max() / np.abs(ref).max()))
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=3e-5 * float(np.abs(ref).max()))
+            np.testing.assert_array_equal(np.asarray(bx.cpu() if torch.is_tensor(bx) else bx, dtype=np.float32), ref_boxes)
+            np.testing.assert_allclose(float(blob_conv.abs().mean()), float(g["blob_conv_absmean"]), rtol=1e-4)
+        if heur == "UNION":                      # T = 8 views in the reference's order, identity LAST
+            assert ref.shape[0] == 8 * n
+            np.testing.assert_allclose(got[-n:], g["scores_ID"], rtol=1e-4, atol=3e-5 * float(np.abs(ref).max()))
+    print("TTA: worst |score - reference| / max|reference| = %.2e" % worst)
+    cfg.TEST.BBOX_AUG.SCORE_HEUR, cfg.TEST.BBOX_AUG.COORD_HEUR = "UNION", "ID"
+    with pytest.raises(AssertionError):          # test.py:154-160
+        ctest.im_detect_bbox_aug(m, im, boxes, masks, flag="ToTensor")
+    cfg.TEST.BBOX_AUG.SCORE_HEUR, cfg.TEST.BBOX_AUG.COORD_HEUR = "AVG", "ID"
+
+
 def test_minibatch_on_device_feeds_the_model():
     """cim_amd.roi_data.get_minibatch (lib/roi_data/minibatch.py:19-89 on the device): blobs have the reference's shapes and
     conventions, the scale draw consumes the global NumPy generator exactly like the reference's, and the dictionary goes
