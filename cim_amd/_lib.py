@@ -33,10 +33,10 @@ SIGNATURES = {
     "cim_conv1x1_bwd_workspace": [c_int, c_int, c_int, c_int],
     "cim_conv1x1_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 4 + [_P, _P, _P, c_int],
     "cim_conv3x3_nchw_splits": [c_int] * 5,
-    "cim_conv3x3_nchw_f32": [_P, _P, _P] + [c_int] * 5 + [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P, _P],
+    "cim_conv3x3_nchw_f32": [_P, _P, _P] + [c_int] * 6 + [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P, _P],
     "cim_conv7x7_nchw_f32": [_P, _P, _P] + [c_int] * 5 + [_P, _P, _P, _P, c_float, c_int, _P],
     "cim_conv3x3_nchw_bwd_workspace": [c_int] * 6,
-    "cim_conv3x3_nchw_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 6 + [_P, _P, _P, c_int],
+    "cim_conv3x3_nchw_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 7 + [_P, _P, _P, c_int],
     "cim_bn_act_fwd": [_P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, _P],
     "cim_bn_act_bwd_chunks": [c_int, c_int, c_int],
     "cim_bn_act_bwd": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],

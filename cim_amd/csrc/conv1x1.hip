@@ -204,12 +204,12 @@ __global__ __launch_bounds__(256) void small_splitk_reduce_kernel(const SmallArg
 // (tap = 3 (dy + 1) + (dx + 1); the weight gradient's C is the weight tensor's own layout).  Gathered elements are 4-byte
 // loads, 8 per thread and slab, issued together; interior float4 pieces of stride-1 convolutions take one 16-byte load.
 enum { CONV_FWD = 0, CONV_DX = 1, CONV_DW = 2 };
-struct ConvGeom { int H, W, Ho, Wo, stride, cin, cout; float inv_w; };
+struct ConvGeom { int H, W, Ho, Wo, stride, cin, cout; float inv_w; int dil; };      // dil: dilation (padding = dil * (k / 2): "same")
 
 // element (k, n) of the implicit B operand; `src` = X (forward, weight gradient) or dY (data gradient)
 template <int MODE, int KS>
 __device__ __forceinline__ bool conv_src(const ConvGeom& c, int ch, int tap, int y, int x, int& off) {
-    const int dy = tap / KS - KS / 2, dx = tap - (tap / KS) * KS - KS / 2;      // padding KS / 2
+    const int dy = (tap / KS - KS / 2) * c.dil, dx = (tap - (tap / KS) * KS - KS / 2) * c.dil;      // padding dil * (KS / 2)
     if (MODE == CONV_DX) {                 // (y, x) = input pixel; the output pixel that reads it through this tap
         const int ty = y - dy, tx = x - dx;
         if (c.stride == 2 && ((ty | tx) & 1)) return false;
@@ -569,19 +569,20 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
     }
     return 0;
 }
-ConvGeom conv_geom(int cin, int cout, int H, int W, int stride, int mode) {
+ConvGeom conv_geom(int cin, int cout, int H, int W, int stride, int mode, int dil = 1) {
     ConvGeom c;
-    c.H = H; c.W = W; c.stride = stride; c.cin = cin; c.cout = cout;
+    c.H = H; c.W = W; c.stride = stride; c.cin = cin; c.cout = cout; c.dil = dil;
     c.Ho = (H - 1) / stride + 1; c.Wo = (W - 1) / stride + 1;            // odd kernel k, padding k / 2
     c.inv_w = 1.0f / (float)(mode == CONV_DX ? W : c.Wo);
     return c;
 }
 }  // namespace
 
-#define CONV3_ARGS_OK()                                                                                              \
+#define CONV3_ARGS_OK(CIN_MULT)                                                                                      \
     CIM_CHECK_ARG(cin > 0 && cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && W <= 4096 &&               \
+                  dilation >= 1 && dilation <= 8 && (dilation == 1 || stride == 1) &&                                 \
                   (long long)H * W < (1ll << 20) && (long long)cin * H * W < (1ll << 31) && (long long)cout * H * W < (1ll << 31) && \
-                  (long long)cin * cout * 9 < (1ll << 31) && cin % 4 == 0)
+                  (long long)cin * cout * 9 < (1ll << 31) && cin % (CIN_MULT) == 0)
 
 extern "C" int cim_conv3x3_nchw_splits(int cin, int cout, int H, int W, int stride) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -589,12 +590,12 @@ extern "C" int cim_conv3x3_nchw_splits(int cin, int cout, int H, int W, int stri
 }
 
 extern "C" int cim_conv3x3_nchw_f32(const float* x, const float* w, float* y, int cin, int cout, int H, int W, int stride,
-                               float* x_raw, const float* gamma, const float* beta, const float* mean, const float* var,
+                               int dilation, float* x_raw, const float* gamma, const float* beta, const float* mean, const float* var,
                                float eps, const float* residual, int relu, int splits, float* workspace, void* stream) {
     CIM_CHECK_ARG(x && w && y && splits >= 1 && splits <= 65535 && (splits == 1 || workspace));
-    CONV3_ARGS_OK();
+    CONV3_ARGS_OK(1);                 // (forward: any cin - the RGB stems of VGG16 / HRNet are frozen, forward only)
     CIM_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (gamma == nullptr) == (mean == nullptr) && (gamma == nullptr) == (var == nullptr));
-    const ConvGeom c = conv_geom(cin, cout, H, W, stride, CONV_FWD);
+    const ConvGeom c = conv_geom(cin, cout, H, W, stride, CONV_FWD, dilation);
     conv3x3_launch(CONV_FWD, w, x, y, cout, c.Ho * c.Wo, 9 * cin, 9 * cin, c.Ho * c.Wo, c, x_raw, gamma, beta, mean, var, eps,
                    residual, relu, splits, workspace, cim::as_stream(stream));
     CIM_CHECK_LAUNCH();
@@ -629,11 +630,12 @@ extern "C" long long cim_conv3x3_nchw_bwd_workspace(int B, int cin, int cout, in
 extern "C" int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                                       const float* gamma, const float* mean, const float* var, float eps, int relu,
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
-                                      int H, int W, int stride, float* workspace, void* stream, void* side_stream, int join) {
+                                      int H, int W, int stride, int dilation, float* workspace, void* stream, void* side_stream,
+                                      int join) {
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0);
-    CONV3_ARGS_OK();
+    CONV3_ARGS_OK(4);
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)) && cout % 4 == 0);
-    const ConvGeom cx = conv_geom(cin, cout, H, W, stride, CONV_DX), cw = conv_geom(cin, cout, H, W, stride, CONV_DW);
+    const ConvGeom cx = conv_geom(cin, cout, H, W, stride, CONV_DX, dilation), cw = conv_geom(cin, cout, H, W, stride, CONV_DW, dilation);
     const int hwo = cx.Ho * cx.Wo, hw = H * W;
     hipStream_t st = cim::as_stream(stream);
     float* dconv = workspace;                                  // [B][cout][Ho Wo]: the gradient of the convolution output

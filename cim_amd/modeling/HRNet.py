@@ -48,7 +48,7 @@ def _downsample(ds, x):
 
 def _is_conv_bn(m):
     return isinstance(m, nn.Sequential) and len(m) in (2, 3) and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.BatchNorm2d) \
-        and m[0].kernel_size == (3, 3) and m[0].bias is None and (len(m) == 2 or isinstance(m[2], nn.ReLU))
+        and m[0].kernel_size == (3, 3) and (len(m) == 2 or isinstance(m[2], nn.ReLU))
 
 
 def _conv_bn_steps(seq, x):
@@ -240,7 +240,7 @@ class HighResolutionNet(nn.Module):
         return {name: name for name, _ in self.named_parameters()}, []
 
     def _stem(self, x):
-        x = bn_act(self.conv1(x), self.bn1)
+        x = conv3x3_bn_act(x, self.conv1, self.bn1)          # (3 input channels: forward only - the stem is frozen)
         x = conv3x3_bn_act(x, self.conv2, self.bn2)
         return self.layer1(x)
 
@@ -265,9 +265,10 @@ class HighResolutionNet(nn.Module):
         ys = self._stage(3, ys)
         ys = self._stage(4, ys)
         y = self.incre_modules[0](ys[0])
-        for i, down in enumerate(self.downsamp_modules):
-            y = self.incre_modules[i + 1](ys[i + 1]) + down(y)
-        return self.final_layer(y)
+        for i, down in enumerate(self.downsamp_modules):           # conv3x3 / 2 (with a bias) -> BN -> ReLU: one launch
+            y = self.incre_modules[i + 1](ys[i + 1]) + _conv_bn_steps(down, y)
+        fl = self.final_layer                                        # conv1x1 (with a bias) -> BN -> ReLU
+        return conv1x1_bn_act(y, fl[0], fl[1], relu=True)
 
 
 def get_HRNet():

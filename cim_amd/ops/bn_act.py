@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from . import fallback
 
 
 class BnActFunction(Function):
@@ -51,6 +52,8 @@ def bn_act(x, bn, residual=None, relu=True):
     fused = (not bn.training) and x.is_cuda and x.dtype == torch.float32 and bn.affine and bn.track_running_stats \
         and x.dim() == 4 and x.is_contiguous()
     if not fused:
+        if x.is_cuda:
+            fallback.note("bn_act", "BatchNorm in training mode" if bn.training else "unsupported layout / dtype")
         out = bn(x)
         if residual is not None:
             out = out + residual

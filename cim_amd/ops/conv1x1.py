@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from . import fallback
 from . import gemm as _gemm_mod
 
 
@@ -32,7 +33,7 @@ class Conv1x1BnActFunction(Function):
         B, cin, H, W = x.shape
         cout, hw = w.shape[0], H * W
         w2 = w.reshape(cout, cin)
-        need_grad = any(ctx.needs_input_grad[:5])
+        need_grad = any(ctx.needs_input_grad[:6])
         y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
         xr = torch.empty_like(y) if need_grad else None            # convolution output: the BatchNorm backward's x
         if res is not None:
@@ -54,7 +55,8 @@ class Conv1x1BnActFunction(Function):
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_res = has_res and ctx.needs_input_grad[2]
-        need_affine = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        need_mean = ctx.needs_input_grad[5]          # a convolution bias folded into the mean: d/dmean = -a sum dz
+        need_affine = ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or need_mean
         # ONE host call: BatchNorm / ReLU backward, data gradient, weight gradient (+ split-K reduces)  (csrc/conv1x1.hip)
         dev = dy.device
         dres = torch.empty_like(dy) if need_res else None
@@ -72,25 +74,30 @@ class Conv1x1BnActFunction(Function):
         if not join:                       # the weight gradient is still running on the side stream: installed as .grad at the join
             _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x)
             dw = None
+        dmean = -(gamma * torch.rsqrt(var + eps)) * dbeta if need_mean else None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
-            None, None, None, None
+            dmean, None, None, None
 
 
 def conv1x1_bn_act(x, conv, bn, residual=None, relu=True):
-    """relu?(bn(conv(x)) + residual) for a 1 x 1 nn.Conv2d `conv` and an nn.BatchNorm2d `bn`."""
+    """relu?(bn(conv(x)) + residual) for a 1 x 1 nn.Conv2d `conv` and an nn.BatchNorm2d `bn`.  A convolution bias (HRNet's
+    final_layer, HRNet.py:298-312) is folded into the BatchNorm's mean: bn(conv + bias) = a conv + (beta - (mean - bias) a)."""
     stride = conv.stride[0]
-    fused = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (1, 1) and conv.bias is None
+    fused = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (1, 1)
              and conv.padding == (0, 0) and conv.stride[0] == conv.stride[1] and conv.groups == 1
              and (not bn.training) and bn.affine and bn.track_running_stats)
     if not fused:
+        if x.is_cuda:
+            fallback.note("conv1x1_bn_act", "BatchNorm in training mode" if bn.training else "unsupported geometry %s" % (conv,))
         out = bn(conv(x))
         if residual is not None:
             out = out + residual
         return F.relu(out) if relu else out
     if stride != 1:                                   # a strided 1 x 1 convolution only sees every stride-th pixel
         x = x[:, :, ::stride, ::stride]
-    args = (x, conv.weight, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
-    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:5])):
+    mean = bn.running_mean if conv.bias is None else bn.running_mean - conv.bias
+    args = (x, conv.weight, residual, bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu)
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:6])):
         with torch.no_grad():
             return Conv1x1BnActFunction.apply(*args)
     return Conv1x1BnActFunction.apply(*args)

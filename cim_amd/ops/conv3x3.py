@@ -13,18 +13,19 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from . import fallback
 from . import gemm as _gemm_mod
 
 
 class Conv3x3BnActFunction(Function):
     @staticmethod
-    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, stride):
+    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, stride, dilation=1):
         x = x.contiguous()
         w = w.contiguous()
         B, cin, H, W = x.shape
         cout = w.shape[0]
         ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-        need_grad = any(ctx.needs_input_grad[:5])
+        need_grad = any(ctx.needs_input_grad[:6])
         y = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=x.device)
         xr = torch.empty_like(y) if need_grad else None            # convolution output: the BatchNorm backward's x
         if res is not None:
@@ -33,23 +34,24 @@ class Conv3x3BnActFunction(Function):
         ws = torch.empty(splits * cout * ho * wo, dtype=torch.float32, device=x.device) if splits > 1 else None
         st = _lib.stream_ptr()
         for b in range(B):
-            _lib.call("cim_conv3x3_nchw_f32", x[b].data_ptr(), w.data_ptr(), y[b].data_ptr(), cin, cout, H, W, stride,
+            _lib.call("cim_conv3x3_nchw_f32", x[b].data_ptr(), w.data_ptr(), y[b].data_ptr(), cin, cout, H, W, stride, dilation,
                       _lib.ptr(xr[b] if xr is not None else None), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(),
                       float(eps), _lib.ptr(res[b] if res is not None else None), int(relu), splits, _lib.ptr(ws), st)
         if need_grad:
             ctx.save_for_backward(x, w, xr, y if relu else None, gamma, mean, var)
         ctx.param = w if isinstance(w, torch.nn.Parameter) else None      # (its .grad tells the backward whether it may defer the join)
-        ctx.cfg = (B, cin, cout, H, W, float(eps), bool(relu), res is not None, stride)
+        ctx.cfg = (B, cin, cout, H, W, float(eps), bool(relu), res is not None, stride, dilation)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, xr, y, gamma, mean, var = ctx.saved_tensors
-        B, cin, cout, H, W, eps, relu, has_res, stride = ctx.cfg
+        B, cin, cout, H, W, eps, relu, has_res, stride, dilation = ctx.cfg
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_res = has_res and ctx.needs_input_grad[2]
-        need_affine = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        need_mean = ctx.needs_input_grad[5]          # a convolution bias folded into the mean (conv3x3_bn_act): d/dmean = -a sum dz
+        need_affine = ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or need_mean
         dev = dy.device
         hwo = dy.shape[2] * dy.shape[3]
         dres = torch.empty_like(dy) if need_res else None
@@ -63,30 +65,73 @@ class Conv3x3BnActFunction(Function):
         side, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
         _lib.call("cim_conv3x3_nchw_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w.data_ptr(),
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres), _lib.ptr(dgamma),
-                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, H, W, stride, ws.data_ptr(), _lib.stream_ptr(), side, join)
+                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, H, W, stride, dilation, ws.data_ptr(), _lib.stream_ptr(), side, join)
         if not join:                       # the weight gradient is still running on the side stream: installed as .grad at the join
             _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x)
             dw = None
+        dmean = -(gamma * torch.rsqrt(var + eps)) * dbeta if need_mean else None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
-            None, None, None, None, None
+            dmean, None, None, None, None, None
+
+
+def _apply(fn, args, n_diff):
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:n_diff])):
+        with torch.no_grad():
+            return fn.apply(*args)
+    return fn.apply(*args)
+
+
+def _same_padded(conv):
+    d = conv.dilation[0]
+    return (conv.kernel_size == (3, 3) and conv.dilation == (d, d) and conv.padding == (d, d) and conv.groups == 1
+            and conv.stride in ((1, 1), (2, 2)) and (d == 1 or conv.stride == (1, 1)) and 1 <= d <= 8)
+
+
+def _geometry_ok(x, conv, needs_backward):
+    return (x.dtype == torch.float32 and x.dim() == 4 and _same_padded(conv) and conv.out_channels % 4 == 0
+            and (conv.in_channels % 4 == 0 or not needs_backward)          # the RGB stems are frozen: forward only
+            and x.shape[3] <= 4096 and x.shape[2] * x.shape[3] < (1 << 20))
 
 
 def conv3x3_bn_act(x, conv, bn, residual=None, relu=True):
-    """relu?(bn(conv(x)) + residual) for a 3 x 3 nn.Conv2d `conv` (padding 1, stride 1 / 2) and an nn.BatchNorm2d `bn`."""
-    fused = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.bias is None
-             and conv.padding == (1, 1) and conv.stride in ((1, 1), (2, 2)) and conv.dilation == (1, 1) and conv.groups == 1
-             and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0 and x.shape[3] <= 4096 and x.shape[2] * x.shape[3] < (1 << 20)
+    """relu?(bn(conv(x)) + residual) for a 3 x 3 nn.Conv2d `conv` ("same" padding, stride 1 / 2, dilation d with padding d)
+    and an nn.BatchNorm2d `bn` in eval() mode.  A convolution bias (HRNet's downsamp_modules, HRNet.py:283-296) is folded
+    into the BatchNorm's mean: bn(conv + bias) = a conv + (beta - (mean - bias) a)."""
+    grad_on = torch.is_grad_enabled()
+    needs_bwd = grad_on and (x.requires_grad or conv.weight.requires_grad)
+    fused = (x.is_cuda and _geometry_ok(x, conv, needs_bwd)
              and (not bn.training) and bn.affine and bn.track_running_stats)
     if not fused:
+        if x.is_cuda:
+            fallback.note("conv3x3_bn_act", "BatchNorm in training mode" if bn.training else "unsupported geometry %s" % (conv,))
         out = bn(conv(x))
         if residual is not None:
             out = out + residual
         return F.relu(out) if relu else out
-    args = (x, conv.weight, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu, conv.stride[0])
-    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:5])):
-        with torch.no_grad():
-            return Conv3x3BnActFunction.apply(*args)
-    return Conv3x3BnActFunction.apply(*args)
+    mean = bn.running_mean if conv.bias is None else bn.running_mean - conv.bias
+    args = (x, conv.weight, residual, bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu, conv.stride[0], conv.dilation[0])
+    return _apply(Conv3x3BnActFunction, args, 6)
+
+
+_IDENTITY_BN = {}      # (device, channels) -> (ones, zeros): BatchNorm statistics that make the epilogue y = x + beta exactly
+
+
+def conv3x3_bias_act(x, conv, relu=True):
+    """relu?(conv(x) + bias) for a 3 x 3 nn.Conv2d with a bias and no BatchNorm - the 13 convolutions of the dilated VGG16 body,
+    /root/reference/lib/modeling/vgg16.py:34-78 (conv5: dilation 2) - on the implicit-GEMM kernel: the BatchNorm epilogue with
+    gamma = 1, mean = 0, var = 1, eps = 0 (a = 1 exactly) and beta = the bias, whose gradient is the epilogue's dbeta."""
+    needs_bwd = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
+    if not (x.is_cuda and conv.bias is not None and _geometry_ok(x, conv, needs_bwd)):
+        if x.is_cuda:
+            fallback.note("conv3x3_bias_act", "unsupported geometry %s" % (conv,))
+        out = conv(x)
+        return F.relu(out) if relu else out
+    key = (x.device, conv.out_channels)
+    if key not in _IDENTITY_BN:
+        _IDENTITY_BN[key] = (torch.ones(conv.out_channels, device=x.device), torch.zeros(conv.out_channels, device=x.device))
+    ones, zeros = _IDENTITY_BN[key]
+    args = (x, conv.weight, None, ones, conv.bias, zeros, ones, 0.0, relu, conv.stride[0], conv.dilation[0])
+    return _apply(Conv3x3BnActFunction, args, 6)
 
 
 def conv7x7_bn_act(x, conv, bn, relu=True):
@@ -98,6 +143,8 @@ def conv7x7_bn_act(x, conv, bn, relu=True):
              and x.shape[3] <= 4096 and x.shape[2] * x.shape[3] < (1 << 20)
              and (not bn.training) and bn.affine and bn.track_running_stats)
     if not fused:
+        if x.is_cuda:
+            fallback.note("conv7x7_bn_act", "stem not frozen / unsupported geometry")
         out = bn(conv(x))
         return F.relu(out) if relu else out
     with torch.no_grad():

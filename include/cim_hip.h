@@ -229,9 +229,13 @@ int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, 
  * cim_gemm_small_f32 (workspace [splits][cout][Ho Wo] floats when cim_conv3x3_nchw_splits(...) > 1).  cin % 4 == 0.
  * Replaces ATen -> MIOpen (miopenSp3AsmConv / Im2d2Col + rocBLAS) for those layers. */
 int cim_conv3x3_nchw_splits(int cin, int cout, int H, int W, int stride);
-int cim_conv3x3_nchw_f32(const float* x, const float* w, float* y, int cin, int cout, int H, int W, int stride, float* x_raw,
-                         const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+int cim_conv3x3_nchw_f32(const float* x, const float* w, float* y, int cin, int cout, int H, int W, int stride, int dilation,
+                         float* x_raw, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                          const float* residual, int relu, int splits, float* workspace, void* stream);
+/* dilation >= 1 with padding = dilation ("same"; dilation > 1 needs stride 1): the dilated conv5 of VGG16
+ * (lib/modeling/vgg16.py:70-78).  A convolution with a bias and no BatchNorm is the same call with gamma = 1, beta = bias,
+ * mean = 0, var = 1, eps = 0 (a = 1 exactly); a bias in front of a BatchNorm is folded into mean (mean - bias).  The forward
+ * takes any cin (the frozen RGB stems); the backward needs cin % 4 == 0. */
 /* The stem of the ResNet body: 7 x 7 convolution (padding 3, stride 1 or 2, no bias, any cin) -> frozen BatchNorm (+ ReLU),
  * forward only (torchvision ResNet conv1 / bn1 / relu, lib/modeling/resnet50.py:20,53-77, frozen by FREEZE_AT): the same
  * implicit GEMM with 49 taps.  x [cin][H][W], w [cout][cin][7][7], y [cout][Ho][Wo].  Replaces ATen -> MIOpen + 2 launches. */
@@ -246,7 +250,7 @@ long long cim_conv3x3_nchw_bwd_workspace(int B, int cin, int cout, int H, int W,
 int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                                 const float* gamma, const float* mean, const float* var, float eps, int relu, float* dres,
                                 float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int H, int W,
-                                int stride, float* workspace, void* stream, void* side_stream, int join);
+                                int stride, int dilation, float* workspace, void* stream, void* side_stream, int join);
 
 /* ------------------------------------------------------------------ backbone BatchNorm chains (a-11)
  * Frozen-statistics BatchNorm (+ residual) (+ ReLU) of the ResNet / HRNet bodies, lib/modeling/resnet50.py:17-44,53-77

@@ -382,6 +382,94 @@ def test_conv3x3_bn_act_matches_aten(dev, cin, cout, H, W, stride, res, relu, B)
         assert err < 2e-5, (name, err)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,dil,relu", [(64, 64, 45, 60, 1, True), (512, 512, 23, 30, 2, True), (128, 256, 31, 17, 1, False),
+                                                     (16, 32, 9, 11, 2, True)])
+def test_conv3x3_bias_act_matches_aten(dev, cin, cout, H, W, dil, relu):
+    """VGG16's convolutions (lib/modeling/vgg16.py:34-78: 3 x 3, bias, no BatchNorm, dilation 2 in conv5) on the
+    implicit-GEMM kernel: forward, dx, dw and the bias gradient against ATen in float64."""
+    from cim_amd.ops import conv3x3_bias_act
+    torch.manual_seed(cin + H + dil)
+    conv = torch.nn.Conv2d(cin, cout, 3, stride=1, padding=dil, dilation=dil, bias=True).to(dev)
+    x = torch.randn(1, cin, H, W, device=dev, requires_grad=True)
+    y = conv3x3_bias_act(x, conv, relu=relu)
+    g = torch.randn_like(y)
+    y.backward(g)
+    c64 = copy.deepcopy(conv).double()
+    for p_ in c64.parameters():
+        p_.grad = None
+    x64 = x.detach().double().requires_grad_(True)
+    o = c64(x64)
+    if relu:
+        o = torch.relu(o)
+    o.backward(g.double())
+    for name, a, b_ in (("y", y.detach(), o.detach()), ("dx", x.grad, x64.grad), ("dw", conv.weight.grad, c64.weight.grad),
+                        ("dbias", conv.bias.grad, c64.bias.grad)):
+        err = float((a.double() - b_).abs().max()) / (float(b_.abs().max()) + 1e-30)
+        assert err < 2e-5, (name, err)
+
+
+def test_conv3x3_rgb_stem_forward_only(dev):
+    """3 input channels (the frozen stems of VGG16, vgg16.py:37, and HRNet, HRNet.py:263-266): forward on the kernel."""
+    from cim_amd.ops import conv3x3_bias_act, conv3x3_bn_act
+    torch.manual_seed(1)
+    x = torch.randn(1, 3, 75, 100, device=dev)
+    conv = torch.nn.Conv2d(3, 64, 3, padding=1, bias=True).to(dev)
+    for p_ in conv.parameters():
+        p_.requires_grad = False
+    y = conv3x3_bias_act(x, conv, relu=True)
+    ref = torch.relu(copy.deepcopy(conv).double()(x.double()))
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    conv2 = torch.nn.Conv2d(3, 64, 3, stride=2, padding=1, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(64).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        y2 = conv3x3_bn_act(x, conv2, bn)
+        ref2 = torch.relu(copy.deepcopy(bn).double()(copy.deepcopy(conv2).double()(x.double())))
+    assert float((y2.double() - ref2).abs().max() / ref2.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("k,stride", [(3, 2), (1, 1)])
+def test_conv_with_bias_in_front_of_batchnorm(dev, k, stride):
+    """HRNet's downsamp_modules / final_layer (HRNet.py:283-312): a convolution WITH a bias followed by a frozen BatchNorm.
+    The bias is folded into the BatchNorm mean; its gradient comes back through that fold."""
+    from cim_amd.ops import conv1x1_bn_act, conv3x3_bn_act
+    torch.manual_seed(k)
+    cin, cout, H, W = 64, 128, 19, 26
+    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=True).to(dev)
+    bn = torch.nn.BatchNorm2d(cout).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(1, cin, H, W, device=dev, requires_grad=True)
+    y = (conv3x3_bn_act if k == 3 else conv1x1_bn_act)(x, conv, bn, relu=True)
+    g = torch.randn_like(y)
+    y.backward(g)
+    c64, b64 = copy.deepcopy(conv).double(), copy.deepcopy(bn).double()
+    for m in (c64, b64):
+        for p_ in m.parameters():
+            p_.grad = None
+    x64 = x.detach().double().requires_grad_(True)
+    o = torch.relu(b64(c64(x64)))
+    o.backward(g.double())
+    for name, a, b_ in (("y", y.detach(), o.detach()), ("dx", x.grad, x64.grad), ("dw", conv.weight.grad, c64.weight.grad),
+                        ("dbias", conv.bias.grad, c64.bias.grad), ("dgamma", bn.weight.grad, b64.weight.grad), ("dbeta", bn.bias.grad, b64.bias.grad)):
+        err = float((a.double() - b_).abs().max()) / (float(b_.abs().max()) + 1e-30)
+        assert err < 2e-5, (name, err)
+
+
+def test_gpu_fallbacks_are_errors_under_strict(dev):
+    """A CUDA tensor that would take an ATen / MIOpen branch raises under CIM_STRICT=1 (the suite's setting) and is counted."""
+    from cim_amd import _lib
+    from cim_amd.ops import conv3x3_bn_act, fallback
+    conv = torch.nn.Conv2d(8, 8, 3, padding=1, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(8).to(dev).train()                  # training-mode statistics: not on the fused path
+    x = torch.randn(1, 8, 5, 5, device=dev)
+    with pytest.raises(_lib.CimHipError):
+        conv3x3_bn_act(x, conv, bn)
+    with fallback.allowed("conv3x3_bn_act"):
+        conv3x3_bn_act(x, conv, bn)
+    assert any(k[0] == "conv3x3_bn_act" for k in fallback.counts())
+
+
 def test_backbone_weight_gradients_deferred_to_the_side_stream(dev, monkeypatch):
     """The body's weight-gradient GEMMs run on the side stream and are joined once, at the end of the backward pass
     (cim_amd/ops/gemm.py: defer_side_join): same gradients as with the join inside every layer, nothing left pending after

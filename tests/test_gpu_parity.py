@@ -340,8 +340,8 @@ def test_losses_on_device_match_reference(dev, name, golden_dir):
 def test_training_step_matches_cpu_oracle(dev, config):
     """Same weights, same synthetic image: the 4 losses and the parameter gradients of the HIP
     model against the host restatement (torch CPU ops + oracle ROIAlign + oracle mining).
-    fp32 conv/GEMM summation order differs between MIOpen/hipBLASLt and the CPU, hence a
-    tolerance; the pseudo labels are index-exact, so the same loss terms are active."""
+    fp32 conv / GEMM summation order differs between the HIP kernels and ATen's CPU kernels (and, for VGG16 / HRNet, MIOpen),
+    hence a tolerance; the pseudo labels are index-exact, so the same loss terms are active."""
     import copy
     from cim_amd import mask_iou, synthetic
     from cim_amd.core.presets import apply_preset
@@ -518,8 +518,7 @@ def test_model_pickle_path_and_eval_branch(dev, tmp_path):
     heads.settle_rng()
     for k in ("bag_loss", "pcl_loss", "cls_loss", "iou_loss"):
         assert a["losses"][k].shape == (1,)
-        # (not bit-equal: MIOpen may pick a different backbone conv algorithm on the second call)
-        np.testing.assert_allclose(float(a["losses"][k]), float(b["losses"][k]), rtol=1e-5)
+        assert float(a["losses"][k]) == float(b["losses"][k])      # same maps, deterministic kernels: bit-equal
     with pytest.raises(NotImplementedError):                  # missing pickle: model_builder.py:150-152
         model(path="/x/missing.jpg", **kw)
     with pytest.raises(ValueError):                           # check_inference: model_builder.py:45-58

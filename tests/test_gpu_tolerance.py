@@ -90,16 +90,25 @@ def test_engine_and_algorithm_deviation(monkeypatch, golden_dir):
     for mod in m.modules():
         if hasattr(mod, "bn3"):
             torch.nn.init.constant_(mod.bn3.weight, 0.25)
+    import copy
+    cpu_m = copy.deepcopy(m).train()                     # the same weights for the fp32 CPU oracle step (oracle/cpu_step.py)
     m = m.to(DEV).train()
     inp = synthetic.make_image_inputs("resnet50_voc", seed=3)
     iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(DEV))
+    from oracle import cpu_step
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cpu_losses = cpu_step.step(cpu_m, inp, iou.cpu().numpy(), asy.cpu().numpy(), seed=77)
+    cpu_g = {n: p.grad.detach().double() for n, p in cpu_m.named_parameters() if p.grad is not None}
     batch = dict(data=torch.from_numpy(inp["data"]).to(DEV), rois=t(inp["rois"]), masks=t(inp["masks"]), labels=t(inp["labels"]),
                  gtrois=None, mat=t(inp["mat"]), index=t(inp["index"]), iou_map=iou, asy_iou_map=asy)
     ref_l = ref_g = None
     for engine, algo in COMBOS:
         _set(monkeypatch, engine, algo)
-        _step(m, batch, 77)                                       # (MIOpen may switch solvers after its first call)
         losses, grads = _step(m, batch, 77)
+        # ... and against the fp32 CPU oracle step (ATen CPU kernels + oracle ROIAlign / mining): which parameter deviates most
+        cl = max(abs(losses[k] - cpu_losses[k]) / abs(cpu_losses[k]) for k in cpu_losses)
+        cg, cwhere = _grad_dev({n: grads[n] for n in cpu_g if n in grads}, {n: cpu_g[n] for n in cpu_g if n in grads})
+        table["cfg2 vs CPU oracle | %s + %s" % (engine, algo)] = dict(loss_rel=cl, grad_rel=cg, worst_param=cwhere)
         if ref_l is None:
             ref_l, ref_g = losses, grads
             l2, g2 = _step(m, batch, 77)                          # run-to-run noise floor of the reference configuration itself
