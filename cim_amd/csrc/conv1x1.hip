@@ -46,6 +46,7 @@ struct SmallArgs {
     int M, N, K, lda, ldb, ldc;
     int a_mcontig, b_kcontig, relu, bn;
     int splits; float* ws;
+    unsigned* tile_cnt;      // split-K: per-tile arrival counters (zero between launches) - the last split of a tile combines
 };
 
 // Tile loaders.  An operand tile is ROWS x 32 (k) floats per slab, moved as 16-byte pieces: piece index p ->
@@ -83,6 +84,59 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, float4 v, int 
         S[(k + 1) * SLD + r] = v.y;
         S[(k + 2) * SLD + r] = v.z;
         S[(k + 3) * SLD + r] = v.w;
+    }
+}
+
+#ifndef CIM_SMALL_FUSED_REDUCE
+#define CIM_SMALL_FUSED_REDUCE 1     // 0 = split-K partial products are combined by a separate reduce launch (round 2)
+#endif
+// Epilogue of one output value (shared by the single-pass kernels, the in-kernel split-K combine and the reduce kernel)
+__device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int col, float v) {
+    const size_t o = (size_t)row * g.ldc + col;
+    if (g.Xraw) g.Xraw[o] = v;
+    float y = v;
+    if (g.bn) {
+        const float a = g.gamma[row] * rsqrtf(g.var[row] + g.eps);
+        y = fmaf(v, a, g.beta[row] - g.mean[row] * a);
+    }
+    if (g.res) y += g.res[o];
+    if (g.relu) y = fmaxf(y, 0.0f);
+    g.C[o] = y;
+}
+
+// Split-K inside the launch: every split stores its partial tile to the workspace and takes a ticket on the tile's counter;
+// the LAST arrival sums the tile's partials in split order (the order the reduce kernel used: same bits) and applies the
+// epilogue.  Publication follows the chip's rules (the 8 XCDs' L2s are not coherent): plain stores, every wave drains
+// vmcnt, barrier, ONE agent-scope release + relaxed agent-scope fetch_add by one lane; the last arrival does one
+// agent-scope acquire, then plain loads.  The counter is left at zero for the next launch that uses the slot.
+// `flag` = a word of the kernel's own LDS array (a second __shared__ object would de-pipeline the k-loop).
+template <int TN>
+__device__ __forceinline__ void small_splitk_combine(const SmallArgs& g, int tile, int m0, int n0, int tid, int nthreads,
+                                                     volatile int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(g.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (unsigned)g.splits - 1u;
+        if (last) {
+            __hip_atomic_store(g.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const size_t mn = (size_t)g.M * g.N;
+    for (int e = tid; e < SBM * TN; e += nthreads) {
+        const int r = e / TN, c = e - r * TN;
+        const int row = m0 + r, col = n0 + c;
+        if (row >= g.M || col >= g.N) continue;
+        const size_t i = (size_t)row * g.N + col;
+        float v = g.ws[i];
+        for (int k = 1; k < g.splits; ++k) v += g.ws[(size_t)k * mn + i];
+        small_finish(g, row, col, v);
     }
 }
 
@@ -150,27 +204,17 @@ __global__ __launch_bounds__(128 * WN) void gemm_small_kernel(const SmallArgs g)
 
     // ---- epilogue: lane holds rows 8*(r/4) + 4*(lane/32) + r%4, column lane%32 of its wave's 32 x 32 tile
     const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= g.N) return;
+    if (col < g.N) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-        if (row >= g.M) continue;
-        const float v = acc[r];
-        if (g.splits > 1) {
-            g.ws[((size_t)split * g.M + row) * g.N + col] = v;
-            continue;
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (row >= g.M) continue;
+            if (g.splits > 1) g.ws[((size_t)split * g.M + row) * g.N + col] = acc[r];
+            else small_finish(g, row, col, acc[r]);
         }
-        const size_t o = (size_t)row * g.ldc + col;
-        if (g.Xraw) g.Xraw[o] = v;
-        float y = v;
-        if (g.bn) {
-            const float a = g.gamma[row] * rsqrtf(g.var[row] + g.eps);
-            y = fmaf(v, a, g.beta[row] - g.mean[row] * a);
-        }
-        if (g.res) y += g.res[o];
-        if (g.relu) y = fmaxf(y, 0.0f);
-        g.C[o] = y;
     }
+    if (g.splits > 1 && g.tile_cnt != nullptr)
+        small_splitk_combine<BNT>(g, tile, m0, n0, tid, NT, reinterpret_cast<volatile int*>(&As[0][0]));
 }
 
 // split-K: sum of the partial products in a fixed order (deterministic) + the same epilogue as the single-pass kernel
@@ -180,17 +224,7 @@ __global__ __launch_bounds__(256) void small_splitk_reduce_kernel(const SmallArg
     if (i >= mn) return;
     float v = g.ws[i];
     for (int k = 1; k < g.splits; ++k) v += g.ws[(size_t)k * mn + i];
-    const int row = (int)(i / g.N);
-    const size_t o = (size_t)row * g.ldc + (i % g.N);
-    if (g.Xraw) g.Xraw[o] = v;
-    float y = v;
-    if (g.bn) {
-        const float a = g.gamma[row] * rsqrtf(g.var[row] + g.eps);
-        y = fmaf(v, a, g.beta[row] - g.mean[row] * a);
-    }
-    if (g.res) y += g.res[o];
-    if (g.relu) y = fmaxf(y, 0.0f);
-    g.C[o] = y;
+    small_finish(g, (int)(i / g.N), (int)(i % g.N), v);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -360,27 +394,17 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
 #undef C3_MMA
     // ---- epilogue (as gemm_small_kernel)
     const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= g.N) return;
+    if (col < g.N) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-        if (row >= g.M) continue;
-        const float v = acc[r];
-        if (g.splits > 1) {
-            g.ws[((size_t)split * g.M + row) * g.N + col] = v;
-            continue;
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (row >= g.M) continue;
+            if (g.splits > 1) g.ws[((size_t)split * g.M + row) * g.N + col] = acc[r];
+            else small_finish(g, row, col, acc[r]);
         }
-        const size_t o = (size_t)row * g.ldc + col;
-        if (g.Xraw) g.Xraw[o] = v;
-        float y = v;
-        if (g.bn) {
-            const float a = g.gamma[row] * rsqrtf(g.var[row] + g.eps);
-            y = fmaf(v, a, g.beta[row] - g.mean[row] * a);
-        }
-        if (g.res) y += g.res[o];
-        if (g.relu) y = fmaxf(y, 0.0f);
-        g.C[o] = y;
     }
+    if (g.splits > 1 && g.tile_cnt != nullptr)
+        small_splitk_combine<SBN>(g, (int)blockIdx.x, m0, n0, tid, NT, reinterpret_cast<volatile int*>(c3_smem));
 }
 
 // w [Cout][Cin][9] -> wt [Cout][9][Cin] (the data gradient's A operand, M-contiguous): one workgroup per output channel,
@@ -395,6 +419,33 @@ __global__ __launch_bounds__(256) void conv3x3_wt_kernel(const float* __restrict
         const int tap = i / cin, ci = i - tap * cin;
         wt[(size_t)co * n + i] = wt_s[ci * 9 + tap];
     }
+}
+
+// Arrival counters of the in-kernel split-K combine: a ring of zeroed words per device, allocated on first use and never
+// freed (4 MiB).  A launch takes the next `tiles` words; every tile's last arrival puts its word back to zero, so a slot is
+// reusable once its launch has finished - with 2^20 words and at most a few thousand tiles per launch, launches that are in
+// flight together (two streams, a few dozen queued kernels) never share a word.
+constexpr long long CNT_RING = 1ll << 20;
+unsigned* splitk_counters(long long tiles) {
+#if !CIM_SMALL_FUSED_REDUCE
+    return nullptr;
+#else
+    static std::mutex mu;
+    static unsigned* ring[64] = {nullptr};
+    static long long next[64] = {0};
+    if (tiles > CNT_RING / 4) return nullptr;          // (an oversize launch keeps the separate reduce pass)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (ring[dev] == nullptr) {
+        if (hipMalloc(reinterpret_cast<void**>(&ring[dev]), sizeof(unsigned) * CNT_RING) != hipSuccess) { ring[dev] = nullptr; return nullptr; }
+        if (hipMemset(ring[dev], 0, sizeof(unsigned) * CNT_RING) != hipSuccess) return nullptr;       // (synchronous: before any launch uses it)
+    }
+    if (next[dev] + tiles > CNT_RING) next[dev] = 0;
+    unsigned* p = ring[dev] + next[dev];
+    next[dev] += tiles;
+    return p;
+#endif
 }
 
 template <bool AM, bool BKc>
@@ -438,13 +489,14 @@ extern "C" int cim_gemm_small_f32(const float* A, const float* B, float* C, int 
     const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
     CIM_CHECK_ARG(tiles * 2 < (1ll << 31) && splits <= 65535);
     const bool narrow = tiles * splits < 128;           // 64 x 32 tiles only for problems that cannot fill the chip otherwise
+    g.tile_cnt = splits > 1 ? splitk_counters(narrow ? (long long)((M + SBM - 1) / SBM) * ((N + 31) / 32) : tiles) : nullptr;
     hipStream_t st = cim::as_stream(stream);
     if (a_mcontig) {
         if (b_kcontig) launch_small<true, true>(g, splits, st, narrow); else launch_small<true, false>(g, splits, st, narrow);
     } else {
         if (b_kcontig) launch_small<false, true>(g, splits, st, narrow); else launch_small<false, false>(g, splits, st, narrow);
     }
-    if (splits > 1) {
+    if (splits > 1 && g.tile_cnt == nullptr) {          // (no counters: the separate, equally ordered reduce pass)
         const size_t n = (size_t)M * N;
         hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
     }
@@ -555,6 +607,7 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
     g.a_mcontig = 0; g.b_kcontig = mode == CONV_DW; g.relu = relu; g.bn = gamma != nullptr;
     g.splits = splits; g.ws = ws;
     const dim3 grid((unsigned)(((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN)), (unsigned)splits);
+    g.tile_cnt = splits > 1 ? splitk_counters((long long)grid.x) : nullptr;
     const size_t lds = sizeof(float) * 4 * CBK * SLD;
     auto kern = ksize == 7 ? conv3x3_small_kernel<CONV_FWD, 7>
                 : mode == CONV_FWD ? conv3x3_small_kernel<CONV_FWD> : mode == CONV_DX ? conv3x3_small_kernel<CONV_DX> : conv3x3_small_kernel<CONV_DW>;
@@ -563,7 +616,7 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, c);
-    if (splits > 1) {
+    if (splits > 1 && g.tile_cnt == nullptr) {
         const size_t n = (size_t)M * N;
         hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
     }
