@@ -87,8 +87,15 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, float4 v, int 
     }
 }
 
+// Split-K combine.  0 (default): a separate reduce launch per split-K product (84 launches per step at cfg2).
+// 1 / 2: combined INSIDE the launch by the tile's last arriving workgroup (below) - built and measured in round 3 because
+// it removes those launches, and kept as an experiment only: whole step at cfg2 (same box, interleaved) 14.87 ms with the
+// separate reduce, 17.92 ms with variant 1 (agent-scope release fence per workgroup + acquire in the last arrival:
+// every fence writes back / invalidates the XCD's L2 under ~500 workgroups per launch), 16.41 ms with variant 2 (sc1
+// partial stores / loads, no fences).  The weight-gradient products run 16-64 splits: one workgroup then reads 0.25-1 MB of
+// partial tiles serially where the reduce launch spreads them over the chip.
 #ifndef CIM_SMALL_FUSED_REDUCE
-#define CIM_SMALL_FUSED_REDUCE 1     // 0 = split-K partial products are combined by a separate reduce launch (round 2)
+#define CIM_SMALL_FUSED_REDUCE 0
 #endif
 // Epilogue of one output value (shared by the single-pass kernels, the in-kernel split-K combine and the reduce kernel)
 __device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int col, float v) {
@@ -110,19 +117,40 @@ __device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int co
 // vmcnt, barrier, ONE agent-scope release + relaxed agent-scope fetch_add by one lane; the last arrival does one
 // agent-scope acquire, then plain loads.  The counter is left at zero for the next launch that uses the slot.
 // `flag` = a word of the kernel's own LDS array (a second __shared__ object would de-pipeline the k-loop).
+// CIM_SMALL_FUSED_REDUCE = 2: the partial tiles travel past the (per-XCD, non-coherent) L2s by themselves - agent-scope relaxed
+// atomic stores / loads compile to sc1 accesses - so the hand-off needs no cache write-back / invalidate fences at all.
+__device__ __forceinline__ void small_put_partial(float* p, float v) {
+#if CIM_SMALL_FUSED_REDUCE == 2
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ float small_get_partial(const float* p) {
+#if CIM_SMALL_FUSED_REDUCE == 2
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+
 template <int TN>
 __device__ __forceinline__ void small_splitk_combine(const SmallArgs& g, int tile, int m0, int n0, int tid, int nthreads,
                                                      volatile int* flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
+#if CIM_SMALL_FUSED_REDUCE != 2
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         const unsigned t = __hip_atomic_fetch_add(g.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = t == (unsigned)g.splits - 1u;
         if (last) {
             __hip_atomic_store(g.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if CIM_SMALL_FUSED_REDUCE != 2
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         }
         *flag = last;
     }
@@ -134,8 +162,8 @@ __device__ __forceinline__ void small_splitk_combine(const SmallArgs& g, int til
         const int row = m0 + r, col = n0 + c;
         if (row >= g.M || col >= g.N) continue;
         const size_t i = (size_t)row * g.N + col;
-        float v = g.ws[i];
-        for (int k = 1; k < g.splits; ++k) v += g.ws[(size_t)k * mn + i];
+        float v = small_get_partial(g.ws + i);
+        for (int k = 1; k < g.splits; ++k) v += small_get_partial(g.ws + (size_t)k * mn + i);
         small_finish(g, row, col, v);
     }
 }
@@ -209,7 +237,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_small_kernel(const SmallArgs g)
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
             if (row >= g.M) continue;
-            if (g.splits > 1) g.ws[((size_t)split * g.M + row) * g.N + col] = acc[r];
+            if (g.splits > 1) small_put_partial(g.ws + ((size_t)split * g.M + row) * g.N + col, acc[r]);
             else small_finish(g, row, col, acc[r]);
         }
     }
@@ -399,7 +427,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
             if (row >= g.M) continue;
-            if (g.splits > 1) g.ws[((size_t)split * g.M + row) * g.N + col] = acc[r];
+            if (g.splits > 1) small_put_partial(g.ws + ((size_t)split * g.M + row) * g.N + col, acc[r]);
             else small_finish(g, row, col, acc[r]);
         }
     }
@@ -425,7 +453,7 @@ __global__ __launch_bounds__(256) void conv3x3_wt_kernel(const float* __restrict
 // freed (4 MiB).  A launch takes the next `tiles` words; every tile's last arrival puts its word back to zero, so a slot is
 // reusable once its launch has finished - with 2^20 words and at most a few thousand tiles per launch, launches that are in
 // flight together (two streams, a few dozen queued kernels) never share a word.
-constexpr long long CNT_RING = 1ll << 20;
+[[maybe_unused]] constexpr long long CNT_RING = 1ll << 20;
 unsigned* splitk_counters(long long tiles) {
 #if !CIM_SMALL_FUSED_REDUCE
     return nullptr;
