@@ -280,6 +280,8 @@ def run(args):
 
     if rank == 0:
         line = report(args, world, elapsed, images, timer, infos, state["feat"], Cf, cfg, gemm_mod, np)
+        from cim_amd.ops import fallback as _fb
+        extra["aten_fallbacks"] = {"%s: %s" % k: v for k, v in _fb.counts().items()}      # GPU tensors that took a library branch (none expected)
         line["extra"] = extra
         # what the process group itself reports (a SCALE run is checkable: ranks, backend, every rank's own rate)
         line["dist"] = dict(world_size=dist.get_world_size() if world > 1 else 1, backend=(dist.get_backend() if world > 1 else None),

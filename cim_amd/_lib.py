@@ -78,6 +78,8 @@ SIGNATURES = {
     "cim_wino_dy_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_wgrad_output": [_P, _P, c_int, c_int, c_int, _P],
     "cim_losses_fwd": [_P, _P],
+    "cim_linear_bias_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
+    "cim_loss_grad_combine": [_P, _P, _P, c_int, c_int, c_int, _P],
     "cim_head_act_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }

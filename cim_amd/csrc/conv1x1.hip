@@ -46,6 +46,7 @@ struct SmallArgs {
     int M, N, K, lda, ldb, ldc;
     int a_mcontig, b_kcontig, relu, bn;
     int splits; float* ws;
+    const float* colbias;    // [N] added per output COLUMN (nn.Linear bias: C = X . W^T + b); null for the convolutions
     unsigned* tile_cnt;      // split-K: per-tile arrival counters (zero between launches) - the last split of a tile combines
 };
 
@@ -107,6 +108,7 @@ __device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int co
         y = fmaf(v, a, g.beta[row] - g.mean[row] * a);
     }
     if (g.res) y += g.res[o];
+    if (g.colbias) y += g.colbias[col];
     if (g.relu) y = fmaxf(y, 0.0f);
     g.C[o] = y;
 }
@@ -513,7 +515,7 @@ extern "C" int cim_gemm_small_f32(const float* A, const float* B, float* C, int 
     g.gamma = gamma; g.beta = beta; g.mean = mean; g.var = var; g.res = residual; g.eps = eps;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_mcontig = a_mcontig; g.b_kcontig = b_kcontig; g.relu = relu; g.bn = gamma != nullptr;
-    g.splits = splits; g.ws = workspace;
+    g.splits = splits; g.ws = workspace; g.colbias = nullptr;
     const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
     CIM_CHECK_ARG(tiles * 2 < (1ll << 31) && splits <= 65535);
     const bool narrow = tiles * splits < 128;           // 64 x 32 tiles only for problems that cannot fill the chip otherwise
@@ -525,6 +527,29 @@ extern "C" int cim_gemm_small_f32(const float* A, const float* B, float* C, int 
         if (b_kcontig) launch_small<false, true>(g, splits, st, narrow); else launch_small<false, false>(g, splits, st, narrow);
     }
     if (splits > 1 && g.tile_cnt == nullptr) {          // (no counters: the separate, equally ordered reduce pass)
+        const size_t n = (size_t)M * N;
+        hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
+    }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+// Y[M][N] = X[M][K] . W[N][K]^T + bias[N]  (nn.Linear on the small-tile fp32-MFMA GEMM): the eight scoring heads of
+// lib/modeling/heads.py:194-219 as ONE product against their concatenated weights (N = 8 (C + 1) = 168 / 648 columns).
+extern "C" int cim_linear_bias_f32(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int splits,
+                                   float* workspace, void* stream) {
+    CIM_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0 && splits >= 1 && splits <= 65535 && (splits == 1 || workspace));
+    SmallArgs g;
+    g.A = X; g.B = W; g.C = Y; g.Xraw = nullptr;
+    g.gamma = g.beta = g.mean = g.var = g.res = nullptr; g.eps = 0.f;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+    g.a_mcontig = 0; g.b_kcontig = 1; g.relu = 0; g.bn = 0;
+    g.splits = splits; g.ws = workspace; g.colbias = bias;
+    const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
+    g.tile_cnt = splits > 1 ? splitk_counters(tiles) : nullptr;
+    hipStream_t st = cim::as_stream(stream);
+    launch_small<false, true>(g, splits, st, false);
+    if (splits > 1 && g.tile_cnt == nullptr) {
         const size_t n = (size_t)M * N;
         hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
     }
@@ -633,7 +658,7 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
     g.gamma = gamma; g.beta = beta; g.mean = mean; g.var = var; g.res = residual; g.eps = eps;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = 0; g.ldc = ldc;
     g.a_mcontig = 0; g.b_kcontig = mode == CONV_DW; g.relu = relu; g.bn = gamma != nullptr;
-    g.splits = splits; g.ws = ws;
+    g.splits = splits; g.ws = ws; g.colbias = nullptr;
     const dim3 grid((unsigned)(((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN)), (unsigned)splits);
     g.tile_cnt = splits > 1 ? splitk_counters((long long)grid.x) : nullptr;
     const size_t lds = sizeof(float) * 4 * CBK * SLD;

@@ -45,7 +45,8 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 }
 
 __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot) {
-    const int N = a.N, C1 = a.C1, tid = threadIdx.x;
+    const int N = a.N, C1 = a.C1, LD = a.ld > 0 ? a.ld : a.C1, tid = threadIdx.x;
+    (void)LD;
     const float* rc = a.rc[li];
     const float* ri = a.ri[li];
     const float* Y = a.pseudo_labels[li];
@@ -71,10 +72,10 @@ __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot)
         hot[n] = h;
         if (h < 0) continue;
         const float wn = ws * w[n];
-        s_cls += -logf(clampf(rc[(size_t)n * C1 + h])) * wn;
+        s_cls += -logf(clampf(rc[(size_t)n * LD + h])) * wn;
         n_lab += 1.0f;
         if (h >= 1) {
-            const float d = clampf(ri[(size_t)n * C1 + h]) - cim::h2f(t16[n]);
+            const float d = clampf(ri[(size_t)n * LD + h]) - cim::h2f(t16[n]);
             const float ad = fabsf(d);
             s_iou += (ad < 1.0f ? 0.5f * d * d : ad - 0.5f) * wn;
             n_fg += 1.0f;
@@ -91,10 +92,10 @@ __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot)
         const int h = hot[n];
         if (h < 0) continue;
         const float wn = ws * w[n];
-        const float x = rc[(size_t)n * C1 + h];
+        const float x = rc[(size_t)n * LD + h];
         g_rc_cls[(size_t)n * C1 + h] = -wn / (clampf(x) * n_lab) * inrange(x);
         if (h >= 1) {
-            const float xi = ri[(size_t)n * C1 + h];
+            const float xi = ri[(size_t)n * LD + h];
             const float d = clampf(xi) - cim::h2f(t16[n]);
             const float dd = fabsf(d) < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f);
             g_ri_iou[(size_t)n * C1 + h] = dd * wn / n_fg * inrange(xi);
@@ -108,7 +109,7 @@ __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot)
         float fv = -INFINITY, uv = -INFINITY;
         int fi = INT_MAX, ui = INT_MAX;
         for (int n = lane; n < N; n += 64) {
-            const float u = clampf(rc[(size_t)n * C1 + c]) * clampf(ri[(size_t)n * C1 + c]);
+            const float u = clampf(rc[(size_t)n * LD + c]) * clampf(ri[(size_t)n * LD + c]);
             const float f = (hot[n] == c) ? u : 0.0f;                            // ind * predict * tmp_pseudo_label
             if (f > fv) { fv = f; fi = n; }
             if (u > uv) { uv = u; ui = n; }
@@ -127,12 +128,12 @@ __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot)
             const float du_f = dagg * L * ((hot[fi] == c) ? 1.0f : 0.0f);
             const float du_u = dagg * (1.0f - L);
             if (du_f != 0.0f) {
-                const float xr = rc[(size_t)fi * C1 + c], xi = ri[(size_t)fi * C1 + c];
+                const float xr = rc[(size_t)fi * LD + c], xi = ri[(size_t)fi * LD + c];
                 g_rc_bag[(size_t)fi * C1 + c] += du_f * clampf(xi) * inrange(xr);
                 g_ri_bag[(size_t)fi * C1 + c] += du_f * clampf(xr) * inrange(xi);
             }
             if (du_u != 0.0f) {
-                const float xr = rc[(size_t)ui * C1 + c], xi = ri[(size_t)ui * C1 + c];
+                const float xr = rc[(size_t)ui * LD + c], xi = ri[(size_t)ui * LD + c];
                 g_rc_bag[(size_t)ui * C1 + c] += du_u * clampf(xi) * inrange(xr);
                 g_ri_bag[(size_t)ui * C1 + c] += du_u * clampf(xr) * inrange(xi);
             }
@@ -143,13 +144,13 @@ __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot)
 }
 
 __device__ void mil_job(const cim_loss_args& a, float* red) {
-    const int N = a.N, C1 = a.C1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N = a.N, C1 = a.C1, LD = a.ld > 0 ? a.ld : a.C1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     float* g_pc = a.grad;                                   // component 0: d bag / d predict_cls
     float* g_pd = a.grad + (size_t)2 * N * C1;              // component 2: d bag / d predict_det
     float bag = 0.0f;
     for (int c = wave; c < C1; c += NT / 64) {              // heads.py:149-166
         float s = 0.0f;
-        for (int n = lane; n < N; n += 64) s += a.pc[(size_t)n * C1 + c] * a.pd[(size_t)n * C1 + c];
+        for (int n = lane; n < N; n += 64) s += a.pc[(size_t)n * LD + c] * a.pd[(size_t)n * LD + c];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float L = (c == 0) ? 1.0f : a.labels[c - 1];
@@ -157,8 +158,8 @@ __device__ void mil_job(const cim_loss_args& a, float* red) {
         if (lane == 0) bag += -(L * logf(p) + (1.0f - L) * logf(1.0f - p)) / (float)C1;
         const float ds = -(L / p - (1.0f - L) / (1.0f - p)) / (float)C1 * inrange(s);
         for (int n = lane; n < N; n += 64) {
-            g_pc[(size_t)n * C1 + c] = ds * a.pd[(size_t)n * C1 + c];
-            g_pd[(size_t)n * C1 + c] = ds * a.pc[(size_t)n * C1 + c];
+            g_pc[(size_t)n * C1 + c] = ds * a.pd[(size_t)n * LD + c];
+            g_pd[(size_t)n * C1 + c] = ds * a.pc[(size_t)n * LD + c];
         }
     }
     bag = block_sum(bag, red);
@@ -183,7 +184,8 @@ __device__ float block_min(float v, float* red) {
 // csize [K].  Returns the number of clusters; *bg = rank of the id found in column 0 (-1: none).
 __device__ int pcl_plan(const cim_loss_args& a, float* red, float* row_val, int16_t* row_col, int16_t* row_cluster,
                         int* csize, int* bg) {
-    const int N = a.N, C1 = a.C1, tid = threadIdx.x;
+    const int N = a.N, C1 = a.C1, LD = a.ld > 0 ? a.ld : a.C1, tid = threadIdx.x;
+    (void)LD;
     float bgv_lo = INFINITY, bgv_hi = -INFINITY;
     int err = 0;
     for (int n = tid; n < N; n += NT) {
@@ -230,7 +232,7 @@ __device__ int pcl_plan(const cim_loss_args& a, float* red, float* row_val, int1
 }
 
 __device__ void pcl_job(const cim_loss_args& a, float* red, unsigned char* scratch) {
-    const int N = a.N, C1 = a.C1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N = a.N, C1 = a.C1, LD = a.ld > 0 ? a.ld : a.C1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     float* g = a.grad + (size_t)1 * N * C1;                 // component 1: d pcl / d predict_cls
     for (int i = tid; i < N * C1; i += NT) g[i] = 0.f;
     float* row_val = reinterpret_cast<float*>(scratch);                       // [N]
@@ -251,7 +253,7 @@ __device__ void pcl_job(const cim_loss_args& a, float* red, unsigned char* scrat
             float s = 0.0f;
             for (int n = lane; n < N; n += 64) {
                 if (row_cluster[n] != k) continue;
-                const float x = a.pc[(size_t)n * C1 + c], p = clampf(x);
+                const float x = a.pc[(size_t)n * LD + c], p = clampf(x);
                 const float t = (row_col[n] == c) ? 1.0f : 0.0f;
                 s += -(t * logf(p) + (1.0f - t) * logf(1.0f - p));
                 g[(size_t)n * C1 + c] = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(x);
@@ -264,7 +266,7 @@ __device__ void pcl_job(const cim_loss_args& a, float* red, unsigned char* scrat
             int any = 0;
             for (int n = lane; n < N; n += 64) {
                 if (row_cluster[n] != k) continue;
-                s += a.pc[(size_t)n * C1 + c];
+                s += a.pc[(size_t)n * LD + c];
                 any |= (row_col[n] == c);
             }
 #pragma unroll
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(NT) void losses_kernel(const cim_loss_args a) {
 extern "C" int cim_losses_fwd(const cim_loss_args* args, void* stream) {
     CIM_CHECK_ARG(args != nullptr);
     const cim_loss_args& a = *args;
-    CIM_CHECK_ARG(a.N > 0 && a.N <= 15000 && a.C1 > 1 && a.C1 <= 32767 && a.R >= 0 && a.R <= 3);
+    CIM_CHECK_ARG(a.N > 0 && a.N <= 15000 && a.C1 > 1 && a.C1 <= 32767 && a.R >= 0 && a.R <= 3 && (a.ld == 0 || a.ld >= a.C1));
     CIM_CHECK_ARG(a.pc && a.pd && a.labels && a.part && a.grad && a.mat && (a.R == 0 || a.layer_valid));
     for (int i = 0; i < a.R; ++i)
         CIM_CHECK_ARG(a.rc[i] && a.ri[i] && a.pseudo_labels[i] && a.pseudo_iou_f16[i] && a.loss_weights[i]);
@@ -409,7 +411,36 @@ __global__ __launch_bounds__(256) void head_act_bwd_kernel(const float* __restri
     }
 }
 
+// d(total loss) / d(score matrix) from the stored components and the four upstream scalars, in the heads' fused layout
+// [N][(2 + 2R) C1] = (predict_cls | predict_det | refine_cls[0..R) | refine_iou[0..R)) - what cim_head_act_bwd consumes:
+//   pc: g_bag G0 + g_pcl G1;  pd: g_bag G2;  rc_i: g_cls G[3+4i] + g_bag G[4+4i];  ri_i: g_iou G[5+4i] + g_bag G[6+4i]
+// (g = (bag, pcl, cls, iou) on the device; replaces ~20 element-wise ATen launches and the 8-way concatenation of their results)
+__global__ __launch_bounds__(256) void loss_grad_combine_kernel(const float* __restrict__ G, const float* __restrict__ g,
+                                                                float* __restrict__ out, int N, int C1, int R) {
+    const size_t plane = (size_t)N * C1;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= plane) return;
+    const int n = (int)(i / C1), c = (int)(i - (size_t)n * C1);
+    const float g_bag = g[0], g_pcl = g[1], g_cls = g[2], g_iou = g[3];
+    float* o = out + (size_t)n * (2 + 2 * R) * C1 + c;
+    o[0] = g_bag * G[i] + g_pcl * G[plane + i];
+    o[C1] = g_bag * G[2 * plane + i];
+    for (int r = 0; r < R; ++r) {
+        const float* Gr = G + (size_t)(3 + 4 * r) * plane + i;
+        o[(2 + r) * C1] = g_cls * Gr[0] + g_bag * Gr[plane];
+        o[(2 + R + r) * C1] = g_iou * Gr[2 * plane] + g_bag * Gr[3 * plane];
+    }
+}
+
 }  // namespace
+
+extern "C" int cim_loss_grad_combine(const float* G, const float* g, float* out, int N, int C1, int R, void* stream) {
+    CIM_CHECK_ARG(G && g && out && N > 0 && C1 > 0 && R >= 0 && R <= 3);
+    const size_t n = (size_t)N * C1;
+    hipLaunchKernelGGL(loss_grad_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), G, g, out, N, C1, R);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int cim_head_act_fwd(const float* logits, float* scores, float* colstat, int N, int C1, int R, void* stream) {
     CIM_CHECK_ARG(logits && scores && colstat && N > 0 && C1 > 0 && R >= 0 && R <= 8);

@@ -151,7 +151,7 @@ class _LossArgs(ctypes.Structure):
                 ("layer_valid", ctypes.c_void_p), ("labels", ctypes.c_void_p),
                 ("mat", ctypes.c_void_p), ("status", ctypes.c_void_p),
                 ("N", ctypes.c_int), ("C1", ctypes.c_int), ("R", ctypes.c_int),
-                ("part", ctypes.c_void_p), ("grad", ctypes.c_void_p)]
+                ("part", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("ld", ctypes.c_int)]
 
 
 STATUS_BITS = {1: "a class produced more than K pseudo ground truths (internal)",
@@ -172,19 +172,29 @@ class FusedLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, pc, pd, *scores):
         R = meta["R"]
-        rc, ri = scores[:R], scores[R:2 * R]
-        N, C1 = pc.shape
+        fused = meta.get("fused", False)        # pc IS the heads' score matrix [N, (2 + 2R) C1]; its column blocks are the scores
         dev = pc.device
-        pc, pd = pc.contiguous(), pd.contiguous()
-        rc = [t.contiguous() for t in rc]
-        ri = [t.contiguous() for t in ri]
+        if fused:
+            all_scores = pc.contiguous()
+            N, C1 = all_scores.shape[0], all_scores.shape[1] // (2 + 2 * R)
+            base, blk = all_scores.data_ptr(), 4 * C1
+            ptrs = [base + h * blk for h in range(2 + 2 * R)]
+            ld = (2 + 2 * R) * C1
+        else:
+            rc, ri = scores[:R], scores[R:2 * R]
+            N, C1 = pc.shape
+            pc, pd = pc.contiguous(), pd.contiguous()
+            rc = [t.contiguous() for t in rc]
+            ri = [t.contiguous() for t in ri]
+            ptrs = [pc.data_ptr(), pd.data_ptr()] + [t.data_ptr() for t in rc] + [t.data_ptr() for t in ri]
+            ld = 0
         part = torch.empty((R + 2, 4), dtype=torch.float32, device=dev)
         grad = torch.empty((3 + 4 * R, N, C1), dtype=torch.float32, device=dev)
         a = _LossArgs()
-        a.pc, a.pd = pc.data_ptr(), pd.data_ptr()
+        a.pc, a.pd, a.ld = ptrs[0], ptrs[1], ld
         keep = []
         for i in range(R):
-            a.rc[i], a.ri[i] = rc[i].data_ptr(), ri[i].data_ptr()
+            a.rc[i], a.ri[i] = ptrs[2 + i], ptrs[2 + R + i]
             y, t16, w = (x.contiguous() for x in meta["pseudo"][i])
             assert t16.dtype == torch.float16 and y.dtype == torch.float32 and w.dtype == torch.float32
             keep += [y, t16, w]
@@ -199,7 +209,7 @@ class FusedLossFunction(torch.autograd.Function):
         a.N, a.C1, a.R = N, C1, R
         a.part, a.grad = part.data_ptr(), grad.data_ptr()
         _lib.call("cim_losses_fwd", ctypes.byref(a), _lib.stream_ptr())
-        ctx.R = R
+        ctx.R, ctx.fused, ctx.dims = R, fused, (N, C1)
         ctx.save_for_backward(grad)
         return part.sum(dim=0)
 
@@ -211,12 +221,34 @@ class FusedLossFunction(torch.autograd.Function):
         # mining consumed (no stall: the GPU finished the mining long before the host gets here)
         if _rng.pending is not None:
             engine.queue_callback(settle_rng)
+        if ctx.fused:       # ONE launch: the gradient of the fused score matrix, ready for the head activations' backward
+            N, C1 = ctx.dims
+            out = torch.empty((N, (2 + 2 * R) * C1), dtype=torch.float32, device=G.device)
+            _lib.call("cim_loss_grad_combine", G.data_ptr(), g.contiguous().data_ptr(), out.data_ptr(), N, C1, R, _lib.stream_ptr())
+            return None, out, None
         g_bag, g_pcl, g_cls, g_iou = g[0], g[1], g[2], g[3]
         d_pc = g_bag * G[0] + g_pcl * G[1]
         d_pd = g_bag * G[2]
         d_rc = [g_cls * G[3 + 4 * i] + g_bag * G[4 + 4 * i] for i in range(R)]
         d_ri = [g_iou * G[5 + 4 * i] + g_bag * G[6 + 4 * i] for i in range(R)]
         return (None, d_pc, d_pd, *d_rc, *d_ri)
+
+
+def _fused_base(predict_cls, predict_det, ref_cls_score, ref_iou_score):
+    """The heads' score matrix [N, (2 + 2R) C1] when the eight score tensors are exactly its column blocks in order (what
+    cls_iou_model.forward returns on the GPU), else None."""
+    ts = [predict_cls, predict_det] + list(ref_cls_score) + list(ref_iou_score)
+    base = getattr(predict_cls, "_base", None)
+    if base is None or base.dim() != 2 or not base.is_contiguous() or not base.is_cuda:
+        return None
+    n, c1 = predict_cls.shape
+    if base.shape != (n, len(ts) * c1):
+        return None
+    for h, t in enumerate(ts):
+        if getattr(t, "_base", None) is not base or t.shape != (n, c1) or t.stride() != (base.shape[1], 1) \
+                or t.storage_offset() != base.storage_offset() + h * c1:
+            return None
+    return base
 
 
 def fused_losses(predict_cls, predict_det, ref_cls_score, ref_iou_score, labels, pseudo, scales, mat,
@@ -240,7 +272,12 @@ def fused_losses(predict_cls, predict_det, ref_cls_score, ref_iou_score, labels,
     if own_status:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
     meta = dict(R=R, pseudo=pseudo, scales=list(scales), labels=labels, mat=mat, valid=valid, status=status)
-    out = FusedLossFunction.apply(meta, predict_cls, predict_det, *ref_cls_score, *ref_iou_score)
+    base = _fused_base(predict_cls, predict_det, ref_cls_score, ref_iou_score)
+    if base is not None:            # the eight scores are column blocks of ONE matrix: no copies in, one gradient tensor out
+        meta["fused"] = True
+        out = FusedLossFunction.apply(meta, base, None)
+    else:
+        out = FusedLossFunction.apply(meta, predict_cls, predict_det, *ref_cls_score, *ref_iou_score)
     if own_status:                     # stand-alone use (tests): report format errors right away
         check_status(int(status.item()))
     return out[0], out[1], out[2], out[3]
@@ -271,14 +308,16 @@ class cls_iou_model(nn.Module):
             seg_feature = seg_feature.squeeze(3).squeeze(2)
         # one [N,dim_in] x [dim_in, 8*dim_out] contraction instead of eight small ones
         layers = [self.classifier, self.detector] + list(self.refine_cls) + list(self.refine_iou)
-        w = torch.cat([l.weight for l in layers], dim=0)
-        b = torch.cat([l.bias for l in layers], dim=0)
-        logits = F.linear(seg_feature, w, b)
         r = len(self.refine_cls)
         c1 = self.classifier.out_features
-        if logits.is_cuda and logits.dtype == torch.float32:
-            scores = HeadActFunction.apply(logits, c1, r).split(c1, dim=1)     # fused HIP epilogue
+        if seg_feature.is_cuda and seg_feature.dtype == torch.float32:
+            # linear (own small-tile fp32-MFMA GEMM against the concatenated weights) + activations: one autograd node, whose
+            # backward hands each head's weight / bias gradient out as a slice of one [8 C1, dim_in] product
+            scores = HeadsFunction.apply(seg_feature, c1, r, *[l.weight for l in layers], *[l.bias for l in layers]).split(c1, dim=1)
         else:   # CPU tensors (host-side tests of the module): the same maths in ATen
+            w = torch.cat([l.weight for l in layers], dim=0)
+            b = torch.cat([l.bias for l in layers], dim=0)
+            logits = F.linear(seg_feature, w, b)
             lg = logits.split(c1, dim=1)
             scores = ([F.softmax(lg[0], dim=-1), F.softmax(lg[1], dim=0)] + [F.softmax(l, dim=-1) for l in lg[2:2 + r]]
                       + [torch.sigmoid(l) for l in lg[2 + r:2 + 2 * r]])
@@ -310,6 +349,65 @@ class HeadActFunction(torch.autograd.Function):
         _lib.call("cim_head_act_bwd", scores.data_ptr(), g.data_ptr(), dx.data_ptr(), dot.data_ptr(), n, c1, r,
                   _lib.stream_ptr())
         return dx, None, None
+
+
+def _small_gemm(a, b, c, m, n, k, lda, ldb, ldc, a_mcontig, b_kcontig):
+    """C[m,n] = A . B on the small-tile fp32-MFMA GEMM (cim_amd/csrc/conv1x1.hip), split-K through a workspace."""
+    splits = _lib.call("cim_gemm_small_splits", m, n, k)
+    ws = torch.empty(splits * m * n, dtype=torch.float32, device=c.device) if splits > 1 else None
+    _lib.call("cim_gemm_small_f32", a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, lda, ldb, ldc, int(a_mcontig), int(b_kcontig),
+              None, None, None, None, None, 0.0, None, 0, splits, _lib.ptr(ws), _lib.stream_ptr())
+
+
+class HeadsFunction(torch.autograd.Function):
+    """The eight heads of heads.py:194-219 as ONE node: scores [N, 8 C1] = act(x . Wcat^T + bcat) with Wcat the eight
+    weights stacked.  Forward: concatenate, one GEMM with the bias in its epilogue, the fused activation launch.  Backward:
+    activation backward, dx = dlogits . Wcat, dWcat = dlogits^T . x, dbcat = column sums - the per-head gradients are
+    row slices of dWcat / dbcat (no 8-way scatter)."""
+
+    @staticmethod
+    def forward(ctx, x, c1, r, *wb):
+        nh = 2 + 2 * r
+        ws_, bs_ = wb[:nh], wb[nh:]
+        x = x.contiguous()
+        n, k = x.shape
+        wcat = torch.cat([w.detach() for w in ws_], dim=0)
+        bcat = torch.cat([b.detach() for b in bs_], dim=0)
+        m = nh * c1
+        logits = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        splits = _lib.call("cim_gemm_small_splits", n, m, k)
+        wsp = torch.empty(splits * n * m, dtype=torch.float32, device=x.device) if splits > 1 else None
+        _lib.call("cim_linear_bias_f32", x.data_ptr(), wcat.data_ptr(), bcat.data_ptr(), logits.data_ptr(), n, m, k, splits,
+                  _lib.ptr(wsp), _lib.stream_ptr())
+        scores = torch.empty_like(logits)
+        stat = torch.empty(2 * c1, dtype=torch.float32, device=x.device)
+        _lib.call("cim_head_act_fwd", logits.data_ptr(), scores.data_ptr(), stat.data_ptr(), n, c1, r, _lib.stream_ptr())
+        ctx.save_for_backward(x, wcat, scores)
+        ctx.dims = (n, k, c1, r)
+        return scores
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wcat, scores = ctx.saved_tensors
+        n, k, c1, r = ctx.dims
+        nh = 2 + 2 * r
+        m = nh * c1
+        g = g.contiguous()
+        dl = torch.empty_like(scores)
+        dot = torch.empty(c1, dtype=torch.float32, device=scores.device)
+        _lib.call("cim_head_act_bwd", scores.data_ptr(), g.data_ptr(), dl.data_ptr(), dot.data_ptr(), n, c1, r, _lib.stream_ptr())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((n, k), dtype=torch.float32, device=x.device)
+            _small_gemm(dl, wcat, dx, n, k, m, m, k, k, False, False)              # dlogits [n,m] . Wcat [m,k]
+        if any(ctx.needs_input_grad[3:3 + nh]):
+            dw = torch.empty((m, k), dtype=torch.float32, device=x.device)
+            _small_gemm(dl, x, dw, m, k, n, m, k, k, True, False)                  # dlogits^T [m,n] . x [n,k]
+        if any(ctx.needs_input_grad[3 + nh:]):
+            db = dl.sum(dim=0)
+        gw = [dw[h * c1:(h + 1) * c1] if dw is not None and ctx.needs_input_grad[3 + h] else None for h in range(nh)]
+        gb = [db[h * c1:(h + 1) * c1] if db is not None and ctx.needs_input_grad[3 + nh + h] else None for h in range(nh)]
+        return (dx, None, None, *gw, *gb)
 
 
 # --------------------------------------------------------------------------- mining

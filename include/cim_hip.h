@@ -447,6 +447,8 @@ typedef struct cim_loss_args {
     int N, C1, R;
     float* part;
     float* grad;
+    int ld;                          /* row stride (floats) of pc / pd / rc / ri: C1 (or 0) for dense [N,C1] tensors, 8 C1 when
+                                        they are the column blocks of the heads' fused score matrix [N, (2 + 2R) C1] */
 } cim_loss_args;
 
 int cim_losses_fwd(const cim_loss_args* args, void* stream);
@@ -456,6 +458,14 @@ int cim_losses_fwd(const cim_loss_args* args, void* stream);
  * logits / scores [N, (2+2R)*C1] with column blocks [classifier | detector | refine_cls[R] | refine_iou[R]]:
  * softmax over classes (classifier, refine_cls), softmax over PROPOSALS (detector), sigmoid (refine_iou).
  * colstat / coldot: [2*C1] / [C1] f32 scratch for the detector's column reductions. */
+/* The linear part of the eight heads on the small-tile fp32-MFMA GEMM (no library GEMM on the path):
+ *   cim_linear_bias_f32: Y[M][N] = X[M][K] . W[N][K]^T + bias[N]   (splits: cim_gemm_small_splits(M, N, K))
+ * and the gradient of the four losses w.r.t. the fused score matrix [N][(2 + 2R) C1] from cim_losses_fwd's `grad`
+ * components and the upstream (bag, pcl, cls, iou) gradients g [4] on the device:
+ *   cim_loss_grad_combine */
+int cim_linear_bias_f32(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int splits,
+                        float* workspace, void* stream);
+int cim_loss_grad_combine(const float* G, const float* g, float* out, int N, int C1, int R, void* stream);
 int cim_head_act_fwd(const float* logits, float* scores, float* colstat, int N, int C1, int R, void* stream);
 int cim_head_act_bwd(const float* scores, const float* grad_scores, float* grad_logits, float* coldot,
                      int N, int C1, int R, void* stream);
