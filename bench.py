@@ -376,7 +376,7 @@ def pmc_traffic(config):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs of this
     script, tools/pmc_traffic.py).  Only a profile of THIS workload counts: files are named per config and record the
     image mix they were taken on; anything else -> {} and `traffic: null`."""
-    path = os.path.join(REPO, "profiles", "r2", "pmc_traffic_%s.json" % config)
+    path = os.path.join(REPO, "profiles", "r3", "pmc_traffic_%s.json" % config)
     if not os.path.exists(path):
         return {}
     with open(path) as f:

@@ -54,6 +54,7 @@ def test_whole_step_full_size(tag):
     iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
     captured = {}
     hook = model.cls_iou_model.register_forward_hook(lambda m, i, o: captured.update(scores=o))
+    hook2 = model.Box_Head.register_forward_hook(lambda m, i, o: captured.update(seg_x=o.detach()))
     t = lambda a: torch.from_numpy(a).unsqueeze(0).to(dev)
     seed = 77
     np.random.seed(seed)
@@ -61,6 +62,7 @@ def test_whole_step_full_size(tag):
                 labels=t(inp["labels"]), gtrois=None, mat=t(inp["mat"]), index=t(inp["index"]),
                 iou_map=iou, asy_iou_map=asy)
     hook.remove()
+    hook2.remove()
     total = sum(v.sum() for v in out["losses"].values())
     total.backward()
     torch.cuda.synchronize()
@@ -70,6 +72,37 @@ def test_whole_step_full_size(tag):
         if p.requires_grad and p.grad is not None:
             assert torch.isfinite(p.grad).all(), name
     assert tuple(out["blob_conv"].shape[1:2]) == (model.Conv_Body.dim_out,)
+
+    # ---- the contraction path VALUE-checked at full size: 64 sampled proposals through the oracle
+    # ROIAlign on the HIP feature map + ATen conv / fc1 / fc2 / heads on the CPU with the same weights, against the rows the
+    # HIP step produced (ROIAlign + mask-cat kernel, pair-image Winograd convolution, fc GEMMs, fused heads)
+    from oracle import roi_align as ora
+    rs = np.random.RandomState(5)
+    pick = np.sort(rs.choice(n, 64, replace=False))
+    feat = out["blob_conv"].detach().float().cpu().numpy()
+    bh = model.Box_Head
+    with torch.no_grad():
+        box = torch.from_numpy(ora.roi_align_fwd(feat, inp["rois"][pick], 7, float(bh.spatial_scale), 0, True))
+        cat = torch.cat((box, box * torch.from_numpy(inp["masks"][pick]).unsqueeze(1)), dim=1)
+        cpu = lambda mod: (mod.weight.detach().cpu(), mod.bias.detach().cpu())
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        y = torch.relu(torch.nn.functional.conv2d(cat, *cpu(bh.mask_branch[0]), padding=1))
+        seg = torch.relu(torch.nn.functional.linear(y.reshape(64, -1), *cpu(bh.seg_fc[0])))
+        seg = torch.relu(torch.nn.functional.linear(seg, *cpu(bh.seg_fc[2])))
+        got_seg = captured["seg_x"][torch.from_numpy(pick).to(dev)].cpu()
+        dev_seg = float((got_seg - seg).abs().max() / seg.abs().max())
+        assert dev_seg < 2e-4, "seg_x rows deviate from the CPU evaluation: %.3g" % dev_seg
+        hm = model.cls_iou_model
+        pc_, _, rc_, ri_ = captured["scores"]
+        rows = torch.from_numpy(pick).to(dev)
+        worst_head = 0.0
+        for lin, got, act in ([(hm.classifier, pc_, "softmax")] + [(l, g, "softmax") for l, g in zip(hm.refine_cls, rc_)]
+                              + [(l, g, "sigmoid") for l, g in zip(hm.refine_iou, ri_)]):
+            logit = torch.nn.functional.linear(seg, *cpu(lin))
+            ref = torch.softmax(logit, dim=1) if act == "softmax" else torch.sigmoid(logit)
+            worst_head = max(worst_head, float((got.detach()[rows].cpu() - ref).abs().max()))
+        assert worst_head < 2e-4, "head scores deviate from the CPU evaluation: %.3g" % worst_head      # probabilities in [0, 1]
+    print("%s full size: 64 sampled proposals vs CPU: seg_x %.2e of max, head scores %.2e absolute" % (tag, dev_seg, worst_head))
 
     # ---- mining: HIP scores -> NumPy oracle, same seed, layers in order
     pc, pd, rc, ri = captured["scores"]

@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_FETCH_SIZE -o r -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_WRITE_SIZE -o r -- python3 bench.py ...
     python3 tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE <conv_algo> <engine> <workload tag> \
-            [--calibrate /tmp/cal_FETCH_SIZE /tmp/cal_WRITE_SIZE]  > profiles/r2/pmc_traffic_<config>.json
+            [--calibrate /tmp/cal_FETCH_SIZE /tmp/cal_WRITE_SIZE]  > profiles/r3/pmc_traffic_<config>.json
 
 Counters are in KiB per dispatch.  MI355X_MICROARCH.md (HBM) warns that on gfx950 FETCH_SIZE can report half of the
 bytes of a wide streaming read and prescribes a calibration on a known byte count with the kernel's own access width.
@@ -17,7 +17,7 @@ import json
 import sys
 
 # product kernels -> the key bench.py looks up
-KEYS = (("gemm_f16x2_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_bf16x3_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_f32_kernel<0, 0>", "wino_gemm_fwd"),
+KEYS = (("gemm_pair_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_f16x2_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_bf16x3_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_f32_kernel<0, 0>", "wino_gemm_fwd"),
         ("roi_align_fwd_rowsum", "cim_roi_align_maskcat_fwd"), ("roi_align_fwd_agg", "cim_roi_align_maskcat_fwd"),
         ("roi_align_bwd_region", "cim_roi_align_maskcat_bwd"), ("roi_align_bwd_gather", "cim_roi_align_maskcat_bwd"),
         ("roi_partial_reduce", "roi_partial_reduce"), ("mask_iou_pair", "mask_iou_pair"), ("mask_pack", "mask_pack"),
@@ -69,8 +69,8 @@ def main():
         if not f or key in out:
             continue
         if key == "wino_gemm_fwd":
-            # the <A_KCONTIG, B_NCONTIG> instantiation is launched three times per image, in this order: the Winograd-domain
-            # forward GEMM of the MaskFuse conv (forward pass), then fc2's and fc1's data-gradient GEMMs (backward pass)
+            # this instantiation is launched three times per image, the Winograd-domain forward GEMM of the MaskFuse conv first
+            # (f16x2p: then fc1's and fc2's forward products; f16x2: then fc2's and fc1's data-gradient GEMMs)
             f, w = f[0::3], w[0::3]
         # (the first launches of a run belong to the warm-up: same kernels, same sizes)
         out[key] = dict(kernel=needle, dispatches=len(f), fetch_kib_mean=sum(f) / len(f), write_kib_mean=(sum(w) / len(w)) if w else None,
