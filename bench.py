@@ -218,7 +218,9 @@ def run(args):
             print("step %d: %.2f ms" % (i, 1e3 * (time.perf_counter() - t1)), file=sys.stderr)
     # one-off set-up, untimed and not counted as warm-up: every distinct image of the cycle once (allocator pools and
     # per-shape kernel attributes for its shapes), so that a short --warmup never leaves a first occurrence in the timed region
-    for _ in range(len(dev_batches) if args.warmup < len(dev_batches) else 0):
+    # (two passes: in the second one the caching allocator has blocks for every size class of the cycle - a first occurrence of
+    # an image still grows pools, measured as isolated 20+ ms steps in the first cycle after one pass)
+    for _ in range(2 * len(dev_batches) if args.warmup < len(dev_batches) else 0):
         step(args.iter_size)
     for _ in range(args.warmup):
         step(args.iter_size)
