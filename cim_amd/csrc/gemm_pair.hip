@@ -402,7 +402,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
     // when the stores start: stores count on vmcnt as well, and a load whose completion the compiler cannot prove at a
     // control-flow join draws an s_waitcnt vmcnt(0) in front of EVERY guarded store (128 per lane, each then waiting for
     // the previous store's acknowledgement).  So the bias is loaded above the loop and consumed here once, and full tiles
-    // take a path without per-row guards.
+    // take a path without per-row guards.  (Tried: each wave passes its 32 x 64 blocks through its slice of the idle LDS and
+    // stores rows as 16 bytes per lane - 32 store instructions per wave instead of 128: SLOWER, 1.43 vs 1.26 ms on the
+    // Winograd-forward launch; a wave's 4-byte stores already cover two whole 128-byte row segments per instruction.)
     const float inv = 1.0f / (g.a_scale[zb] * g.b_scale[zb]);
     asm volatile("" : "+v"(bvj[0]), "+v"(bvj[1]));
     float* C = Cb + (size_t)zsplit * g.c_split_stride;
