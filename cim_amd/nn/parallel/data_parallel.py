@@ -33,6 +33,7 @@ import torch
 import torch.distributed as dist
 
 from ...ops.gemm import join_side as _join_side, gradient_is_deferred as _gradient_is_deferred
+from ...ops import gemm as _gemm_ops
 from ...utils import engine
 from torch import nn
 
@@ -138,6 +139,7 @@ class DataParallel(nn.Module):
         if self.world_size > 1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
+            _gemm_ops.GRAD_PUBLISHER = self._publish_early      # big gradients finished inside a fused node go out at once
             if not engine.HAS_ENGINE_CALLBACK:
                 # no engine callback (see cim_amd/utils/engine.py): the public-API form of "finish the reduction" is a global
                 # optimizer-step pre-hook - whatever the gradient hooks have not reduced is reduced (and waited for) right
@@ -203,13 +205,30 @@ class DataParallel(nn.Module):
             return self._sync and self._fwd_since_step % max(self.iter_size, 1) == 0
         return self._sync and (self._backwards + 1) % max(self.iter_size, 1) == 0
 
-    def _on_grad_ready(self, p):
+    def _backward_started(self):
         if not self._cb_queued:       # first gradient of this backward pass: finish the reduction when the pass ends
             self._cb_queued = True
             self._early_seen = 0
             self._reduced_this_step = False
             if engine.HAS_ENGINE_CALLBACK:
                 engine.queue_callback(self._end_of_backward)
+
+    def _publish_early(self, p, g, stream):
+        """ops.gemm.GRAD_PUBLISHER: a fused Function finished the gradient `g` of the big parameter `p` on `stream` in the middle of
+        its backward.  Install it (autograd will not: the Function returns None for it) and let its bucket's all-reduce start
+        on that stream at once, in the strict bucket order."""
+        self._backward_started()
+        with torch.cuda.stream(stream):
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad += g
+            if self.world_size > 1 and self._sync_this_backward() and p in self._bucket_of:
+                self.buckets[self._bucket_of[p]]["ready"] += 1
+                self._launch_ready_buckets()
+
+    def _on_grad_ready(self, p):
+        self._backward_started()
         if self.world_size == 1:
             self._maybe_step_early(p)
             return

@@ -144,6 +144,13 @@ _DEFERRED = {}        # device -> [main stream, [(param, dw)], [tensors kept ali
 _PENDING_IDS = set()  # id(param) of the weights whose gradient is still on the side stream
 
 
+# nn.DataParallel (several ranks) registers a callable here: publish(param, grad, stream) installs `grad` as param.grad (or
+# adds it) on `stream` and lets the parameter's all-reduce bucket go out AT ONCE - used by fused Functions whose backward
+# computes several big weight gradients (MaskFuse: fc2, fc1, conv) long before it returns: returned through autograd they
+# would all become visible at the end of the node, and the 822 MB fc1 all-reduce would lose ~5 ms of backward to hide under.
+GRAD_PUBLISHER = None
+
+
 def gradient_is_deferred(param):
     """True between a layer's backward and join_side() for a weight whose gradient runs on the side stream (its
     post-accumulate-grad hooks fire at the layer's backward although nothing was accumulated yet)."""

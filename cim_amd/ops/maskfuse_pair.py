@@ -135,6 +135,7 @@ class MaskFusePairFunction(Function):
                               Xp.buf, Xp.scale, Y1p.buf, Y1p.scale)
         ctx.dims = (r, cin, cout, h1, h2, p)
         ctx.has_bias = (bc is not None, b1 is not None, b2 is not None)
+        ctx.weights = (wc, w1, w2)           # the Parameter objects: big gradients may be published early (see backward)
         return Y2
 
     @staticmethod
@@ -159,6 +160,16 @@ class MaskFusePairFunction(Function):
                 out = fn()
             return out
 
+        def publish(w, dw):
+            """Several ranks: hand a finished weight gradient to nn.DataParallel NOW (its all-reduce starts on the side stream
+            right behind the GEMM that wrote it) instead of returning it when the whole node is done.  -> None when published."""
+            pub = G.GRAD_PUBLISHER
+            if pub is None or dw is None or not isinstance(w, torch.nn.Parameter) or not w.is_leaf:
+                return dw
+            pub(w, dw, side if overlap else cur)
+            return None
+
+        wc_p, w1_p, w2_p = ctx.weights
         dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = None
         am = torch.zeros(3, dtype=torch.int32, device=dev)
         # ---- fc2
@@ -169,7 +180,7 @@ class MaskFusePairFunction(Function):
         pair.amax_of(dY2m, am[0:1])
         dY2p = pair.split(dY2m, r, h2, h2, scale=pair.scales_from(am[0:1], 1))
         if need_w2:
-            dw2 = on_side(lambda: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False))
+            dw2 = publish(w2_p, on_side(lambda: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False)))
         dY1 = pair.gemm(dY2p, W2p, r, h1, h2, False, False)
         # ---- fc1
         dY1m = dY1 * (Y1 > 0)
@@ -178,7 +189,7 @@ class MaskFusePairFunction(Function):
         pair.amax_of(dY1m, am[1:2])
         dY1p = pair.split(dY1m, r, h1, h1, scale=pair.scales_from(am[1:2], 1))
         if need_w1:
-            dw1 = on_side(lambda: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False))
+            dw1 = publish(w1_p, on_side(lambda: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False)))
         if need_x or need_wc or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
             dX = pair.gemm(dY1p, W1p, r, cout * p * p, h1, False, False, c_amax=am[2:3])
             # ---- flatten backward + ReLU mask of the conv; conv gradients
@@ -201,7 +212,7 @@ class MaskFusePairFunction(Function):
                     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
                     _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, 7, st2)
                     return dw
-                dwc = on_side(wgrad)
+                dwc = publish(wc_p, on_side(wgrad))
             if need_x:
                 sE = torch.empty(NPOS, dtype=torch.float32, device=dev)
                 _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 3, sE.data_ptr(), st)
