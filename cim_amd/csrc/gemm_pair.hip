@@ -404,7 +404,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
     // the previous store's acknowledgement).  So the bias is loaded above the loop and consumed here once, and full tiles
     // take a path without per-row guards.  (Tried: each wave passes its 32 x 64 blocks through its slice of the idle LDS and
     // stores rows as 16 bytes per lane - 32 store instructions per wave instead of 128: SLOWER, 1.43 vs 1.26 ms on the
-    // Winograd-forward launch; a wave's 4-byte stores already cover two whole 128-byte row segments per instruction.)
+    // Winograd-forward launch; a wave's 4-byte stores already cover two whole 128-byte row segments per instruction.  Also
+    // tried: MFMA operands swapped so that the accumulator tile is the transpose and a lane stores four consecutive columns of
+    // ITS row as 16 bytes - 32 stores per wave, no LDS: 1.33 vs 1.26 ms (32-byte pieces of 32 different rows per
+    // instruction).  The stores themselves cost 4-8 % of a launch (ablation without them: 1.246 vs 1.303 ms).)
     const float inv = 1.0f / (g.a_scale[zb] * g.b_scale[zb]);
     asm volatile("" : "+v"(bvj[0]), "+v"(bvj[1]));
     float* C = Cb + (size_t)zsplit * g.c_split_stride;
