@@ -134,6 +134,30 @@ class Generalized_RCNN(nn.Module):
 
     def forward(self, data, rois, masks, labels, gtrois=None, mat=None, path=None, index=None,
                 iou_map=None, asy_iou_map=None):
+        """model_builder.py:117-213.  The TRAINING step runs on a high-priority HIP stream of its own (ops/gemm.py:
+        main_stream_high_priority; its backward follows it there): the weight-gradient GEMMs that MaskFuse and the backbone leave
+        on the normal-priority side stream then fill the CUs the main chain does not use, instead of halving its GEMMs' share.
+        The caller's stream is ordered before and after, so drivers see ordinary tensors."""
+        if not (self.training and _gemm_ops.HIGH_PRIO and torch.is_tensor(data) and data.is_cuda) or torch.cuda.is_current_stream_capturing():
+            return self._forward_impl(data, rois, masks, labels, gtrois, mat, path, index, iou_map, asy_iou_map)
+        dev = data.device
+        cur, hp = torch.cuda.current_stream(dev), _gemm_ops.main_stream_high_priority(dev)
+        if cur == hp:
+            return self._forward_impl(data, rois, masks, labels, gtrois, mat, path, index, iou_map, asy_iou_map)
+        hp.wait_stream(cur)
+        for t in (data, rois, masks, labels, gtrois, mat, index, iou_map, asy_iou_map):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(hp)
+        with torch.cuda.stream(hp):
+            out = self._forward_impl(data, rois, masks, labels, gtrois, mat, path, index, iou_map, asy_iou_map)
+        cur.wait_stream(hp)
+        out["blob_conv"].record_stream(cur)
+        for v in out.get("losses", {}).values():
+            v.record_stream(cur)
+        return out
+
+    def _forward_impl(self, data, rois, masks, labels, gtrois=None, mat=None, path=None, index=None,
+                      iou_map=None, asy_iou_map=None):
         with torch.set_grad_enabled(self.training):
             im_data = data
             if self.training:

@@ -124,6 +124,19 @@ def _side_stream(dev):
     return s
 
 
+HIGH_PRIO = os.environ.get("CIM_HIGH_PRIO", "1") == "1"
+
+
+def main_stream_high_priority(dev):
+    """A HIGH-priority HIP stream for the training step's main chain (Generalized_RCNN.forward runs on it, so does its
+    backward): side-stream work - the deferred weight-gradient GEMMs - then only takes the CUs the main chain leaves, instead of
+    time-sharing them half and half with the data-gradient GEMMs.  CIM_HIGH_PRIO=0: everything on the caller's stream."""
+    s = _SIDE.get(("main", dev))
+    if s is None:
+        s = _SIDE[("main", dev)] = torch.cuda.Stream(device=dev, priority=-1)
+    return s
+
+
 # ---- weight gradients that run BESIDE the rest of the backward pass (backbone convolutions) ---------------------------
 # A backbone layer's weight-gradient GEMM is only needed by the optimizer.  Joined layer by layer (as the MaskFuse layers
 # above do) it cannot overlap much: the main stream waits for it before the next layer's BatchNorm backward.  Deferred, the

@@ -16,14 +16,22 @@ shapes); what changes is who splits the operands (cim_amd/csrc/gemm_pair.hip hea
             dU = V'^T . D' -> dW  |  Md = E' . U' -> dcat      (weight gradients on the side stream)
 Every image is written once and read by two products (contracted over its columns by one, over its rows by the other).
 """
+import os
 import torch
 from torch.autograd import Function
+_os_env = os.environ
 
 from .. import _lib
 from . import gemm as G
 from . import pair
 
 NPOS = 121
+# The node's weight-gradient GEMMs (fc2, fc1, conv: ~2.5 ms of MFMA work at cfg2) are only needed by the optimizer: joined once, at the
+# end of the backward pass (ops/gemm.py: defer_side_join), they keep running on the (normal-priority) side stream while the
+# high-priority main chain (model_builder.Generalized_RCNN.forward) goes on to the ROIAlign and backbone backward - small latency-bound
+# launches that leave most of the chip idle.  Measured at cfg2 (same box): 15.08 ms joined inside the node, 14.92 deferred,
+# 14.40 deferred + high-priority main stream (15.27 with the priority alone).  CIM_DEFER_MASKFUSE_DW=0 joins inside the node.
+DEFER_DW = _os_env.get("CIM_DEFER_MASKFUSE_DW", "1") == "1"
 
 
 def supported(cat, wc, w1, w2):
@@ -45,9 +53,13 @@ def _weight_amax(w, rows, cols):
 _IMAGES = {}      # id(weight) -> (version, data_ptr, Pair, event or None)
 
 
+import os as _os
+_STALE_FC = _os.environ.get("CIM_DEBUG_STALE_FC_IMAGES", "0") == "1"      # measurement aid: never refresh the fc weights' images
+
+
 def _cached(w):
     e = _IMAGES.get(id(w))
-    if e is not None and e[0] == w._version and e[1] == w.data_ptr():
+    if e is not None and ((e[0] == w._version and e[1] == w.data_ptr()) or (_STALE_FC and w.dim() == 2)):
         return e
     return None
 
@@ -170,7 +182,7 @@ class MaskFusePairFunction(Function):
             return None
 
         wc_p, w1_p, w2_p = ctx.weights
-        dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = None
+        dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = dy_conv = None
         am = torch.zeros(3, dtype=torch.int32, device=dev)
         # ---- fc2
         dY2 = dY2.contiguous()
@@ -222,13 +234,27 @@ class MaskFusePairFunction(Function):
                 dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
                 _lib.call("cim_wino_dx_adjoint_output", M2.data_ptr(), dxp.data_ptr(), r, p, cin, 7, st)
                 dcat = dxp.permute(0, 3, 1, 2)
+            dy_conv = dy
             if overlap:
                 dy.record_stream(side)
         if overlap:
-            cur.wait_stream(side)
-            for t in (dw2, dw1, dwc):
-                if t is not None:
-                    t.record_stream(cur)
+            if DEFER_DW and G.DEFER_DW:
+                # the weight gradients keep running on the side stream while the main stream goes on to the ROIAlign and backbone
+                # backward: joined (and installed as .grad) once, at the end of the backward pass (ops/gemm.py: defer_side_join)
+                keep = [V.buf, Xp.buf, Y1p.buf, dY2p.buf, dY1p.buf, dy_conv]
+                for w, t in ((w2_p, dw2), (w1_p, dw1), (wc_p, dwc)):
+                    if t is not None and isinstance(w, torch.nn.Parameter):
+                        G.defer_side_join(dev, w, t, *[k for k in keep if k is not None])
+                dw2 = None if isinstance(w2_p, torch.nn.Parameter) else dw2
+                dw1 = None if isinstance(w1_p, torch.nn.Parameter) else dw1
+                dwc = None if isinstance(wc_p, torch.nn.Parameter) else dwc
+                if any(t is not None for t in (dw2, dw1, dwc)):
+                    cur.wait_stream(side)
+            else:
+                cur.wait_stream(side)
+                for t in (dw2, dw1, dwc):
+                    if t is not None:
+                        t.record_stream(cur)
         return dcat, dwc, dbc, dw1, db1, dw2, db2, None
 
 

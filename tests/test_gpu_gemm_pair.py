@@ -266,9 +266,11 @@ def test_maskfuse_pair_function_vs_per_layer_path(dev, r):
     params = [conv.weight, conv.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias]
 
     def grads(out):
-        gs = torch.autograd.grad(out, [cat] + params, dy)
+        for t in [cat] + params:
+            t.grad = None
+        out.backward(dy)                  # (.backward(): the node's weight gradients are installed at the end of the pass, not returned)
         torch.cuda.synchronize()
-        return [t.double().cpu() for t in gs]
+        return [t.grad.double().cpu() for t in [cat] + params]
 
     y = conv3x3(cat, conv.weight, conv.bias, relu=True, flatten_chw=True)
     ref = linear(linear(y, fc1.weight, fc1.bias, relu=True), fc2.weight, fc2.bias, relu=True)
