@@ -172,6 +172,10 @@ class DataParallel(nn.Module):
         if not params:
             return False
         self._early = (optimizer, params, frozenset(id(p) for p in params), torch.cuda.Stream(device=self.device))
+        # the early update needs the MaskFuse weight gradients INSIDE the backward pass: they must come through autograd (whose
+        # hooks trigger it), not be installed at the end of the pass
+        from ...ops import maskfuse_pair as _mfp
+        _mfp.DEFER_DW = False
         if self.world_size == 1:          # (with several ranks every parameter already carries the hook)
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
