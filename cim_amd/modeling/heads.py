@@ -221,6 +221,7 @@ class FusedLossFunction(torch.autograd.Function):
         # mining consumed (no stall: the GPU finished the mining long before the host gets here)
         if _rng.pending is not None:
             engine.queue_callback(settle_rng)
+        _order_callers_stream_after_backward(G.device)
         if ctx.fused:       # ONE launch: the gradient of the fused score matrix, ready for the head activations' backward
             N, C1 = ctx.dims
             out = torch.empty((N, (2 + 2 * R) * C1), dtype=torch.float32, device=G.device)
@@ -232,6 +233,25 @@ class FusedLossFunction(torch.autograd.Function):
         d_rc = [g_cls * G[3 + 4 * i] + g_bag * G[4 + 4 * i] for i in range(R)]
         d_ri = [g_iou * G[5 + 4 * i] + g_bag * G[6 + 4 * i] for i in range(R)]
         return (None, d_pc, d_pd, *d_rc, *d_ri)
+
+
+def _order_callers_stream_after_backward(dev):
+    """The training step runs on a high-priority stream of its own (model_builder.Generalized_RCNN.forward) and leaves weight
+    gradients on a side stream.  Autograd orders the caller's stream behind the streams of the leaf accumulations; this makes the
+    ordering explicit for EVERYTHING the step enqueued: at the end of the backward pass the stream `backward()` was called on
+    waits for both (an optimizer that is not ours then needs no knowledge of them)."""
+    from ..ops import gemm as _g
+    if not (engine.HAS_ENGINE_CALLBACK and _g.HIGH_PRIO and dev.type == "cuda"):
+        return
+
+    def order():
+        cur = torch.cuda.current_stream(dev)
+        hp = _g.main_stream_high_priority(dev)
+        if cur != hp:
+            cur.wait_stream(hp)
+        cur.wait_stream(_g._side_stream(dev))
+
+    engine.queue_callback(order)
 
 
 def _fused_base(predict_cls, predict_det, ref_cls_score, ref_iou_score):

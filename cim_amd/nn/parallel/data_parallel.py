@@ -219,17 +219,20 @@ class DataParallel(nn.Module):
 
     def _publish_early(self, p, g, stream):
         """ops.gemm.GRAD_PUBLISHER: a fused Function finished the gradient `g` of the big parameter `p` on `stream` in the middle of
-        its backward.  Install it (autograd will not: the Function returns None for it) and let its bucket's all-reduce start
-        on that stream at once, in the strict bucket order."""
+        its backward.  When `p` is one of this wrapper's parameters and this backward pass communicates: install it (autograd will
+        not: the Function then returns None for it), let its bucket's all-reduce start on that stream at once, in the strict bucket
+        order, and return True.  Otherwise return False: the Function keeps its own (joined or deferred) path."""
+        if self.world_size == 1 or p not in self._bucket_of or not self._sync_this_backward():
+            return False
         self._backward_started()
         with torch.cuda.stream(stream):
             if p.grad is None:
                 p.grad = g
             else:
                 p.grad += g
-            if self.world_size > 1 and self._sync_this_backward() and p in self._bucket_of:
-                self.buckets[self._bucket_of[p]]["ready"] += 1
-                self._launch_ready_buckets()
+            self.buckets[self._bucket_of[p]]["ready"] += 1
+            self._launch_ready_buckets()
+        return True
 
     def _on_grad_ready(self, p):
         self._backward_started()

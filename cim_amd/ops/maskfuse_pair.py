@@ -178,9 +178,12 @@ class MaskFusePairFunction(Function):
             pub = G.GRAD_PUBLISHER
             if pub is None or dw is None or not isinstance(w, torch.nn.Parameter) or not w.is_leaf:
                 return dw
-            pub(w, dw, side if overlap else cur)
-            return None
+            if pub(w, dw, side if overlap else cur):
+                published.append(dw)
+                return None
+            return dw
 
+        published = []
         wc_p, w1_p, w2_p = ctx.weights
         dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = dy_conv = None
         am = torch.zeros(3, dtype=torch.int32, device=dev)
@@ -238,6 +241,11 @@ class MaskFusePairFunction(Function):
             if overlap:
                 dy.record_stream(side)
         if overlap:
+            # operands the side stream's GEMMs read: the allocator must not hand their memory out before that work is done,
+            # whichever way (join here, deferred join, DataParallel's all-reduce) the weight gradients leave this node
+            for t in (V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf, dY1p.scale, dy_conv, am):
+                if t is not None:
+                    t.record_stream(side)
             if DEFER_DW and G.DEFER_DW:
                 # the weight gradients keep running on the side stream while the main stream goes on to the ROIAlign and backbone
                 # backward: joined (and installed as .grad) once, at the end of the backward pass (ops/gemm.py: defer_side_join)

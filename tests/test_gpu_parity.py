@@ -615,6 +615,55 @@ def test_bn_act_matches_aten(dev, relu, with_res, affine_grad):
     torch.testing.assert_close(y2.detach().cpu(), (F.relu(ref2) if relu else ref2).detach(), rtol=1e-4, atol=1e-4)
 
 
+def test_stream_scheduling_does_not_change_a_training_run(dev, monkeypatch):
+    """The step's scheduling options - training forward / backward on a high-priority stream, MaskFuse's and the backbone's weight
+    gradients left on the side stream until the end of the backward pass - must not change a single bit of a training run:
+    40 optimizer steps (fused SGD) with them ON (default) and OFF give the same loss trajectory, and every gradient stays finite.
+    (A buffer the side stream still reads being handed out by the caching allocator showed up here as a NaN weight gradient
+    around step 17 and a derailed run - nothing a one-step test sees.)"""
+    import bench
+    from cim_amd import mask_iou, synthetic
+    from cim_amd.core.config import cfg
+    from cim_amd.core.presets import apply_preset
+    from cim_amd.modeling import heads
+    from cim_amd.modeling.model_builder import Generalized_RCNN
+    from cim_amd.ops import gemm, maskfuse_pair
+
+    def run(flag):
+        monkeypatch.setattr(gemm, "HIGH_PRIO", flag)
+        monkeypatch.setattr(maskfuse_pair, "DEFER_DW", flag)
+        apply_preset("resnet50_voc")
+        torch.manual_seed(cfg.RNG_SEED)
+        model = Generalized_RCNN()
+        bench.init_for_synthetic(model)
+        model = model.to(dev).train()
+        opt = bench.make_optimizer(model, torch)
+        inp = synthetic.make_image_inputs("resnet50_voc", seed=3, n=300)
+        iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
+        t = lambda a: torch.from_numpy(a).unsqueeze(0).to(dev)
+        batch = dict(data=torch.from_numpy(inp["data"]).to(dev), rois=t(inp["rois"]), masks=t(inp["masks"]), labels=t(inp["labels"]),
+                     mat=t(inp["mat"]), index=t(inp["index"]), iou_map=iou, asy_iou_map=asy, gtrois=None)
+        np.random.seed(cfg.RNG_SEED)
+        hist = []
+        for s in range(40):
+            opt.zero_grad(set_to_none=True)
+            out = model(**batch)
+            loss = sum(v.sum() for v in out["losses"].values())
+            loss.backward()
+            if s % 8 == 7:
+                torch.cuda.synchronize()
+                for n, p in model.named_parameters():
+                    assert p.grad is None or bool(torch.isfinite(p.grad).all()), (s, n)
+            opt.step()
+            hist.append(float(loss))
+        heads.settle_rng()
+        return hist
+
+    on, off = run(True), run(False)
+    assert all(np.isfinite(on)) and on[-1] < on[0]
+    assert on == off, [(i, a, b) for i, (a, b) in enumerate(zip(on, off)) if a != b][:3]
+
+
 # ------------------------------------------------------------------ optimizer (csrc/sgd.hip, SURVEY 8 f-4)
 def test_fused_sgd_matches_torch_sgd(dev):
     """cim_amd.optim.SGD == torch.optim.SGD (momentum, weight decay, two groups as tools/train.py:282-311) over several
