@@ -124,13 +124,14 @@ def _side_stream(dev):
     return s
 
 
-HIGH_PRIO = os.environ.get("CIM_HIGH_PRIO", "1") == "1"
+HIGH_PRIO = os.environ.get("CIM_HIGH_PRIO", "0") == "1"      # opt-in experiment: no measured gain (ops/maskfuse_pair.py)
 
 
 def main_stream_high_priority(dev):
     """A HIGH-priority HIP stream for the training step's main chain (Generalized_RCNN.forward runs on it, so does its
     backward): side-stream work - the deferred weight-gradient GEMMs - then only takes the CUs the main chain leaves, instead of
-    time-sharing them half and half with the data-gradient GEMMs.  CIM_HIGH_PRIO=0: everything on the caller's stream."""
+    time-sharing them half and half with the data-gradient GEMMs.  Default off (CIM_HIGH_PRIO=1 to try): everything on the
+    caller's stream."""
     s = _SIDE.get(("main", dev))
     if s is None:
         s = _SIDE[("main", dev)] = torch.cuda.Stream(device=dev, priority=-1)

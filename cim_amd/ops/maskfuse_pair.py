@@ -26,12 +26,17 @@ from . import gemm as G
 from . import pair
 
 NPOS = 121
-# The node's weight-gradient GEMMs (fc2, fc1, conv: ~2.5 ms of MFMA work at cfg2) are only needed by the optimizer: joined once, at the
-# end of the backward pass (ops/gemm.py: defer_side_join), they keep running on the (normal-priority) side stream while the
-# high-priority main chain (model_builder.Generalized_RCNN.forward) goes on to the ROIAlign and backbone backward - small latency-bound
-# launches that leave most of the chip idle.  Measured at cfg2 (same box): 15.08 ms joined inside the node, 14.92 deferred,
-# 14.40 deferred + high-priority main stream (15.27 with the priority alone).  CIM_DEFER_MASKFUSE_DW=0 joins inside the node.
-DEFER_DW = _os_env.get("CIM_DEFER_MASKFUSE_DW", "1") == "1"
+# OPT-IN experiment (CIM_DEFER_MASKFUSE_DW=1, with CIM_HIGH_PRIO=1): the node's weight-gradient GEMMs (fc2, fc1, conv: ~2.5 ms of MFMA
+# work at cfg2) are only needed by the optimizer, so they can be joined once, at the end of the backward pass (ops/gemm.py:
+# defer_side_join), and keep running on the normal-priority side stream while a high-priority main chain
+# (model_builder.Generalized_RCNN.forward) goes on to the ROIAlign and backbone backward.  Measured at cfg2 (same box, interleaved,
+# twice): 15.27 / 15.23 ms as shipped, 15.21 / 15.24 with both, 15.21 deferred only, 15.45 priority only - NO gain: a running
+# 256 x 256 tile holds its CU for ~170 us whatever the queue priority, and the data-gradient chain still shares the chip half and half.
+# (A first measurement said 14.40 ms: its runs were corrupted - buffers the side stream still read were handed out by the caching
+# allocator, weights went NaN, and NaN operands draw less power and run the MFMAs at a higher clock.  The lifetimes are recorded now
+# (record_stream below) and tests/test_gpu_parity.py::test_stream_scheduling_does_not_change_a_training_run runs 40 optimizer steps
+# with the options on and off, bit-equal.)
+DEFER_DW = _os_env.get("CIM_DEFER_MASKFUSE_DW", "0") == "1"
 
 
 def supported(cat, wc, w1, w2):
