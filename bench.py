@@ -269,6 +269,11 @@ def run(args):
                                  ring_bound_ms=1e3 * 2.0 * (world - 1) / world * grad_bytes / 153e9,
                                  buckets=len(dp.buckets))
     heads.settle_rng()
+    # the measured run must have been a VALID training run to the end: every parameter finite (a finite last loss alone does not
+    # show a weight gradient that went NaN a few steps ago - and NaN operands run the MFMAs faster)
+    with torch.no_grad():
+        worst = torch.stack([p.detach().abs().max() for p in model.parameters()]).max()
+    assert torch.isfinite(worst), "non-finite parameters after the timed region: the measurement is invalid"
     # a-7 / f-1: the N x N mask-IoU and containment maps of every image of the cycle, built on the device from the full-
     # resolution proposal masks OUTSIDE the timed step (the reference builds them offline: tools/pre/create_cob_iou.py).
     # Integer work: N^2/2 * ceil(HW/64) 64-bit and + popcount pairs; bytes: N*HW mask bytes in, 4 N^2 out.
