@@ -16,8 +16,22 @@
 #include "common.h"
 #include "../../include/cim_hip.h"
 #include <limits.h>
+#include <mutex>
 
 using cim::h2f;
+
+#ifndef CIM_MINING_CLOCKS
+#define CIM_MINING_CLOCKS 0          // 1: phase stamps (100 MHz wall clock) of launches 1 and 3 -> cim_debug_mining_clocks (tools only)
+#endif
+#if CIM_MINING_CLOCKS
+__device__ unsigned long long g_mining_clk[2][8][16];                    // [kernel][workgroup (first 8)][stamp]
+#define MCLK(KERNEL, WG, I) do { if (threadIdx.x == 0 && (WG) < 8) g_mining_clk[KERNEL][WG][I] = wall_clock64(); } while (0)
+extern "C" int cim_debug_mining_clocks(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mining_clk), sizeof(g_mining_clk)) == hipSuccess ? 0 : 1;
+}
+#else
+#define MCLK(KERNEL, WG, I) do { } while (0)
+#endif
 
 namespace {
 
@@ -137,6 +151,8 @@ __global__ __launch_bounds__(1024) void step_seed_kernel(const cim_mining_args a
         if (tid == 0) L.n_seeds[c] = 0;
         return;
     }
+    [[maybe_unused]] const int wg_act = (int)(l * 2 + (c & 1));          // (debug stamps only)
+    MCLK(0, wg_act, 0);
     const float* __restrict__ score = L.seed_score;
     const int score_ld = L.seed_ld, col = L.seed_off + c;
     // key = (descending score, ascending index): a total order -> the sort is the stable
@@ -175,35 +191,75 @@ __global__ __launch_bounds__(1024) void step_seed_kernel(const cim_mining_args a
         __syncthreads();
     }
 
+    MCLK(0, wg_act, 1);
     // Suppression bit-matrix over the K x K gathered sub-block of the mask-IoU map:
     // bit (i, j) set <=> NOT (iou[idx_i, idx_j] < nms_thr)   (heads.py:250-254, fp16 compare).
     unsigned long long* sup = keys;  // keys are dead from here on
     const int wave = tid >> 6, lane = tid & 63;
     const float nms_thr = L.nms_thr;
-    for (int t = wave; t < K * KW; t += 16) {
-        const int i = t / KW, w = t % KW;
-        const int j = w * 64 + lane;
-        bool bit = false;
-        if (j < K) bit = !(h2f(a.iou[(size_t)kidx[i] * N + kidx[j]]) < nms_thr);
-        const unsigned long long word = __ballot(bit);
-        if (lane == 0) sup[(size_t)i * KW + w] = word;
+    for (int t0 = wave; t0 < K * KW; t0 += 16 * 4) {                     // 4 gathers in flight per wave (latency-bound: the
+        uint16_t v[4];                                                   // map is L2-resident, each gather a round trip)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 16 * u;
+            const int i = t / KW, j = (t % KW) * 64 + lane;
+            v[u] = (t < K * KW && j < K) ? a.iou[(size_t)kidx[i] * N + kidx[j]] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 16 * u;
+            if (t >= K * KW) break;
+            const int j = (t % KW) * 64 + lane;
+            const unsigned long long word = __ballot(j < K && !(h2f(v[u]) < nms_thr));
+            if (lane == 0) sup[t] = word;
+        }
     }
     __syncthreads();
+    MCLK(0, wg_act, 2);
 
-    // Greedy scan in score order by one wave; lane w owns word w of the "removed" set.
+    // Greedy scan in score order by one wave; lane w owns word w of the "removed" set.  The scan is sequential in the
+    // candidates, so it walks them 64 at a time: the block's own 64 x 64 suppression bits sit one row per lane in
+    // registers and the keep / drop decisions inside the block are readlane + scalar bit operations (no LDS on the serial
+    // chain); the rows of the kept candidates are then OR-ed into the later words with independent LDS reads.
     if (wave == 0) {
         int cnt = 0;
         unsigned long long removed = 0ull;  // lane l holds word l (l < KW <= 64)
-        for (int i = 0; i < K; ++i) {
-            const unsigned long long rw = __shfl(removed, i >> 6);
-            if (!((rw >> (i & 63)) & 1ull)) {
-                if (lane == 0) seeds[cnt] = kidx[i];
-                ++cnt;
-                if (lane < KW) removed |= sup[(size_t)i * KW + lane];
+        for (int i0 = 0; i0 < K; i0 += 64) {
+            const int nb = min(64, K - i0), wb = i0 >> 6;
+            const unsigned long long rowblk = lane < nb ? sup[(size_t)(i0 + lane) * KW + wb] : 0ull;
+            const unsigned rlo = (unsigned)rowblk, rhi = (unsigned)(rowblk >> 32);
+            // rem / kept live in SGPRs (readfirstlane): the 64 steps are scalar shifts and selects, the row reads
+            // (v_readlane, independent of rem) run ahead of them
+            const unsigned long long r0 = __shfl(removed, wb);
+            unsigned long long rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(r0 >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)r0);
+            unsigned long long kept = 0ull;
+            for (int t = 0; t < nb; ++t) {
+                const unsigned long long row = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(rhi, t) << 32) |
+                                               (unsigned)__builtin_amdgcn_readlane(rlo, t);          // (readlane returns int)
+                const bool alive = !((rem >> t) & 1ull);
+                kept |= alive ? (1ull << t) : 0ull;
+                rem |= alive ? row : 0ull;
             }
+            if ((kept >> lane) & 1ull) seeds[cnt + __popcll(kept & ((1ull << lane) - 1ull))] = kidx[i0 + lane];
+            cnt += __popcll(kept);
+            if (lane < KW)
+                for (unsigned long long k = kept; k;) {                  // four independent LDS reads per round (a repeated row is harmless)
+                    const int t0 = __builtin_ctzll(k);
+                    k &= k - 1ull;
+                    const int t1 = k ? __builtin_ctzll(k) : t0;
+                    k &= k - 1ull;
+                    const int t2 = k ? __builtin_ctzll(k) : t0;
+                    k &= k - 1ull;
+                    const int t3 = k ? __builtin_ctzll(k) : t0;
+                    k &= k - 1ull;
+                    removed |= (sup[(size_t)(i0 + t0) * KW + lane] | sup[(size_t)(i0 + t1) * KW + lane]) |
+                               (sup[(size_t)(i0 + t2) * KW + lane] | sup[(size_t)(i0 + t3) * KW + lane]);
+                }
         }
         for (int r = cnt + lane; r < K; r += 64) seeds[r] = -1;
         if (lane == 0) L.n_seeds[c] = cnt;
+        MCLK(0, wg_act, 3);
     }
 }
 
@@ -261,10 +317,10 @@ __global__ __launch_bounds__(256) void step_contain_kernel(const cim_mining_args
     }
 }
 
-// ================================================================== fused step: launch 3
-// ONE workgroup walks the layers in order (the uniforms are consumed in the order of the reference's sequential
-// CIM_layer calls): cross-class arbitration (heads.py:397-405 / 306-314), ordered compaction (App. B item 8),
-// anti-noise sampling (heads.py:447-473), compaction of the survivors.
+// ================================================================== fused step: launch 3 - the NumPy arithmetic it restates
+// Per layer: cross-class arbitration (heads.py:397-405 / 306-314), ordered compaction (App. B item 8), anti-noise
+// sampling (heads.py:447-473) on the uniforms the reference's sequential CIM_layer calls would draw, compaction of the
+// survivors.
 //
 // Sampling = np.random.choice(class_idx, size=n, replace=True, p=prob / prob.sum()) + np.unique, restated
 // (numpy/random/mtrand.pyx, RandomState.choice):
@@ -310,24 +366,40 @@ __device__ float np_pairwise_sum(const float* a, int n) {
 }
 
 __device__ int block_exclusive_scan(int v, int* part, int* total) {      // 1024 lanes; returns the exclusive prefix
-    const int tid = threadIdx.x;
-    __syncthreads();
-    part[tid] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int x = (tid >= o) ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += x;
-        __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;       // wave scans in registers, 16 wave totals through LDS:
+    int incl = v;                                                        // two barriers instead of the 20 of an all-LDS scan
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int x = __shfl_up(incl, o);
+        if (lane >= o) incl += x;
     }
-    *total = part[1023];
-    return part[tid] - v;
+    __syncthreads();                                                     // (part[] of the previous scan has been read)
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int p = part[w];
+        tot += p;
+        woff += (w < wave) ? p : 0;
+    }
+    *total = tot;
+    return woff + incl - v;
 }
 
-__global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_mining_args a) {
+// ================================================================== fused step: launch 3 (heads.py:396-466)
+// grid = R, block = 1024: workgroup l = CIM layer l.  Arbitration and the ordered compaction of a layer depend on nothing
+// but that layer's scores, so the layers run side by side; only the anti-noise sampling is ordered across layers, through
+// the position in the pre-drawn uniform stream: layer l consumes uniforms [base_l, base_l + G_l) with base_l = the sum of
+// the earlier sampling layers' list lengths (np.random.choice draws one double per class member, every member of the list
+// belongs to exactly one class).  Each workgroup publishes its G_l in `sync[l]` (tagged with this call's epoch: the words
+// are never reset) and reads the earlier layers' words - R <= 4 workgroups are always co-resident, and workgroup 0 waits
+// for nobody.
+__global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_mining_args a, unsigned long long* __restrict__ sync,
+                                                                     unsigned long long epoch) {
 #pragma clang fp contract(off)                      // the sums below restate NumPy's: no fused multiply-adds
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int N = a.N, K = a.K, C = a.C, tid = threadIdx.x;
+    const int N = a.N, K = a.K, C = a.C, tid = threadIdx.x, l = blockIdx.x;
     // LDS: cdf f64 [K] | part i32 [1024] | prob f32 [K] | pos i32 [K] | gclass i32 [N] | gweight f32 [N] | mark u8 [N]
     double* cdf = reinterpret_cast<double*>(smem);
     int32_t* part = reinterpret_cast<int32_t*>(cdf + K);
@@ -338,143 +410,204 @@ __global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_m
     uint8_t* mark = reinterpret_cast<uint8_t*>(gweight + N);
     __shared__ int s_used;
     __shared__ float s_total;
-    if (tid == 0) s_used = 0;
     const int chunk = (N + 1023) / 1024;
     const int lo = min(N, tid * chunk), hi = min(N, lo + chunk);
+    const cim_mining_layer& L = a.layer[l];
 
-    for (int l = 0; l < a.R; ++l) {
-        const cim_mining_layer& L = a.layer[l];
-        for (int i = tid; i < N; i += 1024) {
-            gclass[i] = 0;
-            gweight[i] = -1.0f;                                          // heads.py:336
+    MCLK(1, l, 0);
+    // the image's classes, ascending (labels[] is read once; the class loops below walk this list)
+    __shared__ int16_t s_act[1024];
+    int n_act;
+    {
+        const int on = (tid < C && a.labels[tid] != 0.0f) ? 1 : 0;
+        const int at = block_exclusive_scan(on, part, &n_act);
+        if (on) s_act[at] = (int16_t)tid;
+    }
+    // ---- arbitration (heads.py:397-405 / 306-314): the reference applies the image's classes one after the other in ascending
+    // order, `w > gt_weight` (strict) deciding - per proposal that is: the largest weight among the classes that list it, the
+    // LOWEST class on equal weights, and nothing unless w > -1 (heads.py:336).  All (class, candidate) pairs go through one
+    // LDS atomic max on key = (orderable(w) << 32) | ~(c + 1) (a proposal listed twice by a class - torch.unique's set
+    // semantics - just repeats its key); the initial key (orderable(-1), ~0) loses to any w > -1 and to nothing else.  NaN
+    // weights never win a strict '>': skipped.  The key array lies over gclass | gweight and is decoded in place through
+    // registers (N <= 8192: at most 8 keys per thread).
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(gclass);
+    const unsigned long long key0 = ((unsigned long long)orderable(-1.0f) << 32) | 0xffffffffull;
+    for (int i = tid; i < N; i += 1024) key[i] = key0;
+    __syncthreads();
+    MCLK(1, l, 1);
+    const int32_t* __restrict__ cand = L.using_cim ? L.res : L.seeds;
+    for (int e = tid; e < n_act * K; e += 1024) {
+        const int c = s_act[e / K];
+        const int32_t p = cand[(size_t)c * K + (e % K)];
+        if (p < 0) continue;
+        float w = L.wa[(size_t)p * L.wa_ld + L.wa_off + c];
+        if (L.wb) w = w * L.wb[(size_t)p * L.wb_ld + L.wb_off + c * L.wb_cs];       // preds = cls * det, heads.py:330
+        if (w == w) atomicMax(key + p, ((unsigned long long)orderable(w) << 32) | (unsigned)~(c + 1));
+    }
+    __syncthreads();
+    MCLK(1, l, 2);
+    {
+        unsigned long long kreg[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * 1024;
+            kreg[u] = i < N ? key[i] : key0;
         }
-        // ---- arbitration: classes applied sequentially in ascending order, strict '>' (App. B item 7)
-        const int32_t* __restrict__ cand = L.using_cim ? L.res : L.seeds;
-        for (int c = 0; c < C; ++c) {
-            if (a.labels[c] == 0.0f) continue;                           // uniform over the workgroup
-            for (int i = tid; i < N; i += 1024) mark[i] = 0;
-            __syncthreads();
-            for (int r = tid; r < K; r += 1024) {
-                const int32_t p = cand[(size_t)c * K + r];
-                if (p >= 0) mark[p] = 1;                                 // torch.unique: set semantics
-            }
-            __syncthreads();
-            for (int i = tid; i < N; i += 1024) {
-                if (!mark[i]) continue;
-                float w = L.wa[(size_t)i * L.wa_ld + L.wa_off + c];
-                if (L.wb) w = w * L.wb[(size_t)i * L.wb_ld + L.wb_off + c * L.wb_cs];   // preds = cls * det, heads.py:330
-                if (w > gweight[i]) {                                    // strict '>' (heads.py:397)
-                    gclass[i] = c + 1;
-                    gweight[i] = w;
-                }
-            }
-            __syncthreads();
-        }
-        for (int i = tid; i < N; i += 1024) {
-            L.gt_class[i] = gclass[i];
-            L.gt_weight[i] = gweight[i];
-        }
-        // ---- ordered compaction of {i : gclass[i] > 0} -> pre-sampling list (ascending proposal index)
-        int cnt = 0;
-        for (int i = lo; i < hi; ++i) cnt += gclass[i] > 0;
-        int G;
-        int p0 = block_exclusive_scan(cnt, part, &G);
-        for (int i = lo; i < hi; ++i)
-            if (gclass[i] > 0) {
-                L.pre_idx[p0] = i;
-                L.pre_keep[p0] = 1;
-                ++p0;
-            }
-        __syncthreads();                                                 // pre_idx visible to the workgroup (global, same block)
-        // ---- anti-noise sampling, class by class in ascending order (heads.py:451-466)
-        if (L.anti_noise && G > 0) {
-            for (int c = 0; c < C; ++c) {
-                if (a.labels[c] == 0.0f) continue;
-                // members of class c in list order: positions j with gclass[pre_idx[j]] == c + 1 (G <= N: chunked like above)
-                const int gchunk = (G + 1023) / 1024;
-                const int glo = min(G, tid * gchunk), ghi = min(G, glo + gchunk);
-                int m = 0;
-                for (int j = glo; j < ghi; ++j) m += gclass[L.pre_idx[j]] == c + 1;
-                int Gc;
-                int q0 = block_exclusive_scan(m, part, &Gc);
-                if (Gc == 0) continue;                                   // heads.py:454-455 (uniform)
-                if (Gc > K) {                                            // cannot happen (<= K candidates per class); stay memory-safe
-                    if (tid == 0) atomicOr(a.status, 1);
-                    continue;
-                }
-                for (int j = glo; j < ghi; ++j) {
-                    const int i = L.pre_idx[j];
-                    if (gclass[i] == c + 1) {
-                        pos[q0] = j;
-                        prob[q0] = gweight[i];
-                        ++q0;
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) s_total = np_pairwise_sum<4>(prob, Gc);
-                __syncthreads();
-                const float total = s_total;
-                if (tid == 0) {
-                    double acc = 0.0;
-                    for (int j = 0; j < Gc; ++j) {
-                        const float pj = (float)((double)prob[j] / (double)total);   // == f32 division, correctly rounded
-                        acc = (j == 0) ? (double)pj : acc + (double)pj;              // np.cumsum: out[0] = p[0]
-                        cdf[j] = acc;
-                    }
-                }
-                __syncthreads();
-                const double last = cdf[Gc - 1];
-                __syncthreads();
-                for (int j = tid; j < Gc; j += 1024) {
-                    cdf[j] = cdf[j] / last;
-                    L.pre_keep[pos[j]] = 0;                              // inds[class_idx] = 0
-                }
-                __syncthreads();
-                const int base = s_used;
-                if (base + Gc > a.max_uniforms) {                        // the host drew too few (cannot happen: bound = R * min(N, classes * K))
-                    if (tid == 0) atomicOr(a.status, 2);
-                } else {
-                    for (int j = tid; j < Gc; j += 1024) {
-                        const double u = a.uniforms[base + j];
-                        int b = 0, e = Gc;                               // searchsorted(side='right'): first index with cdf > u
-                        while (b < e) {
-                            const int mid = (b + e) >> 1;
-                            if (cdf[mid] <= u) b = mid + 1; else e = mid;
-                        }
-                        if (b >= Gc) b = Gc - 1;                         // u < 1 == cdf[-1]: unreachable; memory safety
-                        L.pre_keep[pos[b]] = 1;                          // inds[np.unique(sampled)] = 1
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) s_used = base + Gc;
-                __syncthreads();
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * 1024;
+            if (i < N) {
+                const int gc = (int)~(unsigned)kreg[u];
+                const unsigned o = (unsigned)(kreg[u] >> 32);
+                const float gw = gc > 0 ? __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o) : -1.0f;   // orderable^-1
+                gclass[i] = gc;
+                gweight[i] = gw;
+                L.gt_class[i] = gc;
+                L.gt_weight[i] = gw;
             }
         }
-        // ---- survivors, in list order -> post-sampling list
-        {
-            const int gchunk = (G + 1023) / 1024;
-            const int glo = min(G, tid * gchunk), ghi = min(G, glo + gchunk);
+    }
+    __syncthreads();
+    MCLK(1, l, 3);
+    // ---- ordered compaction of {i : gclass[i] > 0} -> pre-sampling list (ascending proposal index).  Thread t owns the
+    // proposals [lo, hi) and therefore the list positions [p0, p0 + cnt): every later pass walks the list through gclass /
+    // gweight in LDS and these two numbers, never through the list in global memory.
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += gclass[i] > 0;
+    int G;
+    const int p0 = block_exclusive_scan(cnt, part, &G);
+    // ---- this layer's share of the uniform stream, and where it starts
+    const bool sampling = L.anti_noise && G > 0;
+    MCLK(1, l, 4);
+    if (tid == 0) {
+        __hip_atomic_store(sync + l, (epoch << 20) | (unsigned long long)(sampling ? G : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int base = 0;
+        for (int e = 0; e < l; ++e) {
+            unsigned long long v;
+            do {
+                v = __hip_atomic_load(sync + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 20) != epoch) __builtin_amdgcn_s_sleep(2);
+            } while ((v >> 20) != epoch);
+            base += (int)(v & 0xfffffull);
+        }
+        s_used = base;
+    }
+    MCLK(1, l, 5);
+    uint8_t* __restrict__ keep = mark;                                   // keep[j], j = list position (mark[] is dead after the arbitration)
+    for (int i = lo, j = p0; i < hi; ++i)
+        if (gclass[i] > 0) {
+            L.pre_idx[j] = i;
+            keep[j] = 1;
+            ++j;
+        }
+    __syncthreads();                                                     // keep[], s_used
+    MCLK(1, l, 6);
+    // ---- anti-noise sampling, class by class in ascending order (heads.py:451-466)
+    if (sampling) {
+        for (int ac = 0; ac < n_act; ++ac) {
+            const int c = s_act[ac];
+            // members of class c in list order
             int m = 0;
-            for (int j = glo; j < ghi; ++j) m += L.pre_keep[j] != 0;
-            int Gk;
-            int q0 = block_exclusive_scan(m, part, &Gk);
-            for (int j = glo; j < ghi; ++j)
-                if (L.pre_keep[j]) {
-                    const int i = L.pre_idx[j];
+            for (int i = lo; i < hi; ++i) m += gclass[i] == c + 1;
+            int Gc;
+            int q0 = block_exclusive_scan(m, part, &Gc);
+            if (Gc == 0) continue;                                       // heads.py:454-455 (uniform)
+            if (Gc > K) {                                                // cannot happen (<= K candidates per class); stay memory-safe:
+                if (tid == 0) {                                          // the step fails with status bit 1, the uniforms count as drawn
+                    atomicOr(a.status, 1);
+                    s_used += Gc;
+                }
+                __syncthreads();
+                continue;
+            }
+            for (int i = lo, j = p0; i < hi; ++i) {
+                const int gc = gclass[i];
+                if (gc == c + 1) {
+                    pos[q0] = j;
+                    prob[q0] = gweight[i];
+                    keep[j] = 0;                                         // inds[class_idx] = 0
+                    ++q0;
+                }
+                j += gc > 0;
+            }
+            __syncthreads();
+            if (tid == 0) s_total = np_pairwise_sum<4>(prob, Gc);
+            __syncthreads();
+            const float total = s_total;
+            // p = prob / total in f32 (== the f64 quotient rounded once), then np.cumsum in f64: a strictly sequential sum
+            // (out[0] = p[0]).  The divisions are done by everybody; the chain that is left for one lane is load / add / store,
+            // eight loads ahead of the additions.
+            for (int j = tid; j < Gc; j += 1024) cdf[j] = (double)(float)((double)prob[j] / (double)total);
+            __syncthreads();
+            if (tid == 0) {
+                double acc = cdf[0];
+                int j = 1;
+                for (; j + 8 <= Gc; j += 8) {
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = cdf[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        acc += x[u];
+                        cdf[j + u] = acc;
+                    }
+                }
+                for (; j < Gc; ++j) {
+                    acc += cdf[j];
+                    cdf[j] = acc;
+                }
+            }
+            __syncthreads();
+            const double last = cdf[Gc - 1];
+            const int base = s_used;
+            if (base + Gc > a.max_uniforms) {                            // the host drew too few (cannot happen: bound = R * min(N, classes * K))
+                if (tid == 0) atomicOr(a.status, 2);
+            } else {
+                for (int j = tid; j < Gc; j += 1024) {
+                    const double u = a.uniforms[base + j];
+                    int b = 0, e = Gc;                                   // searchsorted(cdf / cdf[-1], u, side='right'): first index with cdf > u
+                    while (b < e) {
+                        const int mid = (b + e) >> 1;
+                        if (cdf[mid] / last <= u) b = mid + 1; else e = mid;
+                    }
+                    if (b >= Gc) b = Gc - 1;                             // u < 1 == cdf[-1]: unreachable; memory safety
+                    keep[pos[b]] = 1;                                    // inds[np.unique(sampled)] = 1
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_used = base + Gc;
+        }
+    }
+    MCLK(1, l, 7);
+    // ---- survivors, in list order -> post-sampling list
+    {
+        int m = 0;
+        for (int j = p0; j < p0 + cnt; ++j) m += keep[j];
+        int Gk;
+        int q0 = block_exclusive_scan(m, part, &Gk);
+        for (int i = lo, j = p0; i < hi; ++i) {
+            const int gc = gclass[i];
+            if (gc > 0) {
+                const uint8_t kp = keep[j];
+                L.pre_keep[j] = kp;
+                if (kp) {
                     L.gt_idx[q0] = i;
-                    L.gt_cls[q0] = gclass[i];
+                    L.gt_cls[q0] = gc;
                     L.gt_w[q0] = gweight[i];
                     ++q0;
                 }
-            if (tid == 0) {
-                L.counts[0] = G;
-                L.counts[1] = Gk;
-                a.layer_valid[l] = G > 0 ? 1 : 0;                        // heads.py:429-430: no pseudo GT -> layer skipped
+                ++j;
             }
         }
-        __syncthreads();
+        if (tid == 0) {
+            L.counts[0] = G;
+            L.counts[1] = Gk;
+            a.layer_valid[l] = G > 0 ? 1 : 0;                            // heads.py:429-430: no pseudo GT -> layer skipped
+            if (l == a.R - 1) a.used[0] = s_used;                        // (the last layer ends where the whole step's stream ends)
+        }
     }
-    if (tid == 0) a.used[0] = s_used;
+    MCLK(1, l, 8);
 }
 
 // ================================================================== fused step: launch 4 (heads.py:435,477-501)
@@ -558,6 +691,26 @@ extern "C" long long cim_mining_lds_bytes(int N, int K) {
     return (long long)K * 8 + 1024 * 4 + (long long)K * 8 + (long long)N * 9 + 16;
 }
 
+// The words through which launch 3's workgroups pass their list lengths: a ring of 64 slots x CIM_MAX_LAYERS per device,
+// one slot per call, never reset - a word counts only when it carries the call's own epoch (a process-wide call counter, so a
+// slot's previous tenant, 64 calls ago, can never be taken for the current one).  Calls in flight together (two streams)
+// use different slots.
+static bool layer_sync_slot(unsigned long long** sync, unsigned long long* epoch) {
+    static std::mutex mu;
+    static unsigned long long* ring[64] = {nullptr};
+    static unsigned long long calls = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (ring[dev] == nullptr) {
+        if (hipMalloc(reinterpret_cast<void**>(&ring[dev]), sizeof(unsigned long long) * 64 * CIM_MAX_LAYERS) != hipSuccess) { ring[dev] = nullptr; return false; }
+        if (hipMemset(ring[dev], 0, sizeof(unsigned long long) * 64 * CIM_MAX_LAYERS) != hipSuccess) return false;   // (synchronous)
+    }
+    *epoch = ++calls;                                   // >= 1: never matches the zero-filled ring; < 2^44 for the tag
+    *sync = ring[dev] + (calls % 64) * CIM_MAX_LAYERS;
+    return true;
+}
+
 extern "C" int cim_mining_step(const cim_mining_args* args, void* stream) {
     CIM_CHECK_ARG(args != nullptr);
     cim_mining_args a = *args;
@@ -598,7 +751,10 @@ extern "C" int cim_mining_step(const cim_mining_args* args, void* stream) {
     if (lds3 > 64 * 1024)
         CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(step_arbitrate_sample_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-    hipLaunchKernelGGL(step_arbitrate_sample_kernel, dim3(1), dim3(1024), lds3, st, a);
+    unsigned long long* sync = nullptr;
+    unsigned long long epoch = 0;
+    CIM_CHECK_ARG(layer_sync_slot(&sync, &epoch) && N < (1 << 20));
+    hipLaunchKernelGGL(step_arbitrate_sample_kernel, dim3(R), dim3(1024), lds3, st, a, sync, epoch);
     hipLaunchKernelGGL(step_assign_kernel, dim3((N + 3) / 4, R), dim3(256), 0, st, a);
     CIM_CHECK_LAUNCH();
     return 0;
