@@ -53,6 +53,7 @@ SIGNATURES = {
     "cim_gemm_f16x2": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "cim_gemm_f16x2_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
                                _P, _P, _P],
+    "cim_gemm_pair_limit": [c_int],
     "cim_gemm_pair_splits": [c_int, c_int, c_int],
     "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P],
     "cim_gemm_pair_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
@@ -84,7 +85,7 @@ SIGNATURES = {
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }
 
-ABI_VERSION = 5          # cim_abi_version() of include/cim_hip.h this binding was written against
+ABI_VERSION = 6          # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 

@@ -67,6 +67,8 @@ struct PairArgs {
     const float* a_scale;   // [batch] power-of-two scales the images were written with
     const float* b_scale;
     unsigned* c_amax;       // optional: max |C| bit pattern (atomicMax; caller zeroes), final outputs only
+    int tn, tm, tz;         // the product's tile grid (N tiles, M tiles, batch entries / k-splits); a launch covers the tiles
+    int tile0;              // tile0 .. tile0 + gridDim.x - 1 of its linear order (all of them unless the launch is chunked)
 };
 
 typedef __attribute__((address_space(3))) char* lds_ptr_t;
@@ -189,14 +191,15 @@ template <int CNT> struct FragSel<L_MC, CNT> { using type = FragMC<CNT>; };
 
 // XCD-aware work order (same policy as gemm_f32.hip: xcd_tile_map): >= 8 z slices -> whole slices per XCD; otherwise a
 // contiguous run of tiles per XCD; inside a run the index walking the smaller operand's panels runs fastest.
-__device__ __forceinline__ void pair_tile_map(int M, int N, int& tile_m, int& tile_n, int& z) {
-    const int tn = gridDim.x, tm = gridDim.y, T = tn * tm, Z = gridDim.z;
-    int b = blockIdx.y * tn + blockIdx.x;
-    z = blockIdx.z;
+__device__ __forceinline__ void pair_tile_map(int M, int N, int tn, int tm, int Z, int vb, int& tile_m, int& tile_n, int& z) {
+    const int T = tn * tm;
+    int b = vb % T;                               // (blockIdx.y * tn + blockIdx.x and blockIdx.z of a (tn, tm, Z) grid)
+    z = vb / T;
+    const int bz = z;
     bool remap_in_slice = true;
     const bool m_fast = N > M;
     if (Z >= 8) {
-        const long long L = (long long)blockIdx.z * T + b;
+        const long long L = (long long)bz * T + b;
         const int zfull = Z & ~7;
         if (L < (long long)zfull * T) {
             const int xcd = (int)(L & 7);
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 2, wn = wave & 3;
     int tile_m, tile_n, zidx;
-    pair_tile_map(g.M, g.N, tile_m, tile_n, zidx);
+    pair_tile_map(g.M, g.N, g.tn, g.tm, g.tz, (int)blockIdx.x + g.tile0, tile_m, tile_n, zidx);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const char* Ab = g.A;
     const char* Bb = g.B;
@@ -542,6 +545,8 @@ __global__ __launch_bounds__(256) void pair_amax_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) cim::amax_publish(out, m);
 }
 
+thread_local int t_pair_limit = 0;      // cim_gemm_pair_limit: workgroups per launch of this thread's next products (0 = all tiles)
+
 template <int AL, int BL>
 int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
@@ -566,7 +571,16 @@ int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st) {
     } else {
         g.c_split_stride = 0;
     }
-    hipLaunchKernelGGL(kern, dim3(tn, tm, g.batch > 1 ? g.batch : splits), dim3(NT), LDS_BYTES, st, g);
+    g.tn = tn; g.tm = tm; g.tz = g.batch > 1 ? g.batch : splits;
+    const long long total = (long long)tn * tm * g.tz;
+    if (total >= (1ll << 31)) return -2;
+    // cim_gemm_pair_limit: the product goes out as consecutive launches of at most that many workgroups.  A workgroup owns its CU
+    // (128 KB of LDS) and the launches of a stream run one after the other, so the product never holds more CUs than that.
+    const long long chunk = t_pair_limit > 0 ? t_pair_limit : total;
+    for (long long t0 = 0; t0 < total; t0 += chunk) {
+        g.tile0 = (int)t0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(total - t0 < chunk ? total - t0 : chunk)), dim3(NT), LDS_BYTES, st, g);
+    }
     if (splits > 1) {
         const long long quads = ((long long)g.M * g.N + 3) / 4;
         hipLaunchKernelGGL(pair_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, workspace,
@@ -590,6 +604,12 @@ static bool pair_dims_ok(int M, int N, int K, int lda, int ldb, int ldc, int a_m
     if (a_mcontig ? (M % 8 != 0 || lda < M) : (lda < K)) return false;
     if (b_kcontig ? (ldb < K) : (N % 8 != 0 || ldb < N)) return false;
     return true;
+}
+
+extern "C" int cim_gemm_pair_limit(int max_workgroups) {
+    CIM_CHECK_ARG(max_workgroups >= 0);
+    t_pair_limit = max_workgroups;
+    return 0;
 }
 
 extern "C" int cim_gemm_pair_splits(int M, int N, int K) {
@@ -617,7 +637,7 @@ extern "C" int cim_gemm_pair(const void* A, const void* B, float* C, const float
     CIM_CHECK_ARG(A && B && C && a_scale && b_scale);
     CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
     CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
-    PairArgs g{(const char*)A, (const char*)B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 1, 0, 0, 0, a_scale, b_scale, c_amax};
+    PairArgs g{(const char*)A, (const char*)B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 1, 0, 0, 0, a_scale, b_scale, c_amax, 0, 0, 0, 0};
     int rc = dispatch_pair(g, a_mcontig, b_kcontig, splits, workspace, cim::as_stream(stream));
     if (rc) { cim::set_error("cim_gemm_pair: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
@@ -630,7 +650,7 @@ extern "C" int cim_gemm_pair_batched(const void* A, const void* B, float* C, int
     CIM_CHECK_ARG(A && B && C && a_scale && b_scale && batch > 0 && batch <= 65535);
     CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
     CIM_CHECK_ARG(a_bs % 8 == 0 && b_bs % 8 == 0 && c_bs % 4 == 0);
-    PairArgs g{(const char*)A, (const char*)B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, batch, a_bs, b_bs, c_bs, a_scale, b_scale, nullptr};
+    PairArgs g{(const char*)A, (const char*)B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, batch, a_bs, b_bs, c_bs, a_scale, b_scale, nullptr, 0, 0, 0, 0};
     int rc = dispatch_pair(g, a_mcontig, b_kcontig, 1, nullptr, cim::as_stream(stream));
     if (rc) { cim::set_error("cim_gemm_pair_batched: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();

@@ -36,7 +36,16 @@ NPOS = 121
 # allocator, weights went NaN, and NaN operands draw less power and run the MFMAs at a higher clock.  The lifetimes are recorded now
 # (record_stream below) and tests/test_gpu_parity.py::test_stream_scheduling_does_not_change_a_training_run runs 40 optimizer steps
 # with the options on and off, bit-equal.)
-DEFER_DW = _os_env.get("CIM_DEFER_MASKFUSE_DW", "0") == "1"
+DEFER_DW = _os_env.get("CIM_DEFER_MASKFUSE_DW", "1") == "1"
+# With the deferred join: the three weight-gradient products are LAUNCHED at the end of this node's backward (behind its
+# data-gradient chain, not beside it) in consecutive launches of DW_WGS workgroups (cim_gemm_pair_limit; a workgroup owns its
+# CU) - they then run beside the ROIAlign and backbone backward, whose small kernels get on the chip between two launches instead
+# of queueing behind several thousand resident-for-70-us workgroups.  Measured at cfg2, interleaved runs on one box, ms per step:
+# beside the data gradients, joined at the node (round 2's schedule) 14.84 / 14.53 / 14.78; late in launches of 256 14.25 / 14.23 /
+# 14.19; late as whole products 14.44 / 14.62 / 14.31; late in launches of 96 / 128 / 192 / 224 (part of the chip left free):
+# 16.9 / 15.8 / 15.1 / 14.9 - the products are MFMA-bound, CUs withheld from them are simply lost.
+# 0: launched where their operands are ready, uncapped (beside the data-gradient products).
+DW_WGS = int(_os_env.get("CIM_MASKFUSE_DW_WGS", "256"))
 
 
 def supported(cat, wc, w1, w2):
@@ -189,6 +198,15 @@ class MaskFusePairFunction(Function):
             return dw
 
         published = []
+        late = []               # (slot, weight, closure) of the weight gradients launched at the end (DW_WGS > 0)
+        run_late = overlap and DEFER_DW and G.DEFER_DW and DW_WGS > 0
+
+        def side_grad(slot, w, fn):
+            if run_late:
+                late.append((slot, w, fn))
+                return None
+            return publish(w, on_side(fn))
+
         wc_p, w1_p, w2_p = ctx.weights
         dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = dy_conv = None
         am = torch.zeros(3, dtype=torch.int32, device=dev)
@@ -200,7 +218,7 @@ class MaskFusePairFunction(Function):
         pair.amax_of(dY2m, am[0:1])
         dY2p = pair.split(dY2m, r, h2, h2, scale=pair.scales_from(am[0:1], 1))
         if need_w2:
-            dw2 = publish(w2_p, on_side(lambda: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False)))
+            dw2 = side_grad(2, w2_p, lambda: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False))
         dY1 = pair.gemm(dY2p, W2p, r, h1, h2, False, False)
         # ---- fc1
         dY1m = dY1 * (Y1 > 0)
@@ -209,7 +227,7 @@ class MaskFusePairFunction(Function):
         pair.amax_of(dY1m, am[1:2])
         dY1p = pair.split(dY1m, r, h1, h1, scale=pair.scales_from(am[1:2], 1))
         if need_w1:
-            dw1 = publish(w1_p, on_side(lambda: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False)))
+            dw1 = side_grad(1, w1_p, lambda: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False))
         if need_x or need_wc or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
             dX = pair.gemm(dY1p, W1p, r, cout * p * p, h1, False, False, c_amax=am[2:3])
             # ---- flatten backward + ReLU mask of the conv; conv gradients
@@ -232,7 +250,7 @@ class MaskFusePairFunction(Function):
                     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
                     _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, 7, st2)
                     return dw
-                dwc = publish(wc_p, on_side(wgrad))
+                dwc = side_grad(0, wc_p, wgrad)
             if need_x:
                 sE = torch.empty(NPOS, dtype=torch.float32, device=dev)
                 _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 3, sE.data_ptr(), st)
@@ -245,6 +263,15 @@ class MaskFusePairFunction(Function):
             dy_conv = dy
             if overlap:
                 dy.record_stream(side)
+        if late:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                _lib.call("cim_gemm_pair_limit", DW_WGS)
+                try:
+                    got = {slot: publish(w, fn()) for slot, w, fn in late}
+                finally:
+                    _lib.call("cim_gemm_pair_limit", 0)
+            dwc, dw1, dw2 = got.get(0, dwc), got.get(1, dw1), got.get(2, dw2)
         if overlap:
             # operands the side stream's GEMMs read: the allocator must not hand their memory out before that work is done,
             # whichever way (join here, deferred join, DataParallel's all-reduce) the weight gradients leave this node

@@ -344,6 +344,11 @@ int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int 
  *   cim_pair_split : fp32 X [batch][rows][ld] -> pair image [batch][rows_pad][ldp], rows >= `rows` zero-filled; relu_y
  *                    (optional, laid out as X): elements with relu_y <= 0 are written as 0 (a fused ReLU backward mask)
  *   cim_pair_amax  : max |x| bit pattern of n floats (atomicMax into a caller-zeroed word) */
+/* Caps the launches of this THREAD's following cim_gemm_pair* products at max_workgroups (0 = one launch over all tiles, the
+ * default): a product then goes out as consecutive launches.  A workgroup of this engine owns its CU (128 KB of LDS), so a
+ * capped product never holds more CUs than that and leaves the rest of the chip to concurrent streams - used for the
+ * MaskFuse weight-gradient products that run beside the backbone's backward (cim_amd/ops/maskfuse_pair.py). */
+int cim_gemm_pair_limit(int max_workgroups);
 int cim_gemm_pair_splits(int M, int N, int K);
 int cim_gemm_pair(const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
                   int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
