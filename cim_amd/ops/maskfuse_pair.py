@@ -264,6 +264,9 @@ class MaskFusePairFunction(Function):
             if overlap:
                 dy.record_stream(side)
         if late:
+            # biggest first: with several ranks a gradient's all-reduce starts right behind its product (publish), and fc1's 822 MB
+            # is the one that needs the rest of the backward pass to hide under
+            late.sort(key=lambda e: -e[1].numel())
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 _lib.call("cim_gemm_pair_limit", DW_WGS)
