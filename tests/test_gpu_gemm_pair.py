@@ -119,6 +119,34 @@ def test_pair_gemm_batched(dev):
     assert float(((c2.cpu().double() - ref2).abs() / scale2).max()) < 2e-6
 
 
+def test_pair_gemm_chunked_launches_are_bit_identical(dev):
+    """cim_gemm_pair_limit(n): a product goes out as consecutive launches of at most n workgroups (the MaskFuse weight gradients
+    beside the backbone backward) - same tiles, same arithmetic, same bits, for a batched product (>= 8 slices: the XCD-slice work
+    order), a split-K product and a plain one; the limit is per thread and 0 restores one launch."""
+    from cim_amd import _lib
+    from cim_amd.ops import pair
+    g = torch.Generator().manual_seed(11)
+    nb, M, N, K = 9, 520, 520, 64
+    A, B = torch.randn(nb, M, K, generator=g).to(dev), torch.randn(nb, K, N, generator=g).to(dev)
+    pa, pb = pair.split(A, M, K, K, batch=nb, x_bs=M * K), pair.split(B, K, N, N, batch=nb, x_bs=K * N)
+    X, W = torch.randn(300, 8192, generator=g).to(dev), torch.randn(264, 8192, generator=g).to(dev)
+    px, pw = pair.split(X), pair.split(W)
+    assert _lib.call("cim_gemm_pair_splits", 300, 264, 8192) > 1
+    ref = (pair.gemm(pa, pb, M, N, K, False, False), pair.gemm(px, pw, 300, 264, 8192, False, True),
+           pair.gemm(pa, pa, K, K, pair.pad32(M), True, False))
+    for limit in (1, 5, 7, 100000):
+        _lib.call("cim_gemm_pair_limit", limit)
+        try:
+            got = (pair.gemm(pa, pb, M, N, K, False, False), pair.gemm(px, pw, 300, 264, 8192, False, True),
+                   pair.gemm(pa, pa, K, K, pair.pad32(M), True, False))
+        finally:
+            _lib.call("cim_gemm_pair_limit", 0)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), limit
+    with pytest.raises(_lib.CimHipError):
+        _lib.call("cim_gemm_pair_limit", -1)
+
+
 @pytest.mark.parametrize("K", [2048, 50176])
 def test_pair_engine_error_class(dev, K):
     """One scale per matrix: on unit-variance data and on data with exponents spread over 2^+-10 the engine sits in the
