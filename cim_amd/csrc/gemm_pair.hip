@@ -282,7 +282,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
     }
     // Ragged last M-tile (800 ... 1200 proposals against 256-row tiles): when the tile's second 128 rows lie past M, the
     // four waves that own them (wm = 1) only stage their share of the operands and keep the barrier sequence - the
-    // tile then costs its four working waves' MFMA time, about half a tile.
+    // tile then costs its four working waves' MFMA time, about half a tile.  (Tried on top: the working waves skip the 32-row
+    // sub-tiles that lie past M - wave-uniform `if (i < valid)` around their fragment reads and MFMAs - SLOWER: the scalar
+    // branches break the MFMA / LDS-read interleaving for every tile; Winograd forward at 857 rows 1.343 vs 1.221 ms, whole
+    // step 15.05 vs 14.66 ms.)
 #if CIM_PAIR_EXP != 6
     if (wm == 1 && m0 + WM >= g.M) {
         if constexpr (AL == L_MC) sa.issue(ak, smem, wave);
