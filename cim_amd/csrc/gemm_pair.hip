@@ -30,6 +30,7 @@
 //       k per lane: two reads = one MFMA operand
 // The swizzles are applied on the SOURCE address of the LDS-DMA (its destination is lane-linear) and on the reads.
 #include "common.h"
+#include <type_traits>
 #include "../../include/cim_hip.h"
 
 namespace {
@@ -282,10 +283,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
     }
     // Ragged last M-tile (800 ... 1200 proposals against 256-row tiles): when the tile's second 128 rows lie past M, the
     // four waves that own them (wm = 1) only stage their share of the operands and keep the barrier sequence - the
-    // tile then costs its four working waves' MFMA time, about half a tile.  (Tried on top: the working waves skip the 32-row
-    // sub-tiles that lie past M - wave-uniform `if (i < valid)` around their fragment reads and MFMAs - SLOWER: the scalar
-    // branches break the MFMA / LDS-read interleaving for every tile; Winograd forward at 857 rows 1.343 vs 1.221 ms, whole
-    // step 15.05 vs 14.66 ms.)
+    // tile then costs its four working waves' MFMA time, about half a tile.  The working waves in turn leave out their 32-row
+    // sub-tiles past M (main_loop<MIV> below).
 #if CIM_PAIR_EXP != 6
     if (wm == 1 && m0 + WM >= g.M) {
         if constexpr (AL == L_MC) sa.issue(ak, smem, wave);
@@ -328,19 +327,27 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
         bk += b_adv;
     }
 
-    f16x8 ah0[MI], al0[MI], bh0[NI], bl0[NI];
-    f16x8 ah1[MI], al1[MI], bh1[NI], bl1[NI];
+    // The main loop, instantiated for MIV = 1 .. 4 valid 32-row sub-tiles of this wave's 128 rows: a working wave of the ragged last
+    // M-tile whose rows reach past M leaves out the sub-tiles that lie entirely outside (their fragment reads and MFMAs) - as a
+    // compile-time bound, selected once per workgroup.  Run-time `if (i < valid)` guards inside the one loop measured SLOWER (they
+    // break the MFMA / LDS-read interleaving of every tile: Winograd forward at 857 rows 1.343 vs 1.221 ms, step 15.05 vs 14.66 ms);
+    // the four instantiations: step 14.54 / 14.71 / 14.37 vs 14.63 / 14.76 / 14.50 ms (same box, interleaved), roofline.frac of the
+    // mix 0.470 -> 0.480; alone the products gain 2-4 % at 1086 rows, the KC x MC one loses 3.6 % at 857 (tools/bench_gemm_pair.py).
+    auto main_loop = [&](auto miv_c) {
+    constexpr int MIV = decltype(miv_c)::value;
+    f16x8 ah0[MIV], al0[MIV], bh0[NI], bl0[NI];
+    f16x8 ah1[MIV], al1[MIV], bh1[NI], bl1[NI];
 #define PAIR_READ(AH, AL_, BH, BL_, BUF, KS)                                                   \
     _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                           \
         BH[j] = fb.read((BUF) + OPER, j, KS, 0);                                               \
         BL_[j] = fb.read((BUF) + OPER, j, KS, 1);                                              \
     }                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                           \
+    _Pragma("unroll") for (int i = 0; i < MIV; ++i) {                                          \
         AL_[i] = fa.read((BUF), i, KS, 1);                                                     \
         AH[i] = fa.read((BUF), i, KS, 0);                                                      \
     }
 #define PAIR_MMA(AF, BF)                                                                       \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
+    _Pragma("unroll") for (int i = 0; i < MIV; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i], BF[j], acc[i][j], 0, 0, 0)
 
 #if CIM_PAIR_EXP == 1
@@ -403,6 +410,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
 #undef PAIR_PRIO
 #undef PAIR_READ
 #undef PAIR_MMA
+    };
+#if CIM_PAIR_EXP == 7
+    main_loop(std::integral_constant<int, MI>{});
+#else
+    switch (__builtin_amdgcn_readfirstlane(min(MI, (g.M - m0 - wm * WM + 31) / 32))) {
+        case 1: main_loop(std::integral_constant<int, 1>{}); break;
+        case 2: main_loop(std::integral_constant<int, 2>{}); break;
+        case 3: main_loop(std::integral_constant<int, 3>{}); break;
+        default: main_loop(std::integral_constant<int, MI>{}); break;
+    }
+#endif
+
 
     // epilogue: undo the two scales (powers of two: exact), bias, ReLU.  Nothing may be in flight on the vector-memory counter
     // when the stores start: stores count on vmcnt as well, and a load whose completion the compiler cannot prove at a
