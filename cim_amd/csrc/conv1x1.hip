@@ -48,7 +48,12 @@ struct SmallArgs {
     int splits; float* ws;
     const float* colbias;    // [N] added per output COLUMN (nn.Linear bias: C = X . W^T + b); null for the convolutions
     unsigned* tile_cnt;      // split-K: per-tile arrival counters (zero between launches) - the last split of a tile combines
+    // data gradients only: the BatchNorm + ReLU backward of the layer that PRODUCED this product's input, applied to the
+    // result - C(row, col) = mask(row, col) > 0 ? C * mgamma[row] rsqrt(mvar[row] + meps) : 0 with mask = that layer's output
+    // (this layer's input, same layout as C): the producer's own backward then starts from the gradient of its convolution
+    const float* mask; const float* mgamma; const float* mvar; float meps;
 };
+struct InputBn { const float* y; const float* gamma; const float* var; float eps; };       // (the four fields above as arguments)
 
 // Tile loaders.  An operand tile is ROWS x 32 (k) floats per slab, moved as 16-byte pieces: piece index p ->
 //   K-contiguous operand (element (r, k) at P[r*ld + k]):  r = p % ROWS, k = (p / ROWS) * 4   (lanes along the rows: the
@@ -110,6 +115,7 @@ __device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int co
     if (g.res) y += g.res[o];
     if (g.colbias) y += g.colbias[col];
     if (g.relu) y = fmaxf(y, 0.0f);
+    if (g.mask) y = g.mask[o] > 0.0f ? y * (g.mgamma[row] * rsqrtf(g.mvar[row] + g.meps)) : 0.0f;
     g.C[o] = y;
 }
 
@@ -503,19 +509,33 @@ extern "C" int cim_gemm_small_splits(int M, int N, int K) {
     return s;
 }
 
+static int gemm_small_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                           int a_mcontig, int b_kcontig, float* x_raw, const float* gamma, const float* beta,
+                           const float* mean, const float* var, float eps, const float* residual, int relu, int splits,
+                           float* workspace, void* stream, const InputBn* in_bn);
+
 extern "C" int cim_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   int a_mcontig, int b_kcontig, float* x_raw, const float* gamma, const float* beta,
                                   const float* mean, const float* var, float eps, const float* residual, int relu, int splits,
                                   float* workspace, void* stream) {
+    return gemm_small_impl(A, B, C, M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig, x_raw, gamma, beta, mean, var, eps, residual, relu,
+                           splits, workspace, stream, nullptr);
+}
+
+static int gemm_small_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                           int a_mcontig, int b_kcontig, float* x_raw, const float* gamma, const float* beta,
+                           const float* mean, const float* var, float eps, const float* residual, int relu, int splits,
+                           float* workspace, void* stream, const InputBn* in_bn) {
     CIM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N && splits >= 1);
     CIM_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (gamma == nullptr) == (mean == nullptr) && (gamma == nullptr) == (var == nullptr));
     CIM_CHECK_ARG(splits == 1 || workspace);
-    SmallArgs g;
+    SmallArgs g{};
     g.A = A; g.B = B; g.C = C; g.Xraw = x_raw;
     g.gamma = gamma; g.beta = beta; g.mean = mean; g.var = var; g.res = residual; g.eps = eps;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_mcontig = a_mcontig; g.b_kcontig = b_kcontig; g.relu = relu; g.bn = gamma != nullptr;
     g.splits = splits; g.ws = workspace; g.colbias = nullptr;
+    if (in_bn) { g.mask = in_bn->y; g.mgamma = in_bn->gamma; g.mvar = in_bn->var; g.meps = in_bn->eps; }
     const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
     CIM_CHECK_ARG(tiles * 2 < (1ll << 31) && splits <= 65535);
     const bool narrow = tiles * splits < 128;           // 64 x 32 tiles only for problems that cannot fill the chip otherwise
@@ -539,7 +559,7 @@ extern "C" int cim_gemm_small_f32(const float* A, const float* B, float* C, int 
 extern "C" int cim_linear_bias_f32(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int splits,
                                    float* workspace, void* stream) {
     CIM_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0 && splits >= 1 && splits <= 65535 && (splits == 1 || workspace));
-    SmallArgs g;
+    SmallArgs g{};
     g.A = X; g.B = W; g.C = Y; g.Xraw = nullptr;
     g.gamma = g.beta = g.mean = g.var = g.res = nullptr; g.eps = 0.f;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
@@ -615,13 +635,16 @@ __global__ __launch_bounds__(256) void small_axpy_kernel(float* __restrict__ y, 
 extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                                       const float* gamma, const float* mean, const float* var, float eps, int relu,
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
-                                      int hw, float* workspace, void* stream, void* side_stream, int join) {
+                                      int hw, float* workspace, void* stream, void* side_stream, int join,
+                                      int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps) {
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0 && cin > 0 && cout > 0 && hw > 0);
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)));
-    float* dconv = workspace;                                  // [B][cout][hw]: dz * a, the gradient of the convolution output
+    CIM_CHECK_ARG(!dy_is_dconv || (dres == nullptr && dgamma == nullptr));       // (the consumer's data gradient already applied this layer's BatchNorm + ReLU backward)
+    CIM_CHECK_ARG((in_gamma == nullptr) == (in_var == nullptr));
+    float* dconv = dy_is_dconv ? const_cast<float*>(dy) : workspace;             // [B][cout][hw]: dz * a, the gradient of the convolution output
     float* ws_dx = workspace + (size_t)B * cout * hw;
     float* ws_dw = ws_dx + (size_t)cim_gemm_small_splits(cin, hw, cout) * cin * hw;
-    int rc = cim_bn_act_bwd(dy, y, x_raw, gamma, mean, var, eps, dconv, dres, dgamma, dbeta, B, cout, hw, relu, stream);
+    int rc = dy_is_dconv ? 0 : cim_bn_act_bwd(dy, y, x_raw, gamma, mean, var, eps, dconv, dres, dgamma, dbeta, B, cout, hw, relu, stream);
     if (rc) return rc;
     ForkJoin fj(cim::as_stream(stream), cim::as_stream(side_stream), dx && dw);
     void* st_dw = fj.fork();                                   // the weight gradient next to the data gradient
@@ -636,9 +659,11 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
             hipLaunchKernelGGL(small_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(st_dw), dw, out, n);
         }
     }
-    for (int b = 0; b < B && dx; ++b) {                        // dX[cin, hw] = W^T . dconv
-        rc = cim_gemm_small_f32(w, dconv + (size_t)b * cout * hw, dx + (size_t)b * cin * hw, cin, hw, cout, cin, hw, hw, 1, 0,
-                                nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, cout), ws_dx, stream);
+    for (int b = 0; b < B && dx; ++b) {                        // dX[cin, hw] = W^T . dconv  (x the BatchNorm + ReLU backward of the layer that made x)
+        const InputBn ib{x + (size_t)b * cin * hw, in_gamma, in_var, in_eps};
+        rc = gemm_small_impl(w, dconv + (size_t)b * cout * hw, dx + (size_t)b * cin * hw, cin, hw, cout, cin, hw, hw, 1, 0,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, cout), ws_dx, stream,
+                             in_gamma ? &ib : nullptr);
         if (rc) return rc;
     }
     if (join) fj.join();                                       // else the caller joins the side stream before the weight gradient is used
@@ -652,13 +677,14 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
 namespace {
 int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldc, const ConvGeom& c,
                    float* x_raw, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
-                   const float* residual, int relu, int splits, float* ws, hipStream_t st, int ksize = 3) {
-    SmallArgs g;
+                   const float* residual, int relu, int splits, float* ws, hipStream_t st, int ksize = 3, const InputBn* in_bn = nullptr) {
+    SmallArgs g{};
     g.A = A; g.B = B; g.C = C; g.Xraw = x_raw;
     g.gamma = gamma; g.beta = beta; g.mean = mean; g.var = var; g.res = residual; g.eps = eps;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = 0; g.ldc = ldc;
     g.a_mcontig = 0; g.b_kcontig = mode == CONV_DW; g.relu = relu; g.bn = gamma != nullptr;
     g.splits = splits; g.ws = ws; g.colbias = nullptr;
+    if (in_bn) { g.mask = in_bn->y; g.mgamma = in_bn->gamma; g.mvar = in_bn->var; g.meps = in_bn->eps; }
     const dim3 grid((unsigned)(((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN)), (unsigned)splits);
     g.tile_cnt = splits > 1 ? splitk_counters((long long)grid.x) : nullptr;
     const size_t lds = sizeof(float) * 4 * CBK * SLD;
@@ -737,19 +763,21 @@ extern "C" int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, cons
                                       const float* gamma, const float* mean, const float* var, float eps, int relu,
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
                                       int H, int W, int stride, int dilation, float* workspace, void* stream, void* side_stream,
-                                      int join) {
+                                      int join, int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps) {
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0);
     CONV3_ARGS_OK(4);
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)) && cout % 4 == 0);
+    CIM_CHECK_ARG(!dy_is_dconv || (dres == nullptr && dgamma == nullptr));
+    CIM_CHECK_ARG((in_gamma == nullptr) == (in_var == nullptr));
     const ConvGeom cx = conv_geom(cin, cout, H, W, stride, CONV_DX, dilation), cw = conv_geom(cin, cout, H, W, stride, CONV_DW, dilation);
     const int hwo = cx.Ho * cx.Wo, hw = H * W;
     hipStream_t st = cim::as_stream(stream);
-    float* dconv = workspace;                                  // [B][cout][Ho Wo]: the gradient of the convolution output
+    float* dconv = dy_is_dconv ? const_cast<float*>(dy) : workspace;      // [B][cout][Ho Wo]: the gradient of the convolution output
     float* wt = workspace + (size_t)B * cout * hwo;            // [cout][9][cin]
     float* ws_dx = wt + (size_t)cout * cin * 9;
     float* ws_dw = ws_dx + (size_t)cim_gemm_small_splits(cin, hw, 9 * cout) * cin * hw;
     CIM_CHECK_ARG((size_t)cin * 9 * sizeof(float) <= 64 * 1024);
-    int rc = cim_bn_act_bwd(dy, y, x_raw, gamma, mean, var, eps, dconv, dres, dgamma, dbeta, B, cout, hwo, relu, stream);
+    int rc = dy_is_dconv ? 0 : cim_bn_act_bwd(dy, y, x_raw, gamma, mean, var, eps, dconv, dres, dgamma, dbeta, B, cout, hwo, relu, stream);
     if (rc) return rc;
     ForkJoin fj(st, cim::as_stream(side_stream), dx && dw);
     hipStream_t st_dw = fj.fork();                             // the weight gradient next to the data gradient
@@ -764,9 +792,12 @@ extern "C" int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, cons
         }
     }
     if (dx) hipLaunchKernelGGL(conv3x3_wt_kernel, dim3(cout), dim3(256), sizeof(float) * cin * 9, st, w, wt, cin);
-    for (int b = 0; b < B && dx; ++b)                          // dX[cin][H W] = sum over (co, tap) W[co][ci][tap] dconv[co][shifted]
+    for (int b = 0; b < B && dx; ++b) {                        // dX[cin][H W] = sum over (co, tap) W[co][ci][tap] dconv[co][shifted]
+        const InputBn ib{x + (size_t)b * cin * hw, in_gamma, in_var, in_eps};
         conv3x3_launch(CONV_DX, wt, dconv + (size_t)b * cout * hwo, dx + (size_t)b * cin * hw, cin, hw, 9 * cout, cin, hw, cx, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, 9 * cout), ws_dx, st);
+                       nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, 9 * cout), ws_dx, st, 3,
+                       in_gamma ? &ib : nullptr);
+    }
     if (join) fj.join();                                       // else the caller joins the side stream before the weight gradient is used
     CIM_CHECK_LAUNCH();
     return 0;

@@ -17,6 +17,7 @@ from .maskfuse import MaskFuse  # noqa: F401  (resolved as "resnet50.MaskFuse" b
 
 
 OWN_3X3 = os.environ.get("CIM_BACKBONE_3X3", "hip") != "aten"      # CIM_BACKBONE_3X3=aten: MIOpen's 3 x 3 kernels + the bn_act launch (A/B runs)
+FUSE_BN_BWD = os.environ.get("CIM_FUSE_BN_BWD", "1") == "1"          # BatchNorm backward of conv1 / conv2 inside the next layer's data gradient
 OWN_1X1 = os.environ.get("CIM_BACKBONE_1X1", "hip") != "aten"      # CIM_BACKBONE_1X1=aten: the MIOpen / rocBLAS path (A/B runs)
 
 
@@ -40,11 +41,13 @@ class Bottleneck(nn.Module):
         # They fall back to the ATen ops for a BN in training mode or CPU tensors.
         identity = x
         if OWN_1X1:
+            # (fuse_input_bn: conv1's / conv2's outputs have one consumer each - their BatchNorm + ReLU backward rides in the next
+            # layer's data-gradient epilogue, ops/chain.py)
             out = conv1x1_bn_act(x, self.conv1, self.bn1)
-            out = conv3x3_bn_act(out, self.conv2, self.bn2) if OWN_3X3 else bn_act(self.conv2(out), self.bn2)
+            out = conv3x3_bn_act(out, self.conv2, self.bn2, fuse_input_bn=FUSE_BN_BWD) if OWN_3X3 else bn_act(self.conv2(out), self.bn2)
             if self.downsample is not None:
                 identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-            return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity)
+            return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity, fuse_input_bn=FUSE_BN_BWD and OWN_3X3)
         out = bn_act(self.conv1(x), self.bn1)
         out = bn_act(self.conv2(out), self.bn2)
         if self.downsample is not None:

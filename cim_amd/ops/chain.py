@@ -1,0 +1,55 @@
+"""Chaining the backward of two fused conv + frozen-BatchNorm + ReLU layers without a BatchNorm-backward launch in between.
+
+When layer P produces x = relu(bn_P(conv_P(.))) (no residual, BatchNorm parameters frozen) and layer Q is its ONLY consumer,
+the data-gradient product of Q can apply P's BatchNorm + ReLU backward in its epilogue (csrc/conv1x1.hip: SmallArgs.mask):
+    dconv_P = (x > 0 ? dx : 0) * gamma_P rsqrt(var_P + eps_P)
+so P's backward starts from the gradient of its convolution output and skips its `bn_act_bwd` launch
+(torchvision Bottleneck conv1 -> conv2 -> conv3 of /root/reference/lib/modeling/resnet50.py:17-44: 20 of the 32 BatchNorm-backward
+launches of a cfg2 step).
+
+Protocol (all on the host, per backward pass):
+  * P's wrapper tags its output: y._cim_bn = (gamma, var, eps, state) when P is eligible;
+  * Q is called with fuse_input_bn=True by code that KNOWS x has no other consumer (the bottleneck): it marks state["taken"],
+    applies the epilogue in its backward and hands the result over: hand_over(dx);
+  * P's backward asks take(dy): True -> dy is already dconv_P.  A taken P that receives anything else (the gradient was
+    accumulated with another one: x had a second consumer after all) raises - it cannot be repaired silently.
+"""
+_HANDED = set()      # (data_ptr, numel) of gradients handed over in the running backward pass
+
+
+def tag(y, gamma, beta, mean, var, eps, relu, has_res):
+    """-> state dict stored with P's autograd node (None when P is not eligible)."""
+    if not relu or has_res or gamma.requires_grad or beta.requires_grad or mean.requires_grad or not y.requires_grad:
+        return None
+    state = {"taken": False}
+    y._cim_bn = (gamma, var, float(eps), state)
+    return state
+
+
+def input_bn(x, enabled):
+    """(gamma, var, eps) of the layer that produced x, marked as taken - or None."""
+    t = getattr(x, "_cim_bn", None) if enabled else None
+    if t is None:
+        return None
+    t[3]["taken"] = True
+    return t[0], t[1], t[2]
+
+
+def hand_over(dx):
+    _HANDED.add((dx.data_ptr(), dx.numel()))
+
+
+def take(dy, state):
+    key = (dy.data_ptr(), dy.numel())
+    if key in _HANDED:
+        _HANDED.discard(key)
+        return True
+    if state is not None and state["taken"]:
+        raise RuntimeError("cim_amd: a layer whose BatchNorm backward was fused into its consumer's data gradient received a "
+                           "different gradient tensor - its output has a second consumer (fuse_input_bn=True is only valid for "
+                           "a single consumer)")
+    return False
+
+
+def reset():
+    _HANDED.clear()

@@ -3,7 +3,7 @@
 
 `conv1x1_bn_act(x, conv, bn, residual=None, relu=True)` == F.relu(bn(conv(x)) + residual) for an nn.Conv2d with a
 1 x 1 kernel (no bias, no padding; a stride is applied by sub-sampling the input first) and an nn.BatchNorm2d in eval()
-mode - /root/reference/lib/modeling/resnet50.py:17-44 (torchvision Bottleneck conv1 / conv3 / downsample) with every
+mode (fuse_input_bn=True: see ops/chain.py) - /root/reference/lib/modeling/resnet50.py:17-44 (torchvision Bottleneck conv1 / conv3 / downsample) with every
 BatchNorm frozen as :53-77 does.  The parameters stay the modules' own tensors (checkpoint surface unchanged).
 In NCHW the convolution of one image is W[Cout,Cin] . X[Cin,HW]: forward, data gradient (W^T . dY) and weight gradient
 (dY . X^T, split-K) are three layouts of the same small-tile fp32-MFMA GEMM; the BatchNorm backward stays the fused
@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from . import chain
 from . import fallback
 from . import gemm as _gemm_mod
 
@@ -28,7 +29,7 @@ def _gemm(a, b, c, m, n, k, lda, ldb, ldc, a_mcontig, b_kcontig, x_raw=None, bn=
 
 class Conv1x1BnActFunction(Function):
     @staticmethod
-    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu):
+    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, in_bn=None, state=None):
         x = x.contiguous()
         B, cin, H, W = x.shape
         cout, hw = w.shape[0], H * W
@@ -45,6 +46,7 @@ class Conv1x1BnActFunction(Function):
             ctx.save_for_backward(x, w2, xr, y if relu else None, gamma, mean, var)
         ctx.param = w if isinstance(w, torch.nn.Parameter) else None      # (its .grad tells the backward whether it may defer the join)
         ctx.cfg = (B, cin, cout, H, W, float(eps), bool(relu), res is not None)
+        ctx.in_bn, ctx.state = in_bn, state          # ops/chain.py: the producer's BatchNorm (fused into dx) / this layer's hand-over state
         return y
 
     @staticmethod
@@ -52,6 +54,7 @@ class Conv1x1BnActFunction(Function):
         x, w2, xr, y, gamma, mean, var = ctx.saved_tensors
         B, cin, cout, H, W, eps, relu, has_res = ctx.cfg
         hw = H * W
+        is_dconv = chain.take(dy, ctx.state)         # the consumer's data gradient already applied this layer's BatchNorm + ReLU backward
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_res = has_res and ctx.needs_input_grad[2]
@@ -70,16 +73,25 @@ class Conv1x1BnActFunction(Function):
         side, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
         _lib.call("cim_conv1x1_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w2.data_ptr(),
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres), _lib.ptr(dgamma),
-                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, join)
+                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, join,
+                  int(is_dconv), *_in_bn_args(ctx.in_bn if need_x else None))
+        if ctx.in_bn is not None and need_x:
+            chain.hand_over(dx)
         if not join:                       # the weight gradient is still running on the side stream: installed as .grad at the join
             _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x)
             dw = None
         dmean = -(gamma * torch.rsqrt(var + eps)) * dbeta if need_mean else None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
-            dmean, None, None, None
+            dmean, None, None, None, None, None
 
 
-def conv1x1_bn_act(x, conv, bn, residual=None, relu=True):
+def _in_bn_args(in_bn):
+    if in_bn is None:
+        return None, None, 0.0
+    return in_bn[0].data_ptr(), in_bn[1].data_ptr(), float(in_bn[2])
+
+
+def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False):
     """relu?(bn(conv(x)) + residual) for a 1 x 1 nn.Conv2d `conv` and an nn.BatchNorm2d `bn`.  A convolution bias (HRNet's
     final_layer, HRNet.py:298-312) is folded into the BatchNorm's mean: bn(conv + bias) = a conv + (beta - (mean - bias) a)."""
     stride = conv.stride[0]
@@ -93,6 +105,7 @@ def conv1x1_bn_act(x, conv, bn, residual=None, relu=True):
         if residual is not None:
             out = out + residual
         return F.relu(out) if relu else out
+    in_bn = chain.input_bn(x, fuse_input_bn and stride == 1 and torch.is_grad_enabled() and x.requires_grad)
     if stride != 1:                                   # a strided 1 x 1 convolution only sees every stride-th pixel
         x = x[:, :, ::stride, ::stride]
     mean = bn.running_mean if conv.bias is None else bn.running_mean - conv.bias
@@ -100,4 +113,8 @@ def conv1x1_bn_act(x, conv, bn, residual=None, relu=True):
     if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:6])):
         with torch.no_grad():
             return Conv1x1BnActFunction.apply(*args)
-    return Conv1x1BnActFunction.apply(*args)
+    state = {"taken": False}
+    out = Conv1x1BnActFunction.apply(*args, in_bn, state)
+    if chain.tag(out, bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu, residual is not None) is not None:
+        out._cim_bn = out._cim_bn[:3] + (state,)      # (the node's own state object: its backward checks it)
+    return out

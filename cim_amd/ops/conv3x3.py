@@ -13,13 +13,15 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from . import chain
 from . import fallback
+from .conv1x1 import _in_bn_args
 from . import gemm as _gemm_mod
 
 
 class Conv3x3BnActFunction(Function):
     @staticmethod
-    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, stride, dilation=1):
+    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, stride, dilation=1, in_bn=None, state=None):
         x = x.contiguous()
         w = w.contiguous()
         B, cin, H, W = x.shape
@@ -41,12 +43,14 @@ class Conv3x3BnActFunction(Function):
             ctx.save_for_backward(x, w, xr, y if relu else None, gamma, mean, var)
         ctx.param = w if isinstance(w, torch.nn.Parameter) else None      # (its .grad tells the backward whether it may defer the join)
         ctx.cfg = (B, cin, cout, H, W, float(eps), bool(relu), res is not None, stride, dilation)
+        ctx.in_bn, ctx.state = in_bn, state          # ops/chain.py
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, xr, y, gamma, mean, var = ctx.saved_tensors
         B, cin, cout, H, W, eps, relu, has_res, stride, dilation = ctx.cfg
+        is_dconv = chain.take(dy, ctx.state)
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_res = has_res and ctx.needs_input_grad[2]
@@ -65,20 +69,27 @@ class Conv3x3BnActFunction(Function):
         side, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
         _lib.call("cim_conv3x3_nchw_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w.data_ptr(),
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres), _lib.ptr(dgamma),
-                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, H, W, stride, dilation, ws.data_ptr(), _lib.stream_ptr(), side, join)
+                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, H, W, stride, dilation, ws.data_ptr(), _lib.stream_ptr(), side, join,
+                  int(is_dconv), *_in_bn_args(ctx.in_bn if need_x else None))
+        if ctx.in_bn is not None and need_x:
+            chain.hand_over(dx)
         if not join:                       # the weight gradient is still running on the side stream: installed as .grad at the join
             _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x)
             dw = None
         dmean = -(gamma * torch.rsqrt(var + eps)) * dbeta if need_mean else None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
-            dmean, None, None, None, None, None
+            dmean, None, None, None, None, None, None, None
 
 
-def _apply(fn, args, n_diff):
+def _apply(fn, args, n_diff, in_bn=None, tag=None):
     if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:n_diff])):
         with torch.no_grad():
             return fn.apply(*args)
-    return fn.apply(*args)
+    state = {"taken": False}
+    out = fn.apply(*args, in_bn, state)
+    if tag is not None and chain.tag(out, *tag) is not None:
+        out._cim_bn = out._cim_bn[:3] + (state,)
+    return out
 
 
 def _same_padded(conv):
@@ -93,7 +104,7 @@ def _geometry_ok(x, conv, needs_backward):
             and x.shape[3] <= 4096 and x.shape[2] * x.shape[3] < (1 << 20))
 
 
-def conv3x3_bn_act(x, conv, bn, residual=None, relu=True):
+def conv3x3_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False):
     """relu?(bn(conv(x)) + residual) for a 3 x 3 nn.Conv2d `conv` ("same" padding, stride 1 / 2, dilation d with padding d)
     and an nn.BatchNorm2d `bn` in eval() mode.  A convolution bias (HRNet's downsamp_modules, HRNet.py:283-296) is folded
     into the BatchNorm's mean: bn(conv + bias) = a conv + (beta - (mean - bias) a)."""
@@ -110,7 +121,8 @@ def conv3x3_bn_act(x, conv, bn, residual=None, relu=True):
         return F.relu(out) if relu else out
     mean = bn.running_mean if conv.bias is None else bn.running_mean - conv.bias
     args = (x, conv.weight, residual, bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu, conv.stride[0], conv.dilation[0])
-    return _apply(Conv3x3BnActFunction, args, 6)
+    in_bn = chain.input_bn(x, fuse_input_bn and torch.is_grad_enabled() and x.requires_grad)       # (ops/chain.py)
+    return _apply(Conv3x3BnActFunction, args, 6, in_bn, (bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu, residual is not None))
 
 
 _IDENTITY_BN = {}      # (device, channels) -> (ones, zeros): BatchNorm statistics that make the epilogue y = x + beta exactly

@@ -215,12 +215,19 @@ int cim_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, i
  * side_stream (may be NULL): a second HIP stream the weight-gradient GEMM is enqueued on, next to the data-gradient GEMM on
  * `stream`, forked after the BatchNorm backward.  join != 0: `stream` waits for it before the call returns (stream order is all the
  * caller needs); join == 0: the CALLER makes `stream` wait for side_stream before dw (and the buffers x, workspace) are used or
- * reused - the weight gradients of a whole backward pass then run beside the data-gradient chain. */
+ * reused - the weight gradients of a whole backward pass then run beside the data-gradient chain.
+ * Chaining two layers' backward without a BatchNorm-backward launch in between (round 3):
+ *   in_gamma, in_var, in_eps (in_gamma may be NULL): frozen BatchNorm of the layer that PRODUCED x as relu(bn(conv)) with no
+ *     residual - dx is then written as  x > 0 ? dx * in_gamma rsqrt(in_var + in_eps) : 0,  i.e. already the gradient of that
+ *     layer's convolution output (its BatchNorm + ReLU backward in this product's epilogue);
+ *   dy_is_dconv != 0: dy IS such a gradient of this layer's convolution output (handed over by the layer after it): the
+ *     BatchNorm backward launch is skipped (dres, dgamma, dbeta must be NULL). */
 long long cim_conv1x1_bwd_workspace(int B, int cin, int cout, int hw);
 int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                            const float* gamma, const float* mean, const float* var, float eps, int relu,
                            float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int hw,
-                           float* workspace, void* stream, void* side_stream, int join);
+                           float* workspace, void* stream, void* side_stream, int join,
+                           int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps);
 
 /* 3 x 3 convolution (padding 1, stride 1 or 2, no bias, groups 1) -> frozen BatchNorm (+ residual) (+ ReLU) of the
  * bottlenecks (torchvision Bottleneck.conv2 / bn2, lib/modeling/resnet50.py:17-44,53-77), NCHW fp32, ONE image per call, as an
@@ -245,12 +252,14 @@ int cim_conv7x7_nchw_f32(const float* x, const float* w, float* y, int cin, int 
 /* Backward of cim_conv3x3_nchw_f32 for B images in one call: BatchNorm / ReLU backward (cim_bn_act_bwd), dx [B,cin,H,W] (transposed
  * convolution as an implicit GEMM over (cout, tap)), dw [cout,cin,3,3] = sum over images and output pixels (split-K).
  * dy, y (may be NULL without relu), x_raw are [B,cout,Ho,Wo]; dres / dgamma+dbeta / dx / dw may be NULL when not needed.
- * workspace: cim_conv3x3_nchw_bwd_workspace(...) bytes.  cin % 4 == 0, cout % 4 == 0.  side_stream as in cim_conv1x1_bn_act_bwd. */
+ * workspace: cim_conv3x3_nchw_bwd_workspace(...) bytes.  cin % 4 == 0, cout % 4 == 0.  side_stream, join, dy_is_dconv and
+ * in_gamma / in_var / in_eps as in cim_conv1x1_bn_act_bwd. */
 long long cim_conv3x3_nchw_bwd_workspace(int B, int cin, int cout, int H, int W, int stride);
 int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                                 const float* gamma, const float* mean, const float* var, float eps, int relu, float* dres,
                                 float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int H, int W,
-                                int stride, int dilation, float* workspace, void* stream, void* side_stream, int join);
+                                int stride, int dilation, float* workspace, void* stream, void* side_stream, int join,
+                                int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps);
 
 /* ------------------------------------------------------------------ backbone BatchNorm chains (a-11)
  * Frozen-statistics BatchNorm (+ residual) (+ ReLU) of the ResNet / HRNet bodies, lib/modeling/resnet50.py:17-44,53-77

@@ -344,6 +344,54 @@ def test_conv1x1_bn_act_vs_aten(B, cin, cout, H, W, stride, relu, res):
     assert torch.equal(y2, y.detach())
 
 
+@pytest.mark.parametrize("inplanes,planes,stride,H,W", [(256, 64, 1, 33, 43), (256, 128, 2, 34, 45), (64, 16, 1, 9, 7)])
+def test_bottleneck_chained_bn_backward_is_bit_identical(dev, inplanes, planes, stride, H, W, monkeypatch):
+    """ops/chain.py: conv1's and conv2's BatchNorm + ReLU backward applied in the NEXT layer's data-gradient epilogue (no
+    bn_act_bwd launch, lib/modeling/resnet50.py:17-44 torchvision Bottleneck) gives the same bits as the unchained backward -
+    input gradient and all four weight gradients, with and without a downsample branch; a second consumer of a chained
+    tensor is an error, not a wrong gradient."""
+    from cim_amd.modeling import resnet50
+    from cim_amd.ops import chain, conv1x1_bn_act, conv3x3_bn_act, fallback, gemm
+    torch.manual_seed(inplanes + planes)
+    ds = None
+    if stride != 1 or inplanes != planes * 4:
+        ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(planes * 4))
+    blk = resnet50.Bottleneck(inplanes, planes, stride, ds).to(dev).eval()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.5, 0.5); m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 2.0)
+                m.weight.requires_grad_(False); m.bias.requires_grad_(False)            # frozen as resnet50.py:53-77
+    x0 = torch.randn(1, inplanes, H, W, device=dev)
+    up = None
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(resnet50, "FUSE_BN_BWD", flag)
+        chain.reset()
+        for p in blk.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        up = torch.randn_like(y) if up is None else up
+        y.backward(up)
+        gemm.join_side()
+        torch.cuda.synchronize()
+        res[flag] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.requires_grad]
+    assert len(res[True]) >= 5
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    # misuse: the chained tensor feeds a second consumer -> its producer refuses the accumulated gradient
+    monkeypatch.setattr(resnet50, "FUSE_BN_BWD", True)
+    chain.reset()
+    x = x0.clone().requires_grad_(True)
+    h1 = conv1x1_bn_act(x, blk.conv1, blk.bn1)
+    h2 = conv3x3_bn_act(h1, blk.conv2, blk.bn2, fuse_input_bn=True)
+    with pytest.raises(RuntimeError, match="second consumer"):
+        (h2.sum() + h1.sum()).backward()
+    chain.reset()
+    gemm.join_side(discard=True)
+
+
 @pytest.mark.parametrize("cin,cout,H,W,stride,res,relu,B", [(64, 64, 20, 27, 1, False, True, 1), (128, 128, 33, 43, 2, False, True, 1),
                                                             (256, 256, 17, 22, 1, True, True, 2), (32, 48, 9, 5, 2, False, False, 1),
                                                             (128, 128, 66, 86, 1, False, True, 1), (4, 8, 1, 7, 1, True, False, 1)])
