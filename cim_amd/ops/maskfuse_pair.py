@@ -269,7 +269,9 @@ class MaskFusePairFunction(Function):
             late.sort(key=lambda e: -e[1].numel())
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                _lib.call("cim_gemm_pair_limit", DW_WGS)
+                # (several ranks: RCCL's all-reduce kernels hold CUs of their own while these products run - a launch of exactly one
+                # workgroup per CU would then need a second, nearly empty round each time: the products go out whole)
+                _lib.call("cim_gemm_pair_limit", DW_WGS if G.GRAD_PUBLISHER is None else 0)
                 try:
                     got = {slot: publish(w, fn()) for slot, w, fn in late}
                 finally:
