@@ -193,12 +193,37 @@ def defer_side_join(dev, param, dw, *keep):
     _PENDING_IDS.add(id(param))
 
 
+# Launches a node's backward postponed to "after the next node's kernels are enqueued": MaskFuse's late weight-gradient products
+# (ops/maskfuse_pair.py) wait for the ROIAlign backward - the node that consumes MaskFuse's input gradient - so that it gets the chip
+# to itself; ops/roi_align.py calls run_postponed() behind its launch, an end-of-backward callback does when no such node ran.
+_POSTPONED = {}       # device -> [closures]
+POSTPONE_DW = os.environ.get("CIM_MASKFUSE_DW_AFTER_ROI", "1") == "1"
+
+
+def postpone(dev, fn):
+    lst = _POSTPONED.setdefault(dev, [])
+    if not lst:
+        engine.queue_callback(run_postponed)
+    lst.append(fn)
+
+
+def run_postponed(dev=None):
+    for d in ([dev] if dev is not None else list(_POSTPONED)):
+        lst = _POSTPONED.get(d)
+        while lst:
+            lst.pop(0)()
+
+
 def join_side(discard=False):
     """Make the stream the backward ran on wait for the deferred side-stream work, install the weight gradients, release
     the kept buffers.  Runs as an autograd-engine callback at the end of the backward pass.
     discard=True (the safety join at the start of a training forward): whatever is still pending belongs to a backward
     pass that was ABORTED (an exception before the engine's callbacks ran) - the streams are joined, but its gradients
     are dropped instead of being installed into the new step's `.grad`."""
+    if discard:
+        _POSTPONED.clear()
+    else:
+        run_postponed()             # (launches still waiting for "the next node": whoever joins needs them enqueued first)
     for dev, ent in list(_DEFERRED.items()):
         if ent[1] or ent[2]:
             ent[0].wait_stream(_side_stream(dev))

@@ -64,7 +64,13 @@ def _weight_amax(w, rows, cols):
     return pair.amax_of(w.detach())
 
 
-_IMAGES = {}      # id(weight) -> (version, data_ptr, Pair, event or None)
+_IMAGES = {}      # id(weight) -> (version, data_ptr, Pair, event or None, weakref to the weight: an id can be reused by another tensor)
+import weakref as _weakref
+
+
+def _store(w, img, ev):
+    key = id(w)
+    _IMAGES[key] = (w._version, w.data_ptr(), img, ev, _weakref.ref(w, lambda _r, key=key: _IMAGES.pop(key, None)))
 
 
 import os as _os
@@ -73,7 +79,7 @@ _STALE_FC = _os.environ.get("CIM_DEBUG_STALE_FC_IMAGES", "0") == "1"      # meas
 
 def _cached(w):
     e = _IMAGES.get(id(w))
-    if e is not None and ((e[0] == w._version and e[1] == w.data_ptr()) or (_STALE_FC and w.dim() == 2)):
+    if e is not None and e[4]() is w and ((e[0] == w._version and e[1] == w.data_ptr()) or (_STALE_FC and w.dim() == 2)):
         return e
     return None
 
@@ -104,7 +110,7 @@ def weight_image(w, conv=False):
         return e[2]
     with torch.no_grad():
         img = _conv_image(w.contiguous()) if conv else _fc_image(w.contiguous())
-    _IMAGES[id(w)] = (w._version, w.data_ptr(), img, None)
+    _store(w, img, None)
     return img
 
 
@@ -124,7 +130,7 @@ def prefetch_weight_images(wc, w1, w2):
             img = _conv_image(w) if conv else _fc_image(w)
             ev = torch.cuda.Event()
             ev.record(side)
-            _IMAGES[id(w)] = (w._version, w.data_ptr(), img, ev)
+            _store(w, img, ev)
 
 
 def _i32(dev):
@@ -267,16 +273,35 @@ class MaskFusePairFunction(Function):
             # biggest first: with several ranks a gradient's all-reduce starts right behind its product (publish), and fc1's 822 MB
             # is the one that needs the rest of the backward pass to hide under
             late.sort(key=lambda e: -e[1].numel())
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                # (several ranks: RCCL's all-reduce kernels hold CUs of their own while these products run - a launch of exactly one
-                # workgroup per CU would then need a second, nearly empty round each time: the products go out whole)
-                _lib.call("cim_gemm_pair_limit", DW_WGS if G.GRAD_PUBLISHER is None else 0)
-                try:
-                    got = {slot: publish(w, fn()) for slot, w, fn in late}
-                finally:
-                    _lib.call("cim_gemm_pair_limit", 0)
-            dwc, dw1, dw2 = got.get(0, dwc), got.get(1, dw1), got.get(2, dw2)
+
+            def launch(defer):
+                c2 = torch.cuda.current_stream(dev)
+                side.wait_stream(c2)
+                with torch.cuda.stream(side):
+                    # (several ranks: RCCL's all-reduce kernels hold CUs of their own while these products run - a launch of exactly
+                    # one workgroup per CU would then need a second, nearly empty round each time: the products go out whole)
+                    _lib.call("cim_gemm_pair_limit", DW_WGS if G.GRAD_PUBLISHER is None else 0)
+                    try:
+                        got = {slot: publish(w, fn()) for slot, w, fn in late}
+                    finally:
+                        _lib.call("cim_gemm_pair_limit", 0)
+                if defer:           # (postponed: this node has returned - the join bookkeeping of the block below happens here)
+                    keep = [t for t in (V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf,
+                                        dY1p.scale, dy_conv, am) if t is not None]
+                    for slot, w, _ in late:
+                        if got[slot] is not None:
+                            G.defer_side_join(dev, w, got[slot], *keep)
+                return got
+
+            # behind the ROIAlign backward (the next node: it gets the chip to itself) when every weight is a Parameter whose
+            # gradient is installed at the join anyway; else here
+            # (not with several ranks: the publisher hands the gradients to nn.DataParallel's bucket bookkeeping, which must see them
+            # inside the backward pass proper, not from an end-of-backward fallback)
+            if G.POSTPONE_DW and G.GRAD_PUBLISHER is None and all(isinstance(w, torch.nn.Parameter) for _, w, _ in late):
+                G.postpone(dev, lambda: launch(True))
+            else:
+                got = launch(False)
+                dwc, dw1, dw2 = got.get(0, dwc), got.get(1, dw1), got.get(2, dw2)
         if overlap:
             # operands the side stream's GEMMs read: the allocator must not hand their memory out before that work is done,
             # whichever way (join here, deferred join, DataParallel's all-reduce) the weight gradients leave this node

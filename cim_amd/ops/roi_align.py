@@ -14,6 +14,7 @@ from torch.autograd import Function
 from torch.nn.modules.utils import _pair
 
 from .. import _lib
+from . import gemm as _gemm
 
 
 # Forward kernel: the aggregated-weight form by default (each bin reads every pixel it touches once; a few ulp from
@@ -116,6 +117,7 @@ class RoIAlignMaskCatFunction(Function):
         _lib.call("cim_roi_align_maskcat_bwd_ws", grad_cat.data_ptr(), rois.data_ptr(), masks.data_ptr(),
                   grad_in.data_ptr(), B, C, H, W, K, P, scale, sr, aligned, ws.data_ptr(), int(ctx.tables is not None),
                   _lib.ptr(_scratch(K, B, C, H, W, grad_cat.device)), _lib.stream_ptr())
+        _gemm.run_postponed(grad_cat.device)        # MaskFuse's late weight gradients start behind this launch (ops/gemm.py)
         return grad_in, None, None, None, None, None, None
 
 
