@@ -364,7 +364,7 @@ def prefetch_filter_transform(w, p):
         _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), cout, cin, 0, tile, _lib.stream_ptr())
         ev = torch.cuda.Event()
         ev.record(side)
-    _U_PREFETCH[id(w)] = (tile, U, ev)
+    _U_PREFETCH[id(w)] = (tile, U, ev, weakref.ref(w), w._version)      # (validated at use: an id can be reused)
 
 
 class Conv3x3Function(Function):
@@ -419,7 +419,7 @@ class Conv3x3Function(Function):
                 if ENGINE == "f16x2":    # one pass over V: row scales for this product, column scales for the weight gradient
                     vr, ctx.v_cols = amax(V, mt, cin, cin, True, ctx.needs_input_grad[1], batch=npos, bs=mt * cin)
             pre = _U_PREFETCH.pop(id(w), None)
-            if pre is not None and pre[0] == tile and pre[1].shape == U.shape:
+            if pre is not None and pre[0] == tile and pre[1].shape == U.shape and pre[3]() is w and pre[4] == w._version:
                 U = pre[1]                                             # transformed ahead, on the side stream
                 torch.cuda.current_stream(dev).wait_event(pre[2])
                 U.record_stream(torch.cuda.current_stream(dev))
