@@ -168,3 +168,66 @@ def test_lr_schedule_and_momentum_correction_match_reference(golden_dir):
     assert out["lrs"][0, 1] == 2 * out["lrs"][0, 0]                     # BIAS_DOUBLE_LR
     for k in ("params", "history", "decay_history", "clip_small", "clip_large"):
         assert np.array_equal(out[k], g[k]), k
+
+
+def test_chained_bn_backward_protocol():
+    """cim_amd/ops/chain.py (host side of the BatchNorm backward folded into the next layer's data gradient): a producer is only
+    tagged when it is eligible (ReLU, no residual, frozen BatchNorm, a differentiable output); the consumer marks it as taken; the
+    producer recognises the handed-over gradient by its storage, exactly once, and refuses anything else once it was taken."""
+    import pytest
+    import torch
+    from cim_amd.ops import chain
+    chain.reset()
+    gamma, beta, mean, var = (torch.ones(4) for _ in range(4))
+    y = torch.zeros(2, 4, 3, 3, requires_grad=True)
+    assert chain.tag(y, gamma, beta, mean, var, 1e-5, relu=False, has_res=False) is None and not hasattr(y, "_cim_bn")
+    assert chain.tag(y, gamma, beta, mean, var, 1e-5, relu=True, has_res=True) is None
+    assert chain.tag(y, gamma.clone().requires_grad_(), beta, mean, var, 1e-5, True, False) is None         # trainable BatchNorm
+    assert chain.tag(torch.zeros(3), gamma, beta, mean, var, 1e-5, True, False) is None                      # nothing to differentiate
+    state = chain.tag(y, gamma, beta, mean, var, 1e-5, relu=True, has_res=False)
+    assert state == {"taken": False} and y._cim_bn[3] is state
+    assert chain.input_bn(y, enabled=False) is None and not state["taken"]
+    assert chain.input_bn(torch.zeros(3), enabled=True) is None                                             # untagged input
+    g, v, eps = chain.input_bn(y, enabled=True)
+    assert g is gamma and v is var and eps == 1e-5 and state["taken"]
+    dx, other = torch.zeros(2, 4, 3, 3), torch.zeros(2, 4, 3, 3)
+    chain.hand_over(dx)
+    assert chain.take(dx.view(2, 4, 9), state)                   # the same storage, whatever the wrapper
+    with pytest.raises(RuntimeError, match="second consumer"):   # consumed: a second take of it is "a different gradient"
+        chain.take(dx, state)
+    with pytest.raises(RuntimeError, match="second consumer"):
+        chain.take(other, state)
+    assert not chain.take(other, {"taken": False}) and not chain.take(other, None)     # a layer nobody chained to: the ordinary path
+    chain.hand_over(dx)
+    chain.reset()
+    assert not chain.take(dx, None)
+
+
+def test_postponed_launches_run_once_in_order_and_are_dropped_by_a_discarding_join():
+    """ops.gemm.postpone / run_postponed (MaskFuse's late weight gradients wait for the next node): closures run once, in order,
+    at run_postponed() or at any join; a discarding join (start of a training forward after an aborted backward) drops them."""
+    from cim_amd.ops import gemm as G
+    from cim_amd.utils import engine
+    calls, queued = [], []
+    orig = engine.queue_callback
+    engine.queue_callback = queued.append                       # (no backward pass is running here)
+    try:
+        G._POSTPONED.clear()
+        G.postpone("dev0", lambda: calls.append(1))
+        G.postpone("dev0", lambda: calls.append(2))
+        assert queued == [G.run_postponed]                      # one end-of-backward fallback per batch of closures
+        G.run_postponed("dev1")
+        assert calls == []
+        G.run_postponed("dev0")
+        G.run_postponed()
+        assert calls == [1, 2]
+        G.postpone("dev0", lambda: calls.append(3))
+        G.join_side()
+        assert calls == [1, 2, 3]
+        G.postpone("dev0", lambda: calls.append(4))
+        G.join_side(discard=True)
+        G.run_postponed()
+        assert calls == [1, 2, 3]
+    finally:
+        engine.queue_callback = orig
+        G._POSTPONED.clear()
