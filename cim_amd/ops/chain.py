@@ -4,8 +4,10 @@ When layer P produces x = relu(bn_P(conv_P(.))) (no residual, BatchNorm paramete
 the data-gradient product of Q can apply P's BatchNorm + ReLU backward in its epilogue (csrc/conv1x1.hip: SmallArgs.mask):
     dconv_P = (x > 0 ? dx : 0) * gamma_P rsqrt(var_P + eps_P)
 so P's backward starts from the gradient of its convolution output and skips its `bn_act_bwd` launch
-(torchvision Bottleneck conv1 -> conv2 -> conv3 of /root/reference/lib/modeling/resnet50.py:17-44: 20 of the 32 BatchNorm-backward
-launches of a cfg2 step).
+(torchvision Bottleneck conv1 -> conv2 -> conv3 of /root/reference/lib/modeling/resnet50.py:17-44).  Eligibility needs the
+BatchNorm's affine parameters FROZEN: with trainable gamma / beta their gradients are per-channel sums the `bn_act_bwd` launch
+computes.  The reference freezes the statistics only (resnet50.py:60: the freeze of the affine layers is commented out), so at
+its configurations nothing is chained; a model whose BatchNorm layers are fully frozen saves 2 of 3 such launches per block.
 
 Protocol (all on the host, per backward pass):
   * P's wrapper tags its output: y._cim_bn = (gamma, var, eps, state) when P is eligible;
