@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--sustained", type=float, default=5.0, help="seconds of the extra sustained loop (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra loops (sustained, iter_size=4, upload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", type=int, default=0, help="extra: N more steps with HIP events at the phase boundaries of the "
+                    "step (main stream, no profiler attached) -> extra.phases")
     ap.add_argument("--cpu-sample", type=int, default=0, help="proposals in the CPU sample (0 = all)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
                                                        "multi-rank check on a box with fewer GPUs than ranks)")
@@ -268,6 +270,8 @@ def run(args):
                                  overlap_frac=(1.0 - exposed / ar_ms) if ar_ms else None, gradient_bytes=grad_bytes,
                                  ring_bound_ms=1e3 * 2.0 * (world - 1) / world * grad_bytes / 153e9,
                                  buckets=len(dp.buckets))
+    if args.phases > 0:
+        extra["phases"] = phase_times(torch, model, opt, step, args.phases, args.iter_size)
     heads.settle_rng()
     # the measured run must have been a VALID training run to the end: every parameter finite (a finite last loss alone does not
     # show a weight gradient that went NaN a few steps ago - and NaN operands run the MFMAs faster)
@@ -299,6 +303,43 @@ def run(args):
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def phase_times(torch, model, opt, step, n, iter_size):
+    """Average ms per phase over n steps, from HIP events recorded on the step's stream at the phase boundaries (module hooks;
+    the gradient hook of the body's output marks the start of the body's backward).  Unlike a rocprofv3 trace this does not slow
+    the host down, so launch-dense phases (the body: ~90 + ~200 launches) show their real wall time."""
+    ev = {}
+    mark = lambda k: ev.setdefault(k, []).append(_rec(torch))
+    hooks = [model.Conv_Body.register_forward_pre_hook(lambda m, i: mark("body0")),
+             model.Conv_Body.register_forward_hook(lambda m, i, o: (mark("body1"), o.register_hook(lambda g: mark("bwd_body0")) if o.requires_grad else None) and None),
+             model.Box_Head.register_forward_hook(lambda m, i, o: mark("maskfuse1")),
+             model.register_forward_hook(lambda m, i, o: mark("fwd1")),
+             opt.register_step_pre_hook(lambda o, a, k: mark("opt0"))]
+    try:
+        for _ in range(n):
+            mark("start")
+            step(iter_size)
+            mark("end")
+    finally:
+        for h in hooks:
+            h.remove()
+    torch.cuda.synchronize()
+    names = [("zero_grad .. body", "start", "body0"), ("body forward", "body0", "body1"), ("ROIAlign + MaskFuse forward", "body1", "maskfuse1"),
+             ("heads + mining + losses", "maskfuse1", "fwd1"), ("backward: losses .. ROIAlign", "fwd1", "bwd_body0"),
+             ("backward: body (+ late weight gradients, join)", "bwd_body0", "opt0"), ("optimizer", "opt0", "end")]
+    out = {}
+    for label, a, b in names:
+        if len(ev.get(a, [])) == len(ev.get(b, [])) == n * (iter_size if a not in ("start", "opt0") and b not in ("end", "opt0") else 1):
+            out[label] = float(sum(x.elapsed_time(y) for x, y in zip(ev[a], ev[b])) / len(ev[a]))
+    out["step"] = float(sum(x.elapsed_time(y) for x, y in zip(ev["start"], ev["end"])) / n)
+    return out
+
+
+def _rec(torch):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
 
 
 class KernelTimer:

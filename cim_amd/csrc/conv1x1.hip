@@ -52,29 +52,59 @@ struct SmallArgs {
     // result - C(row, col) = mask(row, col) > 0 ? C * mgamma[row] rsqrt(mvar[row] + meps) : 0 with mask = that layer's output
     // (this layer's input, same layout as C): the producer's own backward then starts from the gradient of its convolution
     const float* mask; const float* mgamma; const float* mvar; float meps;
+    // ... and, when that layer's gamma / beta TRAIN (the reference's configuration, lib/modeling/resnet50.py:59-60), the per-channel
+    // sums its BatchNorm backward would have made, as partial sums over the 32-column group `col / 32` of every row:
+    //   mpart[0][col / 32][row] = sum dz,   mpart[1][col / 32][row] = sum dz (xraw - mean)     (dz = mask > 0 ? C : 0)
+    // with mxr = that layer's convolution output (layout of C) and mmean its running mean; bn_part_finish_kernel sums the
+    // groups in index order (deterministic) and scales the second by rsqrt(var + eps).  mparts = ceil(N / 32).
+    const float* mxr; const float* mmean; float* mpart; int mparts;
 };
-struct InputBn { const float* y; const float* gamma; const float* var; float eps; };       // (the four fields above as arguments)
+struct InputBn { const float* y; const float* gamma; const float* var; float eps;           // (the fields above as arguments)
+                 const float* xr; const float* mean; float* part; };
 
 // Tile loaders.  An operand tile is ROWS x 32 (k) floats per slab, moved as 16-byte pieces: piece index p ->
 //   K-contiguous operand (element (r, k) at P[r*ld + k]):  r = p % ROWS, k = (p / ROWS) * 4   (lanes along the rows: the
 //     transposing LDS stores are conflict-free; with lanes along k they were 4-way conflicted)
 //   row-contiguous operand (element (r, k) at P[k*ld + r]): k = p / (ROWS/4), r = (p % (ROWS/4)) * 4
 // LDS slabs are k-major ([k][row], stride SLD): row-contiguous pieces are one ds_write_b128, K-contiguous ones transpose.
+// Round 4: the loads are BRANCH-FREE buffer loads.  The first loaders guarded every piece (row / k range, 16-byte or three
+// scalar tail loads): hipcc gave each guarded load its own basic block - ~30 branches and four waits per slab in front of 16
+// MFMAs (found in the ISA: 351 s_cbranch in the kernel).  A raw buffer resource over the operand's exact extent makes the
+// hardware return 0 for everything behind it - the k >= K rows of a row-contiguous operand, rows >= `rows` of a K-contiguous
+// one - the K tail INSIDE a K-contiguous row (the next row's data) is zeroed by four selects, and what a row-contiguous piece
+// reads past `rows` (the next k-row's first elements) only reaches output rows / columns that are never stored.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p, long long floats) {       // (p, floats: wave-uniform kernel arguments)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(unsigned)(floats * 4), 0x00020000);
+}
+__device__ __forceinline__ float4 bld4(rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float bld1(rsrc_t r, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+constexpr unsigned OOB = 0x7fffffffu;          // a byte offset behind every operand (extents are < 2^31 bytes: checked by the launchers)
+// extent of an operand in floats: rows x K elements, leading dimension ld
+__host__ __device__ __forceinline__ long long tile_extent(bool RC, int rows, int K, int ld) {
+    return RC ? (long long)(K - 1) * ld + rows : (long long)(rows - 1) * ld + K;
+}
+// byte offset of piece p of the slab at k0 (tile rows from r0)
 template <bool RC, int ROWS>
-__device__ __forceinline__ float4 tile_load(const float* __restrict__ P, int ld, int rows, int kend, int r0, int k0, int p) {
+__device__ __forceinline__ unsigned tile_off(int ld, int r0, int k0, int p) {
     int r, k;
-    if (RC) { k = k0 + p / (ROWS / 4); r = r0 + (p % (ROWS / 4)) * 4; } else { r = r0 + p % ROWS; k = k0 + (p / ROWS) * 4; }
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (RC) {
-        if (k < kend) {
-            const float* q = P + (size_t)k * ld + r;
-            if (r + 3 < rows) v = ld4(q);
-            else { if (r < rows) v.x = q[0]; if (r + 1 < rows) v.y = q[1]; if (r + 2 < rows) v.z = q[2]; }
-        }
-    } else if (r < rows) {
-        const float* q = P + (size_t)r * ld + k;
-        if (k + 3 < kend) v = ld4(q);
-        else { if (k < kend) v.x = q[0]; if (k + 1 < kend) v.y = q[1]; if (k + 2 < kend) v.z = q[2]; }
+    if (RC) { k = k0 + p / (ROWS / 4); r = r0 + (p % (ROWS / 4)) * 4; return ((unsigned)k * ld + r) * 4u; }
+    r = r0 + p % ROWS; k = k0 + (p / ROWS) * 4;
+    return ((unsigned)r * ld + k) * 4u;
+}
+// (the K tail of a K-contiguous piece is zeroed when the piece is STORED to LDS: a select right behind the load would make the
+// wave wait for the load it has just issued)
+template <bool RC, int ROWS>
+__device__ __forceinline__ float4 tile_ktail(float4 v, int K, int k0, int p) {
+    if (!RC) {
+        const int left = K - (k0 + (p / ROWS) * 4);
+        v.x = left > 0 ? v.x : 0.0f; v.y = left > 1 ? v.y : 0.0f; v.z = left > 2 ? v.z : 0.0f; v.w = left > 3 ? v.w : 0.0f;
     }
     return v;
 }
@@ -104,7 +134,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, float4 v, int 
 #define CIM_SMALL_FUSED_REDUCE 0
 #endif
 // Epilogue of one output value (shared by the single-pass kernels, the in-kernel split-K combine and the reduce kernel)
-__device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int col, float v) {
+__device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int col, float v, float& s1, float& s2) {
     const size_t o = (size_t)row * g.ldc + col;
     if (g.Xraw) g.Xraw[o] = v;
     float y = v;
@@ -115,10 +145,29 @@ __device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int co
     if (g.res) y += g.res[o];
     if (g.colbias) y += g.colbias[col];
     if (g.relu) y = fmaxf(y, 0.0f);
-    if (g.mask) y = g.mask[o] > 0.0f ? y * (g.mgamma[row] * rsqrtf(g.mvar[row] + g.meps)) : 0.0f;
+    if (g.mask) {
+        const bool on = g.mask[o] > 0.0f;
+        if (g.mpart && on) { s1 += y; s2 = fmaf(y, g.mxr[o] - g.mmean[row], s2); }
+        y = on ? y * (g.mgamma[row] * rsqrtf(g.mvar[row] + g.meps)) : 0.0f;
+    }
     g.C[o] = y;
 }
-
+__device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int col, float v) {
+    float s1 = 0.0f, s2 = 0.0f;
+    small_finish(g, row, col, v, s1, s2);
+}
+// the two sums of a row over the 32 lanes of a half-wave (lanes = consecutive columns) -> mpart, written by the group's first lane
+__device__ __forceinline__ void small_put_part(const SmallArgs& g, int row, int group, int lane, float s1, float s2) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if ((lane & 31) == 0 && row < g.M && group < g.mparts) {
+        g.mpart[(size_t)group * g.M + row] = s1;
+        g.mpart[((size_t)g.mparts + group) * g.M + row] = s2;
+    }
+}
 // Split-K inside the launch: every split stores its partial tile to the workspace and takes a ticket on the tile's counter;
 // the LAST arrival sums the tile's partials in split order (the order the reduce kernel used: same bits) and applies the
 // epilogue.  Publication follows the chip's rules (the 8 XCDs' L2s are not coherent): plain stores, every wave drains
@@ -176,6 +225,39 @@ __device__ __forceinline__ void small_splitk_combine(const SmallArgs& g, int til
     }
 }
 
+// Epilogue of a wave's 32 x 32 accumulator tile: lane holds rows 8*(r/4) + 4*(lane/32) + r%4, column lane%32
+__device__ __forceinline__ void small_epilogue(const SmallArgs& g, const f32x16& acc, int row0, int col0, int lane, int split) {
+    const int col = col0 + (lane & 31);
+    if (g.splits > 1) {
+        if (col < g.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (row < g.M) small_put_partial(g.ws + ((size_t)split * g.M + row) * g.N + col, acc[r]);
+            }
+        }
+        return;
+    }
+    if (g.mpart == nullptr) {
+        if (col < g.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (row < g.M) small_finish(g, row, col, acc[r]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {          // (every lane takes part in the row sums)
+        const int row = row0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        float s1 = 0.0f, s2 = 0.0f;
+        if (col < g.N && row < g.M) small_finish(g, row, col, acc[r], s1, s2);
+        small_put_part(g, row, col0 >> 5, lane, s1, s2);
+    }
+}
+
+
 // WN = waves along N: 2 -> 64 x 64 tile, 256 threads; 1 -> 64 x 32 tile, 128 threads (twice the workgroups for the
 // smallest problems).  Tried and measured slower (tools/bench_gemm_small.py, 7 layer shapes, us forward / dX / dW:
 // 158 / 137 / 183 with this kernel): 128- and 256-row tiles (4 waves of 1 x 2 / 2 x 2 MFMA tiles, 134-170 VGPRs) to re-read
@@ -201,36 +283,59 @@ __global__ __launch_bounds__(128 * WN) void gemm_small_kernel(const SmallArgs g)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
-    float4 ra0[PA], rb0[PB];
-#define SM_GLOAD(RA, RB, K0)                                                                                       \
+    // Two register sets of pieces: the loads of slabs s + 1 and s + 2 are in flight while slab s is multiplied (one global
+    // round trip is ~2 MFMA blocks of 16 x 64 cycles), LDS double buffered, ONE barrier per slab.  The LDS operands of a slab
+    // are read in one batch in front of its 16 MFMAs (the first version read two values, waited, multiplied: eight exposed LDS
+    // latencies per slab).
+    const rsrc_t RA_ = make_rsrc(g.A, tile_extent(AM, g.M, g.K, g.lda)), RB_ = make_rsrc(g.B, tile_extent(!BKc, g.N, g.K, g.ldb));
+    unsigned oa[PA], ob[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) oa[i] = tile_off<AM, SBM>(g.lda, m0, kbeg, tid + i * NT);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) ob[i] = tile_off<!BKc, BNT>(g.ldb, n0, kbeg, tid + i * NT);
+    const unsigned sa = (AM ? (unsigned)g.lda * SBK : (unsigned)SBK) * 4u, sb = (!BKc ? (unsigned)g.ldb * SBK : (unsigned)SBK) * 4u;
+    float4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+#define SM_GLOAD(RA, RB, S)                                                                                        \
     {                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < PA; ++i) RA[i] = tile_load<AM, SBM>(g.A, g.lda, g.M, kend, m0, K0, tid + i * NT);   \
-        _Pragma("unroll") for (int i = 0; i < PB; ++i) RB[i] = tile_load<!BKc, BNT>(g.B, g.ldb, g.N, kend, n0, K0, tid + i * NT); \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i) RA[i] = bld4(RA_, oa[i] + (unsigned)(S) * sa);               \
+        _Pragma("unroll") for (int i = 0; i < PB; ++i) RB[i] = bld4(RB_, ob[i] + (unsigned)(S) * sb);               \
     }
-#define SM_PUT(RA, RB, BUF)                                                                                        \
+#define SM_PUT(RA, RB, BUF, S)                                                                                     \
     {                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < PA; ++i) tile_store<AM, SBM>(As[BUF], RA[i], tid + i * NT);           \
-        _Pragma("unroll") for (int i = 0; i < PB; ++i) tile_store<!BKc, BNT>(Bs[BUF], RB[i], tid + i * NT);         \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                             \
+            tile_store<AM, SBM>(As[BUF], tile_ktail<AM, SBM>(RA[i], g.K, kbeg + (S) * SBK, tid + i * NT), tid + i * NT);     \
+        _Pragma("unroll") for (int i = 0; i < PB; ++i)                                                             \
+            tile_store<!BKc, BNT>(Bs[BUF], tile_ktail<!BKc, BNT>(RB[i], g.K, kbeg + (S) * SBK, tid + i * NT), tid + i * NT); \
     }
 #define SM_MMA(BUF)                                                                                                \
     {                                                                                                              \
         const float* __restrict__ a = As[BUF] + (lane >> 5) * SLD + wm * 32 + (lane & 31);                         \
         const float* __restrict__ b = Bs[BUF] + (lane >> 5) * SLD + wn * 32 + (lane & 31);                         \
-        _Pragma("unroll") for (int kk = 0; kk < SBK; kk += 2)                                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk * SLD], b[kk * SLD], acc, 0, 0, 0);                    \
+        float av[SBK / 2], bv[SBK / 2];                                                                            \
+        _Pragma("unroll") for (int t = 0; t < SBK / 2; ++t) { av[t] = a[2 * t * SLD]; bv[t] = b[2 * t * SLD]; }    \
+        _Pragma("unroll") for (int t = 0; t < SBK / 2; ++t)                                                        \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);                                \
+        asm volatile("" : "+a"(acc));      /* (the accumulator stays in AGPRs over the loop: hipcc moved it out and back per slab) */ \
     }
     if (kbeg < kend) {
-        // the next slab's global loads are in flight while the current one is multiplied.  (Two slabs ahead in a second
-        // register set measured slower: 100+ VGPRs; so did 64 x 32 tiles for everything below 1024 workgroups.)
         const int nslab = (kend - kbeg + SBK - 1) / SBK;
-        SM_GLOAD(ra0, rb0, kbeg)
-        SM_PUT(ra0, rb0, 0)
+        // (the loads are issued unconditionally - behind the last slab they fetch it again: behind a uniform branch hipcc's wait
+        // counts assume the path WITHOUT the new loads and wait for them as if they were the old ones)
+        const int last = nslab - 1;
+        SM_GLOAD(ra0, rb0, 0)
+        SM_GLOAD(ra1, rb1, min(1, last))
+        SM_PUT(ra0, rb0, 0, 0)
+        asm volatile("" : "+a"(acc));
         __syncthreads();
-        for (int s = 0; s < nslab; ++s) {
-            const int more = s + 1 < nslab;
-            if (more) SM_GLOAD(ra0, rb0, kbeg + (s + 1) * SBK)
-            if (s & 1) { SM_MMA(1) } else { SM_MMA(0) }
-            if (more) { if (s & 1) { SM_PUT(ra0, rb0, 0) } else { SM_PUT(ra0, rb0, 1) } }
+        for (int s = 0; s < nslab; s += 2) {
+            SM_GLOAD(ra0, rb0, min(s + 2, last))
+            SM_MMA(0)
+            if (s + 1 < nslab) SM_PUT(ra1, rb1, 1, s + 1)
+            __syncthreads();
+            if (s + 1 >= nslab) break;
+            SM_GLOAD(ra1, rb1, min(s + 3, last))
+            SM_MMA(1)
+            if (s + 2 < nslab) SM_PUT(ra0, rb0, 0, s + 2)
             __syncthreads();
         }
     }
@@ -238,29 +343,85 @@ __global__ __launch_bounds__(128 * WN) void gemm_small_kernel(const SmallArgs g)
 #undef SM_PUT
 #undef SM_MMA
 
-    // ---- epilogue: lane holds rows 8*(r/4) + 4*(lane/32) + r%4, column lane%32 of its wave's 32 x 32 tile
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < g.N) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            if (row >= g.M) continue;
-            if (g.splits > 1) small_put_partial(g.ws + ((size_t)split * g.M + row) * g.N + col, acc[r]);
-            else small_finish(g, row, col, acc[r]);
-        }
-    }
+    small_epilogue(g, acc, m0 + wm * 32, n0 + wn * 32, lane, split);
     if (g.splits > 1 && g.tile_cnt != nullptr)
         small_splitk_combine<BNT>(g, tile, m0, n0, tid, NT, reinterpret_cast<volatile int*>(&As[0][0]));
 }
 
-// split-K: sum of the partial products in a fixed order (deterministic) + the same epilogue as the single-pass kernel
+// split-K: sum of the partial products in a fixed order (deterministic) + the same epilogue as the single-pass kernel.
+// The partials of an element are loaded eight at a time (independent loads in flight) and added in split order: with a
+// load-add-load-add loop a thread paid one memory round trip per split (8-64 of them), and the ~90 reduce launches per step
+// were bound by exactly that chain.
+__device__ __forceinline__ float splitk_sum(const float* __restrict__ ws, size_t i, size_t mn, int splits) {
+    float v = ws[i];
+    for (int k0 = 1; k0 < splits; k0 += 8) {
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = k0 + j < splits ? ws[(size_t)(k0 + j) * mn + i] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < splits) v += p[j];
+    }
+    return v;
+}
 __global__ __launch_bounds__(256) void small_splitk_reduce_kernel(const SmallArgs g) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t mn = (size_t)g.M * g.N;
     if (i >= mn) return;
-    float v = g.ws[i];
-    for (int k = 1; k < g.splits; ++k) v += g.ws[(size_t)k * mn + i];
-    small_finish(g, (int)(i / g.N), (int)(i % g.N), v);
+    small_finish(g, (int)(i / g.N), (int)(i % g.N), splitk_sum(g.ws, i, mn, g.splits));
+}
+
+// the same with the producer's affine-gradient partial sums (SmallArgs.mpart): a block owns 256 consecutive columns of ONE row,
+// so that every half-wave is one 32-column group of that row.  grid (ceil(N / 256), M)
+__global__ __launch_bounds__(256) void small_splitk_reduce_rows_kernel(const SmallArgs g) {
+    const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    const size_t mn = (size_t)g.M * g.N;
+    float s1 = 0.0f, s2 = 0.0f;
+    if (col < g.N) {
+        const size_t i = (size_t)row * g.N + col;
+        small_finish(g, row, col, splitk_sum(g.ws, i, mn, g.splits), s1, s2);
+    }
+    small_put_part(g, row, col >> 5, threadIdx.x & 63, s1, s2);
+}
+
+// Finishing the affine gradients of up to 24 chained layers in ONE launch (at the end of the backward pass):
+// dbeta[c] = sum over images and column groups of part[b][0][p][c]; dgamma[c] = rsqrt(var[c] + eps) * sum part[b][1][p][c], in
+// index order.  A block owns 32 channels of one layer: 8 thread groups take every 8th (image, group) pair - four loads in
+// flight each -, then one fixed-order sum in LDS.
+struct BnPartTable { cim_bn_part_desc d[24]; int first[25]; int n; };
+__global__ __launch_bounds__(256) void bn_part_finish_kernel(const BnPartTable t) {
+    __shared__ float sh[2][8][32];
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.first[e + 1]) ++e;
+    const cim_bn_part_desc& d = t.d[e];
+    const int C = d.channels, parts = d.parts, total = d.images * d.parts;
+    const int c = ((int)blockIdx.x - t.first[e]) * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    float t1 = 0.0f, t2 = 0.0f;
+    if (c < C) {
+        for (int i0 = grp; i0 < total; i0 += 32) {
+            float a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + 8 * j;
+                const int img = i / parts, p = i - img * parts;
+                const float* q = d.part + ((size_t)img * 2 * parts + p) * C + c;
+                a[j] = i < total ? q[0] : 0.0f;
+                b[j] = i < total ? q[(size_t)parts * C] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1 += a[j]; t2 += b[j]; }
+        }
+    }
+    sh[0][grp][threadIdx.x & 31] = t1;
+    sh[1][grp][threadIdx.x & 31] = t2;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        float a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a1 += sh[0][k][threadIdx.x]; a2 += sh[1][k][threadIdx.x]; }
+        if (d.dbeta) d.dbeta[c] = a1;
+        if (d.dgamma) d.dgamma[c] = a2 * rsqrtf(d.var[c] + d.eps);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -275,22 +436,6 @@ __global__ __launch_bounds__(256) void small_splitk_reduce_kernel(const SmallArg
 // loads, 8 per thread and slab, issued together; interior float4 pieces of stride-1 convolutions take one 16-byte load.
 enum { CONV_FWD = 0, CONV_DX = 1, CONV_DW = 2 };
 struct ConvGeom { int H, W, Ho, Wo, stride, cin, cout; float inv_w; int dil; };      // dil: dilation (padding = dil * (k / 2): "same")
-
-// element (k, n) of the implicit B operand; `src` = X (forward, weight gradient) or dY (data gradient)
-template <int MODE, int KS>
-__device__ __forceinline__ bool conv_src(const ConvGeom& c, int ch, int tap, int y, int x, int& off) {
-    const int dy = (tap / KS - KS / 2) * c.dil, dx = (tap - (tap / KS) * KS - KS / 2) * c.dil;      // padding dil * (KS / 2)
-    if (MODE == CONV_DX) {                 // (y, x) = input pixel; the output pixel that reads it through this tap
-        const int ty = y - dy, tx = x - dx;
-        if (c.stride == 2 && ((ty | tx) & 1)) return false;
-        const int yo = c.stride == 2 ? ty >> 1 : ty, xo = c.stride == 2 ? tx >> 1 : tx;
-        off = (ch * c.Ho + yo) * c.Wo + xo;
-        return ty >= 0 && tx >= 0 && yo < c.Ho && xo < c.Wo;
-    }
-    const int yi = y * c.stride + dy, xi = x * c.stride + dx;   // (y, x) = output pixel
-    off = (ch * c.H + yi) * c.W + xi;
-    return (unsigned)yi < (unsigned)c.H && (unsigned)xi < (unsigned)c.W;
-}
 
 #ifndef CIM_CONV3_BK
 #define CIM_CONV3_BK 32            // slab depth of the 3 x 3 kernel (K = 9 C is long: 64 halves the barriers and load round trips per k)
@@ -310,135 +455,130 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
     const int split = blockIdx.y;
     const int kper = ((g.K + g.splits - 1) / g.splits + CBK - 1) / CBK * CBK;
     const int kbeg = split * kper, kend = min(g.K, kbeg + kper);
-    const int wsrc = (MODE == CONV_DX) ? c.Wo : c.W;                     // row length of the gathered tensor
-    (void)wsrc;
 
-    // ---- per-thread constants of the B pieces
+    // ---- B pieces.  Round 4: every gathered element is ONE branch-free 4-byte buffer load - an element that falls into the
+    // zero padding (or behind N / K) takes an offset behind the tensor and the hardware returns 0.  (The first loaders chose
+    // per piece between a 16-byte load and four guarded scalar loads: ~400 branches in the kernel, every load in its own basic
+    // block with its own wait; the 3 x 3 kernels ran at a fifth of their MFMA time.)
     // forward / data gradient: B is row-contiguous in n (pixels): piece p -> k = k0 + p / 16, n = n0 + (p % 16) * 4: the
     // four pixels are fixed for the whole K loop, (channel, tap) changes per slab.
     // weight gradient: B is K-contiguous: piece p -> n = n0 + p % 64 (a (channel, tap) pair, fixed), k = k0 + (p / 64) * 4 pixels.
-    int py[PB][4], px[PB][4];            // forward / dX: pixel coordinates of the piece's 4 columns (-1: column >= N)
-    int bch[PB], btap[PB];               // dW: (channel, tap) of the piece's row (-1: row >= N)
+    const rsrc_t RA_ = make_rsrc(g.A, tile_extent(MODE == CONV_DX, g.M, g.K, g.lda));
+    const rsrc_t RB_ = make_rsrc(g.B, (long long)(MODE == CONV_DX ? c.cout * c.Ho * c.Wo : c.cin * c.H * c.W));
+    const int hw_src = MODE == CONV_DX ? c.Ho * c.Wo : c.H * c.W;         // channel stride of the gathered tensor
+    int py[PB][4], px[PB][4];            // forward / dX: pixel coordinates of the piece's 4 columns (y = -2^20: column >= N)
+    int boff[PB], bdy[PB], bdx[PB];      // dW: channel offset and tap displacement of the piece's row (boff < 0: row >= N)
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int p = tid + i * NT;
         if (MODE == CONV_DW) {
             const int n = n0 + p % SBN;
-            bch[i] = n < g.N ? n / TAPS : -1;
-            btap[i] = n - (n / TAPS) * TAPS;
+            const int ch = n / TAPS, tap = n - ch * TAPS;
+            boff[i] = n < g.N ? ch * hw_src : -1;
+            bdy[i] = (tap / KS - KS / 2) * c.dil;
+            bdx[i] = (tap - (tap / KS) * KS - KS / 2) * c.dil;
         } else {
             const int wrow = (MODE == CONV_DX) ? c.W : c.Wo;             // n runs over input pixels (dX) / output pixels (forward)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + (p % 16) * 4 + j;
                 const int y = (int)(((float)n + 0.5f) * c.inv_w);       // n / wrow (exact: see the launcher)
-                py[i][j] = n < g.N ? y : -1;
+                py[i][j] = n < g.N ? y : -(1 << 20);
                 px[i][j] = n - y * wrow;
             }
         }
     }
+    unsigned oa[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) oa[i] = tile_off<MODE == CONV_DX, SBM>(g.lda, m0, kbeg, tid + i * NT);
+    const unsigned sa = (MODE == CONV_DX ? (unsigned)g.lda * CBK : (unsigned)CBK) * 4u;
 
     auto load_b = [&](int k0, float4 (&rb)[PB]) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             const int p = tid + i * NT;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            unsigned off[4];
             if (MODE == CONV_DW) {
                 const int k = k0 + (p / SBN) * 4;                        // 4 consecutive output pixels
-                if (bch[i] >= 0) {
-                    int off[4];
-                    bool ok[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int po = k + j;
-                        const int yo = (int)(((float)po + 0.5f) * c.inv_w), xo = po - yo * c.Wo;
-                        ok[j] = po < kend && conv_src<MODE, KS>(c, bch[i], btap[i], yo, xo, off[j]);
-                    }
-                    if (c.stride == 1 && ok[0] && ok[1] && ok[2] && ok[3] && off[3] == off[0] + 3) {     // all inside: 16-byte load
-                        const float4 t = ld4(g.B + off[0]);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (ok[j]) v[j] = g.B[off[j]];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const int po = k + j;
+                    const int yo = (int)(((float)po + 0.5f) * c.inv_w), xo = po - yo * c.Wo;
+                    const int yi = yo * c.stride + bdy[i], xi = xo * c.stride + bdx[i];
+                    const bool ok = boff[i] >= 0 && po < g.K && (unsigned)yi < (unsigned)c.H && (unsigned)xi < (unsigned)c.W;
+                    off[j] = ok ? (unsigned)(boff[i] + yi * c.W + xi) * 4u : OOB;
                 }
             } else {
-                const int k = k0 + p / 16;
-                if (k < kend) {
-                    const int ch = k / TAPS, tap = k - ch * TAPS;
-                    int off[4];
-                    bool ok[4];
+                const int k = k0 + p / 16;                               // (k >= K: channel >= the tensor's -> behind its extent)
+                const int ch = k / TAPS, tap = k - ch * TAPS;
+                const int dy = (tap / KS - KS / 2) * c.dil, dx = (tap - (tap / KS) * KS - KS / 2) * c.dil;
+                const int base = ch * hw_src;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ok[j] = py[i][j] >= 0 && conv_src<MODE, KS>(c, ch, tap, py[i][j], px[i][j], off[j]);
-                    if (c.stride == 1 && ok[0] && ok[1] && ok[2] && ok[3] && off[3] == off[0] + 3) {     // all inside: 16-byte load
-                        const float4 t = ld4(g.B + off[0]);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                for (int j = 0; j < 4; ++j) {
+                    if (MODE == CONV_DX) {         // (y, x) = input pixel; the output pixel that reads it through this tap
+                        const int ty = py[i][j] - dy, tx = px[i][j] - dx;
+                        const int yo = c.stride == 2 ? ty >> 1 : ty, xo = c.stride == 2 ? tx >> 1 : tx;
+                        const bool ok = ty >= 0 && tx >= 0 && yo < c.Ho && xo < c.Wo && !(c.stride == 2 && ((ty | tx) & 1));
+                        off[j] = ok ? (unsigned)(base + yo * c.Wo + xo) * 4u : OOB;
                     } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (ok[j]) v[j] = g.B[off[j]];
+                        const int yi = py[i][j] * c.stride + dy, xi = px[i][j] * c.stride + dx;
+                        const bool ok = (unsigned)yi < (unsigned)c.H && (unsigned)xi < (unsigned)c.W;
+                        off[j] = ok ? (unsigned)(base + yi * c.W + xi) * 4u : OOB;
                     }
                 }
             }
-            rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+            rb[i] = make_float4(bld1(RB_, off[0]), bld1(RB_, off[1]), bld1(RB_, off[2]), bld1(RB_, off[3]));
         }
     };
-    auto load_a = [&](int k0, float4 (&ra)[PA]) {
+    auto load_a = [&](int s, float4 (&ra)[PA]) {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int p = tid + i * NT;
-            if (MODE == CONV_DX) {       // A = the weight transposed to [(co, tap)][ci] by conv3x3_wt_kernel: M-contiguous rows
-                ra[i] = tile_load<true, SBM>(g.A, g.lda, g.M, kend, m0, k0, p);
-            } else {
-                ra[i] = tile_load<false, SBM>(g.A, g.lda, g.M, kend, m0, k0, p);
-            }
-        }
+        for (int i = 0; i < PA; ++i)     // dX: A = the weight transposed to [(co, tap)][ci] (M-contiguous rows); else K-contiguous
+            ra[i] = bld4(RA_, oa[i] + (unsigned)s * sa);
     };
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    float4 ra0[PA], rb0[PB];
-#define C3_PUT(BUF)                                                                                                 \
+    float4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+#define C3_PUT(RA, RB, BUF, S)                                                                                      \
     {                                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < PA; ++i) tile_store<MODE == CONV_DX, SBM>(As[BUF], ra0[i], tid + i * NT); \
-        _Pragma("unroll") for (int i = 0; i < PB; ++i) tile_store<MODE != CONV_DW, SBN>(Bs[BUF], rb0[i], tid + i * NT); \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                              \
+            tile_store<MODE == CONV_DX, SBM>(As[BUF], tile_ktail<MODE == CONV_DX, SBM>(RA[i], g.K, kbeg + (S) * CBK, tid + i * NT), tid + i * NT); \
+        _Pragma("unroll") for (int i = 0; i < PB; ++i) tile_store<MODE != CONV_DW, SBN>(Bs[BUF], RB[i], tid + i * NT); \
     }
 #define C3_MMA(BUF)                                                                                                 \
     {                                                                                                               \
         const float* __restrict__ a = As[BUF] + (lane >> 5) * SLD + wm * 32 + (lane & 31);                          \
         const float* __restrict__ b = Bs[BUF] + (lane >> 5) * SLD + wn * 32 + (lane & 31);                          \
-        _Pragma("unroll") for (int kk = 0; kk < CBK; kk += 2)                                                       \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk * SLD], b[kk * SLD], acc, 0, 0, 0);                     \
+        float av[CBK / 2], bv[CBK / 2];                                                                             \
+        _Pragma("unroll") for (int t = 0; t < CBK / 2; ++t) { av[t] = a[2 * t * SLD]; bv[t] = b[2 * t * SLD]; }     \
+        _Pragma("unroll") for (int t = 0; t < CBK / 2; ++t)                                                         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);                                 \
+        asm volatile("" : "+a"(acc));                                                                               \
     }
-    if (kbeg < kend) {
+    if (kbeg < kend) {         // two register sets of pieces in flight, as gemm_small_kernel
         const int nslab = (kend - kbeg + CBK - 1) / CBK;
-        load_a(kbeg, ra0);
-        load_b(kbeg, rb0);
-        C3_PUT(0)
+        const int last = nslab - 1;      // (loads unconditional, the slab index clamped: see gemm_small_kernel)
+        load_a(0, ra0); load_b(kbeg, rb0);
+        load_a(min(1, last), ra1); load_b(kbeg + min(1, last) * CBK, rb1);
+        C3_PUT(ra0, rb0, 0, 0)
+        asm volatile("" : "+a"(acc));
         __syncthreads();
-        for (int s = 0; s < nslab; ++s) {
-            const int more = s + 1 < nslab;
-            if (more) { load_a(kbeg + (s + 1) * CBK, ra0); load_b(kbeg + (s + 1) * CBK, rb0); }
-            if (s & 1) { C3_MMA(1) } else { C3_MMA(0) }
-            if (more) { if (s & 1) { C3_PUT(0) } else { C3_PUT(1) } }
+        for (int s = 0; s < nslab; s += 2) {
+            load_a(min(s + 2, last), ra0); load_b(kbeg + min(s + 2, last) * CBK, rb0);
+            C3_MMA(0)
+            if (s + 1 < nslab) C3_PUT(ra1, rb1, 1, s + 1)
+            __syncthreads();
+            if (s + 1 >= nslab) break;
+            load_a(min(s + 3, last), ra1); load_b(kbeg + min(s + 3, last) * CBK, rb1);
+            C3_MMA(1)
+            if (s + 2 < nslab) C3_PUT(ra0, rb0, 0, s + 2)
             __syncthreads();
         }
     }
 #undef C3_PUT
 #undef C3_MMA
-    // ---- epilogue (as gemm_small_kernel)
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < g.N) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            if (row >= g.M) continue;
-            if (g.splits > 1) small_put_partial(g.ws + ((size_t)split * g.M + row) * g.N + col, acc[r]);
-            else small_finish(g, row, col, acc[r]);
-        }
-    }
+    small_epilogue(g, acc, m0 + wm * 32, n0 + wn * 32, lane, split);
     if (g.splits > 1 && g.tile_cnt != nullptr)
         small_splitk_combine<SBN>(g, (int)blockIdx.x, m0, n0, tid, NT, reinterpret_cast<volatile int*>(c3_smem));
 }
@@ -449,6 +589,24 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
 __global__ __launch_bounds__(256) void conv3x3_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin) {
     extern __shared__ float wt_s[];
     const int co = blockIdx.x, n = cin * 9;
+    for (int i = threadIdx.x; i < n; i += 256) wt_s[i] = w[(size_t)co * n + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int tap = i / cin, ci = i - tap * cin;
+        wt[(size_t)co * n + i] = wt_s[ci * 9 + tap];
+    }
+}
+
+// The same for up to 16 layers in ONE launch (the transposes of a whole body, made ahead of the backward pass): workgroup ->
+// (layer, output channel) through the running channel counts `first`.
+struct WtTable { cim_wt_desc d[16]; int first[17]; int n; };
+__global__ __launch_bounds__(256) void conv3x3_wt_multi_kernel(const WtTable t) {
+    extern __shared__ float wt_s[];
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.first[e + 1]) ++e;
+    const int co = blockIdx.x - t.first[e], cin = t.d[e].cin, n = cin * 9;
+    const float* __restrict__ w = t.d[e].w;
+    float* __restrict__ wt = t.d[e].wt;
     for (int i = threadIdx.x; i < n; i += 256) wt_s[i] = w[(size_t)co * n + i];
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -482,6 +640,20 @@ unsigned* splitk_counters(long long tiles) {
     next[dev] += tiles;
     return p;
 #endif
+}
+
+static void set_input_bn(SmallArgs& g, const InputBn* in_bn) {
+    if (in_bn == nullptr) return;
+    g.mask = in_bn->y; g.mgamma = in_bn->gamma; g.mvar = in_bn->var; g.meps = in_bn->eps;
+    g.mxr = in_bn->xr; g.mmean = in_bn->mean; g.mpart = in_bn->part; g.mparts = (g.N + 31) / 32;
+}
+static void launch_splitk_reduce(const SmallArgs& g, hipStream_t st) {
+    if (g.mpart) {
+        hipLaunchKernelGGL(small_splitk_reduce_rows_kernel, dim3((unsigned)((g.N + 255) / 256), (unsigned)g.M), dim3(256), 0, st, g);
+    } else {
+        const size_t n = (size_t)g.M * g.N;
+        hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
+    }
 }
 
 template <bool AM, bool BKc>
@@ -535,21 +707,18 @@ static int gemm_small_impl(const float* A, const float* B, float* C, int M, int 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_mcontig = a_mcontig; g.b_kcontig = b_kcontig; g.relu = relu; g.bn = gamma != nullptr;
     g.splits = splits; g.ws = workspace; g.colbias = nullptr;
-    if (in_bn) { g.mask = in_bn->y; g.mgamma = in_bn->gamma; g.mvar = in_bn->var; g.meps = in_bn->eps; }
+    set_input_bn(g, in_bn);
     const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
-    CIM_CHECK_ARG(tiles * 2 < (1ll << 31) && splits <= 65535);
+    CIM_CHECK_ARG(tiles * 2 < (1ll << 31) && splits <= 65535 && M <= 65535);
     const bool narrow = tiles * splits < 128;           // 64 x 32 tiles only for problems that cannot fill the chip otherwise
-    g.tile_cnt = splits > 1 ? splitk_counters(narrow ? (long long)((M + SBM - 1) / SBM) * ((N + 31) / 32) : tiles) : nullptr;
+    g.tile_cnt = splits > 1 && !g.mpart ? splitk_counters(narrow ? (long long)((M + SBM - 1) / SBM) * ((N + 31) / 32) : tiles) : nullptr;
     hipStream_t st = cim::as_stream(stream);
     if (a_mcontig) {
         if (b_kcontig) launch_small<true, true>(g, splits, st, narrow); else launch_small<true, false>(g, splits, st, narrow);
     } else {
         if (b_kcontig) launch_small<false, true>(g, splits, st, narrow); else launch_small<false, false>(g, splits, st, narrow);
     }
-    if (splits > 1 && g.tile_cnt == nullptr) {          // (no counters: the separate, equally ordered reduce pass)
-        const size_t n = (size_t)M * N;
-        hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
-    }
+    if (splits > 1 && g.tile_cnt == nullptr) launch_splitk_reduce(g, st);      // (no counters: the separate, equally ordered reduce pass)
     CIM_CHECK_LAUNCH();
     return 0;
 }
@@ -636,11 +805,15 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
                                       const float* gamma, const float* mean, const float* var, float eps, int relu,
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
                                       int hw, float* workspace, void* stream, void* side_stream, int join,
-                                      int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps) {
+                                      int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
+                                      const float* in_xr, const float* in_mean, float* in_part) {
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0 && cin > 0 && cout > 0 && hw > 0);
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)));
-    CIM_CHECK_ARG(!dy_is_dconv || (dres == nullptr && dgamma == nullptr));       // (the consumer's data gradient already applied this layer's BatchNorm + ReLU backward)
+    // (dy_is_dconv: the consumer's data gradient already applied this layer's BatchNorm + ReLU backward; its affine gradients
+    // come from the partial sums that product left: cim_bn_part_finish)
+    CIM_CHECK_ARG(!dy_is_dconv || (dres == nullptr && dgamma == nullptr));
     CIM_CHECK_ARG((in_gamma == nullptr) == (in_var == nullptr));
+    CIM_CHECK_ARG(in_part == nullptr || (in_gamma && in_xr && in_mean));
     float* dconv = dy_is_dconv ? const_cast<float*>(dy) : workspace;             // [B][cout][hw]: dz * a, the gradient of the convolution output
     float* ws_dx = workspace + (size_t)B * cout * hw;
     float* ws_dw = ws_dx + (size_t)cim_gemm_small_splits(cin, hw, cout) * cin * hw;
@@ -660,7 +833,8 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
         }
     }
     for (int b = 0; b < B && dx; ++b) {                        // dX[cin, hw] = W^T . dconv  (x the BatchNorm + ReLU backward of the layer that made x)
-        const InputBn ib{x + (size_t)b * cin * hw, in_gamma, in_var, in_eps};
+        const InputBn ib{x + (size_t)b * cin * hw, in_gamma, in_var, in_eps, in_xr ? in_xr + (size_t)b * cin * hw : nullptr, in_mean,
+                         in_part ? in_part + (size_t)b * 2 * ((hw + 31) / 32) * cin : nullptr};
         rc = gemm_small_impl(w, dconv + (size_t)b * cout * hw, dx + (size_t)b * cin * hw, cin, hw, cout, cin, hw, hw, 1, 0,
                              nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, cout), ws_dx, stream,
                              in_gamma ? &ib : nullptr);
@@ -684,9 +858,9 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = 0; g.ldc = ldc;
     g.a_mcontig = 0; g.b_kcontig = mode == CONV_DW; g.relu = relu; g.bn = gamma != nullptr;
     g.splits = splits; g.ws = ws; g.colbias = nullptr;
-    if (in_bn) { g.mask = in_bn->y; g.mgamma = in_bn->gamma; g.mvar = in_bn->var; g.meps = in_bn->eps; }
+    set_input_bn(g, in_bn);
     const dim3 grid((unsigned)(((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN)), (unsigned)splits);
-    g.tile_cnt = splits > 1 ? splitk_counters((long long)grid.x) : nullptr;
+    g.tile_cnt = splits > 1 && !g.mpart ? splitk_counters((long long)grid.x) : nullptr;
     const size_t lds = sizeof(float) * 4 * CBK * SLD;
     auto kern = ksize == 7 ? conv3x3_small_kernel<CONV_FWD, 7>
                 : mode == CONV_FWD ? conv3x3_small_kernel<CONV_FWD> : mode == CONV_DX ? conv3x3_small_kernel<CONV_DX> : conv3x3_small_kernel<CONV_DW>;
@@ -695,10 +869,7 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, c);
-    if (splits > 1 && g.tile_cnt == nullptr) {
-        const size_t n = (size_t)M * N;
-        hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
-    }
+    if (splits > 1 && g.tile_cnt == nullptr) launch_splitk_reduce(g, st);
     return 0;
 }
 ConvGeom conv_geom(int cin, int cout, int H, int W, int stride, int mode, int dil = 1) {
@@ -757,24 +928,75 @@ extern "C" long long cim_conv3x3_nchw_bwd_workspace(int B, int cin, int cout, in
     return (long long)sizeof(float) * (dconv + (long long)cout * cin * 9 + dx + dw);
 }
 
+extern "C" int cim_bn_part_finish(const cim_bn_part_desc* descs, int n, void* stream) {
+    CIM_CHECK_ARG(descs && n > 0);
+    hipStream_t st = cim::as_stream(stream);
+    for (int base = 0; base < n; base += 24) {
+        BnPartTable t{};
+        t.n = n - base < 24 ? n - base : 24;
+        int total = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const cim_bn_part_desc& d = descs[base + i];
+            CIM_CHECK_ARG(d.part && d.var && (d.dgamma || d.dbeta) && d.images > 0 && d.parts > 0 && d.channels > 0);
+            t.d[i] = d;
+            t.first[i] = total;
+            total += (d.channels + 31) / 32;
+        }
+        t.first[t.n] = total;
+        hipLaunchKernelGGL(bn_part_finish_kernel, dim3((unsigned)total), dim3(256), 0, st, t);
+    }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_conv3x3_wt_multi(const cim_wt_desc* descs, int n, void* stream) {
+    CIM_CHECK_ARG(descs && n > 0);
+    hipStream_t st = cim::as_stream(stream);
+    for (int base = 0; base < n; base += 16) {
+        WtTable t{};
+        t.n = n - base < 16 ? n - base : 16;
+        int total = 0, max_cin = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const cim_wt_desc& d = descs[base + i];
+            CIM_CHECK_ARG(d.w && d.wt && d.cin > 0 && d.cout > 0 && (size_t)d.cin * 9 * sizeof(float) <= 64 * 1024);
+            t.d[i] = d;
+            t.first[i] = total;
+            total += d.cout;
+            max_cin = d.cin > max_cin ? d.cin : max_cin;
+        }
+        t.first[t.n] = total;
+        const size_t lds = sizeof(float) * max_cin * 9;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wt_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(conv3x3_wt_multi_kernel, dim3((unsigned)total), dim3(256), lds, st, t);
+    }
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
 // The whole backward of conv3x3 -> BatchNorm (+ residual) (+ ReLU): BatchNorm / ReLU backward (bn_act.hip), data gradient
 // and weight gradient implicit GEMMs with their split-K reduces, enqueued by one host call (as cim_conv1x1_bn_act_bwd).
 extern "C" int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                                       const float* gamma, const float* mean, const float* var, float eps, int relu,
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
                                       int H, int W, int stride, int dilation, float* workspace, void* stream, void* side_stream,
-                                      int join, int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps) {
+                                      int join, int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
+                                      const float* in_xr, const float* in_mean, float* in_part, const float* wt_ready) {
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0);
     CONV3_ARGS_OK(4);
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)) && cout % 4 == 0);
     CIM_CHECK_ARG(!dy_is_dconv || (dres == nullptr && dgamma == nullptr));
     CIM_CHECK_ARG((in_gamma == nullptr) == (in_var == nullptr));
+    CIM_CHECK_ARG(in_part == nullptr || (in_gamma && in_xr && in_mean));
     const ConvGeom cx = conv_geom(cin, cout, H, W, stride, CONV_DX, dilation), cw = conv_geom(cin, cout, H, W, stride, CONV_DW, dilation);
     const int hwo = cx.Ho * cx.Wo, hw = H * W;
     hipStream_t st = cim::as_stream(stream);
     float* dconv = dy_is_dconv ? const_cast<float*>(dy) : workspace;      // [B][cout][Ho Wo]: the gradient of the convolution output
-    float* wt = workspace + (size_t)B * cout * hwo;            // [cout][9][cin]
-    float* ws_dx = wt + (size_t)cout * cin * 9;
+    float* wt_own = workspace + (size_t)B * cout * hwo;        // [cout][9][cin]
+    const float* wt = wt_ready ? wt_ready : wt_own;            // (made ahead of the pass by cim_conv3x3_wt_multi, or here)
+    float* ws_dx = wt_own + (size_t)cout * cin * 9;
     float* ws_dw = ws_dx + (size_t)cim_gemm_small_splits(cin, hw, 9 * cout) * cin * hw;
     CIM_CHECK_ARG((size_t)cin * 9 * sizeof(float) <= 64 * 1024);
     int rc = dy_is_dconv ? 0 : cim_bn_act_bwd(dy, y, x_raw, gamma, mean, var, eps, dconv, dres, dgamma, dbeta, B, cout, hwo, relu, stream);
@@ -791,9 +1013,10 @@ extern "C" int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, cons
             hipLaunchKernelGGL(small_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_dw, dw, out, n);
         }
     }
-    if (dx) hipLaunchKernelGGL(conv3x3_wt_kernel, dim3(cout), dim3(256), sizeof(float) * cin * 9, st, w, wt, cin);
+    if (dx && !wt_ready) hipLaunchKernelGGL(conv3x3_wt_kernel, dim3(cout), dim3(256), sizeof(float) * cin * 9, st, w, wt_own, cin);
     for (int b = 0; b < B && dx; ++b) {                        // dX[cin][H W] = sum over (co, tap) W[co][ci][tap] dconv[co][shifted]
-        const InputBn ib{x + (size_t)b * cin * hw, in_gamma, in_var, in_eps};
+        const InputBn ib{x + (size_t)b * cin * hw, in_gamma, in_var, in_eps, in_xr ? in_xr + (size_t)b * cin * hw : nullptr, in_mean,
+                         in_part ? in_part + (size_t)b * 2 * ((hw + 31) / 32) * cin : nullptr};
         conv3x3_launch(CONV_DX, wt, dconv + (size_t)b * cout * hwo, dx + (size_t)b * cin * hw, cin, hw, 9 * cout, cin, hw, cx, nullptr,
                        nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, 9 * cout), ws_dx, st, 3,
                        in_gamma ? &ib : nullptr);

@@ -28,7 +28,6 @@ import torch.nn as nn
 from ..core.config import cfg
 from ..ops import RoIAlign, RoIPool
 from ..ops import gemm as _gemm_ops
-from ..ops import chain as _chain
 from . import heads
 
 logger = logging.getLogger(__name__)
@@ -165,7 +164,6 @@ class Generalized_RCNN(nn.Module):
                 # its end-of-backward callback: normally nothing is pending here.  They are dropped, not installed: the
                 # driver's zero_grad() for this step has already run)
                 _gemm_ops.join_side(discard=True)
-                _chain.reset()                       # (hand-over marks of an aborted backward pass, ops/chain.py)
                 if hasattr(self.Box_Head, "prefetch"):
                     self.Box_Head.prefetch()        # the MaskFuse filter transform runs under the backbone forward
                 dev, dt = im_data.device, im_data.dtype

@@ -9,10 +9,12 @@ as resnet50.py:53-77 does.
 """
 import os
 
+import torch
 import torch.nn as nn
 
 from ..core.config import cfg
 from ..ops import bn_act, conv1x1_bn_act, conv3x3_bn_act, conv7x7_bn_act
+from ..ops.conv3x3 import prefetch_transposed_weights
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "resnet50.MaskFuse" by get_func)
 
 
@@ -127,6 +129,10 @@ class resnet(nn.Module):
         return {name: name for name, _ in self.named_parameters()}, []
 
     def forward(self, x):
+        if OWN_3X3 and self.training and torch.is_grad_enabled():
+            # the transposed 3 x 3 weights the backward's data gradients read: one launch beside the forward (ops/conv3x3.py)
+            prefetch_transposed_weights([b.conv2 for i in range(cfg.ResNet.FREEZE_AT + 1, self.block_counts + 1)
+                                         for b in getattr(self, "res%d" % i)])
         for i in range(self.block_counts):
             m = getattr(self, "res%d" % (i + 1))
             if i == 0 and OWN_3X3:      # the stem: 7 x 7 convolution + BatchNorm + ReLU in one launch (frozen: forward only), then the max-pool

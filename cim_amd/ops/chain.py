@@ -1,57 +1,70 @@
-"""Chaining the backward of two fused conv + frozen-BatchNorm + ReLU layers without a BatchNorm-backward launch in between.
+"""Chaining the backward of two fused conv + frozen-statistics-BatchNorm + ReLU layers without a BatchNorm-backward launch in between.
 
-When layer P produces x = relu(bn_P(conv_P(.))) (no residual, BatchNorm parameters frozen) and layer Q is its ONLY consumer,
-the data-gradient product of Q can apply P's BatchNorm + ReLU backward in its epilogue (csrc/conv1x1.hip: SmallArgs.mask):
-    dconv_P = (x > 0 ? dx : 0) * gamma_P rsqrt(var_P + eps_P)
-so P's backward starts from the gradient of its convolution output and skips its `bn_act_bwd` launch
-(torchvision Bottleneck conv1 -> conv2 -> conv3 of /root/reference/lib/modeling/resnet50.py:17-44).  Eligibility needs the
-BatchNorm's affine parameters FROZEN: with trainable gamma / beta their gradients are per-channel sums the `bn_act_bwd` launch
-computes.  The reference freezes the statistics only (resnet50.py:60: the freeze of the affine layers is commented out), so at
-its configurations nothing is chained; a model whose BatchNorm layers are fully frozen saves 2 of 3 such launches per block.
+When layer P produces x = relu(bn_P(conv_P(.))) (no residual) and layer Q is its ONLY consumer, the data-gradient product of Q
+applies P's BatchNorm + ReLU backward in its epilogue (csrc/conv1x1.hip: SmallArgs.mask):
+    dz = x > 0 ? dx : 0,   dconv_P = dz * gamma_P rsqrt(var_P + eps_P)
+so P's backward starts from the gradient of its convolution output and skips its `bn_act_bwd` launch (torchvision Bottleneck
+conv1 -> conv2 -> conv3 of /root/reference/lib/modeling/resnet50.py:17-44: 2 of 3 such launches per block).
+The reference freezes the STATISTICS of its BatchNorm layers only (resnet50.py:59-60: the freeze of the affine parameters is
+commented out), so gamma_P / beta_P train: their gradients  dbeta = sum dz,  dgamma = rsqrt(var + eps) sum dz (conv_P - mean)  are
+per-channel sums over the pixels.  Q's epilogue writes them as partial sums per 32-pixel group (SmallArgs.mpart: plain stores, no
+atomics), P's backward finishes them in group order with one small launch beside its weight-gradient product - deterministic, and
+the same gradients as the separate launch up to the summation order.
 
-Protocol (all on the host, per backward pass):
-  * P's wrapper tags its output: y._cim_bn = (gamma, var, eps, state) when P is eligible;
+Protocol (host side, per backward pass; everything hangs off P's own `state` dict - no process-global marks):
+  * P's forward leaves its convolution output in state["xr"]; P's wrapper tags its output: y._cim_bn = InputBn(..., state);
   * Q is called with fuse_input_bn=True by code that KNOWS x has no other consumer (the bottleneck): it marks state["taken"],
-    applies the epilogue in its backward and hands the result over: hand_over(dx);
-  * P's backward asks take(dy): True -> dy is already dconv_P.  A taken P that receives anything else (the gradient was
-    accumulated with another one: x had a second consumer after all) raises - it cannot be repaired silently.
+    applies the epilogue in its backward and hands the result over: hand_over(in_bn, dx, part) -> state["handed"];
+  * P's backward asks take(dy, state): (True, part) -> dy is already dconv_P.  A taken P that receives anything else (the gradient
+    was accumulated with another one: x had a second consumer after all) raises - it cannot be repaired silently.  A mark that is
+    never taken (P's backward did not run) dies with P's state.
 """
-_HANDED = set()      # (data_ptr, numel) of gradients handed over in the running backward pass
+import collections
+
+InputBn = collections.namedtuple("InputBn", "gamma var eps mean affine state")
 
 
-def tag(y, gamma, beta, mean, var, eps, relu, has_res):
-    """-> state dict stored with P's autograd node (None when P is not eligible)."""
-    if not relu or has_res or gamma.requires_grad or beta.requires_grad or mean.requires_grad or not y.requires_grad:
+def tag(y, gamma, beta, mean, var, eps, relu, has_res, state):
+    """Tag P's output `y` for a chaining consumer; -> state (None when P is not eligible).  A BatchNorm whose mean carries a
+    folded convolution bias that trains (HRNet) is not eligible: its gradient is derived from dbeta on the caller's stream."""
+    if state is None or not relu or has_res or mean.requires_grad or not y.requires_grad:
         return None
-    state = {"taken": False}
-    y._cim_bn = (gamma, var, float(eps), state)
+    y._cim_bn = InputBn(gamma, var, float(eps), mean, bool(gamma.requires_grad or beta.requires_grad), state)
     return state
 
 
 def input_bn(x, enabled):
-    """(gamma, var, eps) of the layer that produced x, marked as taken - or None."""
+    """The InputBn of the layer that produced x, marked as taken - or None."""
     t = getattr(x, "_cim_bn", None) if enabled else None
     if t is None:
         return None
-    t[3]["taken"] = True
-    return t[0], t[1], t[2]
+    t.state["taken"] = True
+    return t
 
 
-def hand_over(dx):
-    _HANDED.add((dx.data_ptr(), dx.numel()))
+def c_args(in_bn, part):
+    """(in_gamma, in_var, in_eps, in_xr, in_mean, in_part) of the C entry points."""
+    if in_bn is None:
+        return None, None, 0.0, None, None, None
+    if part is None:
+        return in_bn.gamma.data_ptr(), in_bn.var.data_ptr(), in_bn.eps, None, None, None
+    return (in_bn.gamma.data_ptr(), in_bn.var.data_ptr(), in_bn.eps, in_bn.state["xr"].data_ptr(), in_bn.mean.data_ptr(),
+            part.data_ptr())
+
+
+def hand_over(in_bn, dx, part=None):
+    in_bn.state["handed"] = (dx.data_ptr(), dx.numel(), part)
 
 
 def take(dy, state):
-    key = (dy.data_ptr(), dy.numel())
-    if key in _HANDED:
-        _HANDED.discard(key)
-        return True
-    if state is not None and state["taken"]:
+    """-> (dy is already the gradient of this layer's convolution output, partial sums of its affine gradients or None)"""
+    if state is None:
+        return False, None
+    h = state.pop("handed", None)
+    if h is not None and h[0] == dy.data_ptr() and h[1] == dy.numel():
+        return True, h[2]
+    if state.get("taken"):
         raise RuntimeError("cim_amd: a layer whose BatchNorm backward was fused into its consumer's data gradient received a "
                            "different gradient tensor - its output has a second consumer (fuse_input_bn=True is only valid for "
                            "a single consumer)")
-    return False
-
-
-def reset():
-    _HANDED.clear()
+    return False, None

@@ -8,6 +8,8 @@ BatchNorm frozen as :53-77 does.  The parameters stay the modules' own tensors (
 In NCHW the convolution of one image is W[Cout,Cin] . X[Cin,HW]: forward, data gradient (W^T . dY) and weight gradient
 (dY . X^T, split-K) are three layouts of the same small-tile fp32-MFMA GEMM; the BatchNorm backward stays the fused
 `bn_act` kernel.  CPU tensors, a BatchNorm in training mode or other convolution shapes take the ATen ops."""
+import ctypes
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -47,6 +49,9 @@ class Conv1x1BnActFunction(Function):
         ctx.param = w if isinstance(w, torch.nn.Parameter) else None      # (its .grad tells the backward whether it may defer the join)
         ctx.cfg = (B, cin, cout, H, W, float(eps), bool(relu), res is not None)
         ctx.in_bn, ctx.state = in_bn, state          # ops/chain.py: the producer's BatchNorm (fused into dx) / this layer's hand-over state
+        if state is not None:
+            state["xr"] = xr                         # (a chaining consumer's epilogue needs it for this layer's dgamma)
+        ctx.affine = (gamma, beta)
         return y
 
     @staticmethod
@@ -54,7 +59,9 @@ class Conv1x1BnActFunction(Function):
         x, w2, xr, y, gamma, mean, var = ctx.saved_tensors
         B, cin, cout, H, W, eps, relu, has_res = ctx.cfg
         hw = H * W
-        is_dconv = chain.take(dy, ctx.state)         # the consumer's data gradient already applied this layer's BatchNorm + ReLU backward
+        is_dconv, dy_part = chain.take(dy, ctx.state)       # the consumer's data gradient already applied this layer's BatchNorm + ReLU backward
+        if ctx.state is not None:
+            ctx.state.pop("xr", None)
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_res = has_res and ctx.needs_input_grad[2]
@@ -63,32 +70,72 @@ class Conv1x1BnActFunction(Function):
         # ONE host call: BatchNorm / ReLU backward, data gradient, weight gradient (+ split-K reduces)  (csrc/conv1x1.hip)
         dev = dy.device
         dres = torch.empty_like(dy) if need_res else None
-        dgamma = dbeta = None
-        if need_affine:
-            alloc = torch.zeros if _lib.call("cim_bn_act_bwd_chunks", B, cout, hw) > 1 else torch.empty
-            dgamma, dbeta = alloc(2, cout, dtype=torch.float32, device=dev).unbind(0)
+        dgamma, dbeta, chained = affine_outputs(ctx, is_dconv, dy_part, need_affine, B, cout, hw, dev)
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=dev) if need_w else None
         ws = torch.empty(_lib.call("cim_conv1x1_bwd_workspace", B, cin, cout, hw) // 4, dtype=torch.float32, device=dev)
+        in_bn = ctx.in_bn if need_x else None
+        in_part = torch.empty((B, 2, (hw + 31) // 32, cin), dtype=torch.float32, device=dev) if in_bn is not None and in_bn.affine else None
         side, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
         _lib.call("cim_conv1x1_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w2.data_ptr(),
-                  gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres), _lib.ptr(dgamma),
-                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, join,
-                  int(is_dconv), *_in_bn_args(ctx.in_bn if need_x else None))
-        if ctx.in_bn is not None and need_x:
-            chain.hand_over(dx)
+                  gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres),
+                  _lib.ptr(None if chained else dgamma), _lib.ptr(None if chained else dbeta), _lib.ptr(dx), _lib.ptr(dw),
+                  B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, join, int(is_dconv), *chain.c_args(in_bn, in_part))
+        if in_bn is not None:
+            chain.hand_over(in_bn, dx, in_part)
         if not join:                       # the weight gradient is still running on the side stream: installed as .grad at the join
-            _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x)
+            # (everything the side stream reads stays referenced until then - the handed-over gradient `dy` of a chained layer
+            # included: autograd drops it when this node returns)
+            _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x, *((dy,) if is_dconv else ()))
             dw = None
         dmean = -(gamma * torch.rsqrt(var + eps)) * dbeta if need_mean else None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
             dmean, None, None, None, None, None
 
 
-def _in_bn_args(in_bn):
-    if in_bn is None:
-        return None, None, 0.0
-    return in_bn[0].data_ptr(), in_bn[1].data_ptr(), float(in_bn[2])
+class _BnPartDesc(ctypes.Structure):          # cim_bn_part_desc of include/cim_hip.h
+    _fields_ = [("part", ctypes.c_void_p), ("var", ctypes.c_void_p), ("eps", ctypes.c_float), ("dgamma", ctypes.c_void_p),
+                ("dbeta", ctypes.c_void_p), ("images", ctypes.c_int), ("parts", ctypes.c_int), ("channels", ctypes.c_int)]
+
+
+def finish_affine(records):
+    """ONE launch (per 24 layers) for the affine gradients of chained layers: records = (partial sums [B][2][parts][C], var, eps,
+    gamma or None, beta or None) -> [(parameter, gradient)].  Runs on the current stream."""
+    descs, out = (_BnPartDesc * len(records))(), []
+    for i, (part, var, eps, g, b) in enumerate(records):
+        B, _, parts, C = part.shape
+        dg, db = torch.empty(2, C, dtype=torch.float32, device=part.device).unbind(0)
+        descs[i] = _BnPartDesc(part.data_ptr(), var.data_ptr(), eps, dg.data_ptr() if g is not None else None,
+                               db.data_ptr() if b is not None else None, B, parts, C)
+        out += [(q, t) for q, t in ((g, dg), (b, db)) if q is not None]
+    _lib.call("cim_bn_part_finish", descs, len(records), _lib.stream_ptr())
+    return out
+
+
+def affine_outputs(ctx, is_dconv, dy_part, need_affine, B, cout, hw, dev):
+    """-> (dgamma, dbeta buffers for the call's own BatchNorm backward or None, chained).  A CHAINED layer's affine gradients are
+    finished from the partial sums its consumer left (`dy_part`): at the end of the backward pass, one launch for all layers
+    (ops/gemm.py: defer_finisher; they are then installed as .grad like the deferred weight gradients and do not travel through
+    autograd) - or at once, returned through autograd, when nothing can be deferred (no engine callback, graph capture, affine
+    tensors that are not Parameters)."""
+    if not need_affine:
+        return None, None, False
+    if is_dconv:
+        if dy_part is None:
+            raise RuntimeError("cim_amd: chained BatchNorm backward without the partial sums of its trainable affine parameters")
+        g, b = ctx.affine
+        g, b = (g if ctx.needs_input_grad[3] else None), (b if ctx.needs_input_grad[4] else None)
+        _, _, _, _, gamma, mean, var = ctx.saved_tensors
+        rec = (dy_part, var, ctx.cfg[5], g, b)
+        if (_gemm_mod.DEFER_DW and not torch.cuda.is_current_stream_capturing()
+                and all(q is None or isinstance(q, torch.nn.Parameter) for q in (g, b))):
+            _gemm_mod.defer_finisher(dev, finish_affine, rec, [q for q in (g, b) if q is not None])
+            return None, None, True
+        got = dict((id(q), t) for q, t in finish_affine([rec]))
+        return got.get(id(g)), got.get(id(b)), True
+    alloc = torch.zeros if _lib.call("cim_bn_act_bwd_chunks", B, cout, hw) > 1 else torch.empty
+    dgamma, dbeta = alloc(2, cout, dtype=torch.float32, device=dev).unbind(0)
+    return dgamma, dbeta, False
 
 
 def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False):
@@ -115,6 +162,5 @@ def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False):
             return Conv1x1BnActFunction.apply(*args)
     state = {"taken": False}
     out = Conv1x1BnActFunction.apply(*args, in_bn, state)
-    if chain.tag(out, bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu, residual is not None) is not None:
-        out._cim_bn = out._cim_bn[:3] + (state,)      # (the node's own state object: its backward checks it)
+    chain.tag(out, bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu, residual is not None, state)
     return out

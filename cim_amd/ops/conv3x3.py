@@ -8,6 +8,9 @@
 [Cout, Cin, 3, 3] weight as it is).  Forward, data gradient and weight gradient are three loaders of the same kernel; the
 BatchNorm backward stays the fused `bn_act` kernel.  CPU tensors, a BatchNorm in training mode or other convolution
 shapes take the ATen ops."""
+import ctypes
+import weakref
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -15,8 +18,53 @@ from torch.autograd import Function
 from .. import _lib
 from . import chain
 from . import fallback
-from .conv1x1 import _in_bn_args
+from .conv1x1 import affine_outputs
 from . import gemm as _gemm_mod
+
+
+# ---- the data gradient's A operand: the weight transposed to [cout][3][3][cin].  It depends on the weight only, so a body makes
+# all of its layers' transposes in ONE launch on the side stream at the start of the forward pass (prefetch_transposed_weights:
+# 10 launches per step less on the backward's main chain at cfg2); a layer that was not prefetched transposes in its own backward.
+_WT = {}      # id(weight) -> (version, data_ptr, transposed tensor, event, weak reference: an id can be reused by another tensor)
+
+
+class _WtDesc(ctypes.Structure):              # cim_wt_desc of include/cim_hip.h
+    _fields_ = [("w", ctypes.c_void_p), ("wt", ctypes.c_void_p), ("cin", ctypes.c_int), ("cout", ctypes.c_int)]
+
+
+def _transposed(w):
+    e = _WT.get(id(w))
+    if e is not None and e[4]() is w and e[0] == w._version and e[1] == w.data_ptr():
+        torch.cuda.current_stream(w.device).wait_event(e[3])
+        e[2].record_stream(torch.cuda.current_stream(w.device))
+        return e[2]
+    return None
+
+
+def prefetch_transposed_weights(convs):
+    """`convs`: the 3 x 3 nn.Conv2d modules of a body whose data gradient this step will need."""
+    ws = [c.weight for c in convs if c.weight.is_cuda and c.weight.requires_grad and c.weight.is_contiguous()
+          and c.kernel_size == (3, 3) and c.in_channels * 36 <= 64 * 1024]
+    ws = [w for w in ws if not (id(w) in _WT and _WT[id(w)][4]() is w and _WT[id(w)][0] == w._version and _WT[id(w)][1] == w.data_ptr())]
+    if not ws or not _gemm_mod.OVERLAP or torch.cuda.is_current_stream_capturing():
+        return
+    dev = ws[0].device
+    cur, side = torch.cuda.current_stream(dev), _gemm_mod._side_stream(dev)
+    side.wait_stream(cur)                       # (the optimizer's update of the weights was enqueued on `cur`)
+    with torch.cuda.stream(side), torch.no_grad():
+        buf = torch.empty(sum(w.numel() for w in ws), dtype=torch.float32, device=dev)
+        descs, outs, o = (_WtDesc * len(ws))(), [], 0
+        for i, w in enumerate(ws):
+            t = buf[o:o + w.numel()]
+            o += w.numel()
+            outs.append(t)
+            descs[i] = _WtDesc(w.data_ptr(), t.data_ptr(), w.shape[1], w.shape[0])
+        _lib.call("cim_conv3x3_wt_multi", descs, len(ws), _lib.stream_ptr())
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for w, t in zip(ws, outs):
+        key = id(w)
+        _WT[key] = (w._version, w.data_ptr(), t, ev, weakref.ref(w, lambda _r, key=key: _WT.pop(key, None)))
 
 
 class Conv3x3BnActFunction(Function):
@@ -44,13 +92,18 @@ class Conv3x3BnActFunction(Function):
         ctx.param = w if isinstance(w, torch.nn.Parameter) else None      # (its .grad tells the backward whether it may defer the join)
         ctx.cfg = (B, cin, cout, H, W, float(eps), bool(relu), res is not None, stride, dilation)
         ctx.in_bn, ctx.state = in_bn, state          # ops/chain.py
+        if state is not None:
+            state["xr"] = xr                         # (a chaining consumer's epilogue needs it for this layer's dgamma)
+        ctx.affine = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, xr, y, gamma, mean, var = ctx.saved_tensors
         B, cin, cout, H, W, eps, relu, has_res, stride, dilation = ctx.cfg
-        is_dconv = chain.take(dy, ctx.state)
+        is_dconv, dy_part = chain.take(dy, ctx.state)
+        if ctx.state is not None:
+            ctx.state.pop("xr", None)
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_res = has_res and ctx.needs_input_grad[2]
@@ -59,22 +112,24 @@ class Conv3x3BnActFunction(Function):
         dev = dy.device
         hwo = dy.shape[2] * dy.shape[3]
         dres = torch.empty_like(dy) if need_res else None
-        dgamma = dbeta = None
-        if need_affine:
-            alloc = torch.zeros if _lib.call("cim_bn_act_bwd_chunks", B, cout, hwo) > 1 else torch.empty
-            dgamma, dbeta = alloc(2, cout, dtype=torch.float32, device=dev).unbind(0)
+        dgamma, dbeta, chained = affine_outputs(ctx, is_dconv, dy_part, need_affine, B, cout, hwo, dev)
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty_like(w) if need_w else None
         ws = torch.empty(_lib.call("cim_conv3x3_nchw_bwd_workspace", B, cin, cout, H, W, stride) // 4, dtype=torch.float32, device=dev)
+        in_bn = ctx.in_bn if need_x else None
+        in_part = torch.empty((B, 2, (H * W + 31) // 32, cin), dtype=torch.float32, device=dev) if in_bn is not None and in_bn.affine else None
         side, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
+        wt = _transposed(ctx.param) if (need_x and ctx.param is not None) else None
         _lib.call("cim_conv3x3_nchw_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w.data_ptr(),
-                  gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres), _lib.ptr(dgamma),
-                  _lib.ptr(dbeta), _lib.ptr(dx), _lib.ptr(dw), B, cin, cout, H, W, stride, dilation, ws.data_ptr(), _lib.stream_ptr(), side, join,
-                  int(is_dconv), *_in_bn_args(ctx.in_bn if need_x else None))
-        if ctx.in_bn is not None and need_x:
-            chain.hand_over(dx)
+                  gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres),
+                  _lib.ptr(None if chained else dgamma), _lib.ptr(None if chained else dbeta), _lib.ptr(dx), _lib.ptr(dw),
+                  B, cin, cout, H, W, stride, dilation, ws.data_ptr(), _lib.stream_ptr(), side, join,
+                  int(is_dconv), *chain.c_args(in_bn, in_part), _lib.ptr(wt))
+        if in_bn is not None:
+            chain.hand_over(in_bn, dx, in_part)
         if not join:                       # the weight gradient is still running on the side stream: installed as .grad at the join
-            _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x)
+            # (everything the side stream reads stays referenced until then - a chained layer's handed-over `dy` included)
+            _gemm_mod.defer_side_join(dev, ctx.param, dw, ws, x, *((dy,) if is_dconv else ()))
             dw = None
         dmean = -(gamma * torch.rsqrt(var + eps)) * dbeta if need_mean else None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
@@ -87,8 +142,8 @@ def _apply(fn, args, n_diff, in_bn=None, tag=None):
             return fn.apply(*args)
     state = {"taken": False}
     out = fn.apply(*args, in_bn, state)
-    if tag is not None and chain.tag(out, *tag) is not None:
-        out._cim_bn = out._cim_bn[:3] + (state,)
+    if tag is not None:
+        chain.tag(out, *tag, state)
     return out
 
 

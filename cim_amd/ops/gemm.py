@@ -154,7 +154,7 @@ def main_stream_high_priority(dev):
 # Measured at cfg2: 17.33 -> 16.62 ms per step.  Deferring the MaskFuse layers' weight gradients as well (fc1, fc2, the
 # Winograd convolution: they already run beside their layer's data gradient) changed nothing: 16.71 ms.
 DEFER_DW = OVERLAP and os.environ.get("CIM_DEFER_DW", "1") == "1" and engine.HAS_ENGINE_CALLBACK
-_DEFERRED = {}        # device -> [main stream, [(param, dw)], [tensors kept alive]]
+_DEFERRED = {}        # device -> [main stream, [(param, dw)], [tensors kept alive], [(finisher, record)]]
 _PENDING_IDS = set()  # id(param) of the weights whose gradient is still on the side stream
 
 
@@ -177,20 +177,47 @@ def side_stream_for_backward(dev, param):
     caller's stream (a fork / join inside every layer measured SLOWER than that: 17.0-17.1 vs 16.8 ms per step)."""
     if not DEFER_DW or param is None or torch.cuda.is_current_stream_capturing():
         return None, 1
-    return _side_stream(dev).cuda_stream, 0
+    return _body_stream(dev).cuda_stream, 0
+
+
+def _body_stream(dev):
+    """Third HIP stream per device: the body's deferred weight-gradient GEMMs.  On the side stream they queued behind MaskFuse's
+    late weight-gradient products (~3 ms of 256-workgroup launches, ops/maskfuse_pair.py) and formed the tail of the backward
+    pass; on their own queue they fill the gaps between those launches: 4.49 -> 4.30 ms for the body's backward phase, 14.11 ->
+    13.81 ms per step at cfg2 (same box, round 4; round 3 measured no gain from this, before the late launches existed)."""
+    s = _SIDE.get(("body", dev))
+    if s is None:
+        s = _SIDE[("body", dev)] = torch.cuda.Stream(device=dev)
+    return s
 
 
 def defer_side_join(dev, param, dw, *keep):
     """The layer's weight gradient `dw` was enqueued on the side stream without a join.  It does NOT travel through
     autograd (the layer's backward returns None for the weight: AccumulateGrad may copy a gradient it cannot steal, on the
     main stream, before the side stream has written it): it is installed as param.grad by join_side(), after the join."""
-    ent = _DEFERRED.get(dev)
-    if ent is None or not (ent[1] or ent[2]):
-        ent = _DEFERRED[dev] = [torch.cuda.current_stream(dev), [], []]
-        engine.queue_callback(join_side)
+    ent = _deferred_entry(dev)
     ent[1].append((param, dw))
     ent[2].extend(keep)
     _PENDING_IDS.add(id(param))
+
+
+def _deferred_entry(dev):
+    ent = _DEFERRED.get(dev)
+    if ent is None or not (ent[1] or ent[2] or ent[3]):
+        ent = _DEFERRED[dev] = [torch.cuda.current_stream(dev), [], [], []]
+        engine.queue_callback(join_side)
+    return ent
+
+
+def defer_finisher(dev, finisher, record, params):
+    """Gradients that ONE launch at the end of the backward pass finishes for many layers (the affine gradients of chained
+    BatchNorm layers, ops/conv1x1.py): join_side() calls finisher(list of records) on the stream the backward ran on - every
+    kernel that feeds it is enqueued by then - and installs the (param, grad) pairs it returns like the deferred weight gradients.
+    `params`: the parameters whose gradient is pending until then."""
+    ent = _deferred_entry(dev)
+    ent[3].append((finisher, record))
+    for q in params:
+        _PENDING_IDS.add(id(q))
 
 
 # Launches a node's backward postponed to "after the next node's kernels are enqueued": MaskFuse's late weight-gradient products
@@ -225,11 +252,23 @@ def join_side(discard=False):
     else:
         run_postponed()             # (launches still waiting for "the next node": whoever joins needs them enqueued first)
     for dev, ent in list(_DEFERRED.items()):
+        if ent[3]:
+            if not discard:
+                with torch.cuda.stream(ent[0]), torch.no_grad():
+                    todo = {}
+                    for fn, rec in ent[3]:
+                        todo.setdefault(fn, []).append(rec)
+                    for fn, recs in todo.items():
+                        ent[1].extend(fn(recs))
+            ent[3] = []
         if ent[1] or ent[2]:
-            ent[0].wait_stream(_side_stream(dev))
+            streams = [_side_stream(dev)] + ([_SIDE[("body", dev)]] if ("body", dev) in _SIDE else [])
+            for st in streams:
+                ent[0].wait_stream(st)
             cur = torch.cuda.current_stream(dev)
             if cur != ent[0]:
-                cur.wait_stream(_side_stream(dev))
+                for st in streams:
+                    cur.wait_stream(st)
             with torch.no_grad():
                 for param, dw in ent[1]:
                     if not discard:

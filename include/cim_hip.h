@@ -221,13 +221,26 @@ int cim_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, i
  *     residual - dx is then written as  x > 0 ? dx * in_gamma rsqrt(in_var + in_eps) : 0,  i.e. already the gradient of that
  *     layer's convolution output (its BatchNorm + ReLU backward in this product's epilogue);
  *   dy_is_dconv != 0: dy IS such a gradient of this layer's convolution output (handed over by the layer after it): the
- *     BatchNorm backward launch is skipped (dres, dgamma, dbeta must be NULL). */
+ *     BatchNorm backward launch is skipped (dres must be NULL).
+ * With TRAINABLE gamma / beta in the producing layer (the reference's configuration: lib/modeling/resnet50.py:59-60 leaves the
+ * affine parameters of the frozen-statistics BatchNorm layers trainable) (round 4):
+ *   in_xr, in_mean, in_part (in_part may be NULL): that layer's convolution output [B,cin,hw], its running mean, and
+ *     [B][2][ceil(hw/32)][cin] floats that receive, per 32-pixel group g of every channel c, sum dz and sum dz (in_xr - in_mean)
+ *     over the group (dz = x > 0 ? dx : 0) - the per-channel sums of that layer's BatchNorm backward, written by the same epilogue;
+ *   a layer called with dy_is_dconv gets its own dgamma / dbeta from the array its consumer filled: cim_bn_part_finish below
+ *     (dgamma, dbeta must be NULL in that call). */
 long long cim_conv1x1_bwd_workspace(int B, int cin, int cout, int hw);
 int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                            const float* gamma, const float* mean, const float* var, float eps, int relu,
                            float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int hw,
                            float* workspace, void* stream, void* side_stream, int join,
-                           int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps);
+                           int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
+                           const float* in_xr, const float* in_mean, float* in_part);
+/* The affine gradients of chained layers from those partial sums, for n layers in ceil(n / 24) launches (`descs` is a HOST array):
+ * dbeta[c] = sum over images and groups of part[b][0][g][c], dgamma[c] = rsqrt(var[c] + eps) sum part[b][1][g][c], in index
+ * order (deterministic).  dgamma or dbeta may be NULL.  One call at the end of a backward pass serves the whole body. */
+typedef struct { const float* part; const float* var; float eps; float* dgamma; float* dbeta; int images; int parts; int channels; } cim_bn_part_desc;
+int cim_bn_part_finish(const cim_bn_part_desc* descs, int n, void* stream);
 
 /* 3 x 3 convolution (padding 1, stride 1 or 2, no bias, groups 1) -> frozen BatchNorm (+ residual) (+ ReLU) of the
  * bottlenecks (torchvision Bottleneck.conv2 / bn2, lib/modeling/resnet50.py:17-44,53-77), NCHW fp32, ONE image per call, as an
@@ -259,7 +272,14 @@ int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, const float* x_
                                 const float* gamma, const float* mean, const float* var, float eps, int relu, float* dres,
                                 float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int H, int W,
                                 int stride, int dilation, float* workspace, void* stream, void* side_stream, int join,
-                                int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps);
+                                int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
+                                const float* in_xr, const float* in_mean, float* in_part, const float* wt_ready);
+/* wt_ready (may be NULL): the weight transposed to [cout][3][3][cin] - the data gradient's A operand - when the caller made it
+ * ahead of the pass; else the call makes it itself (one small launch per layer in front of the data gradient).
+ * cim_conv3x3_wt_multi: those transposes for n layers in ceil(n / 16) launches (`descs` is a HOST array; weights only change at
+ * the optimizer step, so a body's transposes are made once per step beside the forward pass). */
+typedef struct { const float* w; float* wt; int cin; int cout; } cim_wt_desc;
+int cim_conv3x3_wt_multi(const cim_wt_desc* descs, int n, void* stream);
 
 /* ------------------------------------------------------------------ backbone BatchNorm chains (a-11)
  * Frozen-statistics BatchNorm (+ residual) (+ ReLU) of the ResNet / HRNet bodies, lib/modeling/resnet50.py:17-44,53-77

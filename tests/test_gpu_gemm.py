@@ -344,14 +344,19 @@ def test_conv1x1_bn_act_vs_aten(B, cin, cout, H, W, stride, relu, res):
     assert torch.equal(y2, y.detach())
 
 
-@pytest.mark.parametrize("inplanes,planes,stride,H,W", [(256, 64, 1, 33, 43), (256, 128, 2, 34, 45), (64, 16, 1, 9, 7)])
-def test_bottleneck_chained_bn_backward_is_bit_identical(dev, inplanes, planes, stride, H, W, monkeypatch):
+@pytest.mark.parametrize("affine", [True, False])
+@pytest.mark.parametrize("inplanes,planes,stride,H,W", [(256, 64, 1, 33, 43), (256, 128, 2, 34, 45), (64, 16, 1, 9, 7), (512, 128, 1, 65, 86)])
+def test_bottleneck_chained_bn_backward_is_bit_identical(dev, inplanes, planes, stride, H, W, affine, monkeypatch):
     """ops/chain.py: conv1's and conv2's BatchNorm + ReLU backward applied in the NEXT layer's data-gradient epilogue (no
     bn_act_bwd launch, lib/modeling/resnet50.py:17-44 torchvision Bottleneck) gives the same bits as the unchained backward -
     input gradient and all four weight gradients, with and without a downsample branch; a second consumer of a chained
-    tensor is an error, not a wrong gradient."""
+    tensor is an error, not a wrong gradient.
+    affine=True is the REFERENCE's configuration (resnet50.py:59-60: statistics frozen, gamma / beta trainable): bn1's and bn2's
+    affine gradients then come from the per-32-pixel partial sums the consumer's epilogue writes, finished in group order - equal
+    to the separate launch up to the summation order (checked against float64 as well), bit-equal from run to run, everything else
+    still bit-identical."""
     from cim_amd.modeling import resnet50
-    from cim_amd.ops import chain, conv1x1_bn_act, conv3x3_bn_act, fallback, gemm
+    from cim_amd.ops import conv1x1_bn_act, conv3x3_bn_act, fallback, gemm
     torch.manual_seed(inplanes + planes)
     ds = None
     if stride != 1 or inplanes != planes * 4:
@@ -361,13 +366,14 @@ def test_bottleneck_chained_bn_backward_is_bit_identical(dev, inplanes, planes, 
         for m in blk.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.5, 0.5); m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 2.0)
-                m.weight.requires_grad_(False); m.bias.requires_grad_(False)            # frozen as resnet50.py:53-77
+                if not affine:
+                    m.weight.requires_grad_(False); m.bias.requires_grad_(False)
     x0 = torch.randn(1, inplanes, H, W, device=dev)
+    names = [n for n, p in blk.named_parameters() if p.requires_grad]
     up = None
     res = {}
-    for flag in (True, False):
-        monkeypatch.setattr(resnet50, "FUSE_BN_BWD", flag)
-        chain.reset()
+    for flag in (True, False, "again"):
+        monkeypatch.setattr(resnet50, "FUSE_BN_BWD", bool(flag))
         for p in blk.parameters():
             p.grad = None
         x = x0.clone().requires_grad_(True)
@@ -377,18 +383,34 @@ def test_bottleneck_chained_bn_backward_is_bit_identical(dev, inplanes, planes, 
         gemm.join_side()
         torch.cuda.synchronize()
         res[flag] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.requires_grad]
-    assert len(res[True]) >= 5
-    for a, b in zip(res[True], res[False]):
-        assert torch.equal(a, b)
+    assert len(res[True]) >= 5 and len(res[True]) == len(names) + 2
+    for name, a, b, c in zip(["y", "dx"] + names, res[True], res[False], res["again"]):
+        assert torch.equal(a, c), name                              # deterministic
+        if name.startswith(("bn1.", "bn2.")):                       # partial sums in another order than the separate launch
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, name
+        else:
+            assert torch.equal(a, b), name
+    if affine:          # the chained affine gradients against float64 autograd of the same block
+        blk64 = resnet50.Bottleneck(inplanes, planes, stride, None if ds is None else torch.nn.Sequential(
+            torch.nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(planes * 4))).to(dev).double().eval()
+        blk64.load_state_dict({k: v.double() for k, v in blk.state_dict().items()})
+        x64 = x0.double().requires_grad_(True)
+        h = torch.relu(blk64.bn1(blk64.conv1(x64)))
+        h = torch.relu(blk64.bn2(blk64.conv2(h)))
+        idn = x64 if ds is None else blk64.downsample(x64)
+        torch.relu(blk64.bn3(blk64.conv3(h)) + idn).backward(up.double())
+        want = dict(blk64.named_parameters())
+        for name, a in zip(names, res[True][2:]):
+            if name.startswith(("bn1.", "bn2.")):
+                err = float((a.double() - want[name].grad).norm() / (want[name].grad.norm() + 1e-30))
+                assert err < 5e-6, (name, err)
     # misuse: the chained tensor feeds a second consumer -> its producer refuses the accumulated gradient
     monkeypatch.setattr(resnet50, "FUSE_BN_BWD", True)
-    chain.reset()
     x = x0.clone().requires_grad_(True)
     h1 = conv1x1_bn_act(x, blk.conv1, blk.bn1)
     h2 = conv3x3_bn_act(h1, blk.conv2, blk.bn2, fuse_input_bn=True)
     with pytest.raises(RuntimeError, match="second consumer"):
         (h2.sum() + h1.sum()).backward()
-    chain.reset()
     gemm.join_side(discard=True)
 
 

@@ -172,35 +172,48 @@ def test_lr_schedule_and_momentum_correction_match_reference(golden_dir):
 
 def test_chained_bn_backward_protocol():
     """cim_amd/ops/chain.py (host side of the BatchNorm backward folded into the next layer's data gradient): a producer is only
-    tagged when it is eligible (ReLU, no residual, frozen BatchNorm, a differentiable output); the consumer marks it as taken; the
-    producer recognises the handed-over gradient by its storage, exactly once, and refuses anything else once it was taken."""
+    tagged when it is eligible (ReLU, no residual, no trainable folded bias, a differentiable output) - with TRAINABLE gamma / beta
+    (the reference's configuration, lib/modeling/resnet50.py:59-60) it is, and the consumer is told to write partial sums; the
+    consumer marks it as taken; the producer recognises the handed-over gradient by its storage, exactly once, and refuses anything
+    else once it was taken.  The marks live in the producer's own state (no process-global set)."""
     import pytest
     import torch
     from cim_amd.ops import chain
-    chain.reset()
     gamma, beta, mean, var = (torch.ones(4) for _ in range(4))
     y = torch.zeros(2, 4, 3, 3, requires_grad=True)
-    assert chain.tag(y, gamma, beta, mean, var, 1e-5, relu=False, has_res=False) is None and not hasattr(y, "_cim_bn")
-    assert chain.tag(y, gamma, beta, mean, var, 1e-5, relu=True, has_res=True) is None
-    assert chain.tag(y, gamma.clone().requires_grad_(), beta, mean, var, 1e-5, True, False) is None         # trainable BatchNorm
-    assert chain.tag(torch.zeros(3), gamma, beta, mean, var, 1e-5, True, False) is None                      # nothing to differentiate
-    state = chain.tag(y, gamma, beta, mean, var, 1e-5, relu=True, has_res=False)
-    assert state == {"taken": False} and y._cim_bn[3] is state
+    st = lambda: {"taken": False, "xr": torch.zeros(2, 4, 3, 3)}
+    assert chain.tag(y, gamma, beta, mean, var, 1e-5, False, False, st()) is None and not hasattr(y, "_cim_bn")     # no ReLU
+    assert chain.tag(y, gamma, beta, mean, var, 1e-5, True, True, st()) is None                                       # residual
+    assert chain.tag(y, gamma, beta, mean.clone().requires_grad_(), var, 1e-5, True, False, st()) is None            # trainable folded bias
+    assert chain.tag(torch.zeros(3), gamma, beta, mean, var, 1e-5, True, False, st()) is None                        # nothing to differentiate
+    assert chain.tag(y, gamma, beta, mean, var, 1e-5, True, False, None) is None                                      # no-grad call
+    state = st()
+    assert chain.tag(y, gamma, beta, mean, var, 1e-5, True, False, state) is state and y._cim_bn.state is state and not y._cim_bn.affine
     assert chain.input_bn(y, enabled=False) is None and not state["taken"]
     assert chain.input_bn(torch.zeros(3), enabled=True) is None                                             # untagged input
-    g, v, eps = chain.input_bn(y, enabled=True)
-    assert g is gamma and v is var and eps == 1e-5 and state["taken"]
+    ib = chain.input_bn(y, enabled=True)
+    assert ib.gamma is gamma and ib.var is var and ib.eps == 1e-5 and ib.mean is mean and state["taken"]
+    assert chain.c_args(None, None) == (None, None, 0.0, None, None, None)
+    assert chain.c_args(ib, None)[3:] == (None, None, None) and chain.c_args(ib, None)[0] == gamma.data_ptr()
+    part = torch.zeros(2, 2, 1, 4)
+    assert chain.c_args(ib, part)[3:] == (state["xr"].data_ptr(), mean.data_ptr(), part.data_ptr())
     dx, other = torch.zeros(2, 4, 3, 3), torch.zeros(2, 4, 3, 3)
-    chain.hand_over(dx)
-    assert chain.take(dx.view(2, 4, 9), state)                   # the same storage, whatever the wrapper
+    chain.hand_over(ib, dx, part)
+    ok, got = chain.take(dx.view(2, 4, 9), state)                # the same storage, whatever the wrapper
+    assert ok and got is part
     with pytest.raises(RuntimeError, match="second consumer"):   # consumed: a second take of it is "a different gradient"
         chain.take(dx, state)
     with pytest.raises(RuntimeError, match="second consumer"):
         chain.take(other, state)
-    assert not chain.take(other, {"taken": False}) and not chain.take(other, None)     # a layer nobody chained to: the ordinary path
-    chain.hand_over(dx)
-    chain.reset()
-    assert not chain.take(dx, None)
+    assert chain.take(other, {"taken": False}) == (False, None) and chain.take(other, None) == (False, None)   # nobody chained: the ordinary path
+    # trainable affine parameters: eligible, flagged
+    y2 = torch.zeros(2, 4, 3, 3, requires_grad=True)
+    s2 = st()
+    chain.tag(y2, gamma.clone().requires_grad_(), beta, mean, var, 1e-5, True, False, s2)
+    assert y2._cim_bn.affine
+    # a mark handed to ANOTHER producer's state is not this layer's (no recycled-address confusion across layers)
+    chain.hand_over(chain.input_bn(y2, True), dx)
+    assert chain.take(dx, {"taken": False}) == (False, None)
 
 
 def test_postponed_launches_run_once_in_order_and_are_dropped_by_a_discarding_join():
