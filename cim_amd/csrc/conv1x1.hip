@@ -348,6 +348,14 @@ __global__ __launch_bounds__(128 * WN) void gemm_small_kernel(const SmallArgs g)
         small_splitk_combine<BNT>(g, tile, m0, n0, tid, NT, reinterpret_cast<volatile int*>(&As[0][0]));
 }
 
+// Round 4, measured and dropped: a REGISTER-DIRECT form of this product - every wave fetches its MFMA operands straight from memory
+// (lane (r, h) takes the 16 k of its half of a slab: four 16-byte loads per K-contiguous row, 16 coalesced 4-byte loads per
+// row-contiguous one; no LDS staging, no barrier in the loop), one 32 x 32 tile per workgroup whose four waves split K and meet in
+// LDS, so that long-K products need no split-K over workgroups and no reduce launch.  Alone (tools/bench_gemm_small.py, 7 layer
+// shapes, us forward / dX / dW) 147 / 126 / 121 against this kernel's 159 / 128 / 147 - but INSIDE the step slower: body forward
+// 2.10 vs 1.87 ms, body backward phase 4.62 vs 4.27 ms, step 14.6-14.7 vs 13.8-14.2 ms (same box, interleaved): its operands are
+// re-read from L2 by every 32 x 32 tile (~90 MB per res4 layer) and its 4x more workgroups queue behind the 256-workgroup
+// launches of MaskFuse's late weight gradients, which is where the body's backward actually runs (bench.py --phases).
 // split-K: sum of the partial products in a fixed order (deterministic) + the same epilogue as the single-pass kernel.
 // The partials of an element are loaded eight at a time (independent loads in flight) and added in split order: with a
 // load-add-load-add loop a thread paid one memory round trip per split (8-64 of them), and the ~90 reduce launches per step
