@@ -718,6 +718,8 @@ static int gemm_small_impl(const float* A, const float* B, float* C, int M, int 
     set_input_bn(g, in_bn);
     const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
     CIM_CHECK_ARG(tiles * 2 < (1ll << 31) && splits <= 65535 && M <= 65535);
+    // (the loaders address the operands through buffer resources with 32-bit byte offsets; OOB = 2^31 - 1 must lie behind them)
+    CIM_CHECK_ARG(tile_extent(a_mcontig != 0, M, K, lda) < (1ll << 29) && tile_extent(b_kcontig == 0, N, K, ldb) < (1ll << 29));
     const bool narrow = tiles * splits < 128;           // 64 x 32 tiles only for problems that cannot fill the chip otherwise
     g.tile_cnt = splits > 1 && !g.mpart ? splitk_counters(narrow ? (long long)((M + SBM - 1) / SBM) * ((N + 31) / 32) : tiles) : nullptr;
     hipStream_t st = cim::as_stream(stream);
@@ -892,8 +894,8 @@ ConvGeom conv_geom(int cin, int cout, int H, int W, int stride, int mode, int di
 #define CONV3_ARGS_OK(CIN_MULT)                                                                                      \
     CIM_CHECK_ARG(cin > 0 && cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && W <= 4096 &&               \
                   dilation >= 1 && dilation <= 8 && (dilation == 1 || stride == 1) &&                                 \
-                  (long long)H * W < (1ll << 20) && (long long)cin * H * W < (1ll << 31) && (long long)cout * H * W < (1ll << 31) && \
-                  (long long)cin * cout * 9 < (1ll << 31) && cin % (CIN_MULT) == 0)
+                  (long long)H * W < (1ll << 20) && (long long)cin * H * W < (1ll << 29) && (long long)cout * H * W < (1ll << 29) && \
+                  (long long)cin * cout * 9 < (1ll << 29) && cin % (CIN_MULT) == 0)       /* (2^29 floats: 32-bit byte offsets of the buffer loads) */
 
 extern "C" int cim_conv3x3_nchw_splits(int cin, int cout, int H, int W, int stride) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -919,7 +921,7 @@ extern "C" int cim_conv7x7_nchw_f32(const float* x, const float* w, float* y, in
                                     const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                                     int relu, void* stream) {
     CIM_CHECK_ARG(x && w && y && cin > 0 && cout > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && W <= 4096);
-    CIM_CHECK_ARG((long long)H * W < (1ll << 20) && (long long)cin * H * W < (1ll << 31) && (long long)cout * H * W < (1ll << 31));
+    CIM_CHECK_ARG((long long)H * W < (1ll << 20) && (long long)cin * H * W < (1ll << 29) && (long long)cout * H * W < (1ll << 29));
     CIM_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (gamma == nullptr) == (mean == nullptr) && (gamma == nullptr) == (var == nullptr));
     const ConvGeom c = conv_geom(cin, cout, H, W, stride, CONV_FWD);
     conv3x3_launch(CONV_FWD, w, x, y, cout, c.Ho * c.Wo, 49 * cin, 49 * cin, c.Ho * c.Wo, c, nullptr, gamma, beta, mean, var, eps,

@@ -625,6 +625,10 @@ static bool pair_dims_ok(int M, int N, int K, int lda, int ldb, int ldc, int a_m
     if (lda % 8 != 0 || ldb % 8 != 0) return false;
     if (a_mcontig ? (M % 8 != 0 || lda < M) : (lda < K)) return false;
     if (b_kcontig ? (ldb < K) : (N % 8 != 0 || ldb < N)) return false;
+    // the stagers address a lane's chunks with 32-bit byte offsets from the operand's base (StageKC / StageMC: r * ld * 4): the
+    // addressed extent of each operand (per batch entry) must stay below 4 GiB - fc1's 822 MB weight is the largest today
+    const long long ext_a = (long long)(a_mcontig ? K : M) * lda * 4, ext_b = (long long)(b_kcontig ? N : K) * ldb * 4;
+    if (ext_a >= (1ll << 32) || ext_b >= (1ll << 32)) return false;
     return true;
 }
 

@@ -751,6 +751,16 @@ extern "C" int cim_mining_step(const cim_mining_args* args, void* stream) {
     if (lds3 > 64 * 1024)
         CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(step_arbitrate_sample_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    // Launch 3's workgroups (one per layer, R <= CIM_MAX_LAYERS) hand their list lengths to the higher-numbered ones through
+    // device words tagged with this CALL's epoch.  No dispatch ORDER is assumed - a waiting workgroup sleeps on the word while
+    // the others are placed wherever a CU is free; at most R - 1 CUs ever hold waiters - but the epoch and the slot are baked
+    // into the launch's arguments: a captured launch would replay with a stale epoch and read the previous replay's words.  So
+    // this entry refuses a capturing stream (the step's mining runs eagerly between the captured body and the losses).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        cim::set_error("cim_mining_step: the stream is capturing a HIP graph - the mining launches cannot be captured (per-call epoch)");
+        return -1;
+    }
     unsigned long long* sync = nullptr;
     unsigned long long epoch = 0;
     CIM_CHECK_ARG(layer_sync_slot(&sync, &epoch) && N < (1 << 20));

@@ -7,20 +7,19 @@ load unchanged: `res1.0`=conv1, `res1.1`=bn1, `res2|res3|res4.<i>.{conv1,bn1,con
 bn3,downsample.0,downsample.1}`.  All BatchNorm layers stay in eval mode and res1-2 are frozen,
 as resnet50.py:53-77 does.
 """
-import os
-
 import torch
 import torch.nn as nn
 
 from ..core.config import cfg
-from ..ops import bn_act, conv1x1_bn_act, conv3x3_bn_act, conv7x7_bn_act
+from ..ops import conv1x1_bn_act, conv3x3_bn_act, conv7x7_bn_act
 from ..ops.conv3x3 import prefetch_transposed_weights
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "resnet50.MaskFuse" by get_func)
 
 
-OWN_3X3 = os.environ.get("CIM_BACKBONE_3X3", "hip") != "aten"      # CIM_BACKBONE_3X3=aten: MIOpen's 3 x 3 kernels + the bn_act launch (A/B runs)
-FUSE_BN_BWD = os.environ.get("CIM_FUSE_BN_BWD", "1") == "1"          # BatchNorm backward of conv1 / conv2 inside the next layer's data gradient
-OWN_1X1 = os.environ.get("CIM_BACKBONE_1X1", "hip") != "aten"      # CIM_BACKBONE_1X1=aten: the MIOpen / rocBLAS path (A/B runs)
+# BatchNorm backward of conv1 / conv2 inside the next layer's data gradient (ops/chain.py); a module attribute so that tests can
+# compare both forms.  (The library paths - MIOpen convolutions, ATen BatchNorm - are not selectable here: tools/bench_library_paths.py
+# patches them in for A/B runs.)
+FUSE_BN_BWD = True
 
 
 class Bottleneck(nn.Module):
@@ -42,19 +41,13 @@ class Bottleneck(nn.Module):
         # (small-tile fp32-MFMA GEMM - implicit for the 3 x 3 - with the chain in its epilogue, cim_amd/csrc/conv1x1.hip).
         # They fall back to the ATen ops for a BN in training mode or CPU tensors.
         identity = x
-        if OWN_1X1:
-            # (fuse_input_bn: conv1's / conv2's outputs have one consumer each - their BatchNorm + ReLU backward rides in the next
-            # layer's data-gradient epilogue, ops/chain.py)
-            out = conv1x1_bn_act(x, self.conv1, self.bn1)
-            out = conv3x3_bn_act(out, self.conv2, self.bn2, fuse_input_bn=FUSE_BN_BWD) if OWN_3X3 else bn_act(self.conv2(out), self.bn2)
-            if self.downsample is not None:
-                identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-            return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity, fuse_input_bn=FUSE_BN_BWD and OWN_3X3)
-        out = bn_act(self.conv1(x), self.bn1)
-        out = bn_act(self.conv2(out), self.bn2)
+        # (fuse_input_bn: conv1's / conv2's outputs have one consumer each - their BatchNorm + ReLU backward rides in the next
+        # layer's data-gradient epilogue, ops/chain.py)
+        out = conv1x1_bn_act(x, self.conv1, self.bn1)
+        out = conv3x3_bn_act(out, self.conv2, self.bn2, fuse_input_bn=FUSE_BN_BWD)
         if self.downsample is not None:
-            identity = bn_act(self.downsample[0](x), self.downsample[1], relu=False)
-        return bn_act(self.conv3(out), self.bn3, residual=identity)
+            identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity, fuse_input_bn=FUSE_BN_BWD)
 
 
 def _make_layer(inplanes, planes, blocks, stride):
@@ -129,13 +122,13 @@ class resnet(nn.Module):
         return {name: name for name, _ in self.named_parameters()}, []
 
     def forward(self, x):
-        if OWN_3X3 and self.training and torch.is_grad_enabled():
+        if self.training and torch.is_grad_enabled():
             # the transposed 3 x 3 weights the backward's data gradients read: one launch beside the forward (ops/conv3x3.py)
             prefetch_transposed_weights([b.conv2 for i in range(cfg.ResNet.FREEZE_AT + 1, self.block_counts + 1)
                                          for b in getattr(self, "res%d" % i)])
         for i in range(self.block_counts):
             m = getattr(self, "res%d" % (i + 1))
-            if i == 0 and OWN_3X3:      # the stem: 7 x 7 convolution + BatchNorm + ReLU in one launch (frozen: forward only), then the max-pool
+            if i == 0:      # the stem: 7 x 7 convolution + BatchNorm + ReLU in one launch (frozen: forward only), then the max-pool
                 x = m[3](conv7x7_bn_act(x, m[0], m[1], relu=True))
             else:
                 x = m(x)

@@ -226,7 +226,18 @@ class DataParallel(nn.Module):
             return False
         self._backward_started()
         with torch.cuda.stream(stream):
-            if p.grad is None:
+            view = self._view_of.get(p)
+            if view is not None:
+                # a parameter of a FLAT bucket (a MaskFuse weight under big_bytes: small-channel configurations): the all-reduce
+                # runs over the flat buffer, so the gradient must be IN its view before the bucket goes out - a fresh tensor
+                # installed as .grad (the driver dropped the views: zero_grad(set_to_none=True)) would only be copied in by
+                # _rebind_views() at the end of the pass, after the bucket was reduced without it
+                if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(g) if p.grad is None else view.copy_(p.grad + g)
+                    p.grad = view
+                else:
+                    view += g
+            elif p.grad is None:
                 p.grad = g
             else:
                 p.grad += g

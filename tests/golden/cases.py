@@ -118,3 +118,56 @@ def tta_inputs():
     boxes = np.stack([x1, y1, np.minimum(x1 + bw, w - 1), np.minimum(y1 + bh, h - 1)], 1).astype(np.float32)
     masks = (rs.rand(n, 7, 7) > 0.4).astype(np.float32)
     return im, boxes, masks
+
+
+# ---- whole-step gradient accounting (shared by the -m gpu parity tests) -----------------------------------------------
+# Every parameter gradient is held to ||g - g_ref|| <= GRAD_RTOL ||g_ref|| (measured on MI355X: <= 2e-4, the BatchNorm affine
+# gradients of res3) - EXCEPT gradients that cancel to nothing: the detector head ends in a softmax over the PROPOSALS
+# (lib/modeling/heads.py:213), so its bias gradient is exactly 0 and, at random initialisation (nearly equal seg_x rows), its
+# weight gradient cancels to ~1e-8 per element.  Both implementations then hold rounding noise; a relative bound on it measures
+# nothing and, used as the bound for everything (rounds 1-3: 6e-3 = 3x the detector bias's 1.8e-3), hid what the other 160
+# parameters do.  A gradient whose reference is below VANISHING per element (rms) is therefore bounded ABSOLUTELY, per element.
+GRAD_RTOL = 5e-4
+VANISHING = 1e-6          # rms per element of the reference gradient below which the absolute bound applies
+VANISHING_ATOL = 1e-7     # rms per element of g - g_ref for such gradients (measured: <= 2e-8)
+
+
+def gradient_deviation(got, ref, rtol=GRAD_RTOL, check=True):
+    """got / ref: {name: gradient tensor}.  -> (worst relative deviation among the ordinary gradients, its parameter, worst
+    per-element rms deviation among the vanishing ones)."""
+    worst, where, van = 0.0, "", 0.0
+    for n, r in ref.items():
+        g = got[n].detach().double().cpu()
+        r = r.detach().double().cpu()
+        rms = r.numel() ** 0.5
+        if float(r.norm()) / rms < VANISHING:
+            e = float((g - r).norm()) / rms
+            van = max(van, e)
+            if check:
+                assert e <= VANISHING_ATOL, "%s: a vanishing gradient (rms %.2e) deviates by %.3g per element" % (n, float(r.norm()) / rms, e)
+            continue
+        d = float((g - r).norm()) / float(r.norm())
+        if d > worst:
+            worst, where = d, n
+        if check:
+            assert d <= rtol, "gradient mismatch at %s: %.3g (bound %.1e)" % (n, d, rtol)
+    return worst, where, van
+
+
+def record_deviation(section, values):
+    """Merge measured deviations into gpurun_out/parity_deviation.json (copied to profiles/rN/ with the round's profiles)."""
+    import json
+    out_dir = os.path.join(_REPO, "gpurun_out")
+    if not os.path.isdir(out_dir):
+        return
+    path = os.path.join(out_dir, "parity_deviation.json")
+    table = {}
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                table = json.load(f)
+        except ValueError:
+            table = {}
+    table[section] = values
+    with open(path, "w") as f:
+        json.dump(table, f, indent=1)

@@ -95,14 +95,23 @@ def test_whole_step_full_size(tag):
         hm = model.cls_iou_model
         pc_, _, rc_, ri_ = captured["scores"]
         rows = torch.from_numpy(pick).to(dev)
+        # head scores as LOG-probabilities (= relative deviation of the probabilities: an absolute 2e-4 on a softmax output of
+        # ~0.05 over C + 1 classes was a 4e-3 relative bound); sigmoid scores on both p and 1 - p
         worst_head = 0.0
         for lin, got, act in ([(hm.classifier, pc_, "softmax")] + [(l, g, "softmax") for l, g in zip(hm.refine_cls, rc_)]
                               + [(l, g, "sigmoid") for l, g in zip(hm.refine_iou, ri_)]):
-            logit = torch.nn.functional.linear(seg, *cpu(lin))
-            ref = torch.softmax(logit, dim=1) if act == "softmax" else torch.sigmoid(logit)
-            worst_head = max(worst_head, float((got.detach()[rows].cpu() - ref).abs().max()))
-        assert worst_head < 2e-4, "head scores deviate from the CPU evaluation: %.3g" % worst_head      # probabilities in [0, 1]
-    print("%s full size: 64 sampled proposals vs CPU: seg_x %.2e of max, head scores %.2e absolute" % (tag, dev_seg, worst_head))
+            logit = torch.nn.functional.linear(seg, *cpu(lin)).double()
+            g64 = got.detach()[rows].cpu().double()
+            if act == "softmax":
+                dev_h = (g64.log() - torch.log_softmax(logit, dim=1)).abs().max()
+            else:
+                dev_h = torch.maximum((g64.log() - torch.nn.functional.logsigmoid(logit)).abs().max(),
+                                      ((1 - g64).log() - torch.nn.functional.logsigmoid(-logit)).abs().max())
+            worst_head = max(worst_head, float(dev_h))
+        assert worst_head < HEAD_LOG_TOL, "head scores deviate from the CPU evaluation: %.3g (log-probability)" % worst_head
+    print("%s full size: 64 sampled proposals vs CPU: seg_x %.2e of max, head scores %.2e relative" % (tag, dev_seg, worst_head))
+    from cases import record_deviation
+    record_deviation("%s full size | 64 sampled proposals vs CPU ATen" % tag, dict(seg_x_rel_of_max=dev_seg, head_log_prob=worst_head))
 
     # ---- mining: HIP scores -> NumPy oracle, same seed, layers in order
     pc, pd, rc, ri = captured["scores"]
@@ -152,21 +161,19 @@ def test_whole_step_full_size(tag):
             got = float(out["losses"][k].detach())
             dev_rel[k] = abs(got - v) / max(abs(v), 1e-12)
             np.testing.assert_allclose(got, v, rtol=WHOLE_STEP_RTOL, atol=1e-6, err_msg=k)
-        worst = 0.0
+        from cases import gradient_deviation
         cpu_p = dict(cpu_model.named_parameters())
-        for name, p in model.named_parameters():
-            if p.grad is None or cpu_p[name].grad is None:
-                continue
-            g_ref = cpu_p[name].grad
-            # absolute floor for vanishing gradients (the detector head: softmax over proposals, exact gradient 0 for the bias)
-            rel = float((p.grad.cpu() - g_ref).norm()) / (float(g_ref.norm()) + 1e-5 * g_ref.numel() ** 0.5)
-            worst = max(worst, rel)
-            assert rel < WHOLE_STEP_GRAD_RTOL, "gradient mismatch at %s: %.3g" % (name, rel)
-        print("cfg2 full size: loss deviations %s, worst gradient deviation %.3g" % ({k: "%.2e" % v for k, v in dev_rel.items()}, worst))
+        got_g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None and cpu_p[n].grad is not None}
+        worst, where, zero_abs = gradient_deviation(got_g, {n: cpu_p[n].grad for n in got_g})      # (asserts per parameter)
+        print("cfg2 full size: loss deviations %s, worst gradient deviation %.3g (%s), vanishing gradients <= %.2e per element"
+              % ({k: "%.2e" % v for k, v in dev_rel.items()}, worst, where, zero_abs))
+        record_deviation("cfg2 full size | HIP step vs CPU oracle step", dict(loss_rel=dev_rel, grad_rel=worst, worst_param=where,
+                                                                              vanishing_gradient_rms=zero_abs))
 
 
-# Measured on MI355X for the default engine (f16x2 + winograd7) against the fp32 CPU oracle at cfg2 full size: losses
-# 1.1e-7 relative, worst ||g - g_ref|| / ||g_ref|| over all parameters 1.8e-3 (tests/test_gpu_tolerance.py records the
-# same numbers per engine / conv algorithm).  The stated tolerance of the build (README): losses 1e-5, gradients 6e-3.
+# Stated tolerance of the build against the fp32 CPU oracle step (README): losses 1e-5 relative; every parameter gradient
+# ||g - g_ref|| <= 5e-4 ||g_ref|| (cases.GRAD_RTOL; measured <= 2e-4), gradients that cancel to < 1e-6 per element (the detector
+# head under its softmax over proposals) <= 1e-7 per element absolute (cases.VANISHING_ATOL; measured 2e-8); head scores 1e-3 in
+# log-probability at the 64 sampled proposals (measured 2e-7).
 WHOLE_STEP_RTOL = 1e-5
-WHOLE_STEP_GRAD_RTOL = 6e-3
+HEAD_LOG_TOL = 1e-3

@@ -340,7 +340,7 @@ def test_losses_on_device_match_reference(dev, name, golden_dir):
 def test_training_step_matches_cpu_oracle(dev, config):
     """Same weights, same synthetic image: the 4 losses and the parameter gradients of the HIP
     model against the host restatement (torch CPU ops + oracle ROIAlign + oracle mining).
-    fp32 conv / GEMM summation order differs between the HIP kernels and ATen's CPU kernels (and, for VGG16 / HRNet, MIOpen),
+    fp32 conv / GEMM summation order differs between the HIP kernels and ATen's CPU kernels,
     hence a tolerance; the pseudo labels are index-exact, so the same loss terms are active."""
     import copy
     from cim_amd import mask_iou, synthetic
@@ -367,8 +367,9 @@ def test_training_step_matches_cpu_oracle(dev, config):
     for k, v in ref.items():
         assert out["losses"][k].shape == (1,)
         np.testing.assert_allclose(float(out["losses"][k]), v, rtol=1e-4, atol=1e-6, err_msg=k)
+    from cases import gradient_deviation
     cpu_p = dict(cpu_model.named_parameters())
-    checked = 0
+    got_g, ref_g = {}, {}
     for name, p in gpu_model.named_parameters():
         if not p.requires_grad:
             assert cpu_p[name].grad is None
@@ -377,13 +378,13 @@ def test_training_step_matches_cpu_oracle(dev, config):
         if p.grad is None or g_ref is None:       # e.g. HRNet's unused `classifier`
             assert p.grad is None and g_ref is None, name
             continue
-        g = p.grad.cpu()
-        # relative to the gradient's own norm, with an absolute floor for vanishing gradients
-        # (the detector head: softmax over proposals, |g| ~ 1e-9)
-        tol = 6e-3 * float(g_ref.norm()) + 1e-6 * (g_ref.numel() ** 0.5)
-        assert float((g - g_ref).norm()) < tol, "gradient mismatch at %s" % name
-        checked += 1
-    assert checked > 20
+        got_g[name], ref_g[name] = p.grad, g_ref
+    # every gradient within 1e-3 of its own norm; gradients that cancel to nothing by an absolute bound (cases.py).  (The full-size
+    # runs of tests/test_gpu_fullsize.py hold 5e-4, measured 1.8e-4; on these small images a BatchNorm shift gradient - a signed sum
+    # over few pixels that cancels to a small remainder - measures 5.0e-4 against ATen's CPU summation order: 2x margin here.)
+    worst, where, _ = gradient_deviation(got_g, ref_g, rtol=1e-3)
+    print("%s: worst gradient deviation %.3g at %s" % (config, worst, where))
+    assert len(got_g) > 20
 
 
 @pytest.mark.parametrize("config", ["resnet50_voc", "vgg16_voc"])
@@ -424,7 +425,7 @@ def test_backbone_hip_graph_replay_matches_eager(dev, config, monkeypatch):
     st = model.__dict__["_graphed_bodies"]
     assert any(g not in (None, False) for g in st["graphs"].values()), "backbone was not captured"
     for got in (graphed, replay):
-        # MIOpen may pick another solver for a conv under capture (no lazily grown workspace): fp32 summation-order noise
+        # (split-K workspaces differ under capture: fp32 summation-order noise)
         torch.testing.assert_close(got[1], eager[1], rtol=1e-4, atol=1e-4)
         for k in eager[0]:
             np.testing.assert_allclose(got[0][k], eager[0][k], rtol=1e-4, atol=1e-6)

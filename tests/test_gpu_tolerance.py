@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from cases import E2E, e2e_inputs, procedural_init
+from cases import E2E, GRAD_RTOL, e2e_inputs, gradient_deviation, procedural_init, record_deviation
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -21,7 +21,7 @@ COMBOS = [("fp32", "direct"), ("fp32", "winograd7"), ("bf16x3", "direct"), ("bf1
           ("f16x2", "direct"), ("f16x2", "winograd7"), ("f16x2p", "winograd7")]
 # bounds = ~3x the values measured on MI355X (see the printed table): (loss rel., gradient rel. vs reference / vs fp32-direct)
 LOSS_TOL = 1e-5
-GRAD_TOL = 6e-3
+GRAD_TOL = GRAD_RTOL          # 5e-4 per parameter; gradients that cancel to nothing are bounded absolutely (cases.py)
 
 
 def _set(monkeypatch, engine, algo):
@@ -46,12 +46,7 @@ def _step(model, batch, seed):
 
 
 def _grad_dev(g, ref):
-    worst, where = 0.0, ""
-    for n, r in ref.items():
-        floor = 1e-5 * r.numel() ** 0.5            # vanishing gradients (detector bias: exact 0 up to rounding)
-        d = float((g[n] - r).norm()) / (float(r.norm()) + floor)
-        if d > worst:
-            worst, where = d, n
+    worst, where, _ = gradient_deviation(g, ref, check=False)
     return worst, where
 
 
@@ -118,11 +113,51 @@ def test_engine_and_algorithm_deviation(monkeypatch, golden_dir):
         ldev = max(abs(losses[k] - ref_l[k]) / abs(ref_l[k]) for k in ref_l)
         gdev, where = _grad_dev(grads, ref_g)
         table["cfg2 vs fp32+direct | %s + %s" % (engine, algo)] = dict(loss_rel=ldev, grad_rel=gdev, worst_param=where)
+    del m, cpu_m
+    # ---- cfg2 at full size with weights under which the LOSSES move with the contraction: with the random initialisation above
+    # the heads' logits are ~1e-2 wide, the scores flat, and the four losses bit-equal in fp32 whatever the engine (loss_rel
+    # exactly 0.0 in rounds 2-3: a vacuous check).  Here the scoring heads' weights are scaled up until the classifier's logits
+    # have unit spread over the proposals: the scores then depend visibly on seg_x, the mining still finds seeds, and the engines
+    # must agree to LOSS_TOL on losses that DO move.
+    torch.manual_seed(3)
+    m = Generalized_RCNN()
+    for mod in m.modules():
+        if hasattr(mod, "bn3"):
+            torch.nn.init.constant_(mod.bn3.weight, 0.25)
+    m = m.to(DEV).train()
+    _set(monkeypatch, "fp32", "direct")
+    got = {}
+    hook = m.Box_Head.register_forward_hook(lambda mod, i, o: got.update(seg_x=o.detach()))
+    with torch.no_grad():
+        np.random.seed(77)
+        m(**batch)
+        hook.remove()
+        spread = float(torch.nn.functional.linear(got["seg_x"], m.cls_iou_model.classifier.weight).std())
+        for p in m.cls_iou_model.parameters():
+            p.mul_(1.0 / spread)
+    from cim_amd.modeling import heads as _heads
+    _heads.settle_rng()
+    ref_l = ref_g = None
+    moved = 0.0
+    for engine, algo in [("fp32", "direct"), ("f16x2", "winograd7"), ("f16x2p", "winograd7")]:
+        _set(monkeypatch, engine, algo)
+        losses, grads = _step(m, batch, 77)
+        assert all(np.isfinite(v) for v in losses.values()), losses
+        if ref_l is None:
+            ref_l, ref_g = losses, grads
+            print("cfg2 scaled heads: losses", losses)
+            assert sum(1 for v in losses.values() if abs(v) > 1e-6) >= 3, "degenerate case (losses %s)" % losses
+            continue
+        ldev = max(abs(losses[k] - ref_l[k]) / abs(ref_l[k]) for k in ref_l if abs(ref_l[k]) > 1e-6)
+        gdev, where = _grad_dev(grads, ref_g)
+        moved = max(moved, ldev)
+        table["cfg2 scaled heads vs fp32+direct | %s + %s" % (engine, algo)] = dict(loss_rel=ldev, grad_rel=gdev, worst_param=where)
+    assert moved > 0.0, "the scaled-heads case is vacuous too: no loss moved between engines"
     print("\nPARITY-DEVIATION " + json.dumps(table))
-    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "parity_deviation.json"), "w") as f:
-            json.dump(table, f, indent=1)
+    for k, v in table.items():
+        record_deviation(k, v)
     for k, v in table.items():
         assert v["loss_rel"] <= LOSS_TOL, (k, v)
-        assert v.get("grad_rel", v.get("grad_norm_rel")) <= GRAD_TOL, (k, v)
+        # (scaled heads: the gradients reaching the body are ~30x larger relative to its activations; measured 5.3e-4 on a
+        # BatchNorm scale gradient of res4 - a sum of ~10^6 products - between the fp16-split Winograd engine and fp32 + direct)
+        assert v.get("grad_rel", v.get("grad_norm_rel")) <= (2 * GRAD_TOL if k.startswith("cfg2 scaled heads") else GRAD_TOL), (k, v)
