@@ -105,8 +105,8 @@ def test_roi_align_maskcat_fused_vs_oracle(dev, monkeypatch):
 
 @pytest.mark.parametrize("B,C,H,W,K", [(2, 8, 13, 17, 300), (3, 1028, 9, 11, 40), (1, 2048, 17, 22, 70)])
 def test_roi_align_batches_groups_and_channel_chunks(dev, B, C, H, W, K):
-    """Aggregated-weight forward / gather backward beyond the benchmark shape: several images per call, more than
-    256 ROIs (K-groups meeting through atomics), channel counts past one 1024-lane chunk and not a multiple of it."""
+    """Table-driven forward / region backward beyond the benchmark shape: several images per call, several ROI groups,
+    channel counts past one 1024-lane chunk and not a multiple of the 256-channel slice."""
     from cim_amd.ops import roi_align
     from oracle import roi_align as oracle
     feat0, rois = _roi_case(B * 31 + K, C, H, W, K)
@@ -125,10 +125,11 @@ def test_roi_align_batches_groups_and_channel_chunks(dev, B, C, H, W, K):
 
 @pytest.mark.parametrize("B,C,H,W,K,gs", [(2, 8, 13, 17, 300, None), (1, 516, 33, 43, 200, None), (1, 256, 25, 30, 700, "128")])
 def test_roi_align_backward_forms_agree_with_oracle(dev, B, C, H, W, K, gs, monkeypatch):
-    """The three backward forms behind cim_roi_align(_maskcat)_bwd_ws - region (default: partial maps, interleaved entry
-    order), its producer / consumer variant (CIM_ROI_BWD_PIPE=1) and the gather form (CIM_ROI_BWD_GATHER=1) - against
-    the fp64 oracle, with several images, several ROI groups (128-ROI groups / two 64-ROI chunks in the last case: the size
-    the launcher picks when 64 would make too many workgroups) and a channel count that is not a multiple of the slice."""
+    """The backward behind cim_roi_align(_maskcat)_bwd_ws - region form with partial maps (interleaved entry order) - and the
+    entry points WITHOUT partial-map scratch (cim_roi_align_maskcat_bwd: the ROI groups then meet through atomics) against the
+    fp64 oracle, with several images, several ROI groups (128-ROI groups in the last case: the size the launcher picks when 64
+    would make too many workgroups) and a channel count that is not a multiple of the slice."""
+    from cim_amd import _lib
     from cim_amd.ops import roi_align_maskcat
     if gs:
         monkeypatch.setenv("CIM_ROI_RG_GS", gs)
@@ -140,19 +141,19 @@ def test_roi_align_backward_forms_agree_with_oracle(dev, B, C, H, W, K, gs, monk
     masks = (rng.rand(K, 7, 7) > 0.4).astype(np.float32)
     g = rng.randn(K, 2 * C, 7, 7).astype(np.float32)
     gref = oracle.roi_align_bwd(g[:, :C] + g[:, C:] * masks[:, None], rois, feat.shape)
-    grads = {}
-    for form, env in (("region", None), ("pipe", "CIM_ROI_BWD_PIPE"), ("gather", "CIM_ROI_BWD_GATHER")):
-        if env:
-            monkeypatch.setenv(env, "1")
-        x = _cl(feat, dev).requires_grad_(True)
-        cat = roi_align_maskcat(x, torch.from_numpy(rois).to(dev), torch.from_numpy(masks).to(dev), 7, 1 / 16.0, 0, True)
-        cat.backward(torch.from_numpy(g).to(dev))
-        grads[form] = x.grad.cpu().numpy()
-        if env:
-            monkeypatch.delenv(env)
-        np.testing.assert_allclose(grads[form], gref, rtol=1e-4, atol=2e-4 * max(1.0, K / 300.0), err_msg=form)
-    if gs is None:      # same entries, same order, same arithmetic per element: the two region forms are bit-identical
-        np.testing.assert_array_equal(grads["region"], grads["pipe"])        # (128-ROI groups interleave 128 ROIs, the chunks 64)
+    tol = dict(rtol=1e-4, atol=2e-4 * max(1.0, K / 300.0))
+    x = _cl(feat, dev).requires_grad_(True)
+    r_d, m_d = torch.from_numpy(rois).to(dev), torch.from_numpy(masks).to(dev)
+    cat = roi_align_maskcat(x, r_d, m_d, 7, 1 / 16.0, 0, True)
+    cat.backward(torch.from_numpy(g).to(dev))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gref, err_msg="region form, partial maps", **tol)
+    # the same gradient through the C entry point without scratch
+    g_nhwc = torch.from_numpy(g).to(dev).permute(0, 2, 3, 1).contiguous()
+    gin = torch.empty(B, H, W, C, device=dev)
+    ws = torch.empty(_lib.call("cim_roi_align_bwd_workspace", K, 7, H, W) // 4 + 1, device=dev)
+    _lib.call("cim_roi_align_maskcat_bwd", g_nhwc.data_ptr(), r_d.data_ptr(), m_d.data_ptr(), gin.data_ptr(), B, C, H, W, K, 7,
+              1 / 16.0, 0, 1, ws.data_ptr(), _lib.stream_ptr())
+    np.testing.assert_allclose(gin.permute(0, 3, 1, 2).cpu().numpy(), gref, err_msg="no scratch: groups meet through atomics", **tol)
 
 
 def test_roi_align_empty_and_bad_args(dev):

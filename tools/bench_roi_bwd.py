@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""ROIAlign(+mask-cat) backward: region form (default) vs its producer / consumer variant (CIM_ROI_BWD_PIPE=1) vs gather form (CIM_ROI_BWD_GATHER=1), same inputs:
-max difference, ms per launch, fraction of the 8 TB/s HBM roofline on SURVEY.md 8(d)'s algorithmic bytes."""
+"""ROIAlign(+mask-cat) backward (region form), the ROI-group-size sweep and any ablation builds (cim_amd/libcim_hip_alt*.so):
+ms per launch, fraction of the 8 TB/s HBM roofline on SURVEY.md 8(d)'s algorithmic bytes."""
 import json
 import os
 import sys
@@ -38,24 +38,13 @@ for cfgname, n, target in (("resnet50_voc", None, None), ("resnet50_voc", 800, 5
     scratch = torch.empty(_lib.call("cim_roi_align_bwd_scratch", K, 1, C, H, W) // 4 + 1, device=dev)
     bwd = lambda: _lib.call("cim_roi_align_maskcat_bwd_ws", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), 0, scratch.data_ptr(), st)
     nbytes = 4.0 * (C * H * W + 5 * K + 49 * K) + 4.0 * K * 2 * C * 49
-    os.environ.pop("CIM_ROI_BWD_GATHER", None)
     t_region = timeit(bwd)
-    g_region = gin.clone()
-    os.environ["CIM_ROI_BWD_PIPE"] = "1"            # the producer / consumer variant (opt-in)
-    t_region_old = timeit(bwd)
-    g_old = gin.clone()
-    os.environ.pop("CIM_ROI_BWD_PIPE", None)
     sweep = {}
     for gs in ("64", "128"):
         os.environ["CIM_ROI_RG_GS"] = gs
         sc2 = torch.empty(_lib.call("cim_roi_align_bwd_scratch", K, 1, C, H, W) // 4 + 1, device=dev)
         sweep[gs] = timeit(lambda: _lib.call("cim_roi_align_maskcat_bwd_ws", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), 0, sc2.data_ptr(), st))
     os.environ.pop("CIM_ROI_RG_GS", None)
-    os.environ["CIM_ROI_BWD_GATHER"] = "1"
-    t_gather = timeit(bwd)
-    g_gather = gin.clone()
-    os.environ.pop("CIM_ROI_BWD_GATHER", None)
-    err = float((g_region - g_gather).abs().max() / g_gather.abs().max())
     import ctypes, glob
     alts = {}
     for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):     # ablation builds
@@ -65,6 +54,6 @@ for cfgname, n, target in (("resnet50_voc", None, None), ("resnet50_voc", 800, 5
         sc = torch.empty(alt.cim_roi_align_bwd_scratch(K, 1, C, H, W) // 4 + 1, device=dev)
         f = lambda: alt.cim_roi_align_maskcat_bwd_ws(gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), 0, sc.data_ptr(), st)
         alts[os.path.basename(path)] = timeit(f)
-    out.append(dict(alts=alts, config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, region_ms=t_region, region_frac=nbytes / t_region / 1e6 / 8000, pipe_ms=t_region_old, group_size_sweep_ms=sweep, max_rel_diff_old=float((g_region - g_old).abs().max() / g_gather.abs().max()),
-                    gather_ms=t_gather, gather_frac=nbytes / t_gather / 1e6 / 8000, max_rel_diff=err))
+    out.append(dict(alts=alts, config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, region_ms=t_region,
+                    region_frac=nbytes / t_region / 1e6 / 8000, group_size_sweep_ms=sweep))
     print(json.dumps(out[-1]))
