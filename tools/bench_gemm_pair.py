@@ -21,6 +21,7 @@ ap.add_argument("--json", default=None)
 ap.add_argument("--only", default=None)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--no-old", action="store_true")
+ap.add_argument("--no-alts", action="store_true", help="ignore the ablation builds next to the product library")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -30,7 +31,7 @@ lib = _lib.load()
 import ctypes
 import glob
 alts = {}
-for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):
+for path in ([] if args.no_alts else sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so")))):
     a = ctypes.CDLL(path)
     for name, argt in _lib.SIGNATURES.items():
         getattr(a, name).argtypes = argt

@@ -12,6 +12,24 @@ import csv
 import sys
 
 
+def product_name(r):
+    """The pair GEMM serves nine products per step under three instantiations: one row per PRODUCT, told apart by the launch's
+    workgroup count (batched Winograd products are multiples of the 121 positions: forward 4 N-tiles per M-tile, data gradient 8;
+    launches of exactly 256 workgroups are the chunked late weight gradients), so that the roofline's dominant launch - the
+    Winograd-domain forward GEMM - has its own average duration in this file."""
+    name = r["Kernel_Name"]
+    if "gemm_pair_kernel" not in name:
+        return name
+    wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+    if wgs % 121 == 0:
+        per = wgs // 121
+        tag = "Winograd forward" if "<0, 0>" in name else "Winograd data gradient" if "<0, 1>" in name else "Winograd weight gradient"
+        return "%s [%s GEMM: 121 x %d tiles]" % (name, tag, per)
+    if wgs == 256:
+        return "%s [late weight-gradient chunk: 256 workgroups]" % name
+    return "%s [fc product: %d workgroups]" % (name, wgs)
+
+
 def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     rows = list(csv.DictReader(open(path)))
@@ -33,7 +51,7 @@ def main():
     stat = collections.OrderedDict()
     for r in sel:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        s = stat.setdefault(r["Kernel_Name"], [0, 0, 1 << 62, 0])
+        s = stat.setdefault(product_name(r), [0, 0, 1 << 62, 0])
         s[0] += 1
         s[1] += d
         s[2] = min(s[2], d)
