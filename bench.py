@@ -267,6 +267,10 @@ def run(args):
                                  overlap_frac=(1.0 - exposed / ar_ms) if ar_ms else None, gradient_bytes=grad_bytes,
                                  ring_bound_ms=1e3 * 2.0 * (world - 1) / world * grad_bytes / 153e9,
                                  buckets=len(dp.buckets))
+    # which backward schedule of the fused MaskFuse node ran (single-process: chunked late launches behind the ROIAlign backward;
+    # several ranks: whole products published to nn.DataParallel at once) - counts over the whole run
+    from cim_amd.ops import maskfuse_pair as _mfp
+    extra.setdefault("comm", {})["maskfuse_backward_schedule"] = dict(_mfp.SCHEDULE)
     if args.phases > 0:
         extra["phases"] = phase_times(torch, model, opt, step, args.phases, args.iter_size)
     heads.settle_rng()

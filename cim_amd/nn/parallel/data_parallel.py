@@ -139,7 +139,7 @@ class DataParallel(nn.Module):
         if self.world_size > 1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
-            _gemm_ops.GRAD_PUBLISHER = self._publish_early      # big gradients finished inside a fused node go out at once
+            _gemm_ops.register_publisher(params, self._publish_early)      # big gradients finished inside a fused node go out at once
             if not engine.HAS_ENGINE_CALLBACK:
                 # no engine callback (see cim_amd/utils/engine.py): the public-API form of "finish the reduction" is a global
                 # optimizer-step pre-hook - whatever the gradient hooks have not reduced is reduced (and waited for) right
@@ -218,7 +218,7 @@ class DataParallel(nn.Module):
                 engine.queue_callback(self._end_of_backward)
 
     def _publish_early(self, p, g, stream):
-        """ops.gemm.GRAD_PUBLISHER: a fused Function finished the gradient `g` of the big parameter `p` on `stream` in the middle of
+        """ops.gemm.publisher_for(param): a fused Function finished the gradient `g` of the big parameter `p` on `stream` in the middle of
         its backward.  When `p` is one of this wrapper's parameters and this backward pass communicates: install it (autograd will
         not: the Function then returns None for it), let its bucket's all-reduce start on that stream at once, in the strict bucket
         order, and return True.  Otherwise return False: the Function keeps its own (joined or deferred) path."""

@@ -158,11 +158,28 @@ _DEFERRED = {}        # device -> [main stream, [(param, dw)], [tensors kept ali
 _PENDING_IDS = set()  # id(param) of the weights whose gradient is still on the side stream
 
 
-# nn.DataParallel (several ranks) registers a callable here: publish(param, grad, stream) installs `grad` as param.grad (or
-# adds it) on `stream` and lets the parameter's all-reduce bucket go out AT ONCE - used by fused Functions whose backward
-# computes several big weight gradients (MaskFuse: fc2, fc1, conv) long before it returns: returned through autograd they
-# would all become visible at the end of the node, and the 822 MB fc1 all-reduce would lose ~5 ms of backward to hide under.
-GRAD_PUBLISHER = None
+# nn.DataParallel (several ranks) registers a publisher for ITS parameters: publish(param, grad, stream) installs `grad` as
+# param.grad (or adds it) on `stream` and lets the parameter's all-reduce bucket go out AT ONCE - used by fused Functions whose
+# backward computes several big weight gradients (MaskFuse: fc2, fc1, conv) long before it returns: returned through autograd
+# they would all become visible at the end of the node, and the 822 MB fc1 all-reduce would lose ~5 ms of backward to hide
+# under.  Keyed by parameter (weak references both ways), so two models in one process - one wrapped for several ranks, one
+# not - each run their own schedule.
+_PUBLISHERS = {}      # id(parameter) -> (weak reference to the parameter, weak reference to the wrapper's bound method)
+
+
+def register_publisher(params, method):
+    wm = weakref.WeakMethod(method)
+    for q in params:
+        key = id(q)
+        _PUBLISHERS[key] = (weakref.ref(q, lambda _r, key=key: _PUBLISHERS.pop(key, None)), wm)
+
+
+def publisher_for(param):
+    """The publish callable of the wrapper that owns `param`, or None (single process / unwrapped model)."""
+    e = _PUBLISHERS.get(id(param)) if param is not None else None
+    if e is None or e[0]() is not param:
+        return None
+    return e[1]()
 
 
 def gradient_is_deferred(param):

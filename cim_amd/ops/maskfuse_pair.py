@@ -46,6 +46,11 @@ DEFER_DW = _os_env.get("CIM_DEFER_MASKFUSE_DW", "1") == "1"
 # 16.9 / 15.8 / 15.1 / 14.9 - the products are MFMA-bound, CUs withheld from them are simply lost.
 # 0: launched where their operands are ready, uncapped (beside the data-gradient products).
 DW_WGS = int(_os_env.get("CIM_MASKFUSE_DW_WGS", "256"))
+# which schedule the backward passes of this process took (counts per pass; bench.py prints it in extra.comm, the 2-rank tests
+# assert on it): the single-process schedule (late launches of DW_WGS workgroups, postponed behind the ROIAlign backward) and the
+# multi-rank one (whole products, handed to nn.DataParallel as soon as they are enqueued) are different code paths
+import collections as _collections
+SCHEDULE = _collections.Counter()
 
 
 def supported(cat, wc, w1, w2):
@@ -195,15 +200,17 @@ class MaskFusePairFunction(Function):
         def publish(w, dw):
             """Several ranks: hand a finished weight gradient to nn.DataParallel NOW (its all-reduce starts on the side stream
             right behind the GEMM that wrote it) instead of returning it when the whole node is done.  -> None when published."""
-            pub = G.GRAD_PUBLISHER
+            pub = publisher
             if pub is None or dw is None or not isinstance(w, torch.nn.Parameter) or not w.is_leaf:
                 return dw
             if pub(w, dw, side if overlap else cur):
                 published.append(dw)
+                SCHEDULE["weight_gradients_published_early"] += 1
                 return None
             return dw
 
         published = []
+        publisher = G.publisher_for(ctx.weights[1])      # several ranks: this model's nn.DataParallel wrapper takes the big gradients early
         late = []               # (slot, weight, closure) of the weight gradients launched at the end (DW_WGS > 0)
         run_late = overlap and DEFER_DW and G.DEFER_DW and DW_WGS > 0
 
@@ -280,7 +287,8 @@ class MaskFusePairFunction(Function):
                 with torch.cuda.stream(side):
                     # (several ranks: RCCL's all-reduce kernels hold CUs of their own while these products run - a launch of exactly
                     # one workgroup per CU would then need a second, nearly empty round each time: the products go out whole)
-                    _lib.call("cim_gemm_pair_limit", DW_WGS if G.GRAD_PUBLISHER is None else 0)
+                    _lib.call("cim_gemm_pair_limit", DW_WGS if publisher is None else 0)
+                    SCHEDULE["late_launches_chunked" if publisher is None else "late_launches_whole_products"] += 1
                     try:
                         got = {slot: publish(w, fn()) for slot, w, fn in late}
                     finally:
@@ -297,7 +305,8 @@ class MaskFusePairFunction(Function):
             # gradient is installed at the join anyway; else here
             # (not with several ranks: the publisher hands the gradients to nn.DataParallel's bucket bookkeeping, which must see them
             # inside the backward pass proper, not from an end-of-backward fallback)
-            if G.POSTPONE_DW and G.GRAD_PUBLISHER is None and all(isinstance(w, torch.nn.Parameter) for _, w, _ in late):
+            if G.POSTPONE_DW and publisher is None and all(isinstance(w, torch.nn.Parameter) for _, w, _ in late):
+                SCHEDULE["late_launches_postponed_behind_roi_align"] += 1
                 G.postpone(dev, lambda: launch(True))
             else:
                 got = launch(False)
