@@ -380,10 +380,11 @@ def test_training_step_matches_cpu_oracle(dev, config):
             assert p.grad is None and g_ref is None, name
             continue
         got_g[name], ref_g[name] = p.grad, g_ref
-    # every gradient within 1e-3 of its own norm; gradients that cancel to nothing by an absolute bound (cases.py).  (The full-size
-    # runs of tests/test_gpu_fullsize.py hold 5e-4, measured 1.8e-4; on these small images a BatchNorm shift gradient - a signed sum
-    # over few pixels that cancels to a small remainder - measures 5.0e-4 against ATen's CPU summation order: 2x margin here.)
-    worst, where, _ = gradient_deviation(got_g, ref_g, rtol=1e-3)
+    # every gradient within 2e-3 of its own norm; gradients that cancel to nothing by an absolute bound (cases.py).  (The full-size
+    # runs of tests/test_gpu_fullsize.py hold 5e-4, measured 1.8e-4; on these SMALL images a BatchNorm scale / shift gradient - a
+    # signed sum over few pixels that cancels to a small remainder - measures 5.3e-4 (ResNet-50 res3) and 1.1e-3 (an HRNet fuse
+    # layer at 1/32 resolution) against ATen's CPU summation order; VGG16, without BatchNorm: 8e-7.)
+    worst, where, _ = gradient_deviation(got_g, ref_g, rtol=2e-3)
     print("%s: worst gradient deviation %.3g at %s" % (config, worst, where))
     assert len(got_g) > 20
 
