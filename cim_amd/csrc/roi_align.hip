@@ -587,8 +587,16 @@ __global__ __launch_bounds__(256) void roi_align_fwd_rowsum2_kernel(const float*
 constexpr int RG_SBH = 3, RG_SBW = 4, RG_WR = 4, RG_WC = 4;
 constexpr int RG_RH = RG_SBH * RG_WR, RG_RW = RG_SBW * RG_WC;          // 12 x 16 pixels
 constexpr int RG_NT = 64 * RG_WR * RG_WC;                               // 1024 threads
-constexpr int RG_WIN = 32;                                              // entries per staging window
-constexpr int RG_MAXE = 256;                                            // entries per super-window (records in LDS)
+#ifndef CIM_ROI_RG_WIN
+#define CIM_ROI_RG_WIN 32
+#endif
+#ifndef CIM_ROI_RG_MAXE
+#define CIM_ROI_RG_MAXE 256
+#endif
+constexpr int RG_WIN = CIM_ROI_RG_WIN;                                  // entries per staging window (32; 16 = 64 lanes x one float4 per entry, 76 KB of LDS: two
+                                                                        // workgroups per CU instead of one - measured equal, 0.19 ms at cfg2, round 4)
+constexpr int RG_MAXE = CIM_ROI_RG_MAXE;                                // entries per super-window (records in LDS)
+static_assert(RG_WIN == 32 || RG_WIN == 16, "staging window: 32 or 16 entries");
 // ROIs per workgroup: 64, or 128 when 64 would make more than ~3.5 workgroups per CU (measured, ms at 64 / 128:
 // 1000 ROIs on 33 x 43: 0.188 / 0.284, 800 on 27 x 36: 0.159 / 0.253, 1200 on 41 x 54: 0.288 / 0.261, 2000 on 33 x 43: 0.353 / 0.321)
 static inline int rg_group_size(int K, int B, int C, int H, int W) {
@@ -728,7 +736,7 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
     const int total = (CIM_ROI_RG_EXP == 6) ? 0 : d_base[RG_GS];
 
     // loader role of this thread inside a staging window: entry le = tid / 32, two float4 of the slice's 64
-    const int le = tid >> 5, lq = (tid & 31) * 2;
+    const int le = RG_WIN == 32 ? tid >> 5 : tid >> 6, lq = RG_WIN == 32 ? (tid & 31) * 2 : (tid & 63);
     const int cbase = slice * 256;
     // consumer role: lane's 4 channels of the slice
     const int my_touch = (7 << (RG_SBH * wr)) | ((15 << (RG_SBW * wc)) << 16);
@@ -787,10 +795,10 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
                 const int off = reinterpret_cast<const int*>(rr)[0];
                 const int c0 = min(cbase + lq * 4, C - 4), c1 = min(cbase + lq * 4 + 4, C - 4);
                 R.r0 = *reinterpret_cast<const float4*>(grad_out + off + c0);
-                R.r1 = *reinterpret_cast<const float4*>(grad_out + off + c1);
+                if (RG_WIN == 32) R.r1 = *reinterpret_cast<const float4*>(grad_out + off + c1);
                 if (MASKCAT) {
                     R.h0 = *reinterpret_cast<const float4*>(grad_out + off + C + c0);
-                    R.h1 = *reinterpret_cast<const float4*>(grad_out + off + C + c1);
+                    if (RG_WIN == 32) R.h1 = *reinterpret_cast<const float4*>(grad_out + off + C + c1);
                     R.m = rr[1];
                 }
             }
@@ -803,7 +811,7 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
             }
             float* sb = &stage[buf][le][lq * 4];
             *reinterpret_cast<float4*>(sb) = a;
-            *reinterpret_cast<float4*>(sb + 4) = c;
+            if (RG_WIN == 32) *reinterpret_cast<float4*>(sb + 4) = c;
         };
         auto consume = [&](int buf, int win) {
             // entries of the window whose bin touches this wave's sub-block
