@@ -20,7 +20,12 @@ def product_name(r):
     name = r["Kernel_Name"]
     if "gemm_pair_kernel" not in name:
         return name
-    wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+    if "Grid_Size" in r:
+        wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+    else:       # kernel-trace CSV: per-dimension columns (work-items)
+        g = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+        w = int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
+        wgs = g // max(w, 1)
     if wgs % 121 == 0:
         per = wgs // 121
         tag = "Winograd forward" if "<0, 0>" in name else "Winograd data gradient" if "<0, 1>" in name else "Winograd weight gradient"
