@@ -74,9 +74,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):       # 3 x 3 convolution + BN (+ residual) + ReLU: one HIP launch each (csrc/conv1x1.hip) when the BN is in eval()
-        out = conv3x3_bn_act(x, self.conv1, self.bn1)
+        out = conv3x3_bn_act(x, self.conv1, self.bn1)      # (one consumer: its BatchNorm + ReLU backward rides in conv2's data gradient, ops/chain.py)
         res = x if self.downsample is None else _downsample(self.downsample, x)
-        return conv3x3_bn_act(out, self.conv2, self.bn2, residual=res)
+        return conv3x3_bn_act(out, self.conv2, self.bn2, residual=res, fuse_input_bn=True)
 
 
 class Bottleneck(nn.Module):
@@ -96,9 +96,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):       # 1 x 1 convolutions + BatchNorm (+ identity) (+ ReLU): one HIP launch each (csrc/conv1x1.hip)
         out = conv1x1_bn_act(x, self.conv1, self.bn1)
-        out = conv3x3_bn_act(out, self.conv2, self.bn2)
+        out = conv3x3_bn_act(out, self.conv2, self.bn2, fuse_input_bn=True)
         res = x if self.downsample is None else _downsample(self.downsample, x)
-        return conv1x1_bn_act(out, self.conv3, self.bn3, residual=res)
+        return conv1x1_bn_act(out, self.conv3, self.bn3, residual=res, fuse_input_bn=True)
 
 
 BLOCKS = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
@@ -256,6 +256,11 @@ class HighResolutionNet(nn.Module):
         return getattr(self, "stage%d" % idx)(xs)
 
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            # the transposed 3 x 3 weights the backward's data gradients read: a few launches beside the forward (ops/conv3x3.py)
+            from ..ops.conv3x3 import prefetch_transposed_weights
+            prefetch_transposed_weights([m for m in self.modules() if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3)
+                                         and m.weight.requires_grad and m.stride == (1, 1)])
         h, w = x.shape[-2:]
         x = F.pad(x, [0, (32 - w % 32) % 32, 0, (32 - h % 32) % 32], mode="constant", value=0)
         with torch.set_grad_enabled(torch.is_grad_enabled() and self.FREEZE_AT < 1):
