@@ -816,8 +816,9 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
                                       int hw, float* workspace, void* stream, void* side_stream, int join,
                                       int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
-                                      const float* in_xr, const float* in_mean, float* in_part) {
+                                      const float* in_xr, const float* in_mean, float* in_part, const float* dx_add) {
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0 && cin > 0 && cout > 0 && hw > 0);
+    CIM_CHECK_ARG(dx_add == nullptr || (dx != nullptr && in_gamma == nullptr));      // (a second branch's gradient of x, added in the epilogue)
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)));
     // (dy_is_dconv: the consumer's data gradient already applied this layer's BatchNorm + ReLU backward; its affine gradients
     // come from the partial sums that product left: cim_bn_part_finish)
@@ -846,8 +847,8 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
         const InputBn ib{x + (size_t)b * cin * hw, in_gamma, in_var, in_eps, in_xr ? in_xr + (size_t)b * cin * hw : nullptr, in_mean,
                          in_part ? in_part + (size_t)b * 2 * ((hw + 31) / 32) * cin : nullptr};
         rc = gemm_small_impl(w, dconv + (size_t)b * cout * hw, dx + (size_t)b * cin * hw, cin, hw, cout, cin, hw, hw, 1, 0,
-                             nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, cout), ws_dx, stream,
-                             in_gamma ? &ib : nullptr);
+                             nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, dx_add ? dx_add + (size_t)b * cin * hw : nullptr, 0,
+                             cim_gemm_small_splits(cin, hw, cout), ws_dx, stream, in_gamma ? &ib : nullptr);
         if (rc) return rc;
     }
     if (join) fj.join();                                       // else the caller joins the side stream before the weight gradient is used

@@ -31,11 +31,12 @@ def _gemm(a, b, c, m, n, k, lda, ldb, ldc, a_mcontig, b_kcontig, x_raw=None, bn=
 
 class Conv1x1BnActFunction(Function):
     @staticmethod
-    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, in_bn=None, state=None):
+    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, in_bn=None, state=None, recv=None, send=None):
         x = x.contiguous()
         B, cin, H, W = x.shape
         cout, hw = w.shape[0], H * W
         w2 = w.reshape(cout, cin)
+        ctx.recv, ctx.send = recv, send          # branch token (see conv1x1_bn_act): receive / send the identity path's gradient
         need_grad = any(ctx.needs_input_grad[:6])
         y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
         xr = torch.empty_like(y) if need_grad else None            # convolution output: the BatchNorm backward's x
@@ -70,6 +71,10 @@ class Conv1x1BnActFunction(Function):
         # ONE host call: BatchNorm / ReLU backward, data gradient, weight gradient (+ split-K reduces)  (csrc/conv1x1.hip)
         dev = dy.device
         dres = torch.empty_like(dy) if need_res else None
+        dx_add = None
+        if ctx.recv is not None and need_x:     # the identity path's gradient of x, stashed by the block's last layer (runs before this one)
+            ctx.recv["received"] = ctx.recv.get("received", 0) + 1
+            dx_add = ctx.recv.pop("dres", None)
         dgamma, dbeta, chained = affine_outputs(ctx, is_dconv, dy_part, need_affine, B, cout, hw, dev)
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=dev) if need_w else None
@@ -80,7 +85,16 @@ class Conv1x1BnActFunction(Function):
         _lib.call("cim_conv1x1_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w2.data_ptr(),
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres),
                   _lib.ptr(None if chained else dgamma), _lib.ptr(None if chained else dbeta), _lib.ptr(dx), _lib.ptr(dw),
-                  B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, join, int(is_dconv), *chain.c_args(in_bn, in_part))
+                  B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, join, int(is_dconv), *chain.c_args(in_bn, in_part),
+                  _lib.ptr(dx_add))
+        if ctx.send is not None and dres is not None:
+            # hand the identity path's gradient to the block's FIRST layer instead of autograd (which would add it to that layer's
+            # data gradient with a launch of its own); that layer's backward runs after this one (later nodes first) - checked
+            if ctx.send.get("sent", 0) != ctx.send.get("received", 0):
+                raise RuntimeError("cim_amd: the bottleneck's first layer ran its backward before its last one - branch hand-over out of order")
+            ctx.send["sent"] = ctx.send.get("sent", 0) + 1
+            ctx.send["dres"] = dres
+            dres = None
         if in_bn is not None:
             chain.hand_over(in_bn, dx, in_part)
         if not join:                       # the weight gradient is still running on the side stream: installed as .grad at the join
@@ -90,7 +104,7 @@ class Conv1x1BnActFunction(Function):
             dw = None
         dmean = -(gamma * torch.rsqrt(var + eps)) * dbeta if need_mean else None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
-            dmean, None, None, None, None, None
+            dmean, None, None, None, None, None, None, None
 
 
 class _BnPartDesc(ctypes.Structure):          # cim_bn_part_desc of include/cim_hip.h
@@ -138,7 +152,7 @@ def affine_outputs(ctx, is_dconv, dy_part, need_affine, B, cout, hw, dev):
     return dgamma, dbeta, False
 
 
-def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False):
+def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False, branch=None):
     """relu?(bn(conv(x)) + residual) for a 1 x 1 nn.Conv2d `conv` and an nn.BatchNorm2d `bn`.  A convolution bias (HRNet's
     final_layer, HRNet.py:298-312) is folded into the BatchNorm's mean: bn(conv + bias) = a conv + (beta - (mean - bias) a)."""
     stride = conv.stride[0]
@@ -160,7 +174,19 @@ def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False):
     if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:6])):
         with torch.no_grad():
             return Conv1x1BnActFunction.apply(*args)
+    # `branch`: a dict shared by the first (no residual) and the last (residual = the block's input) 1 x 1 layer of a bottleneck whose
+    # identity path is the input itself: the last layer's backward hands the identity gradient to the first layer's data-gradient
+    # epilogue (dx_add) instead of returning it to autograd - one add launch per block less.  Only between calls that see the
+    # SAME tensor, with stride 1, when both need its gradient.
+    recv = send = None
+    if branch is not None and stride == 1 and x.requires_grad:
+        if residual is None:
+            branch["x"] = (x.data_ptr(), tuple(x.shape), x._version)
+            recv = branch
+        elif (branch.get("x") == (residual.data_ptr(), tuple(residual.shape), residual._version) and residual.requires_grad
+              and residual.is_contiguous()):
+            send = branch
     state = {"taken": False}
-    out = Conv1x1BnActFunction.apply(*args, in_bn, state)
+    out = Conv1x1BnActFunction.apply(*args, in_bn, state, recv, send)
     chain.tag(out, bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu, residual is not None, state)
     return out

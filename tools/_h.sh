@@ -1,3 +1,2 @@
-python -m pytest "tests/test_gpu_parity.py::test_training_step_matches_cpu_oracle" tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -3
-(cd _ab_base && python bench.py --config hrnet48_coco2017 --steps 8 --warmup 8 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('base hrnet', round(d['ms_per_step'],2))")
-python bench.py --config hrnet48_coco2017 --steps 8 --warmup 8 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('new  hrnet', round(d['ms_per_step'],2), d['extra'].get('aten_fallbacks') if 'extra' in d else '')"
+python -m pytest tests/test_gpu_gemm.py tests/test_gpu_dp.py tests/test_e2e_reference.py "tests/test_gpu_parity.py::test_training_step_matches_cpu_oracle" -x -q -m gpu 2>&1 | tail -3
+bash tools/_ab.sh 3
