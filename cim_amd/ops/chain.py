@@ -8,11 +8,13 @@ conv1 -> conv2 -> conv3 of /root/reference/lib/modeling/resnet50.py:17-44: 2 of 
 The reference freezes the STATISTICS of its BatchNorm layers only (resnet50.py:59-60: the freeze of the affine parameters is
 commented out), so gamma_P / beta_P train: their gradients  dbeta = sum dz,  dgamma = rsqrt(var + eps) sum dz (conv_P - mean)  are
 per-channel sums over the pixels.  Q's epilogue writes them as partial sums per 32-pixel group (SmallArgs.mpart: plain stores, no
-atomics), P's backward finishes them in group order with one small launch beside its weight-gradient product - deterministic, and
-the same gradients as the separate launch up to the summation order.
+atomics); they are finished in group order by ONE launch for all chained layers at the end of the backward pass (ops/conv1x1.py:
+finish_affine through ops/gemm.py: defer_finisher) - deterministic, and the same gradients as the separate launch up to the
+summation order.
 
 Protocol (host side, per backward pass; everything hangs off P's own `state` dict - no process-global marks):
-  * P's forward leaves its convolution output in state["xr"]; P's wrapper tags its output: y._cim_bn = InputBn(..., state);
+  * P's forward leaves its convolution output in state["xr"] (it lives as long as P's autograd node: a retained graph can run its
+    backward again); P's wrapper tags its output: y._cim_bn = InputBn(..., state);
   * Q is called with fuse_input_bn=True by code that KNOWS x has no other consumer (the bottleneck): it marks state["taken"],
     applies the epilogue in its backward and hands the result over: hand_over(in_bn, dx, part) -> state["handed"];
   * P's backward asks take(dy, state): (True, part) -> dy is already dconv_P.  A taken P that receives anything else (the gradient

@@ -61,8 +61,6 @@ class Conv1x1BnActFunction(Function):
         B, cin, cout, H, W, eps, relu, has_res = ctx.cfg
         hw = H * W
         is_dconv, dy_part = chain.take(dy, ctx.state)       # the consumer's data gradient already applied this layer's BatchNorm + ReLU backward
-        if ctx.state is not None:
-            ctx.state.pop("xr", None)
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_res = has_res and ctx.needs_input_grad[2]

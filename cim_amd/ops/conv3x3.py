@@ -102,8 +102,6 @@ class Conv3x3BnActFunction(Function):
         x, w, xr, y, gamma, mean, var = ctx.saved_tensors
         B, cin, cout, H, W, eps, relu, has_res, stride, dilation = ctx.cfg
         is_dconv, dy_part = chain.take(dy, ctx.state)
-        if ctx.state is not None:
-            ctx.state.pop("xr", None)
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_res = has_res and ctx.needs_input_grad[2]

@@ -409,6 +409,21 @@ def test_bottleneck_chained_bn_backward_is_bit_identical(dev, inplanes, planes, 
             if name.startswith(("bn1.", "bn2.")):
                 err = float((a.double() - want[name].grad).norm() / (want[name].grad.norm() + 1e-30))
                 assert err < 5e-6, (name, err)
+    # a RETAINED graph runs its backward twice (hand-over marks, partial sums and the branch token are per pass)
+    monkeypatch.setattr(resnet50, "FUSE_BN_BWD", True)
+    x = x0.clone().requires_grad_(True)
+    y = blk(x)
+    twice = []
+    for keep in (True, False):
+        for p in blk.parameters():
+            p.grad = None
+        x.grad = None
+        y.backward(up, retain_graph=keep)
+        gemm.join_side()
+        torch.cuda.synchronize()
+        twice.append([x.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.requires_grad])
+    for a, b, c in zip(twice[0], twice[1], res[True][1:]):
+        assert torch.equal(a, b) and torch.equal(a, c)
     # misuse: the chained tensor feeds a second consumer -> its producer refuses the accumulated gradient
     monkeypatch.setattr(resnet50, "FUSE_BN_BWD", True)
     x = x0.clone().requires_grad_(True)

@@ -1,2 +1,6 @@
-python -m pytest tests/test_gpu_gemm.py tests/test_gpu_dp.py tests/test_e2e_reference.py "tests/test_gpu_parity.py::test_training_step_matches_cpu_oracle" -x -q -m gpu 2>&1 | tail -3
-bash tools/_ab.sh 3
+run() { python bench.py --no-cpu-baseline --no-extra "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$*', round(d['ms_per_step'],3), round(d['value'],2))"; }
+run --iter-size 4 --steps 8
+run --iter-size 1
+(cd _ab_base && run --iter-size 4 --steps 8)
+run --iter-size 4 --steps 8
+(cd _ab_base && run --iter-size 4 --steps 8)
