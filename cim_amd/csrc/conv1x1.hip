@@ -26,7 +26,7 @@ namespace {
 #ifndef CIM_SMALL_BK
 #define CIM_SMALL_BK 32
 #endif
-constexpr int SBM = 64, SBN = 64, SBK = CIM_SMALL_BK, SNT = 256;
+constexpr int SBM = 64, SBN = 64, SBK = CIM_SMALL_BK;
 constexpr int SLD = 68;                      // padded row stride of a k-major slab (floats); % 4 == 0 for b128 stores
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 16-byte global loads from 4-byte aligned addresses: rows of an NCHW activation [C][HW] start wherever HW puts them
