@@ -242,7 +242,7 @@ class MaskFusePairFunction(Function):
         if need_w1:
             dw1 = side_grad(1, w1_p, lambda: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False))
         if need_x or need_wc or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
-            dX = pair.gemm(dY1p, W1p, r, cout * p * p, h1, False, False, c_amax=am[2:3])
+            dX = pair.gemm(dY1p, W1p, r, cout * p * p, h1, False, False, c_amax=am[2:3], balance=True)
             # ---- flatten backward + ReLU mask of the conv; conv gradients
             st = _lib.stream_ptr()
             dy = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)

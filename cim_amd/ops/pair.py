@@ -75,9 +75,31 @@ def split(x, rows=None, cols=None, ld=None, batch=1, x_bs=0, scale=None, relu_y=
     return p
 
 
-def gemm(a, b, m, n, k, a_mcontig=False, b_kcontig=False, bias=None, relu=False, out=None, c_amax=None):
+def tail_columns(m, n, k):
+    """A product of T = ceil(m / 256) ceil(n / 256) tiles runs in ceil(T / 256) rounds of one workgroup per CU; when the last round
+    holds only a few tiles (fc1's data gradient at <= 1024 proposals: 784 tiles = 3 rounds + 16 tiles - those 16 cost a fourth
+    round: 1.07 ms where 980 tiles take 1.12) the last column tiles are better run as a SEPARATE product with split-K over the
+    idle CUs.  -> (columns of the main product, k-splits of the tail) or None."""
+    tm, tn = (m + 255) // 256, (n + 255) // 256
+    total = tm * tn
+    if total <= 256 or total % 256 == 0 or n % 256:
+        return None
+    main_tn = tn
+    while main_tn > 0 and (main_tn * tm) % 256:
+        main_tn -= 1
+    tail = (tn - main_tn) * tm
+    if main_tn == 0 or tail > 64:
+        return None
+    s = 1
+    while s * 2 * tail <= 256 and k // (s * 2 * 32) >= 8 and s < 16:
+        s *= 2
+    return (main_tn * 256, s) if s > 1 else None
+
+
+def gemm(a, b, m, n, k, a_mcontig=False, b_kcontig=False, bias=None, relu=False, out=None, c_amax=None, balance=False):
     """C[m,n] = A . B (+ bias)(ReLU) on pair images; k must be a multiple of 32 (the images' zero rows / columns pad it).
-    Batched when a.batch > 1 (then no bias / ReLU / split-K)."""
+    Batched when a.batch > 1 (then no bias / ReLU / split-K).  balance=True: a short last round of tiles is run as its own
+    split-K product over the last columns (tail_columns)."""
     dev = a.buf.device
     if a.batch > 1:
         c = out if out is not None else torch.empty((a.batch, m, n), dtype=torch.float32, device=dev)
@@ -87,6 +109,19 @@ def gemm(a, b, m, n, k, a_mcontig=False, b_kcontig=False, bias=None, relu=False,
         return c
     c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=dev)
     splits = _lib.call("cim_gemm_pair_splits", m, n, k)
+    tail = tail_columns(m, n, k) if (balance and splits == 1) else None
+    if tail is not None:
+        n_main, s = tail
+        n_tail = n - n_main
+        ws = torch.empty(s * m * n_tail, dtype=torch.float32, device=dev)
+        # column n_main of B: a row offset for a K-contiguous B ([n][k]), a column offset (4 bytes per element) otherwise
+        b_off = (n_main * b.ld if b_kcontig else n_main) * 4
+        for (cols, col0, boff, sp, w) in ((n_main, 0, 0, 1, None), (n_tail, n_main, b_off, s, ws)):
+            _lib.call("cim_gemm_pair", a.buf.data_ptr(), b.buf.data_ptr() + boff, c.data_ptr() + 4 * col0,
+                      (bias.data_ptr() + 4 * col0) if bias is not None else None, m, cols, k, a.ld, b.ld, n,
+                      int(a_mcontig), int(b_kcontig), int(relu), sp, _lib.ptr(w), a.scale.data_ptr(), b.scale.data_ptr(),
+                      _lib.ptr(c_amax), _lib.stream_ptr())
+        return c
     ws = torch.empty(splits * m * n, dtype=torch.float32, device=dev) if splits > 1 else None
     _lib.call("cim_gemm_pair", a.buf.data_ptr(), b.buf.data_ptr(), c.data_ptr(), _lib.ptr(bias), m, n, k, a.ld, b.ld, n,
               int(a_mcontig), int(b_kcontig), int(relu), splits, _lib.ptr(ws), a.scale.data_ptr(), b.scale.data_ptr(),

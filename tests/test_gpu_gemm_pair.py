@@ -49,7 +49,7 @@ def _operands(M, N, K, a_m, b_k, g, spread=0.0):
     return A, B
 
 
-def _pair_gemm(dev, A, B, a_m, b_k, bias=None, relu=False, c_amax=None):
+def _pair_gemm(dev, A, B, a_m, b_k, bias=None, relu=False, c_amax=None, balance=False):
     from cim_amd.ops import pair
     M, K = A.shape
     N = B.shape[1]
@@ -57,7 +57,7 @@ def _pair_gemm(dev, A, B, a_m, b_k, bias=None, relu=False, c_amax=None):
     pb = pair.split((B.t().contiguous() if b_k else B).to(dev))
     kk = pair.pad32(K)
     return pair.gemm(pa, pb, M, N, kk, bool(a_m), bool(b_k), bias=None if bias is None else bias.to(dev), relu=relu,
-                     c_amax=c_amax)
+                     c_amax=c_amax, balance=balance)
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 1024, 2048), (304, 264, 992), (40, 8, 32), (520, 520, 64), (256, 256, 32)])
@@ -96,6 +96,32 @@ def test_pair_gemm_is_asymmetric_and_deterministic(dev):
     assert torch.equal(y1, y2)
     ref = A.double() @ W.double()
     assert float((y1.cpu().double() - ref).abs().max() / ref.abs().max()) < 3e-5
+
+
+@pytest.mark.parametrize("b_k", [0, 1])
+def test_pair_gemm_balanced_tail_columns(dev, b_k):
+    """balance=True (ops/pair.py: tail_columns): the tiles of a short last round run as a separate split-K product over the last
+    columns - the main columns are bit-identical to the one-launch product, the tail differs by the split-K summation order
+    only, bias / ReLU / the output maximum cover both parts."""
+    from cim_amd.ops import pair
+    M, N, K = 300, 256 * 130, 1024                     # 2 x 130 = 260 tiles: one round of 256 + 4 tiles
+    assert pair.tail_columns(M, N, K) == (256 * 128, 4)
+    assert pair.tail_columns(1000, 50176, 1024) == (192 * 256, 4)       # fc1's data gradient at 1000 proposals
+    assert pair.tail_columns(1000, 12544, 1024) is None and pair.tail_columns(1024, 256 * 64, 1024) is None
+    g = torch.Generator().manual_seed(11 + b_k)
+    A, B = _operands(M, N, K, 0, b_k, g)
+    bias = torch.randn(N, generator=g)
+    am0 = torch.zeros(1, dtype=torch.int32, device=dev)
+    am1 = torch.zeros(1, dtype=torch.int32, device=dev)
+    c0 = _pair_gemm(dev, A, B, 0, b_k, bias, relu=True, c_amax=am0)
+    c1 = _pair_gemm(dev, A, B, 0, b_k, bias, relu=True, c_amax=am1, balance=True)
+    n_main = 256 * 128
+    assert torch.equal(c0[:, :n_main], c1[:, :n_main])
+    ref = (A.double() @ B.double() + bias.double()).clamp(min=0)
+    scale = A.double().abs() @ B.double().abs()
+    assert float(((c1.cpu().double() - ref).abs() / scale).max()) < 2e-6
+    assert float(am1.view(torch.float32)) == float(c1.abs().max())
+    assert abs(float(am1.view(torch.float32)) - float(am0.view(torch.float32))) <= 1e-6 * float(am0.view(torch.float32))
 
 
 def test_pair_gemm_batched(dev):
