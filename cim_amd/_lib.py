@@ -31,7 +31,7 @@ SIGNATURES = {
     "cim_gemm_small_splits": [c_int, c_int, c_int],
     "cim_gemm_small_f32": [_P, _P, _P] + [c_int] * 8 + [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P, _P],
     "cim_conv1x1_bwd_workspace": [c_int, c_int, c_int, c_int],
-    "cim_conv1x1_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 4 + [_P, _P, _P, c_int] + [c_int, _P, _P, c_float] + [_P] * 4,
+    "cim_conv1x1_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 4 + [_P, _P, _P, c_int] + [c_int, _P, _P, c_float] + [_P] * 4 + [c_int],
     "cim_bn_part_finish": [_P, c_int, _P],
     "cim_conv3x3_nchw_splits": [c_int] * 5,
     "cim_conv3x3_nchw_f32": [_P, _P, _P] + [c_int] * 6 + [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P, _P],
@@ -87,7 +87,7 @@ SIGNATURES = {
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }
 
-ABI_VERSION = 9          # cim_abi_version() of include/cim_hip.h this binding was written against
+ABI_VERSION = 10         # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 

@@ -58,6 +58,9 @@ struct SmallArgs {
     // with mxr = that layer's convolution output (layout of C) and mmean its running mean; bn_part_finish_kernel sums the
     // groups in index order (deterministic) and scales the second by rsqrt(var + eps).  mparts = ceil(N / 32).
     const float* mxr; const float* mmean; float* mpart; int mparts;
+    // res_w > 0: `res` is a [M][ceil(H / 2)][ceil(W / 2)] tensor that belongs to every SECOND pixel of the H x W = N output pixels
+    // (W = res_w): the data gradient of a stride-2 1 x 1 convolution of the same input, added where it lands (zero elsewhere)
+    int res_w, res_ws, res_hw;
 };
 struct InputBn { const float* y; const float* gamma; const float* var; float eps;           // (the fields above as arguments)
                  const float* xr; const float* mean; float* part; };
@@ -142,7 +145,13 @@ __device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int co
         const float a = g.gamma[row] * rsqrtf(g.var[row] + g.eps);
         y = fmaf(v, a, g.beta[row] - g.mean[row] * a);
     }
-    if (g.res) y += g.res[o];
+    if (g.res) {
+        if (g.res_w == 0) y += g.res[o];
+        else {
+            const int py = col / g.res_w, px = col - py * g.res_w;
+            if (!((py | px) & 1)) y += g.res[(size_t)row * g.res_hw + (py >> 1) * g.res_ws + (px >> 1)];
+        }
+    }
     if (g.colbias) y += g.colbias[col];
     if (g.relu) y = fmaxf(y, 0.0f);
     if (g.mask) {
@@ -692,7 +701,7 @@ extern "C" int cim_gemm_small_splits(int M, int N, int K) {
 static int gemm_small_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                            int a_mcontig, int b_kcontig, float* x_raw, const float* gamma, const float* beta,
                            const float* mean, const float* var, float eps, const float* residual, int relu, int splits,
-                           float* workspace, void* stream, const InputBn* in_bn);
+                           float* workspace, void* stream, const InputBn* in_bn, int res_w = 0);
 
 extern "C" int cim_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   int a_mcontig, int b_kcontig, float* x_raw, const float* gamma, const float* beta,
@@ -705,7 +714,8 @@ extern "C" int cim_gemm_small_f32(const float* A, const float* B, float* C, int 
 static int gemm_small_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                            int a_mcontig, int b_kcontig, float* x_raw, const float* gamma, const float* beta,
                            const float* mean, const float* var, float eps, const float* residual, int relu, int splits,
-                           float* workspace, void* stream, const InputBn* in_bn) {
+                           float* workspace, void* stream, const InputBn* in_bn, int res_w) {
+    CIM_CHECK_ARG(res_w == 0 || (residual && res_w > 0 && N % res_w == 0 && ldc == N));
     CIM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N && splits >= 1);
     CIM_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (gamma == nullptr) == (mean == nullptr) && (gamma == nullptr) == (var == nullptr));
     CIM_CHECK_ARG(splits == 1 || workspace);
@@ -715,6 +725,8 @@ static int gemm_small_impl(const float* A, const float* B, float* C, int M, int 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_mcontig = a_mcontig; g.b_kcontig = b_kcontig; g.relu = relu; g.bn = gamma != nullptr;
     g.splits = splits; g.ws = workspace; g.colbias = nullptr;
+    g.res_w = res_w;
+    if (res_w) { g.res_ws = (res_w + 1) / 2; g.res_hw = ((N / res_w + 1) / 2) * g.res_ws; }
     set_input_bn(g, in_bn);
     const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
     CIM_CHECK_ARG(tiles * 2 < (1ll << 31) && splits <= 65535 && M <= 65535);
@@ -816,7 +828,9 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
                                       int hw, float* workspace, void* stream, void* side_stream, int join,
                                       int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
-                                      const float* in_xr, const float* in_mean, float* in_part, const float* dx_add) {
+                                      const float* in_xr, const float* in_mean, float* in_part, const float* dx_add, int dx_add_w) {
+    CIM_CHECK_ARG(dx_add_w == 0 || (dx_add != nullptr && dx_add_w > 0 && hw % dx_add_w == 0));
+    const size_t add_bs = dx_add_w ? (size_t)cin * ((hw / dx_add_w + 1) / 2) * ((dx_add_w + 1) / 2) : (size_t)cin * hw;
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0 && cin > 0 && cout > 0 && hw > 0);
     CIM_CHECK_ARG(dx_add == nullptr || (dx != nullptr && in_gamma == nullptr));      // (a second branch's gradient of x, added in the epilogue)
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)));
@@ -847,8 +861,8 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
         const InputBn ib{x + (size_t)b * cin * hw, in_gamma, in_var, in_eps, in_xr ? in_xr + (size_t)b * cin * hw : nullptr, in_mean,
                          in_part ? in_part + (size_t)b * 2 * ((hw + 31) / 32) * cin : nullptr};
         rc = gemm_small_impl(w, dconv + (size_t)b * cout * hw, dx + (size_t)b * cin * hw, cin, hw, cout, cin, hw, hw, 1, 0,
-                             nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, dx_add ? dx_add + (size_t)b * cin * hw : nullptr, 0,
-                             cim_gemm_small_splits(cin, hw, cout), ws_dx, stream, in_gamma ? &ib : nullptr);
+                             nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, dx_add ? dx_add + (size_t)b * add_bs : nullptr, 0,
+                             cim_gemm_small_splits(cin, hw, cout), ws_dx, stream, in_gamma ? &ib : nullptr, dx_add_w);
         if (rc) return rc;
     }
     if (join) fj.join();                                       // else the caller joins the side stream before the weight gradient is used

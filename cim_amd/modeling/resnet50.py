@@ -43,12 +43,13 @@ class Bottleneck(nn.Module):
         identity = x
         # (fuse_input_bn: conv1's / conv2's outputs have one consumer each - their BatchNorm + ReLU backward rides in the next
         # layer's data-gradient epilogue, ops/chain.py)
-        # (branch: without a downsample layer the identity gradient is added in conv1's data-gradient epilogue, ops/conv1x1.py)
-        branch = {} if (self.downsample is None and FUSE_BN_BWD) else None
+        # (branch: the gradient that reaches x through the other path - the identity, or the downsample layer's data gradient (every
+        # second pixel for a stride-2 one) - is added in conv1's data-gradient epilogue, ops/conv1x1.py)
+        branch = {} if FUSE_BN_BWD else None
         out = conv1x1_bn_act(x, self.conv1, self.bn1, branch=branch)
         out = conv3x3_bn_act(out, self.conv2, self.bn2, fuse_input_bn=FUSE_BN_BWD)
         if self.downsample is not None:
-            identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+            identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False, branch=branch)
         return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity, fuse_input_bn=FUSE_BN_BWD, branch=branch)
 
 

@@ -31,7 +31,8 @@ def _gemm(a, b, c, m, n, k, lda, ldb, ldc, a_mcontig, b_kcontig, x_raw=None, bn=
 
 class Conv1x1BnActFunction(Function):
     @staticmethod
-    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, in_bn=None, state=None, recv=None, send=None):
+    def forward(ctx, x, w, res, gamma, beta, mean, var, eps, relu, in_bn=None, state=None, recv=None, send=None, send_dx=None):
+        ctx.send_dx = send_dx                    # (token, full-resolution width or 0): this layer's OWN data gradient goes to the token
         x = x.contiguous()
         B, cin, H, W = x.shape
         cout, hw = w.shape[0], H * W
@@ -69,10 +70,15 @@ class Conv1x1BnActFunction(Function):
         # ONE host call: BatchNorm / ReLU backward, data gradient, weight gradient (+ split-K reduces)  (csrc/conv1x1.hip)
         dev = dy.device
         dres = torch.empty_like(dy) if need_res else None
-        dx_add = None
-        if ctx.recv is not None and need_x:     # the identity path's gradient of x, stashed by the block's last layer (runs before this one)
-            ctx.recv["received"] = ctx.recv.get("received", 0) + 1
+        dx_add, dx_add_w = None, 0
+        if ctx.recv is not None and need_x:     # the other branch's gradient of x, stashed by a layer whose backward runs before this one:
+            ctx.recv["received"] = ctx.recv.get("received", 0) + 1      # the block's last layer (identity path) or its downsample layer
             dx_add = ctx.recv.pop("dres", None)
+            if dx_add is not None and dx_add.shape != x.shape:          # a stride-2 downsample layer's: every second pixel
+                if tuple(dx_add.shape) != (B, cin, (H + 1) // 2, (W + 1) // 2):
+                    raise RuntimeError("cim_amd: branch hand-over of a gradient of shape %s to an input of shape %s"
+                                       % (tuple(dx_add.shape), tuple(x.shape)))
+                dx_add_w = W
         dgamma, dbeta, chained = affine_outputs(ctx, is_dconv, dy_part, need_affine, B, cout, hw, dev)
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=dev) if need_w else None
@@ -84,7 +90,17 @@ class Conv1x1BnActFunction(Function):
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres),
                   _lib.ptr(None if chained else dgamma), _lib.ptr(None if chained else dbeta), _lib.ptr(dx), _lib.ptr(dw),
                   B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, join, int(is_dconv), *chain.c_args(in_bn, in_part),
-                  _lib.ptr(dx_add))
+                  _lib.ptr(dx_add), dx_add_w)
+        if ctx.send_dx is not None and dx is not None:
+            # a downsample layer: its data gradient is the SECOND gradient of the block's input - handed to the block's first layer
+            # (whose backward runs later: checked) instead of autograd, which would scatter a stride-2 layer's into a zero-filled
+            # tensor through two slice nodes (two fills + two copies) and add the two gradients with a launch of its own
+            tok = ctx.send_dx
+            if tok.get("sent", 0) != tok.get("received", 0):
+                raise RuntimeError("cim_amd: the bottleneck's first layer ran its backward before its downsample layer - branch hand-over out of order")
+            tok["sent"] = tok.get("sent", 0) + 1
+            tok["dres"] = dx
+            dx = None
         if ctx.send is not None and dres is not None:
             # hand the identity path's gradient to the block's FIRST layer instead of autograd (which would add it to that layer's
             # data gradient with a launch of its own); that layer's backward runs after this one (later nodes first) - checked
@@ -102,7 +118,7 @@ class Conv1x1BnActFunction(Function):
             dw = None
         dmean = -(gamma * torch.rsqrt(var + eps)) * dbeta if need_mean else None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
-            dmean, None, None, None, None, None, None, None
+            dmean, None, None, None, None, None, None, None, None
 
 
 class _BnPartDesc(ctypes.Structure):          # cim_bn_part_desc of include/cim_hip.h
@@ -165,6 +181,10 @@ def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False, b
             out = out + residual
         return F.relu(out) if relu else out
     in_bn = chain.input_bn(x, fuse_input_bn and stride == 1 and torch.is_grad_enabled() and x.requires_grad)
+    send_dx = None
+    if (branch is not None and residual is None and stride in (1, 2) and x.requires_grad and x.is_contiguous()
+            and branch.get("x") == (x.data_ptr(), tuple(x.shape), x._version)):
+        send_dx = branch            # the block's downsample layer, called after the first layer registered the same input
     if stride != 1:                                   # a strided 1 x 1 convolution only sees every stride-th pixel
         x = x[:, :, ::stride, ::stride]
     mean = bn.running_mean if conv.bias is None else bn.running_mean - conv.bias
@@ -177,7 +197,7 @@ def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False, b
     # epilogue (dx_add) instead of returning it to autograd - one add launch per block less.  Only between calls that see the
     # SAME tensor, with stride 1, when both need its gradient.
     recv = send = None
-    if branch is not None and stride == 1 and x.requires_grad:
+    if branch is not None and send_dx is None and stride == 1 and x.requires_grad:
         if residual is None:
             branch["x"] = (x.data_ptr(), tuple(x.shape), x._version)
             recv = branch
@@ -185,6 +205,6 @@ def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False, b
               and residual.is_contiguous()):
             send = branch
     state = {"taken": False}
-    out = Conv1x1BnActFunction.apply(*args, in_bn, state, recv, send)
+    out = Conv1x1BnActFunction.apply(*args, in_bn, state, recv, send, send_dx)
     chain.tag(out, bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu, residual is not None, state)
     return out

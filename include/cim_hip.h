@@ -235,10 +235,13 @@ int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, 
                            float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int hw,
                            float* workspace, void* stream, void* side_stream, int join,
                            int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
-                           const float* in_xr, const float* in_mean, float* in_part, const float* dx_add);
+                           const float* in_xr, const float* in_mean, float* in_part, const float* dx_add, int dx_add_w);
 /* dx_add (may be NULL; round 4): [B,cin,hw] added to dx in the data gradient's epilogue - the gradient that reaches x through a
- * SECOND branch (the identity path of a bottleneck: lib/modeling/resnet50.py:17-44 torchvision Bottleneck `out += identity`), so
- * that autograd needs no separate add launch per block.
+ * SECOND branch (the identity path of a bottleneck: lib/modeling/resnet50.py:17-44 torchvision Bottleneck `out += identity`, or
+ * the block's downsample convolution), so that autograd needs no separate add launch per block.
+ * dx_add_w = 0: dx_add has dx's shape.  dx_add_w = W > 0 (hw = H W): dx_add is [B,cin,ceil(H/2),ceil(W/2)], the data gradient of
+ * a STRIDE-2 1 x 1 convolution of the same x - added at the pixels (2i, 2j) it belongs to (replaces autograd's zero-filled
+ * scatter of the strided slice: two fills, two copies and an add per downsample block).
  * The affine gradients of chained layers from those partial sums, for n layers in ceil(n / 24) launches (`descs` is a HOST array):
  * dbeta[c] = sum over images and groups of part[b][0][g][c], dgamma[c] = rsqrt(var[c] + eps) sum part[b][1][g][c], in index
  * order (deterministic).  dgamma or dbeta may be NULL.  One call at the end of a backward pass serves the whole body. */

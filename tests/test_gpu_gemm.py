@@ -345,12 +345,14 @@ def test_conv1x1_bn_act_vs_aten(B, cin, cout, H, W, stride, relu, res):
 
 
 @pytest.mark.parametrize("affine", [True, False])
-@pytest.mark.parametrize("inplanes,planes,stride,H,W", [(256, 64, 1, 33, 43), (256, 128, 2, 34, 45), (64, 16, 1, 9, 7), (512, 128, 1, 65, 86)])
+@pytest.mark.parametrize("inplanes,planes,stride,H,W", [(256, 64, 1, 33, 43), (256, 128, 2, 34, 45), (64, 16, 1, 9, 7), (512, 128, 1, 65, 86),
+                                                        (64, 64, 1, 17, 23), (128, 64, 2, 35, 47)])
 def test_bottleneck_chained_bn_backward_is_bit_identical(dev, inplanes, planes, stride, H, W, affine, monkeypatch):
     """ops/chain.py: conv1's and conv2's BatchNorm + ReLU backward applied in the NEXT layer's data-gradient epilogue (no
     bn_act_bwd launch, lib/modeling/resnet50.py:17-44 torchvision Bottleneck) gives the same bits as the unchained backward -
-    input gradient and all four weight gradients, with and without a downsample branch; a second consumer of a chained
-    tensor is an error, not a wrong gradient.
+    input gradient and all four weight gradients, with and without a downsample branch (stride 1 and 2, odd and even map sizes:
+    the downsample layer's data gradient is added in conv1's data-gradient epilogue - at every second pixel for stride 2 - instead
+    of autograd's zero-filled scatter + add); a second consumer of a chained tensor is an error, not a wrong gradient.
     affine=True is the REFERENCE's configuration (resnet50.py:59-60: statistics frozen, gamma / beta trainable): bn1's and bn2's
     affine gradients then come from the per-32-pixel partial sums the consumer's epilogue writes, finished in group order - equal
     to the separate launch up to the summation order (checked against float64 as well), bit-equal from run to run, everything else
