@@ -174,7 +174,9 @@ def run(args):
         timer.image = j
         out = dp(**{k: [v] for k, v in b.items()}, gtrois=[None])
         state["feat"][j] = tuple(out["blob_conv"].shape[-2:])
-        loss = sum(v.sum() for v in out["losses"].values())
+        # (tools/train.py:435 differentiates `total_loss`: the reference's training_stats adds the four losses up on the host side of
+        # the loop; the model here returns that sum itself, from the loss launch)
+        loss = out["total_loss"] if "total_loss" in out else sum(v.sum() for v in out["losses"].values())
         loss.backward()          # gradient all-reduce + NumPy-generator settle happen inside (end-of-backward callbacks)
         return loss
 

@@ -82,7 +82,8 @@ SIGNATURES = {
     "cim_wino_wgrad_output": [_P, _P, c_int, c_int, c_int, _P],
     "cim_losses_fwd": [_P, _P],
     "cim_linear_bias_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
-    "cim_loss_grad_combine": [_P, _P, _P, c_int, c_int, c_int, _P],
+    "cim_loss_finish": [_P, c_int, _P, _P],
+    "cim_loss_grad_combine": [_P] * 8 + [c_int, c_int, c_int, _P],
     "cim_head_act_fwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }

@@ -415,13 +415,18 @@ __global__ __launch_bounds__(256) void head_act_bwd_kernel(const float* __restri
 // [N][(2 + 2R) C1] = (predict_cls | predict_det | refine_cls[0..R) | refine_iou[0..R)) - what cim_head_act_bwd consumes:
 //   pc: g_bag G0 + g_pcl G1;  pd: g_bag G2;  rc_i: g_cls G[3+4i] + g_bag G[4+4i];  ri_i: g_iou G[5+4i] + g_bag G[6+4i]
 // (g = (bag, pcl, cls, iou) on the device; replaces ~20 element-wise ATen launches and the 8-way concatenation of their results)
-__global__ __launch_bounds__(256) void loss_grad_combine_kernel(const float* __restrict__ G, const float* __restrict__ g,
+// g: the six gradient pointers of cim_loss_finish's outputs (bag, pcl, cls, iou, 3 iou, total), any of them null
+struct LossGrads { const float* p[6]; };
+__global__ __launch_bounds__(256) void loss_grad_combine_kernel(const float* __restrict__ G, const LossGrads g,
                                                                 float* __restrict__ out, int N, int C1, int R) {
     const size_t plane = (size_t)N * C1;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= plane) return;
     const int n = (int)(i / C1), c = (int)(i - (size_t)n * C1);
-    const float g_bag = g[0], g_pcl = g[1], g_cls = g[2], g_iou = g[3];
+    float v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = g.p[k] ? g.p[k][0] : 0.0f;
+    const float g_bag = v[0] + v[5], g_pcl = v[1] + v[5], g_cls = v[2] + v[5], g_iou = v[3] + 3.0f * (v[4] + v[5]);
     float* o = out + (size_t)n * (2 + 2 * R) * C1 + c;
     o[0] = g_bag * G[i] + g_pcl * G[plane + i];
     o[C1] = g_bag * G[2 * plane + i];
@@ -432,10 +437,34 @@ __global__ __launch_bounds__(256) void loss_grad_combine_kernel(const float* __r
     }
 }
 
+// part [rows][4] (bag, pcl, cls, iou partial sums of the loss launch) -> out[6] = (bag, pcl, cls, iou, 3 iou, total) with
+// total = ((bag + pcl) + cls) + 3 iou  (model_builder.py:199 weights the IoU loss by 3; lib/utils/training_stats.py:72-83 adds
+// the four up in dictionary order for the backward pass) - one launch instead of a reduction, a scaling and the driver's
+// per-loss means and adds
+__global__ void loss_finish_kernel(const float* __restrict__ part, int rows, float* __restrict__ out) {
+    const int k = threadIdx.x;
+    float s = 0.0f;
+    if (k < 4)
+        for (int r = 0; r < rows; ++r) s += part[r * 4 + k];
+    const float bag = __shfl(s, 0), pcl = __shfl(s, 1), cls = __shfl(s, 2), iou = __shfl(s, 3);
+    if (k < 4) out[k] = s;
+    if (k == 4) out[4] = 3.0f * iou;
+    if (k == 5) out[5] = ((bag + pcl) + cls) + 3.0f * iou;
+}
+
 }  // namespace
 
-extern "C" int cim_loss_grad_combine(const float* G, const float* g, float* out, int N, int C1, int R, void* stream) {
-    CIM_CHECK_ARG(G && g && out && N > 0 && C1 > 0 && R >= 0 && R <= 3);
+extern "C" int cim_loss_finish(const float* part, int rows, float* out, void* stream) {
+    CIM_CHECK_ARG(part && out && rows > 0);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, cim::as_stream(stream), part, rows, out);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_loss_grad_combine(const float* G, const float* g_bag, const float* g_pcl, const float* g_cls, const float* g_iou,
+                                     const float* g_iou3, const float* g_total, float* out, int N, int C1, int R, void* stream) {
+    CIM_CHECK_ARG(G && out && N > 0 && C1 > 0 && R >= 0 && R <= 3);
+    const LossGrads g{{g_bag, g_pcl, g_cls, g_iou, g_iou3, g_total}};
     const size_t n = (size_t)N * C1;
     hipLaunchKernelGGL(loss_grad_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), G, g, out, N, C1, R);
     CIM_CHECK_LAUNCH();

@@ -165,8 +165,9 @@ STATUS_BITS = {1: "a class produced more than K pseudo ground truths (internal)"
 
 class FusedLossFunction(torch.autograd.Function):
     """All four losses of the training step in one HIP launch (cim_amd/csrc/losses.hip).
-    Returns a tensor [4] = (bag_loss, pcl_loss, cls_loss, iou_loss) with the per-layer lmda weights
-    applied and iou NOT yet multiplied by 3 (model_builder.py:199 does that).  Nothing is read back: which layers
+    Returns six 0-dim tensors (bag_loss, pcl_loss, cls_loss, iou_loss, 3 iou_loss, total) with the per-layer lmda weights
+    applied: iou as the layers produce it, 3 iou as model_builder.py:199 reports it, total = bag + pcl + cls + 3 iou - what the
+    driver sums up for the backward pass (lib/utils/training_stats.py:72-83).  Nothing is read back: which layers
     count (`valid`, from the mining launches) and the PRM cluster structure of `mat` are resolved on the device."""
 
     @staticmethod
@@ -211,10 +212,13 @@ class FusedLossFunction(torch.autograd.Function):
         _lib.call("cim_losses_fwd", ctypes.byref(a), _lib.stream_ptr())
         ctx.R, ctx.fused, ctx.dims = R, fused, (N, C1)
         ctx.save_for_backward(grad)
-        return part.sum(dim=0)
+        ctx.set_materialize_grads(False)        # (unused outputs arrive as None, not as zero tensors made by a launch each)
+        out = torch.empty(6, dtype=torch.float32, device=dev)
+        _lib.call("cim_loss_finish", part.data_ptr(), R + 2, out.data_ptr(), _lib.stream_ptr())
+        return tuple(out.unbind(0))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *g):
         (G,) = ctx.saved_tensors
         R = ctx.R
         # when the whole backward pass has been queued: bring the host's NumPy generator to the position the
@@ -225,9 +229,12 @@ class FusedLossFunction(torch.autograd.Function):
         if ctx.fused:       # ONE launch: the gradient of the fused score matrix, ready for the head activations' backward
             N, C1 = ctx.dims
             out = torch.empty((N, (2 + 2 * R) * C1), dtype=torch.float32, device=G.device)
-            _lib.call("cim_loss_grad_combine", G.data_ptr(), g.contiguous().data_ptr(), out.data_ptr(), N, C1, R, _lib.stream_ptr())
+            g = [None if t is None else t.contiguous() for t in g]
+            _lib.call("cim_loss_grad_combine", G.data_ptr(), *[_lib.ptr(t) for t in g], out.data_ptr(), N, C1, R, _lib.stream_ptr())
             return None, out, None
-        g_bag, g_pcl, g_cls, g_iou = g[0], g[1], g[2], g[3]
+        zero = G.new_zeros(())
+        v = [zero if t is None else t for t in g]
+        g_bag, g_pcl, g_cls, g_iou = v[0] + v[5], v[1] + v[5], v[2] + v[5], v[3] + 3 * (v[4] + v[5])
         d_pc = g_bag * G[0] + g_pcl * G[1]
         d_pd = g_bag * G[2]
         d_rc = [g_cls * G[3 + 4 * i] + g_bag * G[4 + 4 * i] for i in range(R)]
@@ -272,11 +279,12 @@ def _fused_base(predict_cls, predict_det, ref_cls_score, ref_iou_score):
 
 
 def fused_losses(predict_cls, predict_det, ref_cls_score, ref_iou_score, labels, pseudo, scales, mat,
-                 valid=None, status=None):
+                 valid=None, status=None, with_total=False):
     """pseudo[i] = (pseudo_labels, pseudo_iou_labels, loss_weights) of CIM_layer i (or None: layer skipped on the
     host's say-so); scales[i] = lmda; mat = the PRM cluster matrix [N,C+1]; valid = device int32 [R] from
     `mine_step` (1 = the layer found pseudo ground truths), status = device int32 [1] error word.
-    Returns (bag_loss, pcl_loss, cls_loss, iou_loss) as 0-dim tensors."""
+    Returns (bag_loss, pcl_loss, cls_loss, iou_loss) as 0-dim tensors; with_total: also (3 iou_loss, bag + pcl + cls + 3 iou)
+    from the same launch."""
     R = len(ref_cls_score)
     dev = predict_cls.device
     pseudo = list(pseudo)
@@ -300,7 +308,7 @@ def fused_losses(predict_cls, predict_det, ref_cls_score, ref_iou_score, labels,
         out = FusedLossFunction.apply(meta, predict_cls, predict_det, *ref_cls_score, *ref_iou_score)
     if own_status:                     # stand-alone use (tests): report format errors right away
         check_status(int(status.item()))
-    return out[0], out[1], out[2], out[3]
+    return tuple(out) if with_total else (out[0], out[1], out[2], out[3])
 
 
 def check_status(word):

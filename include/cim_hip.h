@@ -500,12 +500,16 @@ int cim_losses_fwd(const cim_loss_args* args, void* stream);
  * colstat / coldot: [2*C1] / [C1] f32 scratch for the detector's column reductions. */
 /* The linear part of the eight heads on the small-tile fp32-MFMA GEMM (no library GEMM on the path):
  *   cim_linear_bias_f32: Y[M][N] = X[M][K] . W[N][K]^T + bias[N]   (splits: cim_gemm_small_splits(M, N, K))
- * and the gradient of the four losses w.r.t. the fused score matrix [N][(2 + 2R) C1] from cim_losses_fwd's `grad`
- * components and the upstream (bag, pcl, cls, iou) gradients g [4] on the device:
- *   cim_loss_grad_combine */
+ * cim_loss_finish: cim_losses_fwd's partial sums part[rows][4] -> out[6] = (bag, pcl, cls, iou, 3 iou, total) on the device, with
+ *   total = ((bag + pcl) + cls) + 3 iou: the IoU loss's weight of lib/modeling/model_builder.py:199 and the sum the driver
+ *   differentiates (lib/utils/training_stats.py:72-83 `total_loss += loss` in dictionary order) in the same launch.
+ * cim_loss_grad_combine: the gradient of the losses w.r.t. the fused score matrix [N][(2 + 2R) C1] from cim_losses_fwd's `grad`
+ *   components and the upstream gradients of cim_loss_finish's six outputs (device scalars; NULL = zero). */
 int cim_linear_bias_f32(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int splits,
                         float* workspace, void* stream);
-int cim_loss_grad_combine(const float* G, const float* g, float* out, int N, int C1, int R, void* stream);
+int cim_loss_finish(const float* part, int rows, float* out, void* stream);
+int cim_loss_grad_combine(const float* G, const float* g_bag, const float* g_pcl, const float* g_cls, const float* g_iou,
+                          const float* g_iou3, const float* g_total, float* out, int N, int C1, int R, void* stream);
 int cim_head_act_fwd(const float* logits, float* scores, float* colstat, int N, int C1, int R, void* stream);
 int cim_head_act_bwd(const float* scores, const float* grad_scores, float* grad_logits, float* coldot,
                      int N, int C1, int R, void* stream);

@@ -46,6 +46,33 @@ def _loss(out):
     return sum(v.sum() for v in out["losses"].values())
 
 
+def test_total_loss_key_is_the_sum_the_driver_differentiates():
+    """model_out['total_loss'] (made by the loss launch's finishing kernel): equal to the sum of the four reported losses the
+    reference's loop builds (lib/utils/training_stats.py:72-83, tools/train.py:435), and differentiating it gives the same
+    gradients bit for bit as differentiating that sum."""
+    from cim_amd.nn import DataParallel
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True)
+    batch = _small_batch(77, n=40, dev=dev)
+    grads, vals = [], []
+    for use_total in (False, True):
+        dp.zero_grad()
+        np.random.seed(9)
+        out = dp(**batch)
+        assert out["total_loss"].shape == (1,) and all(v.shape == (1,) for v in out["losses"].values())
+        total = 0
+        for v in out["losses"].values():          # the driver's own accumulation
+            total = total + v.mean(dim=0, keepdim=True)
+        assert torch.equal(total.detach(), out["total_loss"].detach())
+        (out["total_loss"] if use_total else total).backward()
+        torch.cuda.synchronize()
+        grads.append(_flat_grads(model).clone())
+        vals.append(float(out["total_loss"].detach()))
+    assert vals[0] == vals[1] and vals[0] > 0
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
+
+
 def test_iter_size_4_accumulation_real_model():
     from cim_amd.nn import DataParallel
     dev = torch.device("cuda:0")
