@@ -515,6 +515,43 @@ using cim::pair_split2;
 using cim::pair_scale_of;
 
 // scale[i] = pair_scale_of(amax[min(i, n_amax - 1)] * factor[i])   (factor may be null = 1; amax entries are bit patterns)
+// ReLU backward of a fully connected layer in front of its split: with dz = y > 0 ? dy : 0 (never stored)
+//   amax = max |dz| (atomicMax of the bit pattern, caller-zeroed word) and, when `part` is given, the bias gradient's partial
+//   sums part[rows_chunk][col] = sum of dz over the chunk's 64 rows, added up in row order (the caller sums the chunks).
+// A block owns 64 columns x 64 rows: thread = (4 consecutive columns, row lane of 16), 4 rows each, fixed-order sum in LDS.
+__global__ __launch_bounds__(256) void pair_masked_stats_kernel(const float* __restrict__ dy, const float* __restrict__ y, int rows,
+                                                                int cols, float* __restrict__ part, unsigned* __restrict__ amax) {
+    __shared__ float4 red[16][16];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + cx * 4, r0 = blockIdx.y * 64;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned m = 0;
+    if (col < cols) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + ry * 4 + i;                      // a thread's 4 rows are consecutive: row order inside the chunk
+            if (r < rows) {
+                const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * cols + col);
+                const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * cols + col);
+                const float4 z = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+                s.x += z.x; s.y += z.y; s.z += z.z; s.w += z.w;
+                m = max(m, max(max(__float_as_uint(z.x) & 0x7fffffffu, __float_as_uint(z.y) & 0x7fffffffu),
+                               max(__float_as_uint(z.z) & 0x7fffffffu, __float_as_uint(z.w) & 0x7fffffffu)));
+            }
+        }
+    }
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0) cim::amax_publish(amax, m);
+    if (part == nullptr) return;
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < cols) {
+        float4 t = red[0][cx];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 u = red[k][cx]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * cols + col) = t;
+    }
+}
 __global__ void pair_scales_kernel(const unsigned* __restrict__ amax, int n_amax, const float* __restrict__ factor,
                                    float* __restrict__ scale, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -697,6 +734,14 @@ extern "C" int cim_pair_split(const float* X, void* P, int rows, int rows_pad, i
     const long long chunks = (long long)rows_pad * (cols / 8);
     hipLaunchKernelGGL(pair_split_kernel, dim3((unsigned)((chunks + 255) / 256), batch), dim3(256), 0, cim::as_stream(stream), X,
                        (char*)P, rows, rows_pad, cols, ld, ldp, x_bs, p_bs, scale, relu_y);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_pair_masked_stats(const float* dy, const float* y, int rows, int cols, float* part, uint32_t* amax, void* stream) {
+    CIM_CHECK_ARG(dy && y && amax && rows > 0 && cols > 0 && cols % 4 == 0);
+    hipLaunchKernelGGL(pair_masked_stats_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0,
+                       cim::as_stream(stream), dy, y, rows, cols, part, amax);
     CIM_CHECK_LAUNCH();
     return 0;
 }

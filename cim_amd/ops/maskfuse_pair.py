@@ -224,21 +224,16 @@ class MaskFusePairFunction(Function):
         dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = dy_conv = None
         am = torch.zeros(3, dtype=torch.int32, device=dev)
         # ---- fc2
+        # (the ReLU mask is applied by the split; one launch gives max |dz| and the bias gradient's partial sums)
         dY2 = dY2.contiguous()
-        dY2m = dY2 * (Y2 > 0)
-        if ctx.has_bias[2] and ctx.needs_input_grad[6]:
-            db2 = dY2m.sum(dim=0)
-        pair.amax_of(dY2m, am[0:1])
-        dY2p = pair.split(dY2m, r, h2, h2, scale=pair.scales_from(am[0:1], 1))
+        db2 = pair.masked_stats(dY2, Y2, am[0:1], ctx.has_bias[2] and ctx.needs_input_grad[6])
+        dY2p = pair.split(dY2, r, h2, h2, scale=pair.scales_from(am[0:1], 1), relu_y=Y2)
         if need_w2:
             dw2 = side_grad(2, w2_p, lambda: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False))
         dY1 = pair.gemm(dY2p, W2p, r, h1, h2, False, False)
         # ---- fc1
-        dY1m = dY1 * (Y1 > 0)
-        if ctx.has_bias[1] and ctx.needs_input_grad[4]:
-            db1 = dY1m.sum(dim=0)
-        pair.amax_of(dY1m, am[1:2])
-        dY1p = pair.split(dY1m, r, h1, h1, scale=pair.scales_from(am[1:2], 1))
+        db1 = pair.masked_stats(dY1, Y1, am[1:2], ctx.has_bias[1] and ctx.needs_input_grad[4])
+        dY1p = pair.split(dY1, r, h1, h1, scale=pair.scales_from(am[1:2], 1), relu_y=Y1)
         if need_w1:
             dw1 = side_grad(1, w1_p, lambda: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False))
         if need_x or need_wc or (ctx.has_bias[0] and ctx.needs_input_grad[2]):

@@ -46,6 +46,15 @@ def amax_of(x, out=None):
     return out
 
 
+def masked_stats(dy, y, amax, want_colsum):
+    """ReLU backward in front of a split, dz = y > 0 ? dy : 0 (not stored: split(dy, relu_y=y) applies the same mask): max |dz| into
+    the zeroed int32[1] `amax`; -> column sums of dz (the layer's bias gradient) or None."""
+    rows, cols = dy.shape
+    part = torch.empty(((rows + 63) // 64, cols), dtype=torch.float32, device=dy.device) if want_colsum else None
+    _lib.call("cim_pair_masked_stats", dy.data_ptr(), y.data_ptr(), rows, cols, _lib.ptr(part), amax.data_ptr(), _lib.stream_ptr())
+    return part.sum(dim=0) if want_colsum else None
+
+
 def scales_from(amax, n=1, factor=None):
     """float32[n] power-of-two scales 2^(14 - exponent(amax * factor[i])) (amax: int32 bit patterns, [1] or [n])."""
     s = torch.empty(n, dtype=torch.float32, device=amax.device)

@@ -378,7 +378,11 @@ int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int 
  *   cim_pair_scales: scale[i] = 2^(14 - exponent(amax[min(i, n_amax - 1)] * factor[i]))  (factor may be NULL)
  *   cim_pair_split : fp32 X [batch][rows][ld] -> pair image [batch][rows_pad][ldp], rows >= `rows` zero-filled; relu_y
  *                    (optional, laid out as X): elements with relu_y <= 0 are written as 0 (a fused ReLU backward mask)
- *   cim_pair_amax  : max |x| bit pattern of n floats (atomicMax into a caller-zeroed word) */
+ *   cim_pair_amax  : max |x| bit pattern of n floats (atomicMax into a caller-zeroed word)
+ *   cim_pair_masked_stats: the ReLU backward of a fully connected layer in front of its split, dz = y > 0 ? dy : 0 on [rows][cols]
+ *                    (never stored: cim_pair_split applies the same mask): max |dz| as cim_pair_amax and, when `part`
+ *                    ([ceil(rows / 64)][cols], may be NULL) is given, the bias gradient's partial sums over chunks of 64 rows, each
+ *                    added up in row order - the caller sums the chunks (lib/modeling/resnet50.py:107-110 seg_fc's ReLUs) */
 /* Caps the launches of this THREAD's following cim_gemm_pair* products at max_workgroups (0 = one launch over all tiles, the
  * default): a product then goes out as consecutive launches.  A workgroup of this engine owns its CU (128 KB of LDS), so a
  * capped product never holds more CUs than that and leaves the rest of the chip to concurrent streams - used for the
@@ -396,6 +400,7 @@ int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float
 int cim_pair_split(const float* X, void* P, int rows, int rows_pad, int cols, int ld, int ldp, int batch,
                    long long x_bs, long long p_bs, const float* scale, const float* relu_y, void* stream);
 int cim_pair_amax(const float* X, long long n, uint32_t* amax, void* stream);
+int cim_pair_masked_stats(const float* dy, const float* y, int rows, int cols, float* part, uint32_t* amax, void* stream);
 
 /* Producers of pair images for the MaskFuse convolution in the mixed 4 + 3 Winograd tiling (121 positions, P = 7; the
  * fp32 stages are cim_wino_* with tile = 7 below) and for seg_fc.0's input:

@@ -98,6 +98,29 @@ def test_pair_gemm_is_asymmetric_and_deterministic(dev):
     assert float((y1.cpu().double() - ref).abs().max() / ref.abs().max()) < 3e-5
 
 
+@pytest.mark.parametrize("rows,cols", [(1000, 4096), (37, 72), (130, 260)])
+def test_masked_stats_in_front_of_a_split(dev, rows, cols):
+    """pair.masked_stats: max |dz| and the column sums of dz = y > 0 ? dy : 0 without storing dz; split(dy, relu_y=y) writes the
+    image of the same dz."""
+    from cim_amd.ops import pair
+    g = torch.Generator().manual_seed(rows + cols)
+    dy = torch.randn(rows, cols, generator=g).to(dev)
+    y = torch.randn(rows, cols, generator=g).clamp(min=0).to(dev)
+    dz = torch.where(y > 0, dy, torch.zeros_like(dy))         # (dy * (y > 0) leaves -0.0 behind)
+    am = torch.zeros(1, dtype=torch.int32, device=dev)
+    db = pair.masked_stats(dy, y, am, True)
+    assert float(am.view(torch.float32)) == float(dz.abs().max())
+    ref = dz.double().sum(dim=0)
+    assert float((db.double() - ref).abs().max()) <= 1e-5 * float(dz.abs().sum(dim=0).max())
+    am2 = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert pair.masked_stats(dy, y, am2, False) is None and torch.equal(am, am2)
+    if cols % 8 == 0:
+        sc = pair.scales_from(am, 1)
+        a = pair.split(dy, rows, cols, cols, scale=sc, relu_y=y)
+        b = pair.split(dz, rows, cols, cols, scale=sc)
+        assert torch.equal(a.buf, b.buf)
+
+
 @pytest.mark.parametrize("b_k", [0, 1])
 def test_pair_gemm_balanced_tail_columns(dev, b_k):
     """balance=True (ops/pair.py: tail_columns): the tiles of a short last round run as a separate split-K product over the last
