@@ -574,6 +574,16 @@ class MiningResult:
 
 
 @torch.no_grad()
+def _rows_in_place(t):
+    """(tensor to keep alive, row stride in elements) of a 2-D fp32 score tensor whose rows are contiguous - a column block of a
+    wider matrix is read where it lies; anything else is copied."""
+    t = t.detach()
+    if t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t, t.stride(0)
+    t = t.to(torch.float32).contiguous()
+    return t, t.shape[-1]
+
+
 def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None):
     """The mining + assignment of all CIM layers of one training step (reference: the three CIM_layer.forward calls
     of model_builder.py:170-187) in 5 launches, nothing read back.  layers: CIM_layer modules (thresholds);
@@ -632,11 +642,12 @@ def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None):
     keep = [labels, iou_map, asy_iou_map, uniforms, u8, ints, f32]
     for i, (layer, (pcls, pdet)) in enumerate(zip(layers, scores)):
         L = a.layer[i]
-        cls = pcls.detach().to(torch.float32).contiguous()
+        # (the scores are column blocks of the heads' ONE score matrix: read in place through their row stride, no copies)
+        cls, cls_ld = _rows_in_place(pcls)
         assert cls.shape[0] == N
         cls_off = 1 if cls.shape[-1] - 1 == C else 0
         if using_CIM[i]:
-            det = pdet.detach().to(torch.float32).contiguous()
+            det, det_ld = _rows_in_place(pdet)
             if det.shape[-1] - 1 == C:
                 det_off, det_cs = 1, 1
             elif det.shape[-1] == C:
@@ -645,14 +656,14 @@ def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None):
                 det_off, det_cs = 0, 0
             else:
                 raise NotImplementedError("Detector only supports class-specific and class-agnostic methods")
-            L.seed_score, L.seed_ld, L.seed_off = cls.data_ptr(), cls.shape[-1], cls_off
-            L.det, L.det_ld, L.det_off, L.det_cs = det.data_ptr(), det.shape[-1], det_off, det_cs
-            L.wa, L.wa_ld, L.wa_off = cls.data_ptr(), cls.shape[-1], cls_off
-            L.wb, L.wb_ld, L.wb_off, L.wb_cs = det.data_ptr(), det.shape[-1], det_off, det_cs
+            L.seed_score, L.seed_ld, L.seed_off = cls.data_ptr(), cls_ld, cls_off
+            L.det, L.det_ld, L.det_off, L.det_cs = det.data_ptr(), det_ld, det_off, det_cs
+            L.wa, L.wa_ld, L.wa_off = cls.data_ptr(), cls_ld, cls_off
+            L.wb, L.wb_ld, L.wb_off, L.wb_cs = det.data_ptr(), det_ld, det_off, det_cs
             L.flag_slot = thr_slots.index(float(layer.con_thr))
             keep += [cls, det]
         else:                                                            # MIST_label, heads.py:421-427,261-316
-            preds = (cls * pdet.detach().to(torch.float32) if pdet is not None else cls).contiguous()
+            preds = (cls * pdet.detach().to(torch.float32) if pdet is not None else cls).contiguous()      # (a fresh [N, C1] tensor)
             L.seed_score, L.seed_ld, L.seed_off = preds.data_ptr(), preds.shape[-1], cls_off
             L.wa, L.wa_ld, L.wa_off = preds.data_ptr(), preds.shape[-1], cls_off
             L.det = L.wb = None
