@@ -78,7 +78,7 @@ def _load_map(directory, stem, what, device, index):
 
 
 PCL_GENERAL = os.environ.get("CIM_PCL_GENERAL", "0") == "1"            # losses in ATen ops (general `mat` format)
-GRAPH_BACKBONE = os.environ.get("CIM_GRAPH_BACKBONE", "0") == "1"     # opt-in: measured SLOWER on ROCm 7.2 (see _conv_body)
+GRAPH_BACKBONE = os.environ.get("CIM_GRAPH_BACKBONE", "0") == "1"     # opt-in: measured SLOWER than eager (see _conv_body)
 GRAPH_AFTER = 3         # graph a shape from its 3rd occurrence
 GRAPH_SHAPES = 4        # distinct image shapes kept as graphs
 
@@ -226,14 +226,14 @@ class Generalized_RCNN(nn.Module):
             return return_dict
 
     def _conv_body(self, im_data):
-        """Backbone forward.  The body is ~200 small library kernels forward and ~250 backward - launched one by one
-        the host cannot keep the GPU fed (the kernels take ~5 us, a PyTorch launch ~8 us).  For an image shape that
-        keeps coming back (training scales are a small set: SURVEY App. C) the body's forward AND backward are
-        captured as HIP graphs (torch.cuda.make_graphed_callables) and replayed: one launch each way.  Shapes are
-        graphed from their GRAPH_AFTER-th occurrence, at most GRAPH_SHAPES of them (each capture pins its
-        activations).  OPT-IN (CIM_GRAPH_BACKBONE=1): measured on MI355X / ROCm 7.2 the replayed step is SLOWER
-        (22.0 vs 20.5 ms at cfg2) - hipGraph kernel nodes cost about as much as eager launches and MIOpen picks
-        workspace-free solvers under capture - so the default stays eager."""
+        """Backbone forward.  OPT-IN (CIM_GRAPH_BACKBONE=1): for an image shape that keeps coming back (training scales are a small
+        set: SURVEY App. C) the body's forward AND backward are captured as HIP graphs (torch.cuda.make_graphed_callables) and
+        replayed - from the shape's GRAPH_AFTER-th occurrence, at most GRAPH_SHAPES shapes (each capture pins its activations).
+        The default stays eager: the host keeps ahead of the body's ~90 forward / ~170 backward launches (bench.py --phases: the
+        body's forward takes its kernels' time, no launch gaps), a replayed graph runs on ONE stream (the deferred weight gradients
+        lose their side stream) and hipGraph kernel nodes cost about what eager launches do: +4.6 ms per step when last measured
+        (round 3).  Kept as a tested path (tests/test_gpu_parity.py) because it proves that every body kernel
+        is capture-safe (no allocation, no host synchronisation inside)."""
         state = self.__dict__.setdefault("_graphed_bodies", {"seen": {}, "graphs": {}})
         if not (GRAPH_BACKBONE and self.training and im_data.is_cuda and torch.is_grad_enabled()
                 and any(p.requires_grad for p in self.Conv_Body.parameters())):
