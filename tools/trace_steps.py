@@ -52,7 +52,14 @@ def main():
         if any(t in rows[i]["Kernel_Name"] for t in ("multi_tensor_apply", "FusedSgd", "sgd_multi_kernel")):
             start = i + 1
             break
-    sel = rows[start:]
+    # ... and end with the optimizer launch that closes the last step (what follows is bench.py's own end-of-run work: its check
+    # that every parameter is finite - 2 launches per tensor - and the extra loops)
+    end = len(rows)
+    for i in range(len(rows) - 1, start, -1):
+        if any(t in rows[i]["Kernel_Name"] for t in ("multi_tensor_apply", "FusedSgd", "sgd_multi_kernel")):
+            end = i + 1
+            break
+    sel = rows[start:end]
     stat = collections.OrderedDict()
     for r in sel:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
