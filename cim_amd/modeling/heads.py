@@ -223,7 +223,7 @@ class FusedLossFunction(torch.autograd.Function):
         R = ctx.R
         # when the whole backward pass has been queued: bring the host's NumPy generator to the position the
         # mining consumed (no stall: the GPU finished the mining long before the host gets here)
-        if _rng.pending is not None:
+        if _rng.pending is not None and not LAZY_SETTLE:
             engine.queue_callback(settle_rng)
         _order_callers_stream_after_backward(G.device)
         if ctx.fused:       # ONE launch: the gradient of the fused score matrix, ready for the head activations' backward
@@ -529,6 +529,13 @@ class _RngLedger:
 
 _rng = _RngLedger()
 MINING_SYNC = os.environ.get("CIM_MINING_SYNC", "0") == "1" or not engine.HAS_ENGINE_CALLBACK
+# Opt-in (CIM_LAZY_SETTLE=1 or heads.LAZY_SETTLE = True): do NOT settle at the end of the backward pass - the generator is settled
+# right before the NEXT step's draw (always) or by settle_rng().  The settle waits for the step's mining launches to have run on
+# the GPU: at the end of backward that caps the host's lead over the GPU at about half a step; one step later the wait is never
+# felt.  Valid only when nothing in this process draws from np.random between a backward pass and the next forward without
+# calling settle_rng() first (the reference's epoch sampler does draw there, lib/roi_data/loader.py:94: a training loop calls
+# settle_rng() before it asks the sampler for a new epoch, or leaves this off).
+LAZY_SETTLE = os.environ.get("CIM_LAZY_SETTLE", "0") == "1"
 # CIM_STRICT=1 (the test suite sets it): leaving the reference's NumPy stream is an error, not a warning
 STRICT_RNG = os.environ.get("CIM_STRICT", "0") == "1"
 

@@ -73,6 +73,41 @@ def test_total_loss_key_is_the_sum_the_driver_differentiates():
     assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
 
 
+def test_lazy_settle_keeps_the_numpy_stream(monkeypatch):
+    """heads.LAZY_SETTLE (bench.py's mode): the generator is not settled at the end of backward but right before the next step's
+    draw - three steps give the same losses, the same parameters and the same final np.random position as the default mode, and
+    between a backward pass and settle_rng() the generator stands where the pre-drawn uniforms left it."""
+    from cim_amd.modeling import heads
+    from cim_amd.nn import DataParallel
+    from cim_amd.optim import SGD
+    dev = torch.device("cuda:0")
+    batches = [_small_batch(400 + i, n=40, dev=dev) for i in range(3)]
+
+    def run(lazy):
+        monkeypatch.setattr(heads, "LAZY_SETTLE", lazy)
+        model = _model(dev, seed=3)
+        dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True)
+        opt = SGD([p for p in model.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=5e-4)
+        np.random.seed(123)
+        losses, unsettled = [], 0
+        for b in batches:
+            dp.zero_grad()
+            out = dp(**b)
+            out["total_loss"].backward()
+            unsettled += int(heads._rng.pending is not None)
+            opt.step()
+            losses.append(float(out["total_loss"].detach()))
+        heads.settle_rng()
+        probe = np.random.random_sample()
+        torch.cuda.synchronize()
+        return losses, probe, unsettled, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+
+    l0, p0, u0, w0 = run(False)
+    l1, p1, u1, w1 = run(True)
+    assert u0 == 0 and u1 == 3            # eager: settled by the end-of-backward callback; lazy: still pending after every backward
+    assert l0 == l1 and p0 == p1 and torch.equal(w0, w1)
+
+
 def test_iter_size_4_accumulation_real_model():
     from cim_amd.nn import DataParallel
     dev = torch.device("cuda:0")
