@@ -140,8 +140,13 @@ def call(name, *args):
 
 
 def stream_ptr():
+    """Raw hipStream_t of the calling thread's current stream on its current device (called ~120 times per training step:
+    torch.cuda.current_stream().cuda_stream builds a Stream object through three Python layers, ~9 us; the raw query ~0.3 us)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:              # (a torch build without the private query)
+        return torch.cuda.current_stream().cuda_stream
 
 
 def ptr(t):
