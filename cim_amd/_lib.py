@@ -130,7 +130,20 @@ def load():
 VALUE_RETURNING = {"cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_gemm_get_engine"}      # return a count, not a status
 
 
+# split counts / workspace sizes of the body's layers: pure functions of their integer arguments (their tuning switches are read
+# once per process), asked ~100 times per training step with the step's few dozen layer shapes
+PURE = {"cim_gemm_small_splits", "cim_conv3x3_nchw_splits", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace",
+        "cim_bn_act_bwd_chunks", "cim_gemm_pair_splits"}
+_PURE_VALUES = {}
+
+
 def call(name, *args):
+    if name in PURE:
+        key = (name,) + args
+        v = _PURE_VALUES.get(key)
+        if v is None:
+            v = _PURE_VALUES[key] = getattr(load(), name)(*args)
+        return v
     lib = load()
     rc = getattr(lib, name)(*args)
     if name in VALUE_RETURNING:
