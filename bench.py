@@ -228,7 +228,7 @@ def run(args):
     # (two passes: in the second one the caching allocator has blocks for every size class of the cycle - a first occurrence of
     # an image still grows pools, measured as isolated 20+ ms steps in the first cycle after one pass)
     # (more set-up passes do not steady the short timed region: two passes before a warm-up of 8: 14.36 / 16.01 / 14.40 ms against
-    # 15.60 / 15.06 / 14.38 without, one shared box, interleaved - what moves it there is the host: a step is enqueued in ~8 ms, and
+    # 15.60 / 15.06 / 14.38 without, one shared box, interleaved - what moves it there is the host: a step is enqueued in ~6.4 ms, and
     # on a loaded box single steps take the host 11-16 ms (CIM_BENCH_PER_STEP=1 prints both times); extra.sustained is the steadier figure)
     for _ in range(2 * len(dev_batches) if args.warmup < len(dev_batches) else 0):
         step(args.iter_size)
