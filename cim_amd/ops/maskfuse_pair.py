@@ -264,7 +264,7 @@ class MaskFusePairFunction(Function):
                 _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 3, sE.data_ptr(), st)
                 E = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sE)
                 _lib.call("cim_wino7_dy_pair", dy.data_ptr(), E.buf.data_ptr(), sE.data_ptr(), r, rp, cout, 1, st)
-                M2 = pair.gemm(E, Up, r, cin, cout, False, False)
+                M2 = pair.gemm(E, Up, r, cin, cout, False, False, balance=True)
                 dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
                 _lib.call("cim_wino_dx_adjoint_output", M2.data_ptr(), dxp.data_ptr(), r, p, cin, 7, st)
                 dcat = dxp.permute(0, 3, 1, 2)

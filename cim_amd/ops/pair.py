@@ -105,16 +105,38 @@ def tail_columns(m, n, k):
     return (main_tn * 256, s) if s > 1 else None
 
 
+def tail_entries(m, n, k, batch):
+    """Batched form of tail_columns: when the last round of batch * T tiles holds only a few of them (the Winograd data gradient at
+    <= 1024 proposals: 121 x 32 = 15 rounds of 256 + 32 tiles - one more round, 82 us, for an eighth of the chip), the entries those
+    tiles belong to are better run as single split-K products.  -> (entries, k-splits) or None."""
+    t = ((m + 255) // 256) * ((n + 255) // 256)
+    rem = (batch * t) % 256
+    if batch * t <= 256 or rem == 0 or rem > 64 or rem % t:
+        return None
+    s = 1
+    while s * 2 * t <= 256 and k // (s * 2 * 32) >= 8 and s < 16:
+        s *= 2
+    return (rem // t, s) if s > 1 else None
+
+
 def gemm(a, b, m, n, k, a_mcontig=False, b_kcontig=False, bias=None, relu=False, out=None, c_amax=None, balance=False):
     """C[m,n] = A . B (+ bias)(ReLU) on pair images; k must be a multiple of 32 (the images' zero rows / columns pad it).
     Batched when a.batch > 1 (then no bias / ReLU / split-K).  balance=True: a short last round of tiles is run as its own
-    split-K product over the last columns (tail_columns)."""
+    split-K product over the last columns (tail_columns) / over the last batch entries (tail_entries)."""
     dev = a.buf.device
     if a.batch > 1:
         c = out if out is not None else torch.empty((a.batch, m, n), dtype=torch.float32, device=dev)
+        tail = tail_entries(m, n, k, a.batch) if balance else None
+        main = a.batch - (tail[0] if tail else 0)
         _lib.call("cim_gemm_pair_batched", a.buf.data_ptr(), b.buf.data_ptr(), c.data_ptr(), m, n, k, a.ld, b.ld, n,
-                  int(a_mcontig), int(b_kcontig), a.batch, a.bs, b.bs, m * n, a.scale.data_ptr(), b.scale.data_ptr(),
+                  int(a_mcontig), int(b_kcontig), main, a.bs, b.bs, m * n, a.scale.data_ptr(), b.scale.data_ptr(),
                   _lib.stream_ptr())
+        if tail:
+            ws = torch.empty(tail[1] * m * n, dtype=torch.float32, device=dev)
+            for z in range(main, a.batch):
+                _lib.call("cim_gemm_pair", a.buf.data_ptr() + 4 * z * a.bs, b.buf.data_ptr() + 4 * z * b.bs, c.data_ptr() + 4 * z * m * n,
+                          None, m, n, k, a.ld, b.ld, n, int(a_mcontig), int(b_kcontig), 0, tail[1], ws.data_ptr(),
+                          a.scale.data_ptr() + 4 * z, b.scale.data_ptr() + 4 * z, None, _lib.stream_ptr())
         return c
     c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=dev)
     splits = _lib.call("cim_gemm_pair_splits", m, n, k)

@@ -147,6 +147,28 @@ def test_pair_gemm_balanced_tail_columns(dev, b_k):
     assert abs(float(am1.view(torch.float32)) - float(am0.view(torch.float32))) <= 1e-6 * float(am0.view(torch.float32))
 
 
+def test_pair_gemm_batched_balanced_tail_entries(dev):
+    """balance=True on a batched product (ops/pair.py: tail_entries): the entries whose tiles would form a short last round run as
+    single split-K products - the others are bit-identical to the one-launch product, the tail differs by the summation order."""
+    from cim_amd.ops import pair
+    assert pair.tail_entries(1000, 2048, 1024, 121) == (1, 4)           # the Winograd data gradient at 1000 proposals
+    assert pair.tail_entries(1000, 1024, 2048, 121) is None and pair.tail_entries(1200, 2048, 1024, 121) is None
+    nb, M, N, K = 33, 300, 1024, 1024                                    # 33 x 8 tiles = 256 + 8: the last entry
+    assert pair.tail_entries(M, N, K, nb) == (1, 4)
+    g = torch.Generator().manual_seed(21)
+    A = torch.randn(nb, M, K, generator=g)
+    B = torch.randn(nb, K, N, generator=g) * torch.exp2(torch.arange(nb).float() % 5)[:, None, None]
+    amax_b = torch.stack([b.abs().max() for b in B]).to(dev).view(torch.int32)
+    pa = pair.split(A.to(dev), M, K, K, batch=nb, x_bs=M * K)
+    pb = pair.split(B.to(dev), K, N, N, batch=nb, x_bs=K * N, scale=pair.scales_from(amax_b, nb))
+    c0 = pair.gemm(pa, pb, M, N, K, False, False)
+    c1 = pair.gemm(pa, pb, M, N, K, False, False, balance=True)
+    assert torch.equal(c0[:nb - 1], c1[:nb - 1])
+    ref = A.double() @ B.double()
+    scale = A.double().abs() @ B.double().abs()
+    assert float(((c1.cpu().double() - ref).abs() / scale).max()) < 2e-6
+
+
 def test_pair_gemm_batched(dev):
     from cim_amd.ops import pair
     g = torch.Generator().manual_seed(5)
