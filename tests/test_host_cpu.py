@@ -244,3 +244,37 @@ def test_postponed_launches_run_once_in_order_and_are_dropped_by_a_discarding_jo
     finally:
         engine.queue_callback = orig
         G._POSTPONED.clear()
+
+
+def test_pair_tile_balancing_rules():
+    """ops/pair.py: which products run their last tiles as separate split-K launches (pure host arithmetic on the 256 x 256 tile
+    grid of csrc/gemm_pair.hip and the chip's 256 CUs)."""
+    from cim_amd.ops import pair
+    # fc1's data gradient: 4 x 196 = 784 tiles = 3 rounds + 16 -> the last 4 column tiles, 4 k-splits (8 slabs of 32 each)
+    assert pair.tail_columns(1000, 50176, 1024) == (192 * 256, 4)
+    assert pair.tail_columns(1200, 50176, 1024) is None          # 5 x 196 = 980: the last round is 83 % full
+    assert pair.tail_columns(1000, 12544, 1024) is None          # 196 tiles: less than one round
+    assert pair.tail_columns(1000, 50176 + 8, 1024) is None      # ragged last column tile: not split
+    assert pair.tail_columns(1024, 256 * 64, 1024) is None       # exactly one round
+    # Winograd data gradient, 121 positions of 4 x 8 tiles = 15 rounds + 32 tiles -> the last position alone
+    assert pair.tail_entries(1000, 2048, 1024, 121) == (1, 4)
+    assert pair.tail_entries(1000, 1024, 2048, 121) is None      # forward: 1936 = 7 rounds + 144 tiles (56 % of a round)
+    assert pair.tail_entries(1200, 2048, 1024, 121) is None
+    assert pair.tail_entries(300, 1024, 1024, 33) == (1, 4)
+    assert pair.tail_entries(300, 1024, 1024, 32) is None        # exactly one round
+    assert pair.tail_entries(300, 1024, 128, 33) is None         # K too short to split
+
+
+def test_mining_reads_score_blocks_in_place():
+    """modeling/heads.py: a column block of the fused score matrix is handed to the mining launch with its row stride; anything
+    that is not row-contiguous fp32 is copied."""
+    import torch
+    from cim_amd.modeling.heads import _rows_in_place
+    base = torch.arange(5 * 12, dtype=torch.float32).reshape(5, 12)
+    blk = base[:, 4:8]
+    t, ld = _rows_in_place(blk)
+    assert ld == 12 and t.data_ptr() == blk.data_ptr() and not t.requires_grad
+    t, ld = _rows_in_place(base.t())                             # column-major view: copied
+    assert ld == 5 and t.is_contiguous() and torch.equal(t, base.t())
+    t, ld = _rows_in_place(blk.double())
+    assert ld == 4 and t.dtype == torch.float32
