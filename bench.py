@@ -559,7 +559,7 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
                 dtype_note={"f16x2p": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
                                       "two-term fp16 operand split written by the operands' producers (3 MFMA products, dropped "
                                       "term <= 2^-22, one power-of-two scale per matrix) - measured deviation of losses / "
-                                      "gradients from the reference in tests/test_gpu_tolerance.py (profiles/r3/parity_deviation.json)",
+                                      "gradients from the reference in tests/test_gpu_tolerance.py (profiles/r4/parity_deviation.json)",
                             "f16x2": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
                                      "two-term fp16 operand split (3 MFMA products, dropped term <= 2^-22, rms 2^-25.6) - "
                                      "measured error vs fp64 in the class of the f32-multiply engine (CIM_GEMM_ENGINE=fp32)",
