@@ -26,40 +26,39 @@ SIGNATURES = {
     "cim_mask_pack": [_P, _P, c_int, c_int, _P],
     "cim_mask_iou_pair": [_P, c_int, c_int, _P, _P, _P, _P],
     "cim_asy_flag": [_P, c_int, c_float, _P, _P],
-    "cim_mining_step": [_P, _P],
+    "cim_asy_prep": [_P, c_int, _P, c_int, _P, _P, _P],
+    "cim_mining_step": [_P, _P, _P],
     "cim_mining_lds_bytes": [c_int, c_int],
+    "cim_mining_sync_bytes": [],
     "cim_gemm_small_splits": [c_int, c_int, c_int],
     "cim_gemm_small_f32": [_P, _P, _P] + [c_int] * 8 + [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P, _P],
     "cim_conv1x1_bwd_workspace": [c_int, c_int, c_int, c_int],
-    "cim_conv1x1_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 4 + [_P, _P, _P, c_int] + [c_int, _P, _P, c_float] + [_P] * 4 + [c_int],
+    "cim_conv1x1_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 4 + [_P, _P, _P, _P, _P, c_int] + [c_int, _P, _P, c_float] + [_P] * 4 + [c_int],
     "cim_bn_part_finish": [_P, c_int, _P],
     "cim_conv3x3_nchw_splits": [c_int] * 5,
     "cim_conv3x3_nchw_f32": [_P, _P, _P] + [c_int] * 6 + [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P, _P],
     "cim_conv7x7_nchw_f32": [_P, _P, _P] + [c_int] * 5 + [_P, _P, _P, _P, c_float, c_int, _P],
     "cim_conv3x3_nchw_bwd_workspace": [c_int] * 6,
-    "cim_conv3x3_nchw_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 7 + [_P, _P, _P, c_int] + [c_int, _P, _P, c_float] + [_P] * 4,
+    "cim_conv3x3_nchw_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 7 + [_P, _P, _P, _P, _P, c_int] + [c_int, _P, _P, c_float] + [_P] * 4,
     "cim_conv3x3_wt_multi": [_P, c_int, _P],
     "cim_bn_act_fwd": [_P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, _P],
     "cim_bn_act_bwd_chunks": [c_int, c_int, c_int],
     "cim_bn_act_bwd": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_sgd_multi": [_P, _P, c_int, c_float, _P],
-    "cim_gemm_set_engine": [c_int],
-    "cim_gemm_get_engine": [],
-    "cim_gemm_f32_splits": [c_int, c_int, c_int],
-    "cim_gemm_f32": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P],
-    "cim_conv3x3_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
-    "cim_conv3x3_wgrad_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
-    "cim_gemm_f32_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, _P],
+    "cim_gemm_f32_splits": [c_int, c_int, c_int, c_int],
+    "cim_gemm_f32": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, c_int, _P],
+    "cim_conv3x3_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "cim_conv3x3_wgrad_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
+    "cim_gemm_f32_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_int, _P],
     "cim_gemm_f16x2_splits": [c_int, c_int, c_int],
     "cim_amax_rowcol": [_P, c_int, c_int, c_int, c_int, c_longlong, _P, _P, _P],
     "cim_gemm_f16x2": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "cim_gemm_f16x2_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
                                _P, _P, _P],
-    "cim_gemm_pair_limit": [c_int],
     "cim_gemm_pair_splits": [c_int, c_int, c_int],
-    "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P],
+    "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P],
     "cim_gemm_pair_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
-                              _P, _P, _P],
+                              _P, _P, c_int, _P],
     "cim_pair_scales": [_P, c_int, _P, _P, c_int, _P],
     "cim_pair_split": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, _P, _P, _P],
     "cim_pair_amax": [_P, c_longlong, _P, _P],
@@ -89,7 +88,7 @@ SIGNATURES = {
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }
 
-ABI_VERSION = 10         # cim_abi_version() of include/cim_hip.h this binding was written against
+ABI_VERSION = 11         # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 
@@ -119,15 +118,12 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = c_longlong if name in ("cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_mining_lds_bytes") else c_int
-    # CIM_GEMM_ENGINE = f16x2p (default) | f16x2 (both: own entry points, chosen in cim_amd/ops/gemm.py) | bf16x3 | fp32.
-    # cim_gemm_f32 / cim_conv3x3_f32 (operands without scales) run bf16x3 unless fp32 is asked for.
-    lib.cim_gemm_set_engine(0 if os.environ.get("CIM_GEMM_ENGINE", "f16x2p") == "fp32" else 1)
+        fn.restype = c_longlong if name in ("cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_mining_lds_bytes", "cim_mining_sync_bytes") else c_int
     _lib = lib
     return lib
 
 
-VALUE_RETURNING = {"cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch", "cim_gemm_get_engine"}      # return a count, not a status
+VALUE_RETURNING = {"cim_mining_sync_bytes", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch"}      # return a count, not a status
 
 
 # split counts / workspace sizes of the body's layers: pure functions of their integer arguments (their tuning switches are read

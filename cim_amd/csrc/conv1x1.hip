@@ -19,7 +19,6 @@
 // a = gamma * rsqrt(var + eps), b = beta - mean * a: the BatchNorm (+ identity) (+ ReLU) of the bottleneck costs no pass.
 #include "common.h"
 #include "../../include/cim_hip.h"
-#include <mutex>
 
 namespace {
 
@@ -47,7 +46,6 @@ struct SmallArgs {
     int a_mcontig, b_kcontig, relu, bn;
     int splits; float* ws;
     const float* colbias;    // [N] added per output COLUMN (nn.Linear bias: C = X . W^T + b); null for the convolutions
-    unsigned* tile_cnt;      // split-K: per-tile arrival counters (zero between launches) - the last split of a tile combines
     // data gradients only: the BatchNorm + ReLU backward of the layer that PRODUCED this product's input, applied to the
     // result - C(row, col) = mask(row, col) > 0 ? C * mgamma[row] rsqrt(mvar[row] + meps) : 0 with mask = that layer's output
     // (this layer's input, same layout as C): the producer's own backward then starts from the gradient of its convolution
@@ -126,16 +124,10 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, float4 v, int 
     }
 }
 
-// Split-K combine.  0 (default): a separate reduce launch per split-K product (84 launches per step at cfg2).
-// 1 / 2: combined INSIDE the launch by the tile's last arriving workgroup (below) - built and measured in round 3 because
-// it removes those launches, and kept as an experiment only: whole step at cfg2 (same box, interleaved) 14.87 ms with the
-// separate reduce, 17.92 ms with variant 1 (agent-scope release fence per workgroup + acquire in the last arrival:
-// every fence writes back / invalidates the XCD's L2 under ~500 workgroups per launch), 16.41 ms with variant 2 (sc1
-// partial stores / loads, no fences).  The weight-gradient products run 16-64 splits: one workgroup then reads 0.25-1 MB of
-// partial tiles serially where the reduce launch spreads them over the chip.
-#ifndef CIM_SMALL_FUSED_REDUCE
-#define CIM_SMALL_FUSED_REDUCE 0
-#endif
+// Split-K: every split stores its partial tile to the workspace, a separate reduce launch (small_splitk_reduce*_kernel) sums them in
+// split order and applies the epilogue.  (Round 3 built the combine INSIDE the launch - the tile's last arriving workgroup sums the
+// partials, arrival counters in device memory - and measured it slower in the whole step: 17.92 / 16.41 ms against 14.87 ms with the
+// separate reduce; removed in round 5 together with its library-owned counter ring)
 // Epilogue of one output value (shared by the single-pass kernels, the in-kernel split-K combine and the reduce kernel)
 __device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int col, float v, float& s1, float& s2) {
     const size_t o = (size_t)row * g.ldc + col;
@@ -177,63 +169,6 @@ __device__ __forceinline__ void small_put_part(const SmallArgs& g, int row, int 
         g.mpart[((size_t)g.mparts + group) * g.M + row] = s2;
     }
 }
-// Split-K inside the launch: every split stores its partial tile to the workspace and takes a ticket on the tile's counter;
-// the LAST arrival sums the tile's partials in split order (the order the reduce kernel used: same bits) and applies the
-// epilogue.  Publication follows the chip's rules (the 8 XCDs' L2s are not coherent): plain stores, every wave drains
-// vmcnt, barrier, ONE agent-scope release + relaxed agent-scope fetch_add by one lane; the last arrival does one
-// agent-scope acquire, then plain loads.  The counter is left at zero for the next launch that uses the slot.
-// `flag` = a word of the kernel's own LDS array (a second __shared__ object would de-pipeline the k-loop).
-// CIM_SMALL_FUSED_REDUCE = 2: the partial tiles travel past the (per-XCD, non-coherent) L2s by themselves - agent-scope relaxed
-// atomic stores / loads compile to sc1 accesses - so the hand-off needs no cache write-back / invalidate fences at all.
-__device__ __forceinline__ void small_put_partial(float* p, float v) {
-#if CIM_SMALL_FUSED_REDUCE == 2
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ float small_get_partial(const float* p) {
-#if CIM_SMALL_FUSED_REDUCE == 2
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    return *p;
-#endif
-}
-
-template <int TN>
-__device__ __forceinline__ void small_splitk_combine(const SmallArgs& g, int tile, int m0, int n0, int tid, int nthreads,
-                                                     volatile int* flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-#if CIM_SMALL_FUSED_REDUCE != 2
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        const unsigned t = __hip_atomic_fetch_add(g.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == (unsigned)g.splits - 1u;
-        if (last) {
-            __hip_atomic_store(g.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if CIM_SMALL_FUSED_REDUCE != 2
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    if (!*flag) return;
-    const size_t mn = (size_t)g.M * g.N;
-    for (int e = tid; e < SBM * TN; e += nthreads) {
-        const int r = e / TN, c = e - r * TN;
-        const int row = m0 + r, col = n0 + c;
-        if (row >= g.M || col >= g.N) continue;
-        const size_t i = (size_t)row * g.N + col;
-        float v = small_get_partial(g.ws + i);
-        for (int k = 1; k < g.splits; ++k) v += small_get_partial(g.ws + (size_t)k * mn + i);
-        small_finish(g, row, col, v);
-    }
-}
-
 // Epilogue of a wave's 32 x 32 accumulator tile: lane holds rows 8*(r/4) + 4*(lane/32) + r%4, column lane%32
 __device__ __forceinline__ void small_epilogue(const SmallArgs& g, const f32x16& acc, int row0, int col0, int lane, int split) {
     const int col = col0 + (lane & 31);
@@ -242,7 +177,7 @@ __device__ __forceinline__ void small_epilogue(const SmallArgs& g, const f32x16&
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                if (row < g.M) small_put_partial(g.ws + ((size_t)split * g.M + row) * g.N + col, acc[r]);
+                if (row < g.M) g.ws[((size_t)split * g.M + row) * g.N + col] = acc[r];
             }
         }
         return;
@@ -353,8 +288,6 @@ __global__ __launch_bounds__(128 * WN) void gemm_small_kernel(const SmallArgs g)
 #undef SM_MMA
 
     small_epilogue(g, acc, m0 + wm * 32, n0 + wn * 32, lane, split);
-    if (g.splits > 1 && g.tile_cnt != nullptr)
-        small_splitk_combine<BNT>(g, tile, m0, n0, tid, NT, reinterpret_cast<volatile int*>(&As[0][0]));
 }
 
 // Round 4, measured and dropped: a REGISTER-DIRECT form of this product - every wave fetches its MFMA operands straight from memory
@@ -596,8 +529,6 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
 #undef C3_PUT
 #undef C3_MMA
     small_epilogue(g, acc, m0 + wm * 32, n0 + wn * 32, lane, split);
-    if (g.splits > 1 && g.tile_cnt != nullptr)
-        small_splitk_combine<SBN>(g, (int)blockIdx.x, m0, n0, tid, NT, reinterpret_cast<volatile int*>(c3_smem));
 }
 
 // w [Cout][Cin][9] -> wt [Cout][9][Cin] (the data gradient's A operand, M-contiguous): one workgroup per output channel,
@@ -632,33 +563,6 @@ __global__ __launch_bounds__(256) void conv3x3_wt_multi_kernel(const WtTable t) 
     }
 }
 
-// Arrival counters of the in-kernel split-K combine: a ring of zeroed words per device, allocated on first use and never
-// freed (4 MiB).  A launch takes the next `tiles` words; every tile's last arrival puts its word back to zero, so a slot is
-// reusable once its launch has finished - with 2^20 words and at most a few thousand tiles per launch, launches that are in
-// flight together (two streams, a few dozen queued kernels) never share a word.
-[[maybe_unused]] constexpr long long CNT_RING = 1ll << 20;
-unsigned* splitk_counters(long long tiles) {
-#if !CIM_SMALL_FUSED_REDUCE
-    return nullptr;
-#else
-    static std::mutex mu;
-    static unsigned* ring[64] = {nullptr};
-    static long long next[64] = {0};
-    if (tiles > CNT_RING / 4) return nullptr;          // (an oversize launch keeps the separate reduce pass)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (ring[dev] == nullptr) {
-        if (hipMalloc(reinterpret_cast<void**>(&ring[dev]), sizeof(unsigned) * CNT_RING) != hipSuccess) { ring[dev] = nullptr; return nullptr; }
-        if (hipMemset(ring[dev], 0, sizeof(unsigned) * CNT_RING) != hipSuccess) return nullptr;       // (synchronous: before any launch uses it)
-    }
-    if (next[dev] + tiles > CNT_RING) next[dev] = 0;
-    unsigned* p = ring[dev] + next[dev];
-    next[dev] += tiles;
-    return p;
-#endif
-}
-
 static void set_input_bn(SmallArgs& g, const InputBn* in_bn) {
     if (in_bn == nullptr) return;
     g.mask = in_bn->y; g.mgamma = in_bn->gamma; g.mvar = in_bn->var; g.meps = in_bn->eps;
@@ -691,8 +595,7 @@ extern "C" int cim_gemm_small_splits(int M, int N, int K) {
     const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
     // (sweep, tools/bench_gemm_small.py, us over 7 layer shapes forward / dX / dW: 157 / 136 / 182 with these limits; 2 slabs
     // per workgroup or up to 768-1024 workgroups: 188 / 178 / 219 - more partial products than the latency chain gains)
-    static const int min_k = getenv("CIM_SMALL_MINK") ? atoi(getenv("CIM_SMALL_MINK")) : 4 * SBK;      // sweep switches
-    static const int want = getenv("CIM_SMALL_WGS") ? atoi(getenv("CIM_SMALL_WGS")) : 512;
+    constexpr int min_k = 4 * SBK, want = 512;
     int s = 1;
     while (tiles * s < want && K / (s * 2) >= min_k && s < 64) s *= 2;
     return s;
@@ -733,14 +636,13 @@ static int gemm_small_impl(const float* A, const float* B, float* C, int M, int 
     // (the loaders address the operands through buffer resources with 32-bit byte offsets; OOB = 2^31 - 1 must lie behind them)
     CIM_CHECK_ARG(tile_extent(a_mcontig != 0, M, K, lda) < (1ll << 29) && tile_extent(b_kcontig == 0, N, K, ldb) < (1ll << 29));
     const bool narrow = tiles * splits < 128;           // 64 x 32 tiles only for problems that cannot fill the chip otherwise
-    g.tile_cnt = splits > 1 && !g.mpart ? splitk_counters(narrow ? (long long)((M + SBM - 1) / SBM) * ((N + 31) / 32) : tiles) : nullptr;
     hipStream_t st = cim::as_stream(stream);
     if (a_mcontig) {
         if (b_kcontig) launch_small<true, true>(g, splits, st, narrow); else launch_small<true, false>(g, splits, st, narrow);
     } else {
         if (b_kcontig) launch_small<false, true>(g, splits, st, narrow); else launch_small<false, false>(g, splits, st, narrow);
     }
-    if (splits > 1 && g.tile_cnt == nullptr) launch_splitk_reduce(g, st);      // (no counters: the separate, equally ordered reduce pass)
+    if (splits > 1) launch_splitk_reduce(g, st);
     CIM_CHECK_LAUNCH();
     return 0;
 }
@@ -756,11 +658,9 @@ extern "C" int cim_linear_bias_f32(const float* X, const float* W, const float* 
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
     g.a_mcontig = 0; g.b_kcontig = 1; g.relu = 0; g.bn = 0;
     g.splits = splits; g.ws = workspace; g.colbias = bias;
-    const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
-    g.tile_cnt = splits > 1 ? splitk_counters(tiles) : nullptr;
     hipStream_t st = cim::as_stream(stream);
     launch_small<false, true>(g, splits, st, false);
-    if (splits > 1 && g.tile_cnt == nullptr) {
+    if (splits > 1) {
         const size_t n = (size_t)M * N;
         hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
     }
@@ -783,37 +683,26 @@ extern "C" long long cim_conv1x1_bwd_workspace(int B, int cin, int cout, int hw)
 namespace {
 // Fork / join between the caller's stream and a side stream inside one host call: the weight-gradient GEMM of a layer
 // runs on the side stream next to the data-gradient GEMM (both only read the BatchNorm backward's output; each fills a
-// fraction of the chip - they are latency bound).  Events come from a small round-robin pool (recorded and waited on at
-// once, so reuse is safe).
+// fraction of the chip - they are latency bound).  The two events are the CALLER's (hipEvent_t created with
+// hipEventDisableTiming, passed as void*): the library creates nothing.  They are recorded and waited on inside the call, so the
+// caller may hand the same pair to its next call on the same streams.
 struct ForkJoin {
     hipStream_t main, side;
-    hipEvent_t ev[2];
+    hipEvent_t ev_fork, ev_join;
     bool on;
-    ForkJoin(hipStream_t m, hipStream_t s, bool want) : main(m), side(s), on(want && s != nullptr && s != m) {
-        static std::mutex mu;
-        static hipEvent_t pool[64];
-        static int next = -1;            // -1: pool not created yet
-        if (!on) return;
-        std::lock_guard<std::mutex> lock(mu);
-        if (next < 0) {
-            for (int i = 0; i < 64; ++i)
-                if (hipEventCreateWithFlags(&pool[i], hipEventDisableTiming) != hipSuccess) { on = false; return; }
-            next = 0;
-        }
-        ev[0] = pool[next];
-        ev[1] = pool[next + 1];
-        next = (next + 2) % 64;
-    }
+    ForkJoin(hipStream_t m, hipStream_t s, void* fork_event, void* join_event, bool want)
+        : main(m), side(s), ev_fork(static_cast<hipEvent_t>(fork_event)), ev_join(static_cast<hipEvent_t>(join_event)),
+          on(want && s != nullptr && s != m) {}
     hipStream_t fork() {                 // side stream, ordered after everything enqueued on main so far
         if (!on) return main;
-        (void)hipEventRecord(ev[0], main);
-        (void)hipStreamWaitEvent(side, ev[0], 0);
+        (void)hipEventRecord(ev_fork, main);
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
         return side;
     }
     void join() {                        // main waits for the side stream's work
         if (!on) return;
-        (void)hipEventRecord(ev[1], side);
-        (void)hipStreamWaitEvent(main, ev[1], 0);
+        (void)hipEventRecord(ev_join, side);
+        (void)hipStreamWaitEvent(main, ev_join, 0);
     }
 };
 
@@ -826,10 +715,11 @@ __global__ __launch_bounds__(256) void small_axpy_kernel(float* __restrict__ y, 
 extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                                       const float* gamma, const float* mean, const float* var, float eps, int relu,
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
-                                      int hw, float* workspace, void* stream, void* side_stream, int join,
+                                      int hw, float* workspace, void* stream, void* side_stream, void* fork_event, void* join_event, int join,
                                       int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
                                       const float* in_xr, const float* in_mean, float* in_part, const float* dx_add, int dx_add_w) {
     CIM_CHECK_ARG(dx_add_w == 0 || (dx_add != nullptr && dx_add_w > 0 && hw % dx_add_w == 0));
+    CIM_CHECK_ARG(side_stream == nullptr || side_stream == stream || (fork_event != nullptr && (!join || join_event != nullptr)));
     const size_t add_bs = dx_add_w ? (size_t)cin * ((hw / dx_add_w + 1) / 2) * ((dx_add_w + 1) / 2) : (size_t)cin * hw;
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0 && cin > 0 && cout > 0 && hw > 0);
     CIM_CHECK_ARG(dx_add == nullptr || (dx != nullptr && in_gamma == nullptr));      // (a second branch's gradient of x, added in the epilogue)
@@ -844,7 +734,7 @@ extern "C" int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const flo
     float* ws_dw = ws_dx + (size_t)cim_gemm_small_splits(cin, hw, cout) * cin * hw;
     int rc = dy_is_dconv ? 0 : cim_bn_act_bwd(dy, y, x_raw, gamma, mean, var, eps, dconv, dres, dgamma, dbeta, B, cout, hw, relu, stream);
     if (rc) return rc;
-    ForkJoin fj(cim::as_stream(stream), cim::as_stream(side_stream), dx && dw);
+    ForkJoin fj(cim::as_stream(stream), cim::as_stream(side_stream), fork_event, join_event, dx && dw);
     void* st_dw = fj.fork();                                   // the weight gradient next to the data gradient
     for (int b = 0; b < B && dw; ++b) {                        // dW[cout, cin] = dconv . X^T  (K = hw)
         const int sp = cim_gemm_small_splits(cout, cin, hw);
@@ -885,7 +775,6 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
     g.splits = splits; g.ws = ws; g.colbias = nullptr;
     set_input_bn(g, in_bn);
     const dim3 grid((unsigned)(((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN)), (unsigned)splits);
-    g.tile_cnt = splits > 1 && !g.mpart ? splitk_counters((long long)grid.x) : nullptr;
     const size_t lds = sizeof(float) * 4 * CBK * SLD;
     auto kern = ksize == 7 ? conv3x3_small_kernel<CONV_FWD, 7>
                 : mode == CONV_FWD ? conv3x3_small_kernel<CONV_FWD> : mode == CONV_DX ? conv3x3_small_kernel<CONV_DX> : conv3x3_small_kernel<CONV_DW>;
@@ -894,7 +783,7 @@ int conv3x3_launch(int mode, const float* A, const float* B, float* C, int M, in
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, c);
-    if (splits > 1 && g.tile_cnt == nullptr) launch_splitk_reduce(g, st);
+    if (splits > 1) launch_splitk_reduce(g, st);
     return 0;
 }
 ConvGeom conv_geom(int cin, int cout, int H, int W, int stride, int mode, int dil = 1) {
@@ -1007,9 +896,10 @@ extern "C" int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, cons
                                       const float* gamma, const float* mean, const float* var, float eps, int relu,
                                       float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout,
                                       int H, int W, int stride, int dilation, float* workspace, void* stream, void* side_stream,
-                                      int join, int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
+                                      void* fork_event, void* join_event, int join, int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
                                       const float* in_xr, const float* in_mean, float* in_part, const float* wt_ready) {
     CIM_CHECK_ARG(dy && x_raw && x && w && gamma && mean && var && workspace && B > 0);
+    CIM_CHECK_ARG(side_stream == nullptr || side_stream == stream || (fork_event != nullptr && (!join || join_event != nullptr)));
     CONV3_ARGS_OK(4);
     CIM_CHECK_ARG((y != nullptr || !relu) && ((dgamma == nullptr) == (dbeta == nullptr)) && cout % 4 == 0);
     CIM_CHECK_ARG(!dy_is_dconv || (dres == nullptr && dgamma == nullptr));
@@ -1026,7 +916,7 @@ extern "C" int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, cons
     CIM_CHECK_ARG((size_t)cin * 9 * sizeof(float) <= 64 * 1024);
     int rc = dy_is_dconv ? 0 : cim_bn_act_bwd(dy, y, x_raw, gamma, mean, var, eps, dconv, dres, dgamma, dbeta, B, cout, hwo, relu, stream);
     if (rc) return rc;
-    ForkJoin fj(st, cim::as_stream(side_stream), dx && dw);
+    ForkJoin fj(st, cim::as_stream(side_stream), fork_event, join_event, dx && dw);
     hipStream_t st_dw = fj.fork();                             // the weight gradient next to the data gradient
     for (int b = 0; b < B && dw; ++b) {                        // dW[cout][cin 9] = dconv . im2col(X)^T  (K = Ho Wo)
         const int sp = cim_gemm_small_splits(cout, 9 * cin, hwo);

@@ -1106,12 +1106,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = s;
 }
 
-int g_engine = 1;      // 0: v_mfma_f32_32x32x2_f32;  1: bf16x3 split on v_mfma_f32_32x32x16_bf16 (default)
-
+// engine: 0 = v_mfma_f32_32x32x2_f32;  1 = bf16x3 split on v_mfma_f32_32x32x16_bf16;  2 = f16x2 (operand scales given).
+// An ARGUMENT of every entry point: the library keeps no engine state.
 template <int AL, int BL>
-int launch(GemmArgs g, int splits, float* workspace, hipStream_t st, int engine = -1) {
+int launch(GemmArgs g, int splits, float* workspace, hipStream_t st, int engine) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
-    if (engine < 0) engine = g_engine;
     const size_t lds = engine == 2 ? (size_t)3 * X2_SLAB : engine == 1 ? (size_t)3 * X3_SLAB : sizeof(float) * 3 * SLAB;
     auto kern = engine == 1 ? gemm_bf16x3_kernel<AL, BL> : gemm_f32_kernel<AL, BL>;
     if constexpr (AL == A_KCONTIG || AL == A_MCONTIG) {
@@ -1150,14 +1149,6 @@ int launch(GemmArgs g, int splits, float* workspace, hipStream_t st, int engine 
 
 }  // namespace
 
-extern "C" int cim_gemm_set_engine(int engine) {
-    CIM_CHECK_ARG(engine == 0 || engine == 1);
-    g_engine = engine;
-    return 0;
-}
-
-extern "C" int cim_gemm_get_engine(void) { return g_engine; }
-
 static int pick_splits(int M, int N, int K, int engine) {
     // RESIDENT 512-thread workgroups fit per CU, so a launch runs in rounds of 256*RESIDENT tiles;
     // split-K fills the last round (e.g. direct conv wgrad: 288 tiles -> 2 rounds at 56 %; x8 -> 9 full
@@ -1183,13 +1174,13 @@ static int pick_splits(int M, int N, int K, int engine) {
     return best;
 }
 
-extern "C" int cim_gemm_f32_splits(int M, int N, int K) { return pick_splits(M, N, K, g_engine); }
+extern "C" int cim_gemm_f32_splits(int M, int N, int K, int engine) { return pick_splits(M, N, K, engine == 0 ? 0 : 1); }
 extern "C" int cim_gemm_f16x2_splits(int M, int N, int K) { return pick_splits(M, N, K, 2); }
 
 extern "C" int cim_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                             int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
-                            void* stream) {
-    CIM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
+                            int engine, void* stream) {
+    CIM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && (engine == 0 || engine == 1));
     CIM_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N);
     CIM_CHECK_ARG(a_mcontig ? (M % 4 == 0 && lda % 4 == 0 && lda >= M) : (K % 4 == 0 && lda % 4 == 0 && lda >= K));
     CIM_CHECK_ARG(b_kcontig ? (K % 4 == 0 && ldb % 4 == 0 && ldb >= K) : (ldb % 4 == 0 && ldb >= N));
@@ -1197,33 +1188,33 @@ extern "C" int cim_gemm_f32(const float* A, const float* B, float* C, const floa
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 0, 0, 1, 0, 0, 0, nullptr, nullptr};
     hipStream_t st = cim::as_stream(stream);
     int rc;
-    if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, splits, workspace, st);
-    else if (!a_mcontig && b_kcontig) rc = launch<A_KCONTIG, B_KCONTIG>(g, splits, workspace, st);
-    else if (a_mcontig && !b_kcontig) rc = launch<A_MCONTIG, B_NCONTIG>(g, splits, workspace, st);
-    else rc = launch<A_MCONTIG, B_KCONTIG>(g, splits, workspace, st);
+    if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, splits, workspace, st, engine);
+    else if (!a_mcontig && b_kcontig) rc = launch<A_KCONTIG, B_KCONTIG>(g, splits, workspace, st, engine);
+    else if (a_mcontig && !b_kcontig) rc = launch<A_MCONTIG, B_NCONTIG>(g, splits, workspace, st, engine);
+    else rc = launch<A_MCONTIG, B_KCONTIG>(g, splits, workspace, st, engine);
     if (rc) { cim::set_error("cim_gemm_f32: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int cim_conv3x3_f32(const float* X, const float* Whwio, const float* bias, float* Y, int R, int P, int Cin,
-                               int Cout, int relu, void* stream) {
-    CIM_CHECK_ARG(X && Whwio && Y && R > 0 && P > 0 && Cin > 0 && Cout > 0);
+                               int Cout, int relu, int engine, void* stream) {
+    CIM_CHECK_ARG(X && Whwio && Y && R > 0 && P > 0 && Cin > 0 && Cout > 0 && (engine == 0 || engine == 1));
     CIM_CHECK_ARG(Cin % BK == 0 && Cout % 4 == 0);
     GemmArgs g{X, Whwio, Y, bias, R * P * P, Cout, 9 * Cin, Cin, Cout, Cout, relu, 0, 0, P, Cin, 1, 0, 0, 0, nullptr, nullptr};
-    int rc = launch<A_CONV_K, B_NCONTIG>(g, 1, nullptr, cim::as_stream(stream));
+    int rc = launch<A_CONV_K, B_NCONTIG>(g, 1, nullptr, cim::as_stream(stream), engine);
     if (rc) { cim::set_error("cim_conv3x3_f32: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int cim_conv3x3_wgrad_f32(const float* X, const float* dY, float* dWhwio, int R, int P, int Cin, int Cout,
-                                     int splits, float* workspace, void* stream) {
-    CIM_CHECK_ARG(X && dY && dWhwio && R > 0 && P > 0 && Cin > 0 && Cout > 0);
+                                     int splits, float* workspace, int engine, void* stream) {
+    CIM_CHECK_ARG(X && dY && dWhwio && R > 0 && P > 0 && Cin > 0 && Cout > 0 && (engine == 0 || engine == 1));
     CIM_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0);
     CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
     GemmArgs g{X, dY, dWhwio, nullptr, 9 * Cin, Cout, R * P * P, Cin, Cout, Cout, 0, 0, 0, P, Cin, 1, 0, 0, 0, nullptr, nullptr};
-    int rc = launch<A_CONV_M, B_NCONTIG>(g, splits, workspace, cim::as_stream(stream));
+    int rc = launch<A_CONV_M, B_NCONTIG>(g, splits, workspace, cim::as_stream(stream), engine);
     if (rc) { cim::set_error("cim_conv3x3_wgrad_f32: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;
@@ -1231,18 +1222,18 @@ extern "C" int cim_conv3x3_wgrad_f32(const float* X, const float* dY, float* dWh
 
 extern "C" int cim_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
                                     int ldc, int a_mcontig, int b_kcontig, int batch, long long a_bs, long long b_bs,
-                                    long long c_bs, void* stream) {
-    CIM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535);
+                                    long long c_bs, int engine, void* stream) {
+    CIM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535 && (engine == 0 || engine == 1));
     CIM_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N && a_bs % 4 == 0 && b_bs % 4 == 0 && c_bs % 4 == 0);
     CIM_CHECK_ARG(a_mcontig ? (M % 4 == 0 && lda % 4 == 0 && lda >= M) : (K % 4 == 0 && lda % 4 == 0 && lda >= K));
     CIM_CHECK_ARG(b_kcontig ? (K % 4 == 0 && ldb % 4 == 0 && ldb >= K) : (ldb % 4 == 0 && ldb >= N));
     GemmArgs g{A, B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, 0, batch, a_bs, b_bs, c_bs, nullptr, nullptr};
     hipStream_t st = cim::as_stream(stream);
     int rc;
-    if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, 1, nullptr, st);
-    else if (!a_mcontig && b_kcontig) rc = launch<A_KCONTIG, B_KCONTIG>(g, 1, nullptr, st);
-    else if (a_mcontig && !b_kcontig) rc = launch<A_MCONTIG, B_NCONTIG>(g, 1, nullptr, st);
-    else rc = launch<A_MCONTIG, B_KCONTIG>(g, 1, nullptr, st);
+    if (!a_mcontig && !b_kcontig) rc = launch<A_KCONTIG, B_NCONTIG>(g, 1, nullptr, st, engine);
+    else if (!a_mcontig && b_kcontig) rc = launch<A_KCONTIG, B_KCONTIG>(g, 1, nullptr, st, engine);
+    else if (a_mcontig && !b_kcontig) rc = launch<A_MCONTIG, B_NCONTIG>(g, 1, nullptr, st, engine);
+    else rc = launch<A_MCONTIG, B_KCONTIG>(g, 1, nullptr, st, engine);
     if (rc) { cim::set_error("cim_gemm_f32_batched: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;

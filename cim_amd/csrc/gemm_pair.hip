@@ -604,10 +604,8 @@ __global__ __launch_bounds__(256) void pair_amax_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) cim::amax_publish(out, m);
 }
 
-thread_local int t_pair_limit = 0;      // cim_gemm_pair_limit: workgroups per launch of this thread's next products (0 = all tiles)
-
 template <int AL, int BL>
-int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st) {
+int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st, int max_workgroups) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     auto kern = gemm_pair_kernel<AL, BL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -633,9 +631,9 @@ int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st) {
     g.tn = tn; g.tm = tm; g.tz = g.batch > 1 ? g.batch : splits;
     const long long total = (long long)tn * tm * g.tz;
     if (total >= (1ll << 31)) return -2;
-    // cim_gemm_pair_limit: the product goes out as consecutive launches of at most that many workgroups.  A workgroup owns its CU
+    // max_workgroups > 0: the product goes out as consecutive launches of at most that many workgroups.  A workgroup owns its CU
     // (128 KB of LDS) and the launches of a stream run one after the other, so the product never holds more CUs than that.
-    const long long chunk = t_pair_limit > 0 ? t_pair_limit : total;
+    const long long chunk = max_workgroups > 0 ? max_workgroups : total;
     for (long long t0 = 0; t0 < total; t0 += chunk) {
         g.tile0 = (int)t0;
         hipLaunchKernelGGL(kern, dim3((unsigned)(total - t0 < chunk ? total - t0 : chunk)), dim3(NT), LDS_BYTES, st, g);
@@ -648,11 +646,11 @@ int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st) {
     return 0;
 }
 
-int dispatch_pair(const PairArgs& g, int a_mcontig, int b_kcontig, int splits, float* workspace, hipStream_t st) {
-    if (!a_mcontig && !b_kcontig) return launch_pair<L_KC, L_MC>(g, splits, workspace, st);
-    if (!a_mcontig && b_kcontig) return launch_pair<L_KC, L_KC>(g, splits, workspace, st);
-    if (a_mcontig && !b_kcontig) return launch_pair<L_MC, L_MC>(g, splits, workspace, st);
-    return launch_pair<L_MC, L_KC>(g, splits, workspace, st);
+int dispatch_pair(const PairArgs& g, int a_mcontig, int b_kcontig, int splits, float* workspace, hipStream_t st, int max_workgroups) {
+    if (!a_mcontig && !b_kcontig) return launch_pair<L_KC, L_MC>(g, splits, workspace, st, max_workgroups);
+    if (!a_mcontig && b_kcontig) return launch_pair<L_KC, L_KC>(g, splits, workspace, st, max_workgroups);
+    if (a_mcontig && !b_kcontig) return launch_pair<L_MC, L_MC>(g, splits, workspace, st, max_workgroups);
+    return launch_pair<L_MC, L_KC>(g, splits, workspace, st, max_workgroups);
 }
 
 }  // namespace
@@ -667,12 +665,6 @@ static bool pair_dims_ok(int M, int N, int K, int lda, int ldb, int ldc, int a_m
     const long long ext_a = (long long)(a_mcontig ? K : M) * lda * 4, ext_b = (long long)(b_kcontig ? N : K) * ldb * 4;
     if (ext_a >= (1ll << 32) || ext_b >= (1ll << 32)) return false;
     return true;
-}
-
-extern "C" int cim_gemm_pair_limit(int max_workgroups) {
-    CIM_CHECK_ARG(max_workgroups >= 0);
-    t_pair_limit = max_workgroups;
-    return 0;
 }
 
 extern "C" int cim_gemm_pair_splits(int M, int N, int K) {
@@ -696,12 +688,12 @@ extern "C" int cim_gemm_pair_splits(int M, int N, int K) {
 
 extern "C" int cim_gemm_pair(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda,
                              int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
-                             const float* a_scale, const float* b_scale, uint32_t* c_amax, void* stream) {
-    CIM_CHECK_ARG(A && B && C && a_scale && b_scale);
+                             const float* a_scale, const float* b_scale, uint32_t* c_amax, int max_workgroups, void* stream) {
+    CIM_CHECK_ARG(A && B && C && a_scale && b_scale && max_workgroups >= 0);
     CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
     CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
     PairArgs g{(const char*)A, (const char*)B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 1, 0, 0, 0, a_scale, b_scale, c_amax, 0, 0, 0, 0};
-    int rc = dispatch_pair(g, a_mcontig, b_kcontig, splits, workspace, cim::as_stream(stream));
+    int rc = dispatch_pair(g, a_mcontig, b_kcontig, splits, workspace, cim::as_stream(stream), max_workgroups);
     if (rc) { cim::set_error("cim_gemm_pair: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;
@@ -709,12 +701,12 @@ extern "C" int cim_gemm_pair(const void* A, const void* B, float* C, const float
 
 extern "C" int cim_gemm_pair_batched(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb,
                                      int ldc, int a_mcontig, int b_kcontig, int batch, long long a_bs, long long b_bs,
-                                     long long c_bs, const float* a_scale, const float* b_scale, void* stream) {
-    CIM_CHECK_ARG(A && B && C && a_scale && b_scale && batch > 0 && batch <= 65535);
+                                     long long c_bs, const float* a_scale, const float* b_scale, int max_workgroups, void* stream) {
+    CIM_CHECK_ARG(A && B && C && a_scale && b_scale && batch > 0 && batch <= 65535 && max_workgroups >= 0);
     CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
     CIM_CHECK_ARG(a_bs % 8 == 0 && b_bs % 8 == 0 && c_bs % 4 == 0);
     PairArgs g{(const char*)A, (const char*)B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, batch, a_bs, b_bs, c_bs, a_scale, b_scale, nullptr, 0, 0, 0, 0};
-    int rc = dispatch_pair(g, a_mcontig, b_kcontig, 1, nullptr, cim::as_stream(stream));
+    int rc = dispatch_pair(g, a_mcontig, b_kcontig, 1, nullptr, cim::as_stream(stream), max_workgroups);
     if (rc) { cim::set_error("cim_gemm_pair_batched: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;

@@ -1,30 +1,33 @@
 // Complete-Instances-Mining kernels for gfx950: containment flag, per-class seed selection
 // (stable top-K + greedy mask-IoU NMS), containment argmax, cross-class arbitration,
 // anti-noise sampling (NumPy's np.random.choice restated on pre-drawn MT19937 uniforms),
-// IoU-based pseudo-label assignment - for ALL CIM layers of a training step in 4 launches
-// (+ 1 per distinct con_thr for the containment flags), with no host round trip.
+// IoU-based pseudo-label assignment - for ALL CIM layers of a training step in 2 launches on the step's stream
+// (+ the input-only preparation of the containment map - flags and a transposed copy - which the host runs ahead of the
+// backbone on a side stream), with no host round trip.
 //
 // Replaces CIM_layer.{instance_nms, MIST_label, CIM_label, forward} of
 // /root/reference/lib/modeling/heads.py:237-503.  All results are integer indices or exact
 // copies of inputs, so they are bit-identical to the reference CPU path; the tie / compare
 // rules are the ones listed in SURVEY.md App. B.  Everything here is HBM/latency-bound
-// integer and fp16-compare work: no MFMA, LDS for the sort / NMS bit-matrix / scans.
+// integer and fp16-compare work: no MFMA, LDS for the select / NMS bit-matrix / scans.
 //
 // The image's class list is never known to the host: every kernel reads `labels` [C] on the device
 // (class c is active iff labels[c] != 0, heads.py:340) and the per-class outputs are indexed by the
 // class id itself ([C][K] arrays), inactive classes exit at once.
+//
+// No library state: the words through which the workgroups of the mining launch meet (arrival counters, list lengths) live in a
+// CALLER-owned scratch (cim_mining_sync_bytes(), zero-filled once at allocation) that every call leaves zeroed again.
 #include "common.h"
 #include "../../include/cim_hip.h"
 #include <limits.h>
-#include <mutex>
 
 using cim::h2f;
 
 #ifndef CIM_MINING_CLOCKS
-#define CIM_MINING_CLOCKS 0          // 1: phase stamps (100 MHz wall clock) of launches 1 and 3 -> cim_debug_mining_clocks (tools only)
+#define CIM_MINING_CLOCKS 0          // 1: phase stamps (100 MHz wall clock) of the mining launch -> cim_debug_mining_clocks (tools only)
 #endif
 #if CIM_MINING_CLOCKS
-__device__ unsigned long long g_mining_clk[2][8][16];                    // [kernel][workgroup (first 8)][stamp]
+__device__ unsigned long long g_mining_clk[2][8][16];                    // [phase: seed / arbitrate][workgroup (first 8)][stamp]
 #define MCLK(KERNEL, WG, I) do { if (threadIdx.x == 0 && (WG) < 8) g_mining_clk[KERNEL][WG][I] = wall_clock64(); } while (0)
 extern "C" int cim_debug_mining_clocks(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mining_clk), sizeof(g_mining_clk)) == hipSuccess ? 0 : 1;
@@ -63,6 +66,26 @@ __global__ __launch_bounds__(256) void asy_flag_kernel(const uint16_t* __restric
     if (lane == 0) flag[row] = ((double)cnt < limit) ? 1 : 0;
 }
 
+// The containment map transposed (asy_t[j][i] = asy[i][j]): the mining reads COLUMNS of the map (every proposal against one
+// seed, heads.py:386) - in the transposed copy such a column is one contiguous 2N-byte row.  64 x 64 tiles through LDS, both
+// global sides in 128-byte runs.
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int N) {
+    __shared__ uint16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int k = ty; k < 64; k += 4) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < N && c < N) ? src[(size_t)r * N + c] : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = ty; k < 64; k += 4) {
+        const int r = c0 + k, c = r0 + tx;          // row of dst = column of src
+        if (r < N && c < N) dst[(size_t)r * N + c] = tile[tx][k];
+    }
+}
+
 // ---------------------------------------------------------------- heads.py:354-380
 __device__ __forceinline__ uint32_t orderable(float f) {
     if (f == 0.0f) f = 0.0f;  // -0 == +0 for the comparison sort
@@ -70,143 +93,187 @@ __device__ __forceinline__ uint32_t orderable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// Bitonic sort of NP = R * 1024 keys held R per lane (element e = r * 1024 + tid): partners at distance < 64 are in the
-// same wave (__shfl_xor, no barrier), at distance >= 1024 in the same lane (registers); only the distances 64 ... 512 go
-// through LDS - 10 exchanges (two barriers each) instead of the 55 barrier stages of the all-LDS network.  Keys are a
-// total order, so any correct sort gives the stable descending argsort of heads.py:354.
-template <int R>      // R = 1 or 2
-__device__ __forceinline__ void seed_sort_regs(unsigned long long (&k)[R], unsigned long long* __restrict__ keys, int tid) {
-    constexpr int NP = R * 1024;
-#pragma unroll 1
-    for (int size = 2; size <= NP; size <<= 1) {
-#pragma unroll 1
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride >= 1024) {
-                if constexpr (R == 2) {              // stride == 1024: both elements live in this lane
-                    const bool up = (tid & size) == 0;
-                    const unsigned long long a = k[0], b = k[R - 1];
-                    if ((a > b) == up) { k[0] = b; k[R - 1] = a; }
-                }
-            } else if (stride >= 64) {
+__device__ int block_exclusive_scan(int v, int* part, int* total) {      // 1024 lanes; returns the exclusive prefix
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;       // wave scans in registers, 16 wave totals through LDS:
+    int incl = v;                                                        // two barriers instead of the 20 of an all-LDS scan
 #pragma unroll
-                for (int r = 0; r < R; ++r) keys[r * 1024 + tid] = k[r];
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int e = r * 1024 + tid;
-                    const unsigned long long o = keys[e ^ stride];
-                    const bool lower = (e & stride) == 0, up = (e & size) == 0;
-                    const bool take_min = lower == up;
-                    k[r] = take_min ? (o < k[r] ? o : k[r]) : (o > k[r] ? o : k[r]);
-                }
-                __syncthreads();
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int e = r * 1024 + tid;
-                    const unsigned long long o = __shfl_xor(k[r], stride);
-                    const bool lower = (e & stride) == 0, up = (e & size) == 0;
-                    const bool take_min = lower == up;
-                    k[r] = take_min ? (o < k[r] ? o : k[r]) : (o > k[r] ? o : k[r]);
-                }
-            }
-        }
+    for (int o = 1; o < 64; o <<= 1) {
+        const int x = __shfl_up(incl, o);
+        if (lane >= o) incl += x;
     }
+    __syncthreads();                                                     // (part[] of the previous scan has been read)
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int p = part[w];
+        tot += p;
+        woff += (w < wave) ? p : 0;
+    }
+    *total = tot;
+    return woff + incl - v;
 }
 
-template <int R>
-__device__ __forceinline__ void seed_topk_regs(const float* __restrict__ score, int score_ld, int col, int N,
-                                               unsigned long long* __restrict__ keys, int32_t* __restrict__ kidx,
-                                               int32_t* __restrict__ topk_out, int K, int tid) {
-    unsigned long long k[R];
+// The words the workgroups of the mining launch meet through (caller-owned, zero between calls).
+struct MiningSync {
+    unsigned arrive[CIM_MAX_LAYERS];                 // (class, layer) workgroups of a layer that finished their seed phase
+    unsigned done;                                   // arbitrators that finished
+    unsigned pad_[3];
+    unsigned long long gword[CIM_MAX_LAYERS];        // bit 63: published | error bits << 32 | list length of a sampling layer
+};
+
+// LDS layout of the seed phase (byte offsets; the arbitration phase re-uses the array from offset 0)
+struct SeedLayout {
+    int off_cand, off_sup, off_kidx, off_seed, off_det, off_flag;
+    int det_lds;                                     // the layer's detector column and the flags staged in LDS (else read from memory)
+    int total;
+};
+
+// ================================================================== the mining launch, phase 1: seeds of one (class, layer)
+// Top-K by RADIX SELECT (the reference takes argsort(descending)[:K], heads.py:354: only K = ceil(0.1 N) of the N keys are
+// wanted in order): four 8-bit histogram passes over the orderable score bits find the K-th largest value T and how many
+// keys equal to T belong to the top K (ties: the lowest proposal indices - a stable descending sort, App. B item 4); the K
+// survivors are ranked among themselves by counting (K^2 / 1024 compares per lane).  Round 4 sorted all N keys (bitonic,
+// 55 exchange stages): 12.5 of the kernel's 37 us.
+template <int MAXR>
+__device__ __forceinline__ void seed_topk_select(const float* __restrict__ score, int score_ld, int col, int N, int K,
+                                                 unsigned* __restrict__ hist, unsigned long long* __restrict__ cand,
+                                                 int32_t* __restrict__ kidx, int32_t* __restrict__ topk_out, int* s_misc,
+                                                 int* s_part, int tid) {
+    const int lane = tid & 63;
+    const int Rk = (N + 1023) >> 10;                 // keys per lane: lane t owns the proposals [t Rk, t Rk + Rk)
+    unsigned key[MAXR];
+    unsigned valid = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = r * 1024 + tid;
-        k[r] = ~0ull;
-        if (i < N) k[r] = ((unsigned long long)(~orderable(score[(size_t)i * score_ld + col])) << 32) | (unsigned)i;
+    for (int r = 0; r < MAXR; ++r) {
+        key[r] = 0;
+        const int i = tid * Rk + r;
+        if (r < Rk && i < N) {
+            key[r] = orderable(score[(size_t)i * score_ld + col]);
+            valid |= 1u << r;
+        }
     }
-    seed_sort_regs<R>(k, keys, tid);
-    if (tid < K) {                                   // K <= 1024: the K smallest keys sit in k[0] of lanes 0 .. K-1
-        const int32_t id = (int32_t)(k[0] & 0xffffffffu);
-        kidx[tid] = id;
-        topk_out[tid] = id;
+    unsigned prefix = 0, pmask = 0;
+    int need = K;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        if (tid == 0) s_misc[2] = 0;                 // (the compaction counter below)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            if (((valid >> r) & 1u) && (key[r] & pmask) == prefix) atomicAdd(&hist[(key[r] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < 64) {                              // lane holds the bins 4 lane .. 4 lane + 3; suffix sums from the top bin down
+            const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];
+            const int cnt[4] = {(int)h.x, (int)h.y, (int)h.z, (int)h.w};
+            const int s4 = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+            int suf = s4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int x = __shfl_down(suf, o);
+                if (lane + o < 64) suf += x;
+            }
+            int above = suf - s4;                    // keys in the bins of higher lanes
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                if (above < need && need <= above + cnt[b]) {
+                    s_misc[0] = 4 * lane + b;        // the bin that holds the need-th largest key
+                    s_misc[1] = need - above;
+                }
+                above += cnt[b];
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)s_misc[0] << shift;
+        pmask |= 255u << shift;
+        need = s_misc[1];
     }
+    // T = prefix: `need` of the keys equal to T are in, in proposal order
+    int tie = 0;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) tie += (((valid >> r) & 1u) && key[r] == prefix) ? 1 : 0;
+    int tie_total;
+    int tie_before = block_exclusive_scan(tie, s_part, &tie_total);
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        if (!((valid >> r) & 1u)) continue;
+        bool take = key[r] > prefix;
+        if (key[r] == prefix) take = tie_before++ < need;
+        if (take) {
+            const int at = atomicAdd(&s_misc[2], 1);
+            cand[at] = ((unsigned long long)(~key[r]) << 32) | (unsigned)(tid * Rk + r);     // (descending score, ascending index)
+        }
+    }
+    __syncthreads();
+    // rank of each survivor among the K: G lanes per survivor count a share of the list each
+    int Kp = 1;
+    while (Kp < K) Kp <<= 1;
+    int G = 1024 / Kp;
+    if (G > 64) G = 64;
+    const int j = tid / G, sub = tid - j * G;
+    unsigned long long me = 0ull;
+    int cnt = 0;
+    if (j < K) {
+        me = cand[j];
+        for (int m = sub; m < K; m += G) cnt += cand[m] < me ? 1 : 0;
+    }
+    for (int o = G >> 1; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (j < K && sub == 0) {
+        const int32_t id = (int32_t)(me & 0xffffffffu);
+        kidx[cnt] = id;
+        topk_out[cnt] = id;
+    }
+    (void)lane;
     __syncthreads();
 }
 
-
-// ================================================================== fused step: launch 1
-// grid = (C, R), block = 1024: workgroup (c, l) = class c of CIM layer l.  Dynamic LDS: [max(NP*8, K*KW*8)] + K*4 bytes.
-__global__ __launch_bounds__(1024) void step_seed_kernel(const cim_mining_args a, int NP, int KW, size_t idx_off) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-    int32_t* kidx = reinterpret_cast<int32_t*>(smem + idx_off);
-    const int c = blockIdx.x, l = blockIdx.y;
+// Seeds of (class c, layer l): top-K select, K x K suppression bit-matrix, greedy scan, and - CIM layers - the containment
+// arg-max of every seed (heads.py:386-395; round 4: a launch of its own, one workgroup per seed column): one wave per seed
+// walks the seed's column of the containment map - a contiguous row of the transposed copy - against the layer's detector
+// column, first-index arg-max.
+__device__ __forceinline__ void seed_phase(const cim_mining_args& a, const SeedLayout& lay, unsigned char* smem, int* s_misc,
+                                           int* s_part, int c, int l) {
     const cim_mining_layer& L = a.layer[l];
     const int tid = threadIdx.x, N = a.N, K = a.K;
-    if (c == 0 && l == 0 && tid == 0) *a.status = 0;                    // error bits of this step (launches 3 / losses OR into it)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int KW = (K + 63) >> 6;
+    unsigned* hist = reinterpret_cast<unsigned*>(smem);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem + lay.off_cand);
+    unsigned long long* sup = reinterpret_cast<unsigned long long*>(smem + lay.off_sup);
+    int32_t* kidx = reinterpret_cast<int32_t*>(smem + lay.off_kidx);
+    int32_t* sseed = reinterpret_cast<int32_t*>(smem + lay.off_seed);
+    float* sdet = reinterpret_cast<float*>(smem + lay.off_det);
+    uint8_t* sflag = smem + lay.off_flag;
     int32_t* __restrict__ topk_out = L.topk + (size_t)c * K;
     int32_t* __restrict__ seeds = L.seeds + (size_t)c * K;
-    if (a.labels[c] == 0.0f) {                                          // heads.py:340: only the image's classes
-        if (tid == 0) L.n_seeds[c] = 0;
-        return;
-    }
     [[maybe_unused]] const int wg_act = (int)(l * 2 + (c & 1));          // (debug stamps only)
     MCLK(0, wg_act, 0);
-    const float* __restrict__ score = L.seed_score;
-    const int score_ld = L.seed_ld, col = L.seed_off + c;
-    // key = (descending score, ascending index): a total order -> the sort is the stable
-    // descending argsort of heads.py:354 (App. B item 4).
-    if (NP == 1024) {
-        seed_topk_regs<1>(score, score_ld, col, N, keys, kidx, topk_out, K, tid);
-    } else if (NP == 2048) {
-        seed_topk_regs<2>(score, score_ld, col, N, keys, kidx, topk_out, K, tid);
-    } else {
-        for (int i = tid; i < NP; i += 1024) {
-            unsigned long long key = ~0ull;
-            if (i < N) key = ((unsigned long long)(~orderable(score[(size_t)i * score_ld + col])) << 32) | (unsigned)i;
-            keys[i] = key;
+    const uint8_t* __restrict__ flag = L.using_cim ? a.flags + (size_t)L.flag_slot * N : nullptr;
+    if (L.using_cim && lay.det_lds) {                                    // staged first: the loads fly under the select passes
+        for (int i = tid; i < N; i += 1024) {
+            sdet[i] = L.det[(size_t)i * L.det_ld + L.det_off + c * L.det_cs];
+            sflag[i] = flag[i];
         }
-        __syncthreads();
-        for (int size = 2; size <= NP; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int t = tid; t < NP / 2; t += 1024) {
-                    const int lo = (t / stride) * (2 * stride) + (t % stride);
-                    const int hi = lo + stride;
-                    const bool up = ((lo & size) == 0);
-                    const unsigned long long x = keys[lo], y = keys[hi];
-                    if ((x > y) == up) {
-                        keys[lo] = y;
-                        keys[hi] = x;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        for (int r = tid; r < K; r += 1024) {
-            const int32_t id = (int32_t)(keys[r] & 0xffffffffu);
-            kidx[r] = id;
-            topk_out[r] = id;
-        }
-        __syncthreads();
     }
-
+    // key = (descending score, ascending index): a total order -> the stable descending argsort of heads.py:354 (App. B item 4)
+    seed_topk_select<8>(L.seed_score, L.seed_ld, L.seed_off + c, N, K, hist, cand, kidx, topk_out, s_misc, s_part, tid);
     MCLK(0, wg_act, 1);
     // Suppression bit-matrix over the K x K gathered sub-block of the mask-IoU map:
     // bit (i, j) set <=> NOT (iou[idx_i, idx_j] < nms_thr)   (heads.py:250-254, fp16 compare).
-    unsigned long long* sup = keys;  // keys are dead from here on
-    const int wave = tid >> 6, lane = tid & 63;
     const float nms_thr = L.nms_thr;
-    for (int t0 = wave; t0 < K * KW; t0 += 16 * 4) {                     // 4 gathers in flight per wave (latency-bound: the
-        uint16_t v[4];                                                   // map is L2-resident, each gather a round trip)
+    for (int t0 = wave; t0 < K * KW; t0 += 16 * 8) {                     // 8 gathers in flight per wave (latency-bound: the
+        uint16_t v[8];                                                   // map is L2-resident, each gather a round trip)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int t = t0 + 16 * u;
             const int i = t / KW, j = (t % KW) * 64 + lane;
             v[u] = (t < K * KW && j < K) ? a.iou[(size_t)kidx[i] * N + kidx[j]] : (uint16_t)0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int t = t0 + 16 * u;
             if (t >= K * KW) break;
             const int j = (t % KW) * 64 + lane;
@@ -241,7 +308,12 @@ __global__ __launch_bounds__(1024) void step_seed_kernel(const cim_mining_args a
                 kept |= alive ? (1ull << t) : 0ull;
                 rem |= alive ? row : 0ull;
             }
-            if ((kept >> lane) & 1ull) seeds[cnt + __popcll(kept & ((1ull << lane) - 1ull))] = kidx[i0 + lane];
+            if ((kept >> lane) & 1ull) {
+                const int at = cnt + __popcll(kept & ((1ull << lane) - 1ull));
+                const int32_t id = kidx[i0 + lane];
+                seeds[at] = id;
+                sseed[at] = id;
+            }
             cnt += __popcll(kept);
             if (lane < KW)
                 for (unsigned long long k = kept; k;) {                  // four independent LDS reads per round (a repeated row is harmless)
@@ -258,66 +330,81 @@ __global__ __launch_bounds__(1024) void step_seed_kernel(const cim_mining_args a
                 }
         }
         for (int r = cnt + lane; r < K; r += 64) seeds[r] = -1;
-        if (lane == 0) L.n_seeds[c] = cnt;
-        MCLK(0, wg_act, 3);
+        if (lane == 0) {
+            L.n_seeds[c] = cnt;
+            s_misc[3] = cnt;
+        }
     }
-}
+    __syncthreads();
+    MCLK(0, wg_act, 3);
+    if (!L.using_cim) return;                                            // MIST_label: the seeds are the pseudo ground truths
 
-// ================================================================== fused step: launch 2 (heads.py:386-395)
-// grid = (K, C, R), block = 256: one workgroup per seed column of the containment map; inactive classes,
-// exhausted seed slots and MIST layers (no containment step) leave at once.
-__global__ __launch_bounds__(256) void step_contain_kernel(const cim_mining_args a) {
-    const int s = blockIdx.x, c = blockIdx.y, l = blockIdx.z;
-    const cim_mining_layer& L = a.layer[l];
-    if (!L.using_cim || a.labels[c] == 0.0f) return;
-    const int K = a.K, N = a.N;
-    if (s >= L.n_seeds[c]) {
-        if (threadIdx.x == 0) L.res[(size_t)c * K + s] = -1;
-        return;
-    }
-    const uint8_t* __restrict__ flag = a.flags + (size_t)L.flag_slot * N;
+    // ---- containment arg-max (heads.py:386-395): res[s] = the best-det proposal among {i : asy[i, seed_s] > con_thr and not huge(i)}
+    const int n_seeds = s_misc[3];
     const float thr = L.con_thr;
-    const int seed = L.seeds[(size_t)c * K + s];
-    float best = -INFINITY;
-    int besti = INT_MAX;
-    int any = 0;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const bool cond = (h2f(a.asy[(size_t)i * N + seed]) > thr) && flag[i];
-        any |= cond;
-        const float v = cond ? L.det[(size_t)i * L.det_ld + L.det_off + c * L.det_cs] : 0.0f;   // heads.py:393
-        if (v > best) {  // ascending i per thread: strict '>' keeps the first maximum
-            best = v;
-            besti = i;
+    int32_t* __restrict__ res = L.res + (size_t)c * K;
+    for (int s = wave; s < K; s += 16) {
+        if (s >= n_seeds) {
+            if (lane == 0) res[s] = -1;
+            continue;
         }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o);
-        const int oi = __shfl_xor(besti, o);
-        if (ov > best || (ov == best && oi < besti)) {
-            best = ov;
-            besti = oi;
-        }
-    }
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        sv[wave] = best;
-        si[wave] = besti;
-    }
-    any = __syncthreads_or(any);
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (sv[w] > best || (sv[w] == best && si[w] < besti)) {
-                best = sv[w];
-                besti = si[w];
+        const int seed = sseed[s];
+        float best = -INFINITY;
+        int besti = INT_MAX;
+        int any = 0;
+        if (a.asy_t != nullptr) {
+            const uint16_t* __restrict__ colp = a.asy_t + (size_t)seed * N;      // column `seed` of the map, contiguous
+            if (lay.det_lds) {
+#pragma unroll 4
+                for (int i = lane; i < N; i += 64) {
+                    const bool cond = (h2f(colp[i]) > thr) && sflag[i];
+                    any |= cond;
+                    const float v = cond ? sdet[i] : 0.0f;               // heads.py:393
+                    if (v > best) {  // ascending i per lane: strict '>' keeps the first maximum
+                        best = v;
+                        besti = i;
+                    }
+                }
+            } else {
+#pragma unroll 4
+                for (int i = lane; i < N; i += 64) {
+                    const bool cond = (h2f(colp[i]) > thr) && flag[i];
+                    any |= cond;
+                    const float v = cond ? L.det[(size_t)i * L.det_ld + L.det_off + c * L.det_cs] : 0.0f;
+                    if (v > best) {
+                        best = v;
+                        besti = i;
+                    }
+                }
             }
-        L.res[(size_t)c * K + s] = any ? besti : -1;
+        } else {                                                         // no transposed copy: strided reads of the map's column
+#pragma unroll 4
+            for (int i = lane; i < N; i += 64) {
+                const bool cond = (h2f(a.asy[(size_t)i * N + seed]) > thr) && flag[i];
+                any |= cond;
+                const float v = cond ? L.det[(size_t)i * L.det_ld + L.det_off + c * L.det_cs] : 0.0f;
+                if (v > best) {
+                    best = v;
+                    besti = i;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(besti, o);
+            if (ov > best || (ov == best && oi < besti)) {
+                best = ov;
+                besti = oi;
+            }
+        }
+        any = __any(any);
+        if (lane == 0) res[s] = any ? besti : -1;
     }
+    MCLK(0, wg_act, 4);
 }
 
-// ================================================================== fused step: launch 3 - the NumPy arithmetic it restates
+// ================================================================== the mining launch, phase 2 - the NumPy arithmetic it restates
 // Per layer: cross-class arbitration (heads.py:397-405 / 306-314), ordered compaction (App. B item 8), anti-noise
 // sampling (heads.py:447-473) on the uniforms the reference's sequential CIM_layer calls would draw, compaction of the
 // survivors.
@@ -365,41 +452,16 @@ __device__ float np_pairwise_sum(const float* a, int n) {
     }
 }
 
-__device__ int block_exclusive_scan(int v, int* part, int* total) {      // 1024 lanes; returns the exclusive prefix
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;       // wave scans in registers, 16 wave totals through LDS:
-    int incl = v;                                                        // two barriers instead of the 20 of an all-LDS scan
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int x = __shfl_up(incl, o);
-        if (lane >= o) incl += x;
-    }
-    __syncthreads();                                                     // (part[] of the previous scan has been read)
-    if (lane == 63) part[wave] = incl;
-    __syncthreads();
-    int woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const int p = part[w];
-        tot += p;
-        woff += (w < wave) ? p : 0;
-    }
-    *total = tot;
-    return woff + incl - v;
-}
-
-// ================================================================== fused step: launch 3 (heads.py:396-466)
-// grid = R, block = 1024: workgroup l = CIM layer l.  Arbitration and the ordered compaction of a layer depend on nothing
-// but that layer's scores, so the layers run side by side; only the anti-noise sampling is ordered across layers, through
-// the position in the pre-drawn uniform stream: layer l consumes uniforms [base_l, base_l + G_l) with base_l = the sum of
-// the earlier sampling layers' list lengths (np.random.choice draws one double per class member, every member of the list
-// belongs to exactly one class).  Each workgroup publishes its G_l in `sync[l]` (tagged with this call's epoch: the words
-// are never reset) and reads the earlier layers' words - R <= 4 workgroups are always co-resident, and workgroup 0 waits
-// for nobody.
-__global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_mining_args a, unsigned long long* __restrict__ sync,
-                                                                     unsigned long long epoch) {
+// Arbitration + sampling of layer l by ONE workgroup - the layer's LAST ARRIVING seed workgroup (round 4: a launch of its
+// own, one workgroup per layer).  Arbitration and the ordered compaction of a layer depend on nothing but that layer's
+// scores, so the layers run side by side; only the anti-noise sampling is ordered across layers, through the position in the
+// pre-drawn uniform stream: layer l consumes uniforms [base_l, base_l + G_l) with base_l = the sum of the earlier sampling
+// layers' list lengths (np.random.choice draws one double per class member, every member of the list belongs to exactly one
+// class).  Each arbitrator publishes its G_l in sync->gword[l] and reads the earlier layers' words: at most R <= 4 workgroups
+// ever wait, on workgroups that are running or will be dispatched whatever the waiters hold, and layer 0 waits for nobody.
+__device__ void arbitrate_phase(const cim_mining_args& a, MiningSync* __restrict__ sync, unsigned char* smem, int l) {
 #pragma clang fp contract(off)                      // the sums below restate NumPy's: no fused multiply-adds
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int N = a.N, K = a.K, C = a.C, tid = threadIdx.x, l = blockIdx.x;
+    const int N = a.N, K = a.K, C = a.C, tid = threadIdx.x;
     // LDS: cdf f64 [K] | part i32 [1024] | prob f32 [K] | pos i32 [K] | gclass i32 [N] | gweight f32 [N] | mark u8 [N]
     double* cdf = reinterpret_cast<double*>(smem);
     int32_t* part = reinterpret_cast<int32_t*>(cdf + K);
@@ -410,11 +472,13 @@ __global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_m
     uint8_t* mark = reinterpret_cast<uint8_t*>(gweight + N);
     __shared__ int s_used;
     __shared__ float s_total;
+    __shared__ int s_err;
     const int chunk = (N + 1023) / 1024;
     const int lo = min(N, tid * chunk), hi = min(N, lo + chunk);
     const cim_mining_layer& L = a.layer[l];
 
     MCLK(1, l, 0);
+    if (tid == 0) s_err = 0;
     // the image's classes, ascending (labels[] is read once; the class loops below walk this list)
     __shared__ int16_t s_act[1024];
     int n_act;
@@ -481,14 +545,14 @@ __global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_m
     const bool sampling = L.anti_noise && G > 0;
     MCLK(1, l, 4);
     if (tid == 0) {
-        __hip_atomic_store(sync + l, (epoch << 20) | (unsigned long long)(sampling ? G : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync->gword + l, (1ull << 63) | (unsigned long long)(sampling ? G : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         int base = 0;
         for (int e = 0; e < l; ++e) {
             unsigned long long v;
             do {
-                v = __hip_atomic_load(sync + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 20) != epoch) __builtin_amdgcn_s_sleep(2);
-            } while ((v >> 20) != epoch);
+                v = __hip_atomic_load(sync->gword + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(v >> 63)) __builtin_amdgcn_s_sleep(2);
+            } while (!(v >> 63));
             base += (int)(v & 0xfffffull);
         }
         s_used = base;
@@ -515,7 +579,7 @@ __global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_m
             if (Gc == 0) continue;                                       // heads.py:454-455 (uniform)
             if (Gc > K) {                                                // cannot happen (<= K candidates per class); stay memory-safe:
                 if (tid == 0) {                                          // the step fails with status bit 1, the uniforms count as drawn
-                    atomicOr(a.status, 1);
+                    s_err |= 1;
                     s_used += Gc;
                 }
                 __syncthreads();
@@ -562,7 +626,7 @@ __global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_m
             const double last = cdf[Gc - 1];
             const int base = s_used;
             if (base + Gc > a.max_uniforms) {                            // the host drew too few (cannot happen: bound = R * min(N, classes * K))
-                if (tid == 0) atomicOr(a.status, 2);
+                if (tid == 0) s_err |= 2;
             } else {
                 for (int j = tid; j < Gc; j += 1024) {
                     const double u = a.uniforms[base + j];
@@ -605,12 +669,57 @@ __global__ __launch_bounds__(1024) void step_arbitrate_sample_kernel(const cim_m
             L.counts[1] = Gk;
             a.layer_valid[l] = G > 0 ? 1 : 0;                            // heads.py:429-430: no pseudo GT -> layer skipped
             if (l == a.R - 1) a.used[0] = s_used;                        // (the last layer ends where the whole step's stream ends)
+            // This arbitrator is done.  Its error bits travel in its word; the LAST of the R arbitrators to finish writes the
+            // step's status word (the losses launch ORs its own bits into it later) and puts every sync word back to zero -
+            // all R have read what they needed by then, and every seed workgroup has arrived (each layer's arbitrator was
+            // elected by its last arrival): the scratch is as the caller handed it over.
+            if (s_err) __hip_atomic_fetch_or(sync->gword + l, (unsigned long long)s_err << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned fin = __hip_atomic_fetch_add(&sync->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (fin == (unsigned)a.R - 1u) {
+                int bits = 0;
+                for (int e = 0; e < a.R; ++e) {
+                    bits |= (int)((__hip_atomic_load(sync->gword + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) & 0xffu);
+                    __hip_atomic_store(sync->gword + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sync->arrive + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(&sync->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *a.status = bits;
+            }
         }
     }
     MCLK(1, l, 8);
 }
 
-// ================================================================== fused step: launch 4 (heads.py:435,477-501)
+// ================================================================== the mining launch
+// grid = (C, R), block = 1024: workgroup (c, l) = class c of CIM layer l; inactive classes leave at once.  The last of a layer's
+// active workgroups to finish its seeds goes on as the layer's arbitrator (with no class at all, workgroup (0, l) does).
+__global__ __launch_bounds__(1024) void step_mine_kernel(const cim_mining_args a, MiningSync* __restrict__ sync, const SeedLayout lay) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_misc[8];
+    __shared__ int s_part[16];
+    const int c = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+    const cim_mining_layer& L = a.layer[l];
+    const int n_act = __syncthreads_count(tid < a.C && a.labels[tid] != 0.0f);
+    if (a.labels[c] == 0.0f) {                                           // heads.py:340: only the image's classes
+        if (tid == 0) L.n_seeds[c] = 0;
+        if (n_act != 0 || c != 0) return;
+    } else {
+        seed_phase(a, lay, smem, s_misc, s_part, c, l);
+        // arrival: this workgroup's seeds / res are in memory (release), then one ticket on the layer's counter
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(sync->arrive + l, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_misc[4] = old == (unsigned)n_act - 1u;
+        }
+        __syncthreads();
+        if (!s_misc[4]) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // the other classes' lists
+    }
+    arbitrate_phase(a, sync, smem, l);
+}
+
+// ================================================================== the assignment launch (heads.py:435,477-501)
 // grid = (ceil(N/4), R): one wave per proposal row and layer: gather the G' surviving pseudo-GT columns of the fp16
 // mask-IoU map, first-index arg-max, then the ignore / background / IoU-label rules.
 __device__ __forceinline__ void assign_row(const uint16_t* __restrict__ r, int row, int lane, const int32_t* __restrict__ gt_idx,
@@ -673,6 +782,29 @@ __global__ __launch_bounds__(256) void step_assign_kernel(const cim_mining_args 
                L.pseudo_labels, L.pseudo_iou, L.loss_weights, L.max_idx);
 }
 
+long long arbitrate_lds_bytes(int N, int K) {
+    return (long long)K * 8 + 1024 * 4 + (long long)K * 8 + (long long)N * 9 + 16;
+}
+
+SeedLayout seed_layout(int N, int K) {
+    const long long KW = (K + 63) / 64;
+    auto up16 = [](long long v) { return (v + 15) & ~15ll; };
+    SeedLayout s{};
+    long long o = 1024;                                                  // the 256-bin histogram
+    s.off_cand = (int)o; o = up16(o + (long long)K * 8);
+    s.off_sup = (int)o;  o = up16(o + (long long)K * KW * 8);
+    s.off_kidx = (int)o; o = up16(o + (long long)K * 4);
+    s.off_seed = (int)o; o = up16(o + (long long)K * 4);
+    const long long det = up16((long long)N * 4) + up16(N);
+    s.det_lds = (o + det <= 160 * 1024) ? 1 : 0;
+    s.off_det = (int)o;
+    s.off_flag = (int)(o + up16((long long)N * 4));
+    if (s.det_lds) o += det;
+    const long long arb = arbitrate_lds_bytes(N, K);
+    s.total = (int)(o > arb ? o : arb);
+    return s;
+}
+
 }  // namespace
 
 extern "C" int cim_asy_flag(const uint16_t* asy_f16, int N, float con_thr, uint8_t* flag, void* stream) {
@@ -687,32 +819,32 @@ extern "C" int cim_asy_flag(const uint16_t* asy_f16, int N, float con_thr, uint8
     return 0;
 }
 
-extern "C" long long cim_mining_lds_bytes(int N, int K) {
-    return (long long)K * 8 + 1024 * 4 + (long long)K * 8 + (long long)N * 9 + 16;
-}
-
-// The words through which launch 3's workgroups pass their list lengths: a ring of 64 slots x CIM_MAX_LAYERS per device,
-// one slot per call, never reset - a word counts only when it carries the call's own epoch (a process-wide call counter, so a
-// slot's previous tenant, 64 calls ago, can never be taken for the current one).  Calls in flight together (two streams)
-// use different slots.
-static bool layer_sync_slot(unsigned long long** sync, unsigned long long* epoch) {
-    static std::mutex mu;
-    static unsigned long long* ring[64] = {nullptr};
-    static unsigned long long calls = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    std::lock_guard<std::mutex> lock(mu);
-    if (ring[dev] == nullptr) {
-        if (hipMalloc(reinterpret_cast<void**>(&ring[dev]), sizeof(unsigned long long) * 64 * CIM_MAX_LAYERS) != hipSuccess) { ring[dev] = nullptr; return false; }
-        if (hipMemset(ring[dev], 0, sizeof(unsigned long long) * 64 * CIM_MAX_LAYERS) != hipSuccess) return false;   // (synchronous)
+extern "C" int cim_asy_prep(const uint16_t* asy_f16, int N, const float* con_thr_host, int n_slots, uint8_t* flags,
+                            uint16_t* asy_t, void* stream) {
+    CIM_CHECK_ARG(N >= 0 && n_slots >= 0 && n_slots <= CIM_MAX_LAYERS);
+    if (N == 0) return 0;
+    CIM_CHECK_ARG(asy_f16 && (n_slots == 0 || (con_thr_host && flags)));
+    for (int s = 0; s < n_slots; ++s) {
+        const int rc = cim_asy_flag(asy_f16, N, con_thr_host[s], flags + (size_t)s * N, stream);
+        if (rc) return rc;
     }
-    *epoch = ++calls;                                   // >= 1: never matches the zero-filled ring; < 2^44 for the tag
-    *sync = ring[dev] + (calls % 64) * CIM_MAX_LAYERS;
-    return true;
+    if (asy_t != nullptr) {
+        const unsigned t = (unsigned)((N + 63) / 64);
+        hipLaunchKernelGGL(transpose_f16_kernel, dim3(t, t), dim3(256), 0, cim::as_stream(stream), asy_f16, asy_t, N);
+    }
+    CIM_CHECK_LAUNCH();
+    return 0;
 }
 
-extern "C" int cim_mining_step(const cim_mining_args* args, void* stream) {
-    CIM_CHECK_ARG(args != nullptr);
+extern "C" long long cim_mining_lds_bytes(int N, int K) {
+    if (N <= 0 || K <= 0) return 0;
+    return seed_layout(N, K).total;
+}
+
+extern "C" long long cim_mining_sync_bytes(void) { return (long long)sizeof(MiningSync); }
+
+extern "C" int cim_mining_step(const cim_mining_args* args, void* sync, void* stream) {
+    CIM_CHECK_ARG(args != nullptr && sync != nullptr && (reinterpret_cast<uintptr_t>(sync) & 7) == 0);
     cim_mining_args a = *args;
     const int N = a.N, K = a.K, C = a.C, R = a.R;
     CIM_CHECK_ARG(N > 0 && N <= 8192 && K > 0 && K <= 1024 && K <= N && C > 0 && C <= 1024 && R >= 1 && R <= CIM_MAX_LAYERS);
@@ -731,40 +863,17 @@ extern "C" int cim_mining_step(const cim_mining_args* args, void* stream) {
         L.iou_thr = cim::round_to_f16(L.iou_thr);
         L.con_thr = cim::round_to_f16(L.con_thr);
     }
-    CIM_CHECK_ARG(!any_cim || (a.asy && a.flags));                       // MIST-only steps never touch the containment map
+    CIM_CHECK_ARG(!any_cim || ((a.asy || a.asy_t) && a.flags));          // MIST-only steps never touch the containment map
     hipStream_t st = cim::as_stream(stream);
-    int NP = 2;
-    while (NP < N) NP <<= 1;
-    const int KW = (K + 63) / 64;
-    size_t big = (size_t)NP * 8;
-    if ((size_t)K * KW * 8 > big) big = (size_t)K * KW * 8;
-    big = (big + 15) & ~(size_t)15;
-    const size_t lds1 = big + (size_t)K * 4;
-    CIM_CHECK_ARG(lds1 <= 160 * 1024);
-    if (lds1 > 64 * 1024)
-        CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(step_seed_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    hipLaunchKernelGGL(step_seed_kernel, dim3(C, R), dim3(1024), lds1, st, a, NP, KW, big);
-    if (any_cim) hipLaunchKernelGGL(step_contain_kernel, dim3(K, C, R), dim3(256), 0, st, a);
-    const size_t lds3 = (size_t)cim_mining_lds_bytes(N, K);
-    CIM_CHECK_ARG(lds3 <= 160 * 1024);
-    if (lds3 > 64 * 1024)
-        CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(step_arbitrate_sample_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-    // Launch 3's workgroups (one per layer, R <= CIM_MAX_LAYERS) hand their list lengths to the higher-numbered ones through
-    // device words tagged with this CALL's epoch.  No dispatch ORDER is assumed - a waiting workgroup sleeps on the word while
-    // the others are placed wherever a CU is free; at most R - 1 CUs ever hold waiters - but the epoch and the slot are baked
-    // into the launch's arguments: a captured launch would replay with a stale epoch and read the previous replay's words.  So
-    // this entry refuses a capturing stream (the step's mining runs eagerly between the captured body and the losses).
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
-        cim::set_error("cim_mining_step: the stream is capturing a HIP graph - the mining launches cannot be captured (per-call epoch)");
-        return -1;
-    }
-    unsigned long long* sync = nullptr;
-    unsigned long long epoch = 0;
-    CIM_CHECK_ARG(layer_sync_slot(&sync, &epoch) && N < (1 << 20));
-    hipLaunchKernelGGL(step_arbitrate_sample_kernel, dim3(R), dim3(1024), lds3, st, a, sync, epoch);
+    const SeedLayout lay = seed_layout(N, K);
+    CIM_CHECK_ARG(lay.total <= 160 * 1024);
+    if (lay.total > 64 * 1024)
+        CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(step_mine_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lay.total));
+    // The layer arbitrators (at most R workgroups) wait for each other's list lengths inside the launch: no dispatch ORDER is
+    // assumed - a waiting workgroup sleeps on the word while the others are placed wherever a CU is free.  Nothing per call is
+    // baked into the arguments (the sync words are left zeroed), so the launches may be captured into a HIP graph and replayed.
+    hipLaunchKernelGGL(step_mine_kernel, dim3(C, R), dim3(1024), (size_t)lay.total, st, a, static_cast<MiningSync*>(sync), lay);
     hipLaunchKernelGGL(step_assign_kernel, dim3((N + 3) / 4, R), dim3(256), 0, st, a);
     CIM_CHECK_LAUNCH();
     return 0;

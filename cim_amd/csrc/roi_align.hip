@@ -600,8 +600,6 @@ static_assert(RG_WIN == 32 || RG_WIN == 16, "staging window: 32 or 16 entries");
 // ROIs per workgroup: 64, or 128 when 64 would make more than ~3.5 workgroups per CU (measured, ms at 64 / 128:
 // 1000 ROIs on 33 x 43: 0.188 / 0.284, 800 on 27 x 36: 0.159 / 0.253, 1200 on 41 x 54: 0.288 / 0.261, 2000 on 33 x 43: 0.353 / 0.321)
 static inline int rg_group_size(int K, int B, int C, int H, int W) {
-    const char* e = getenv("CIM_ROI_RG_GS");                // 64 / 128: sweep switch (tools/bench_roi_bwd.py)
-    if (e && (atoi(e) == 64 || atoi(e) == 128)) return atoi(e);
     const long long wgs = (long long)B * ((K + 63) / 64) * ((H + 11) / 12) * ((W + 15) / 16) * ((C + 255) / 256);
     return wgs > 900 ? 128 : 64;
 }
@@ -949,8 +947,7 @@ int launch_fwd(const float* feat, const float* rois, const float* masks, float* 
     dim3 grid(K, P), block(256);
     // table-driven kernels: need the table workspace, 16-byte channel rows and maps of <= 64 rows.  Row-sum kernel (two bin rows
     // per workgroup) for maps up to 64 columns and P <= 7; the flat entry-list kernel otherwise.
-    if (ws != nullptr && C % 4 == 0 && P <= FW_MAXP && (long long)H * W * C < (1ll << 30) && H <= 64 &&
-        getenv("CIM_ROI_FWD_EXACT") == nullptr) {
+    if (ws != nullptr && C % 4 == 0 && P <= FW_MAXP && (long long)H * W * C < (1ll << 30) && H <= 64) {
         hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), sizeof(float) * roi_rec_words(P, H, W), st, rois, ws, K, P, H, W, scale, sr, aligned);
         if (P <= 7 && W <= RS_MAXD) {
             const int nth = C >= 1024 ? 256 : ((C / 4 + 63) / 64) * 64;       // narrow maps: no idle waves

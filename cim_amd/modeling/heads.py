@@ -6,9 +6,10 @@ behaviour): `cls_iou_model` (:168-219), `CIM_layer` (:222-503), `cls_iou_loss` (
 `PCL_loss` (:10-41).
 
 The mining (`CIM_layer`) runs on hand-written HIP kernels through the C ABI of
-include/cim_hip.h (cim_amd/csrc/mining.hip); only the anti-noise sampling stays on the host,
-because the reference draws it from the process-global legacy NumPy RNG (heads.py:459) and
-bit-identical pseudo labels require the identical stream.  There is no CPU fallback.
+include/cim_hip.h (cim_amd/csrc/mining.hip) - the anti-noise sampling included: the reference draws it from the
+process-global legacy NumPy RNG (heads.py:459), so the host pre-draws the doubles `np.random.choice` would consume,
+the device restates choice() on them, and the generator is rewound to the consumed count afterwards (`_RngLedger`):
+same pseudo labels, same stream position, no host wait inside the step.  There is no CPU fallback.
 """
 import ctypes
 import os
@@ -461,7 +462,7 @@ class _MiningArgs(ctypes.Structure):
     """Mirror of `cim_mining_args` in include/cim_hip.h."""
     _P, _I = ctypes.c_void_p, ctypes.c_int32
     _fields_ = [("N", _I), ("C", _I), ("K", _I), ("R", _I),
-                ("labels", _P), ("iou", _P), ("asy", _P), ("flags", _P), ("uniforms", _P),
+                ("labels", _P), ("iou", _P), ("asy", _P), ("asy_t", _P), ("flags", _P), ("uniforms", _P),
                 ("max_uniforms", _I), ("reserved_", _I),
                 ("used", _P), ("status", _P), ("layer_valid", _P),
                 ("layer", _MiningLayer * MAX_LAYERS)]
@@ -580,7 +581,6 @@ class MiningResult:
         return self
 
 
-@torch.no_grad()
 def _rows_in_place(t):
     """(tensor to keep alive, row stride in elements) of a 2-D fp32 score tensor whose rows are contiguous - a column block of a
     wider matrix is read where it lies; anything else is copied."""
@@ -591,10 +591,80 @@ def _rows_in_place(t):
     return t, t.shape[-1]
 
 
-def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None):
+class ContainmentPrep:
+    """What the mining needs from the containment map alone (cim_asy_prep): flags [slots, N] (heads.py:338, one row per distinct
+    con_thr) and the transposed map [N, N]; `event` (or None) orders them before their first use on another stream."""
+    __slots__ = ("thr_slots", "flags", "asy_t", "event", "src", "n")
+
+    def matches(self, asy_iou_map, n, thr_slots):
+        return (self.n == n and self.src is not None and asy_iou_map is not None and self.src.data_ptr() == asy_iou_map.data_ptr()
+                and self.src._version == asy_iou_map._version and self.thr_slots == thr_slots)
+
+
+def _thr_slots(layers, using_CIM):
+    slots = []
+    for l, u in zip(layers, using_CIM):
+        if u and float(l.con_thr) not in slots:
+            slots.append(float(l.con_thr))
+    return slots
+
+
+@torch.no_grad()
+def prepare_containment(layers, asy_iou_map, using_CIM=None, ahead=True):
+    """Launch the input-only part of a step's mining NOW: the "not a huge proposal" flags (one N x N scan per DISTINCT con_thr; the
+    reference rescans in every layer, heads.py:338) and the transposed containment map (the containment step reads columns).
+    ahead=True: on the side stream - Generalized_RCNN.forward calls this before the backbone, whose small kernels leave most of
+    the chip idle; mine_step(prep=...) then waits for the event.  -> ContainmentPrep or None (no CIM layer)."""
+    using_CIM = [True] * len(layers) if using_CIM is None else list(using_CIM)
+    slots = _thr_slots(layers, using_CIM)
+    if not slots or asy_iou_map is None:
+        return None
+    n = asy_iou_map.shape[0]
+    asy = _f16_map(asy_iou_map, "asy_iou_map", n)
+    dev = asy.device
+    from ..ops import gemm as _G
+    cur = torch.cuda.current_stream(dev)
+    side = _G._side_stream(dev) if (ahead and _G.OVERLAP and not torch.cuda.is_current_stream_capturing()) else None
+    prep = ContainmentPrep()
+    prep.thr_slots, prep.src, prep.n, prep.event = slots, asy, n, None
+    thr = (ctypes.c_float * len(slots))(*slots)
+
+    def launch():
+        prep.flags = torch.empty((len(slots), n), dtype=torch.uint8, device=dev)
+        prep.asy_t = torch.empty((n, n), dtype=torch.float16, device=dev)
+        _lib.call("cim_asy_prep", asy.data_ptr(), n, thr, len(slots), prep.flags.data_ptr(), prep.asy_t.data_ptr(), _lib.stream_ptr())
+
+    if side is None:
+        launch()
+    else:
+        side.wait_stream(cur)                    # (whoever made the map enqueued it on `cur`)
+        with torch.cuda.stream(side):
+            launch()
+            prep.event = torch.cuda.Event()
+            prep.event.record(side)
+        asy.record_stream(side)
+    return prep
+
+
+_SYNC = {}       # (device, raw stream) -> zeroed int64 scratch of cim_mining_sync_bytes(): the mining launch's meeting words
+
+
+def _sync_scratch(dev, st):
+    """The caller-owned scratch of cim_mining_step: one per (device, stream) - calls that can be in flight together must not share
+    it; zero-filled once here, every call leaves it zeroed (include/cim_hip.h)."""
+    key = (dev.index, st)
+    t = _SYNC.get(key)
+    if t is None:
+        t = _SYNC[key] = torch.zeros((int(_lib.call("cim_mining_sync_bytes")) + 7) // 8, dtype=torch.int64, device=dev)
+    return t
+
+
+@torch.no_grad()
+def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None, prep=None):
     """The mining + assignment of all CIM layers of one training step (reference: the three CIM_layer.forward calls
-    of model_builder.py:170-187) in 5 launches, nothing read back.  layers: CIM_layer modules (thresholds);
-    scores[i] = (predict_cls, predict_det) fed to layer i; labels [1,C] / [C] device tensor."""
+    of model_builder.py:170-187) in 2 launches, nothing read back.  layers: CIM_layer modules (thresholds);
+    scores[i] = (predict_cls, predict_det) fed to layer i; labels [1,C] / [C] device tensor.  prep: prepare_containment()'s
+    result for this step's asy_iou_map when the caller launched it ahead (else made here, on the current stream)."""
     R = len(layers)
     assert 1 <= R <= MAX_LAYERS
     using_CIM = [True] * R if using_CIM is None else list(using_CIM)
@@ -615,15 +685,20 @@ def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None):
         asy_iou_map = _f16_map(asy_iou_map, "asy_iou_map", N)
     st = _lib.stream_ptr()
 
-    # containment flags: one N x N scan per DISTINCT con_thr (the reference rescans in every layer, heads.py:338)
-    thr_slots = []
-    for l, u in zip(layers, using_CIM):
-        if u and float(l.con_thr) not in thr_slots:
-            thr_slots.append(float(l.con_thr))
-    u8 = torch.empty((max(len(thr_slots), 1) + R, N), dtype=torch.uint8, device=dev)
-    flags, pre_keep = u8[:max(len(thr_slots), 1)], u8[max(len(thr_slots), 1):]
-    for slot, thr in enumerate(thr_slots):
-        _lib.call("cim_asy_flag", asy_iou_map.data_ptr(), N, thr, flags[slot].data_ptr(), st)
+    # containment flags + transposed map: input-only work, launched ahead by the model (else here)
+    thr_slots = _thr_slots(layers, using_CIM)
+    if any_cim:
+        if prep is None or not prep.matches(asy_iou_map, N, thr_slots):
+            prep = prepare_containment(layers, asy_iou_map, using_CIM, ahead=False)
+        elif prep.event is not None:
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(prep.event)
+            prep.flags.record_stream(cur)
+            prep.asy_t.record_stream(cur)
+        flags, asy_t = prep.flags, prep.asy_t
+    else:
+        flags, asy_t = torch.empty((1, N), dtype=torch.uint8, device=dev), None
+    pre_keep = torch.empty((R, N), dtype=torch.uint8, device=dev)
 
     per_i = 3 * C * K + C + 5 * N
     ints = torch.empty(R * per_i + 2 + 3 * R, dtype=torch.int32, device=dev)
@@ -643,10 +718,11 @@ def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None):
     a = _MiningArgs()
     a.N, a.C, a.K, a.R = N, C, K, R
     a.labels, a.iou, a.asy = labels.data_ptr(), iou_map.data_ptr(), _lib.ptr(asy_iou_map if any_cim else None)
+    a.asy_t = _lib.ptr(asy_t)
     a.flags, a.uniforms, a.max_uniforms = flags.data_ptr(), uniforms.data_ptr(), max_u
     a.used, a.status, a.layer_valid = meta[0:1].data_ptr(), meta[1:2].data_ptr(), valid.data_ptr()
     out = MiningResult()
-    keep = [labels, iou_map, asy_iou_map, uniforms, u8, ints, f32]
+    keep = [labels, iou_map, asy_iou_map, uniforms, flags, asy_t, pre_keep, ints, f32]
     for i, (layer, (pcls, pdet)) in enumerate(zip(layers, scores)):
         L = a.layer[i]
         # (the scores are column blocks of the heads' ONE score matrix: read in place through their row stride, no copies)
@@ -697,7 +773,7 @@ def mine_step(layers, scores, labels, iou_map, asy_iou_map, using_CIM=None):
                      asy_flag=flags[L.flag_slot] if using_CIM[i] else None, C=C, K=K)
         out.debug.append(views)
     try:
-        _lib.call("cim_mining_step", ctypes.byref(a), st)
+        _lib.call("cim_mining_step", ctypes.byref(a), _sync_scratch(dev, st).data_ptr(), st)
     except Exception:
         if _rng.snapshot is not None:                   # nothing was launched: give the drawn uniforms back
             np.random.set_state(_rng.snapshot[0])

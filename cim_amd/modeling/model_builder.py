@@ -174,6 +174,12 @@ class Generalized_RCNN(nn.Module):
                 if index is not None:
                     index = index.squeeze(dim=0).to(device=dev).long()
             return_dict = {}
+            prep = None
+            if self.training and asy_iou_map is not None and asy_iou_map.is_cuda:
+                # what the mining needs from the containment map alone (flags, transposed copy) runs on the side stream under the
+                # backbone forward (heads.prepare_containment); maps that come from the reference's pickles are loaded after the
+                # heads as the reference does (model_builder.py:147-159) and prepared there
+                prep = heads.prepare_containment(self.CIM_layer_list, asy_iou_map, self.using_CIM)
             blob_conv = self._conv_body(im_data)
             return_dict["blob_conv"] = blob_conv
             seg_x = self.Box_Head(blob_conv, rois, masks.detach())
@@ -192,7 +198,7 @@ class Generalized_RCNN(nn.Module):
             # classes, pseudo-GT counts, the anti-noise sampling and "no pseudo GT -> skip the layer" stay on the device
             scores = [(predict_cls, predict_det) if i == 0 else (ref_cls_score[i - 1], ref_iou_score[i - 1])
                       for i in range(len(self.CIM_layer_list))]
-            mined = heads.mine_step(self.CIM_layer_list, scores, labels, iou_map, asy_iou_map, self.using_CIM)
+            mined = heads.mine_step(self.CIM_layer_list, scores, labels, iou_map, asy_iou_map, self.using_CIM, prep=prep)
             scales = [3 if i == 0 else 1 for i in range(len(self.CIM_layer_list))]      # lmda, model_builder.py:172
             if cfg.REFINE_TIMES <= 3 and not PCL_GENERAL:
                 # all four losses + their gradient components in one HIP launch (csrc/losses.hip)

@@ -20,8 +20,15 @@ Protocol (host side, per backward pass; everything hangs off P's own `state` dic
   * P's backward asks take(dy, state): (True, part) -> dy is already dconv_P.  A taken P that receives anything else (the gradient
     was accumulated with another one: x had a second consumer after all) raises - it cannot be repaired silently.  A mark that is
     never taken (P's backward did not run) dies with P's state.
+  * Someone who looks AT x's gradient would see dconv_P instead (the chain rewrites what flows along that edge).  So Q checks, at
+    its backward, that x is still private (still_private): no tensor hook, no retain_grad() on x, and P's node is part of the
+    running backward pass (torch.autograd.grad(loss, [x]) stops at x: P's backward never runs).  If not, Q computes the plain data
+    gradient and P its own BatchNorm backward - the ordinary autograd path, correct for every observer.  What cannot be seen from
+    here - torch.autograd.grad with x AND something upstream of P among its inputs - is documented in INTEGRATION.md section 4.
 """
 import collections
+
+import torch
 
 InputBn = collections.namedtuple("InputBn", "gamma var eps mean affine state")
 
@@ -42,6 +49,27 @@ def input_bn(x, enabled):
         return None
     t.state["taken"] = True
     return t
+
+
+def node_runs(fn):
+    """Will the autograd node `fn` be executed by the backward pass that is running now?  (torch.autograd.grad(outputs, inputs) only
+    runs the nodes between them.)  True when the engine cannot be asked."""
+    if fn is None:
+        return False
+    try:
+        return bool(torch._C._will_engine_execute_node(fn))
+    except (AttributeError, RuntimeError):
+        return True
+
+
+def still_private(x, in_bn):
+    """Q's backward: may x's incoming gradient still be rewritten into the gradient of P's convolution output?  Not when somebody
+    observes x's gradient (hook, retain_grad) or P's backward is not part of this pass - then the chain is undone for this pass."""
+    ok = (not getattr(x, "retains_grad", False) and not getattr(x, "_backward_hooks", None)
+          and not getattr(x, "_post_accumulate_grad_hooks", None) and node_runs(x.grad_fn))
+    if not ok:
+        in_bn.state["taken"] = False             # P sees an ordinary gradient and runs its own BatchNorm backward
+    return ok
 
 
 def c_args(in_bn, part):

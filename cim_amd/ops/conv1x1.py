@@ -9,6 +9,7 @@ In NCHW the convolution of one image is W[Cout,Cin] . X[Cin,HW]: forward, data g
 (dY . X^T, split-K) are three layouts of the same small-tile fp32-MFMA GEMM; the BatchNorm backward stays the fused
 `bn_act` kernel.  CPU tensors, a BatchNorm in training mode or other convolution shapes take the ATen ops."""
 import ctypes
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -84,14 +85,16 @@ class Conv1x1BnActFunction(Function):
         dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=dev) if need_w else None
         ws = torch.empty(_lib.call("cim_conv1x1_bwd_workspace", B, cin, cout, hw) // 4, dtype=torch.float32, device=dev)
         in_bn = ctx.in_bn if need_x else None
+        if in_bn is not None and not chain.still_private(x, in_bn):
+            in_bn = None                         # somebody looks at x's gradient / the producer's backward is not in this pass
         in_part = torch.empty((B, 2, (hw + 31) // 32, cin), dtype=torch.float32, device=dev) if in_bn is not None and in_bn.affine else None
-        side, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
+        side, ev_fork, ev_join, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
         _lib.call("cim_conv1x1_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w2.data_ptr(),
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres),
                   _lib.ptr(None if chained else dgamma), _lib.ptr(None if chained else dbeta), _lib.ptr(dx), _lib.ptr(dw),
-                  B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, join, int(is_dconv), *chain.c_args(in_bn, in_part),
+                  B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, ev_fork, ev_join, join, int(is_dconv), *chain.c_args(in_bn, in_part),
                   _lib.ptr(dx_add), dx_add_w)
-        if ctx.send_dx is not None and dx is not None:
+        if ctx.send_dx is not None and dx is not None and _receiver_runs(ctx.send_dx):
             # a downsample layer: its data gradient is the SECOND gradient of the block's input - handed to the block's first layer
             # (whose backward runs later: checked) instead of autograd, which would scatter a stride-2 layer's into a zero-filled
             # tensor through two slice nodes (two fills + two copies) and add the two gradients with a launch of its own
@@ -101,7 +104,7 @@ class Conv1x1BnActFunction(Function):
             tok["sent"] = tok.get("sent", 0) + 1
             tok["dres"] = dx
             dx = None
-        if ctx.send is not None and dres is not None:
+        if ctx.send is not None and dres is not None and _receiver_runs(ctx.send):
             # hand the identity path's gradient to the block's FIRST layer instead of autograd (which would add it to that layer's
             # data gradient with a launch of its own); that layer's backward runs after this one (later nodes first) - checked
             if ctx.send.get("sent", 0) != ctx.send.get("received", 0):
@@ -119,6 +122,14 @@ class Conv1x1BnActFunction(Function):
         dmean = -(gamma * torch.rsqrt(var + eps)) * dbeta if need_mean else None
         return dx, dw, dres, (dgamma if ctx.needs_input_grad[3] else None), (dbeta if ctx.needs_input_grad[4] else None), \
             dmean, None, None, None, None, None, None, None, None
+
+
+def _receiver_runs(tok):
+    """Branch hand-over: the block's first layer takes the second gradient of the block's input in its data-gradient epilogue - only
+    if its backward is part of the running pass (torch.autograd.grad towards this layer's weight alone never reaches it); else the
+    gradient goes back to autograd as usual."""
+    r = tok.get("recv_node")
+    return chain.node_runs(r() if r is not None else None)
 
 
 class _BnPartDesc(ctypes.Structure):          # cim_bn_part_desc of include/cim_hip.h
@@ -180,10 +191,15 @@ def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False, b
         if residual is not None:
             out = out + residual
         return F.relu(out) if relu else out
+    if (fuse_input_bn and branch is not None and residual is None and getattr(x, "_cim_bn", None) is not None
+            and torch.is_grad_enabled() and x.requires_grad):
+        raise ValueError("conv1x1_bn_act: `branch` on a layer without a residual makes it the RECEIVER of a second gradient of its "
+                         "input (added in its data-gradient epilogue); that cannot be combined with fuse_input_bn=True on an input "
+                         "whose producer is chained (the same epilogue slot) - pass one of the two")
     in_bn = chain.input_bn(x, fuse_input_bn and stride == 1 and torch.is_grad_enabled() and x.requires_grad)
     send_dx = None
-    if (branch is not None and residual is None and stride in (1, 2) and x.requires_grad and x.is_contiguous()
-            and branch.get("x") == (x.data_ptr(), tuple(x.shape), x._version)):
+    same = lambda t: branch.get("x") is not None and branch["x"]() is t       # the very tensor object the first layer registered
+    if (branch is not None and residual is None and stride in (1, 2) and x.requires_grad and x.is_contiguous() and same(x)):
         send_dx = branch            # the block's downsample layer, called after the first layer registered the same input
     if stride != 1:                                   # a strided 1 x 1 convolution only sees every stride-th pixel
         x = x[:, :, ::stride, ::stride]
@@ -199,12 +215,13 @@ def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, fuse_input_bn=False, b
     recv = send = None
     if branch is not None and send_dx is None and stride == 1 and x.requires_grad:
         if residual is None:
-            branch["x"] = (x.data_ptr(), tuple(x.shape), x._version)
+            branch["x"] = weakref.ref(x)          # identity, not address: a different autograd tensor over the same storage is not x
             recv = branch
-        elif (branch.get("x") == (residual.data_ptr(), tuple(residual.shape), residual._version) and residual.requires_grad
-              and residual.is_contiguous()):
+        elif same(residual) and residual.requires_grad and residual.is_contiguous():
             send = branch
     state = {"taken": False}
     out = Conv1x1BnActFunction.apply(*args, in_bn, state, recv, send, send_dx)
+    if recv is not None and out.grad_fn is not None:
+        recv["recv_node"] = weakref.ref(out.grad_fn)      # the senders ask the engine whether this node is part of their pass
     chain.tag(out, bn.weight, bn.bias, mean, bn.running_var, bn.eps, relu, residual is not None, state)
     return out

@@ -33,6 +33,11 @@ class _WtDesc(ctypes.Structure):              # cim_wt_desc of include/cim_hip.h
 
 
 def _transposed(w):
+    # Under HIP-graph capture the prefetched buffer must NOT be used: its address would be baked into the graph, replays never
+    # re-run the prefetch, and after the first optimizer step the captured data gradient would read the capture-time weights
+    # (later: freed memory).  The captured call then makes the transpose itself, in its own workspace, on every replay.
+    if torch.cuda.is_current_stream_capturing():
+        return None
     e = _WT.get(id(w))
     if e is not None and e[4]() is w and e[0] == w._version and e[1] == w.data_ptr():
         torch.cuda.current_stream(w.device).wait_event(e[3])
@@ -115,13 +120,15 @@ class Conv3x3BnActFunction(Function):
         dw = torch.empty_like(w) if need_w else None
         ws = torch.empty(_lib.call("cim_conv3x3_nchw_bwd_workspace", B, cin, cout, H, W, stride) // 4, dtype=torch.float32, device=dev)
         in_bn = ctx.in_bn if need_x else None
+        if in_bn is not None and not chain.still_private(x, in_bn):
+            in_bn = None                         # somebody looks at x's gradient / the producer's backward is not in this pass
         in_part = torch.empty((B, 2, (H * W + 31) // 32, cin), dtype=torch.float32, device=dev) if in_bn is not None and in_bn.affine else None
-        side, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
+        side, ev_fork, ev_join, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
         wt = _transposed(ctx.param) if (need_x and ctx.param is not None) else None
         _lib.call("cim_conv3x3_nchw_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w.data_ptr(),
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres),
                   _lib.ptr(None if chained else dgamma), _lib.ptr(None if chained else dbeta), _lib.ptr(dx), _lib.ptr(dw),
-                  B, cin, cout, H, W, stride, dilation, ws.data_ptr(), _lib.stream_ptr(), side, join,
+                  B, cin, cout, H, W, stride, dilation, ws.data_ptr(), _lib.stream_ptr(), side, ev_fork, ev_join, join,
                   int(is_dconv), *chain.c_args(in_bn, in_part), _lib.ptr(wt))
         if in_bn is not None:
             chain.hand_over(in_bn, dx, in_part)

@@ -33,6 +33,12 @@ if PAIR:
     ENGINE = "f16x2"
 
 
+def engine_code():
+    """`engine` argument of the cim_gemm_f32 / cim_conv3x3_f32 entry points (operands without scales): 0 = f32 MFMA multiplies,
+    1 = the exact three-term bf16 split.  The library keeps no engine state: every call says which arithmetic it wants."""
+    return 0 if ENGINE == "fp32" else 1
+
+
 def _zeros_i32(dev, *sizes):
     """Zeroed int32 arrays of the given sizes carved out of ONE allocation / fill (0 -> None)."""
     pad = [(n + 3) & ~3 for n in sizes]
@@ -93,10 +99,10 @@ def gemm(a, b, m, n, k, lda, ldb, a_mcontig=False, b_kcontig=False, bias=None, r
         raise _lib.CimHipError("cim_amd.ops.gemm: CUDA/HIP tensors required (no CPU fallback)")
     c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=a.device)
     if ENGINE != "f16x2":
-        splits = _lib.call("cim_gemm_f32_splits", m, n, k)
+        splits = _lib.call("cim_gemm_f32_splits", m, n, k, engine_code())
         ws = _ws(m, n, splits, a)
         _lib.call("cim_gemm_f32", a.data_ptr(), b.data_ptr(), c.data_ptr(), _lib.ptr(bias), m, n, k, lda, ldb, n,
-                  int(a_mcontig), int(b_kcontig), int(relu), splits, _lib.ptr(ws), _lib.stream_ptr())
+                  int(a_mcontig), int(b_kcontig), int(relu), splits, _lib.ptr(ws), engine_code(), _lib.stream_ptr())
         return c
     if a_amax is None:
         a_amax = amax(a, k, m, lda, want_cols=True)[1] if a_mcontig else amax(a, m, k, lda, want_rows=True)[0]
@@ -188,13 +194,34 @@ def gradient_is_deferred(param):
     return id(param) in _PENDING_IDS
 
 
+_FORK_EVENTS = {}     # device -> [next index, [(torch event, raw hipEvent_t), ...]]
+
+
+def fork_event(dev):
+    """Raw hipEvent_t (an int) for the fork inside a cim_*_bn_act_bwd call: the C library creates nothing, the events are the
+    host's.  A small round-robin pool per device - an event is recorded and waited on inside the call that gets it, so it can go
+    to the next call at once.  (torch creates the underlying hipEvent_t at the first record().)"""
+    ent = _FORK_EVENTS.get(dev)
+    if ent is None:
+        evs = []
+        cur = torch.cuda.current_stream(dev)
+        for _ in range(16):
+            e = torch.cuda.Event(enable_timing=False)
+            e.record(cur)
+            evs.append((e, e.cuda_event))
+        ent = _FORK_EVENTS[dev] = [0, evs]
+    ent[0] = (ent[0] + 1) % len(ent[1])
+    return ent[1][ent[0]][1]
+
+
 def side_stream_for_backward(dev, param):
-    """(side stream pointer or None, join flag) for a backbone layer's backward whose weight is `param`: deferred to the
-    side stream, or - HIP-graph capture, CIM_DEFER_DW=0, a weight that is not a Parameter - everything on the
-    caller's stream (a fork / join inside every layer measured SLOWER than that: 17.0-17.1 vs 16.8 ms per step)."""
+    """(side stream pointer or None, fork event, join event, join flag) for a backbone layer's backward whose weight is `param`:
+    deferred to the side stream (the caller joins later: no join event), or - HIP-graph capture, CIM_DEFER_DW=0, a weight that is
+    not a Parameter - everything on the caller's stream (a fork / join inside every layer measured SLOWER than that: 17.0-17.1 vs
+    16.8 ms per step)."""
     if not DEFER_DW or param is None or torch.cuda.is_current_stream_capturing():
-        return None, 1
-    return _body_stream(dev).cuda_stream, 0
+        return None, None, None, 1
+    return _body_stream(dev).cuda_stream, fork_event(dev), None, 0
 
 
 def _body_stream(dev):
@@ -360,7 +387,7 @@ def _bgemm(a, b, c, m, n, k, lda, ldb, a_mcontig, batch, a_bs, b_bs, c_bs, a_ama
     scales [batch, n]."""
     if ENGINE != "f16x2":
         _lib.call("cim_gemm_f32_batched", a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, lda, ldb, n,
-                  int(a_mcontig), int(b_kcontig), batch, a_bs, b_bs, c_bs, _lib.stream_ptr())
+                  int(a_mcontig), int(b_kcontig), batch, a_bs, b_bs, c_bs, engine_code(), _lib.stream_ptr())
         return
     if a_amax is None:
         a_amax = (amax(a, k, m, lda, want_cols=True, batch=batch, bs=a_bs)[1] if a_mcontig
@@ -486,7 +513,7 @@ class Conv3x3Function(Function):
         else:
             whwio = w.permute(2, 3, 1, 0).contiguous()
             _lib.call("cim_conv3x3_f32", x.data_ptr(), whwio.data_ptr(), _lib.ptr(b), y.data_ptr(), r, p, cin, cout,
-                      int(relu), st)
+                      int(relu), engine_code(), st)
         # mixed tiling: the data gradient is evaluated as the adjoint of this product and reuses U (no second filter transform)
         ctx.save_for_backward(x, w, y if relu else None, V, U if (tile == 7 and ctx.needs_input_grad[0]) else None)
         ctx.relu = relu
@@ -555,7 +582,7 @@ class Conv3x3Function(Function):
                 _lib.call("cim_wino_output_transform", M2.data_ptr(), None, dxp.data_ptr(), r, p, cin, 0, tile, st)
             else:
                 w2 = w.flip(2, 3).permute(2, 3, 0, 1).contiguous()                     # [3,3,Cout,Cin]
-                _lib.call("cim_conv3x3_f32", dy.data_ptr(), w2.data_ptr(), None, dxp.data_ptr(), r, p, cout, cin, 0, st)
+                _lib.call("cim_conv3x3_f32", dy.data_ptr(), w2.data_ptr(), None, dxp.data_ptr(), r, p, cout, cin, 0, engine_code(), st)
             return dxp.permute(0, 3, 1, 2)
 
         def weight_grad():
@@ -572,11 +599,11 @@ class Conv3x3Function(Function):
                 _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, tile, st)
             else:
                 m, n, k = 9 * cin, cout, r * p * p
-                splits = _lib.call("cim_gemm_f32_splits", m, n, k)
+                splits = _lib.call("cim_gemm_f32_splits", m, n, k, engine_code())
                 ws = _ws(m, n, splits, x)
                 dwh = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=dev)
                 _lib.call("cim_conv3x3_wgrad_f32", x.data_ptr(), dy.data_ptr(), dwh.data_ptr(), r, p, cin, cout, splits,
-                          _lib.ptr(ws), st)
+                          _lib.ptr(ws), engine_code(), st)
                 dw = dwh.permute(3, 2, 0, 1)
             return dw
 

@@ -38,7 +38,7 @@ NPOS = 121
 # with the options on and off, bit-equal.)
 DEFER_DW = _os_env.get("CIM_DEFER_MASKFUSE_DW", "1") == "1"
 # With the deferred join: the three weight-gradient products are LAUNCHED at the end of this node's backward (behind its
-# data-gradient chain, not beside it) in consecutive launches of DW_WGS workgroups (cim_gemm_pair_limit; a workgroup owns its
+# data-gradient chain, not beside it) in consecutive launches of DW_WGS workgroups (the `max_workgroups` argument of cim_gemm_pair*; a workgroup owns its
 # CU) - they then run beside the ROIAlign and backbone backward, whose small kernels get on the chip between two launches instead
 # of queueing behind several thousand resident-for-70-us workgroups.  Measured at cfg2, interleaved runs on one box, ms per step:
 # beside the data gradients, joined at the node (round 2's schedule) 14.84 / 14.53 / 14.78; late in launches of 256 14.25 / 14.23 /
@@ -229,13 +229,13 @@ class MaskFusePairFunction(Function):
         db2 = pair.masked_stats(dY2, Y2, am[0:1], ctx.has_bias[2] and ctx.needs_input_grad[6])
         dY2p = pair.split(dY2, r, h2, h2, scale=pair.scales_from(am[0:1], 1), relu_y=Y2)
         if need_w2:
-            dw2 = side_grad(2, w2_p, lambda: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False))
+            dw2 = side_grad(2, w2_p, lambda limit=0: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False, limit=limit))
         dY1 = pair.gemm(dY2p, W2p, r, h1, h2, False, False)
         # ---- fc1
         db1 = pair.masked_stats(dY1, Y1, am[1:2], ctx.has_bias[1] and ctx.needs_input_grad[4])
         dY1p = pair.split(dY1, r, h1, h1, scale=pair.scales_from(am[1:2], 1), relu_y=Y1)
         if need_w1:
-            dw1 = side_grad(1, w1_p, lambda: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False))
+            dw1 = side_grad(1, w1_p, lambda limit=0: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False, limit=limit))
         if need_x or need_wc or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
             dX = pair.gemm(dY1p, W1p, r, cout * p * p, h1, False, False, c_amax=am[2:3], balance=True)
             # ---- flatten backward + ReLU mask of the conv; conv gradients
@@ -248,13 +248,13 @@ class MaskFusePairFunction(Function):
             if want_dbc:
                 dbc = bpart.sum(dim=0)          # per-ROI partial sums from the flatten kernel: 4 MB instead of a pass over dy
             if need_wc:
-                def wgrad():
+                def wgrad(limit=0):
                     st2 = _lib.stream_ptr()
                     sD = torch.empty(NPOS, dtype=torch.float32, device=dev)
                     _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 2, sD.data_ptr(), st2)
                     D = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sD)
                     _lib.call("cim_wino7_dy_pair", dy.data_ptr(), D.buf.data_ptr(), sD.data_ptr(), r, rp, cout, 0, st2)
-                    dU = pair.gemm(V, D, cin, cout, rp, True, False)
+                    dU = pair.gemm(V, D, cin, cout, rp, True, False, limit=limit)
                     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
                     _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, 7, st2)
                     return dw
@@ -282,12 +282,9 @@ class MaskFusePairFunction(Function):
                 with torch.cuda.stream(side):
                     # (several ranks: RCCL's all-reduce kernels hold CUs of their own while these products run - a launch of exactly
                     # one workgroup per CU would then need a second, nearly empty round each time: the products go out whole)
-                    _lib.call("cim_gemm_pair_limit", DW_WGS if publisher is None else 0)
+                    limit = DW_WGS if publisher is None else 0
                     SCHEDULE["late_launches_chunked" if publisher is None else "late_launches_whole_products"] += 1
-                    try:
-                        got = {slot: publish(w, fn()) for slot, w, fn in late}
-                    finally:
-                        _lib.call("cim_gemm_pair_limit", 0)
+                    got = {slot: publish(w, fn(limit)) for slot, w, fn in late}
                 if defer:           # (postponed: this node has returned - the join bookkeeping of the block below happens here)
                     keep = [t for t in (V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf,
                                         dY1p.scale, dy_conv, am) if t is not None]

@@ -6,8 +6,11 @@
  *   - returns 0 on success, a positive hipError_t on a HIP failure, -1 on bad arguments;
  *     cim_last_error() returns a thread-local description of the last failure;
  *   - every pointer is a caller-owned DEVICE pointer to a dense array of the stated dtype
- *     (the Python host passes torch.Tensor.data_ptr()); nothing is allocated or freed,
- *     no host synchronisation happens, no global state is kept (re-entrant);
+ *     (the Python host passes torch.Tensor.data_ptr()); nothing is allocated or freed (no hipMalloc, no events, no streams:
+ *     device scratch, fork / join events and side streams are the caller's and come in as arguments), no host synchronisation
+ *     happens, no state is kept between calls (no process-wide or per-thread switches, counters or pools): the library is
+ *     re-entrant - host threads may call it concurrently on different streams (tests/test_gpu_reentrant.py);
+ *     the only per-thread datum is the message behind cim_last_error();
  *   - the last argument is the hipStream_t to launch on, passed as void*
  *     (torch.cuda.current_stream().cuda_stream);
  *   - "f16" arrays hold IEEE binary16 bit patterns (uint16_t).  Python-float thresholds are
@@ -111,8 +114,15 @@ int cim_mask_iou_pair(const uint64_t* packed, int N, int words, int32_t* area,
 /* heads.py:338: flag[i] = (#{j : asy[i,j] > con_thr}) < 0.9*N     (flag: uint8 [N]) */
 int cim_asy_flag(const uint16_t* asy_f16, int N, float con_thr, uint8_t* flag, void* stream);
 
+/* Everything the mining needs from the containment map ALONE (an input of the step: the host runs this on a side stream under
+ * the backbone forward): flags [n_slots, N] = cim_asy_flag for each of the n_slots distinct con_thr values (con_thr_host: HOST
+ * array), and asy_t [N,N] = the map transposed (may be NULL) - the containment step reads whole COLUMNS of the map
+ * (heads.py:386: every proposal against one seed), contiguous rows of the transposed copy. */
+int cim_asy_prep(const uint16_t* asy_f16, int N, const float* con_thr_host, int n_slots, uint8_t* flags, uint16_t* asy_t,
+                 void* stream);
+
 /* The whole mining + assignment of ONE training step - all REFINE_TIMES CIM layers - without a host round trip:
- * 4 launches (seed selection; containment arg-max; arbitration + anti-noise sampling; assignment).
+ * 2 launches (seed selection + containment arg-max + arbitration + anti-noise sampling; assignment).
  * Replaces, per layer, CIM_layer.forward = CIM_label / MIST_label + instance_nms + the sampling loop + the assignment,
  * lib/modeling/heads.py:237-503, as called three times per image from lib/modeling/model_builder.py:170-187.
  *
@@ -163,6 +173,7 @@ typedef struct cim_mining_args {
     const float* labels;             /* [C] image labels */
     const uint16_t* iou;             /* [N,N] binary16 mask-IoU map */
     const uint16_t* asy;             /* [N,N] binary16 containment map */
+    const uint16_t* asy_t;           /* [N,N] its transpose from cim_asy_prep (NULL: the map's columns are read with strided loads) */
     const uint8_t* flags;            /* [n_slots, N] from cim_asy_flag */
     const double* uniforms;          /* [max_uniforms] */
     int32_t max_uniforms, reserved_;
@@ -172,9 +183,15 @@ typedef struct cim_mining_args {
     cim_mining_layer layer[CIM_MAX_LAYERS];
 } cim_mining_args;
 
-/* Dynamic LDS of the arbitration + sampling launch (must be <= 160 KiB). */
+/* Dynamic LDS of the mining launch (must be <= 156 KiB).
+ * sync: cim_mining_sync_bytes() bytes of caller-owned device scratch, 8-byte aligned, ZERO-FILLED ONCE by the caller when it
+ * is allocated: the workgroups of the mining launch meet through it (arrival counters of the (class, layer) workgroups - a
+ * layer's last arrival runs its arbitration -, the list lengths the layers hand each other for the position in the uniform
+ * stream) and the call leaves every word zero again, so the same scratch serves the next call on that stream and the launches
+ * can be captured into a HIP graph.  Calls that may be in flight TOGETHER (two streams) need a scratch each. */
 long long cim_mining_lds_bytes(int N, int K);
-int cim_mining_step(const cim_mining_args* args, void* stream);
+long long cim_mining_sync_bytes(void);
+int cim_mining_step(const cim_mining_args* args, void* sync, void* stream);
 
 /* ------------------------------------------------------------------ network-input image (f-3: the data side of the step)
  * Replaces prep_im_for_blob(flag="ToTensor"), lib/utils/blob.py:93-147, called from lib/roi_data/minibatch.py:109-150
@@ -213,9 +230,12 @@ int cim_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, i
  * be NULL without relu), x_raw (convolution output) are [B,cout,hw]; x is the convolution input [B,cin,hw]; w [cout,cin].
  * dres / dgamma+dbeta / dx / dw may be NULL when not needed.  workspace: cim_conv1x1_bwd_workspace(B,cin,cout,hw) bytes.
  * side_stream (may be NULL): a second HIP stream the weight-gradient GEMM is enqueued on, next to the data-gradient GEMM on
- * `stream`, forked after the BatchNorm backward.  join != 0: `stream` waits for it before the call returns (stream order is all the
+ * `stream`, forked after the BatchNorm backward through fork_event (a hipEvent_t of the CALLER, created with
+ * hipEventDisableTiming, passed as void*; needed whenever side_stream is given - the library creates no events).  join != 0:
+ * `stream` waits for it through join_event (the caller's as well) before the call returns (stream order is all the
  * caller needs); join == 0: the CALLER makes `stream` wait for side_stream before dw (and the buffers x, workspace) are used or
- * reused - the weight gradients of a whole backward pass then run beside the data-gradient chain.
+ * reused - the weight gradients of a whole backward pass then run beside the data-gradient chain.  Both events are recorded and
+ * waited on inside the call: the caller may pass the same pair to its next call.
  * Chaining two layers' backward without a BatchNorm-backward launch in between (round 3):
  *   in_gamma, in_var, in_eps (in_gamma may be NULL): frozen BatchNorm of the layer that PRODUCED x as relu(bn(conv)) with no
  *     residual - dx is then written as  x > 0 ? dx * in_gamma rsqrt(in_var + in_eps) : 0,  i.e. already the gradient of that
@@ -233,7 +253,7 @@ long long cim_conv1x1_bwd_workspace(int B, int cin, int cout, int hw);
 int cim_conv1x1_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                            const float* gamma, const float* mean, const float* var, float eps, int relu,
                            float* dres, float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int hw,
-                           float* workspace, void* stream, void* side_stream, int join,
+                           float* workspace, void* stream, void* side_stream, void* fork_event, void* join_event, int join,
                            int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
                            const float* in_xr, const float* in_mean, float* in_part, const float* dx_add, int dx_add_w);
 /* dx_add (may be NULL; round 4): [B,cin,hw] added to dx in the data gradient's epilogue - the gradient that reaches x through a
@@ -271,14 +291,14 @@ int cim_conv7x7_nchw_f32(const float* x, const float* w, float* y, int cin, int 
 /* Backward of cim_conv3x3_nchw_f32 for B images in one call: BatchNorm / ReLU backward (cim_bn_act_bwd), dx [B,cin,H,W] (transposed
  * convolution as an implicit GEMM over (cout, tap)), dw [cout,cin,3,3] = sum over images and output pixels (split-K).
  * dy, y (may be NULL without relu), x_raw are [B,cout,Ho,Wo]; dres / dgamma+dbeta / dx / dw may be NULL when not needed.
- * workspace: cim_conv3x3_nchw_bwd_workspace(...) bytes.  cin % 4 == 0, cout % 4 == 0.  side_stream, join, dy_is_dconv and
- * in_gamma / in_var / in_eps as in cim_conv1x1_bn_act_bwd. */
+ * workspace: cim_conv3x3_nchw_bwd_workspace(...) bytes.  cin % 4 == 0, cout % 4 == 0.  side_stream, fork_event, join_event, join,
+ * dy_is_dconv and in_gamma / in_var / in_eps as in cim_conv1x1_bn_act_bwd. */
 long long cim_conv3x3_nchw_bwd_workspace(int B, int cin, int cout, int H, int W, int stride);
 int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                                 const float* gamma, const float* mean, const float* var, float eps, int relu, float* dres,
                                 float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int H, int W,
-                                int stride, int dilation, float* workspace, void* stream, void* side_stream, int join,
-                                int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
+                                int stride, int dilation, float* workspace, void* stream, void* side_stream, void* fork_event,
+                                void* join_event, int join, int dy_is_dconv, const float* in_gamma, const float* in_var, float in_eps,
                                 const float* in_xr, const float* in_mean, float* in_part, const float* wt_ready);
 /* wt_ready (may be NULL): the weight transposed to [cout][3][3][cin] - the data gradient's A operand - when the caller made it
  * ahead of the pass; else the call makes it itself (one small launch per layer in front of the data gradient).
@@ -311,35 +331,33 @@ int cim_bn_act_bwd(const float* dy, const float* y, const float* x, const float*
  *     product evaluated as six v_mfma_f32_32x32x16_bf16 products with fp32 accumulation
  *     (dropped terms < 2^-23 |a*b|: two orders below the fp32 accumulation rounding itself);
  *   engine 0: v_mfma_f32_32x32x2_f32 (f32 multiplies).
- * cim_gemm_set_engine() selects process-wide (host code sets it from CIM_GEMM_ENGINE = bf16x3 | fp32).
+ * `engine` is an ARGUMENT of every such call (0 or 1): the library keeps no engine switch.
  *
  * C[M,N] = A . B (+ bias[N]) (ReLU optional), row-major C with leading dimension ldc.
  *   a_mcontig = 0: A element (m,k) at A[m*lda + k];  1: at A[k*lda + m]
  *   b_kcontig = 0: B element (k,n) at B[k*ldb + n];  1: at B[n*ldb + k]   (nn.Linear weight)
  * splits > 1: split-K through `workspace` (splits*M*N floats), reduced in a fixed order
  * (deterministic).  cim_gemm_f32_splits() returns the split count the library would choose. */
-int cim_gemm_set_engine(int engine);
-int cim_gemm_get_engine(void);
-int cim_gemm_f32_splits(int M, int N, int K);
+int cim_gemm_f32_splits(int M, int N, int K, int engine);
 int cim_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                  int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu,
-                 int splits, float* workspace, void* stream);
+                 int splits, float* workspace, int engine, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution on R independent P x P maps as an implicit GEMM
  * (no im2col buffer): X [R,P,P,Cin] (NHWC), Whwio [3,3,Cin,Cout], Y [R,P,P,Cout].
  * The data gradient is the same call on dY with the spatially flipped, in/out-swapped weights. */
 int cim_conv3x3_f32(const float* X, const float* Whwio, const float* bias, float* Y,
-                    int R, int P, int Cin, int Cout, int relu, void* stream);
+                    int R, int P, int Cin, int Cout, int relu, int engine, void* stream);
 
 /* Weight gradient: dWhwio [3,3,Cin,Cout] = im2col(X)^T . dY, dY [R,P,P,Cout]. */
 int cim_conv3x3_wgrad_f32(const float* X, const float* dY, float* dWhwio,
-                          int R, int P, int Cin, int Cout, int splits, float* workspace, void* stream);
+                          int R, int P, int Cin, int Cout, int splits, float* workspace, int engine, void* stream);
 
 /* `batch` independent GEMMs of identical shape in one launch (strides in elements between
  * consecutive problems); used for the 16 positions of the Winograd-domain convolution. */
 int cim_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K,
                          int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
-                         int batch, long long a_bs, long long b_bs, long long c_bs, void* stream);
+                         int batch, long long a_bs, long long b_bs, long long c_bs, int engine, void* stream);
 
 /* f16x2 engine (the host's default, CIM_GEMM_ENGINE=f16x2): the same contractions as cim_gemm_f32 /
  * cim_gemm_f32_batched with every fp32 operand scaled by a power of two per A row / per B column and split
@@ -383,19 +401,18 @@ int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int 
  *                    (never stored: cim_pair_split applies the same mask): max |dz| as cim_pair_amax and, when `part`
  *                    ([ceil(rows / 64)][cols], may be NULL) is given, the bias gradient's partial sums over chunks of 64 rows, each
  *                    added up in row order - the caller sums the chunks (lib/modeling/resnet50.py:107-110 seg_fc's ReLUs) */
-/* Caps the launches of this THREAD's following cim_gemm_pair* products at max_workgroups (0 = one launch over all tiles, the
- * default): a product then goes out as consecutive launches.  A workgroup of this engine owns its CU (128 KB of LDS), so a
- * capped product never holds more CUs than that and leaves the rest of the chip to concurrent streams - used for the
- * MaskFuse weight-gradient products that run beside the backbone's backward (cim_amd/ops/maskfuse_pair.py). */
-int cim_gemm_pair_limit(int max_workgroups);
+/* max_workgroups (0 = one launch over all tiles): caps the launches of THIS product - it then goes out as consecutive launches
+ * of at most that many workgroups.  A workgroup of this engine owns its CU (128 KB of LDS), so a capped product never holds
+ * more CUs than that and leaves the rest of the chip to concurrent streams - used for the MaskFuse weight-gradient products
+ * that run beside the backbone's backward (cim_amd/ops/maskfuse_pair.py).  Same tiles, same arithmetic, same bits. */
 int cim_gemm_pair_splits(int M, int N, int K);
 int cim_gemm_pair(const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
                   int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
-                  const float* a_scale, const float* b_scale, uint32_t* c_amax, void* stream);
+                  const float* a_scale, const float* b_scale, uint32_t* c_amax, int max_workgroups, void* stream);
 int cim_gemm_pair_batched(const void* A, const void* B, float* C, int M, int N, int K,
                           int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
                           int batch, long long a_bs, long long b_bs, long long c_bs,
-                          const float* a_scale, const float* b_scale, void* stream);
+                          const float* a_scale, const float* b_scale, int max_workgroups, void* stream);
 int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float* scale, int n, void* stream);
 int cim_pair_split(const float* X, void* P, int rows, int rows_pad, int cols, int ld, int ldp, int batch,
                    long long x_bs, long long p_bs, const float* scale, const float* relu_y, void* stream);

@@ -32,15 +32,13 @@ class _engine:
     def __enter__(self):
         from cim_amd import _lib
         from cim_amd.ops import gemm as G
-        self.G, self.lib, self.saved = G, _lib, (G.ENGINE, _lib.call("cim_gemm_get_engine"), G.PAIR)
-        G.ENGINE = "f16x2" if self.name == "f16x2p" else self.name
+        self.G, self.lib, self.saved = G, _lib, (G.ENGINE, G.PAIR)
+        G.ENGINE = "f16x2" if self.name == "f16x2p" else self.name       # (the engine is an argument of every library call)
         G.PAIR = self.name == "f16x2p"
-        _lib.call("cim_gemm_set_engine", 0 if self.name == "fp32" else 1)
 
     def __exit__(self, *exc):
         self.G.ENGINE = self.saved[0]
-        self.G.PAIR = self.saved[2]
-        self.lib.call("cim_gemm_set_engine", self.saved[1])
+        self.G.PAIR = self.saved[1]
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 4096, 4096), (300, 260, 1000), (37, 8, 20), (513, 516, 48), (256, 256, 16)])
@@ -433,6 +431,74 @@ def test_bottleneck_chained_bn_backward_is_bit_identical(dev, inplanes, planes, 
     h2 = conv3x3_bn_act(h1, blk.conv2, blk.bn2, fuse_input_bn=True)
     with pytest.raises(RuntimeError, match="second consumer"):
         (h2.sum() + h1.sum()).backward()
+    gemm.join_side(discard=True)
+
+
+def test_bottleneck_inner_activation_gradients_are_the_plain_ones(dev):
+    """The chained BatchNorm backward and the branch hand-over rewrite what flows along edges INSIDE a bottleneck (ops/chain.py,
+    ops/conv1x1.py).  Whoever looks at such an edge - torch.autograd.grad towards an inner activation or a single weight, a tensor
+    hook, retain_grad() - must get the ordinary gradient, not the rewritten one: the fused layers notice at their backward
+    (hooks / retain_grad on the activation, torch._C._will_engine_execute_node for the node that would receive the hand-over) and
+    take the plain autograd path for that pass (task 8)."""
+    from cim_amd.modeling import resnet50
+    from cim_amd.ops import conv1x1_bn_act, conv3x3_bn_act, gemm
+    torch.manual_seed(3)
+    blk = resnet50.Bottleneck(256, 64, 1, None).to(dev).eval()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.5, 0.5); m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 2.0)
+    x0 = torch.randn(1, 256, 17, 23, device=dev)
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        branch = {} if fused else None
+        h1 = conv1x1_bn_act(x, blk.conv1, blk.bn1, branch=branch)
+        h2 = conv3x3_bn_act(h1, blk.conv2, blk.bn2, fuse_input_bn=fused)
+        y = conv1x1_bn_act(h2, blk.conv3, blk.bn3, residual=x, fuse_input_bn=fused, branch=branch)
+        return x, h1, h2, y
+
+    def full(y, x, up, retain=False):
+        for p in blk.parameters():
+            p.grad = None
+        x.grad = None
+        y.backward(up, retain_graph=retain)
+        gemm.join_side()
+        torch.cuda.synchronize()
+        return [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+
+    x, h1, h2, y = run(False)
+    up = torch.randn_like(y)
+    ref_h1, ref_h2, ref_w3 = torch.autograd.grad(y, [h1, h2, blk.conv3.weight], up, retain_graph=True)
+    ref_full = full(y, x, up)
+    close = lambda a, b: float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7      # (affine sums: another order)
+    # (a) torch.autograd.grad towards inner activations / one weight: the hand-overs' receivers are not part of the pass
+    x, h1, h2, y = run(True)
+    g1, = torch.autograd.grad(y, [h1], up, retain_graph=True)
+    g2, = torch.autograd.grad(y, [h2], up, retain_graph=True)
+    gw, = torch.autograd.grad(y, [blk.conv3.weight], up, retain_graph=True)
+    assert torch.equal(g1, ref_h1) and torch.equal(g2, ref_h2) and torch.equal(gw, ref_w3)
+    # ... and the complete pass on the same graph afterwards is the chained one, unchanged
+    got = full(y, x, up)
+    assert all(close(a, b) for a, b in zip(got, ref_full)) and torch.equal(got[0], ref_full[0])
+    # (b) a hook on an inner activation sees the plain gradient; the pass is still right
+    x, h1, h2, y = run(True)
+    seen = {}
+    h2.register_hook(lambda g: seen.__setitem__("h2", g.clone()))
+    got = full(y, x, up)
+    assert torch.equal(seen["h2"], ref_h2) and all(close(a, b) for a, b in zip(got, ref_full))
+    # (c) retain_grad()
+    x, h1, h2, y = run(True)
+    h1.retain_grad()
+    got = full(y, x, up)
+    assert torch.equal(h1.grad, ref_h1) and all(close(a, b) for a, b in zip(got, ref_full))
+    # (d) a receiver with a chained producer is refused up front, with a message
+    x = x0.clone().requires_grad_(True)
+    h1 = conv1x1_bn_act(x, blk.conv1, blk.bn1)
+    conv = torch.nn.Conv2d(64, 64, 1, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(64).to(dev).eval()
+    with pytest.raises(ValueError, match="RECEIVER"):
+        conv1x1_bn_act(h1, conv, bn, fuse_input_bn=True, branch={})
     gemm.join_side(discard=True)
 
 

@@ -191,9 +191,9 @@ def test_pair_gemm_batched(dev):
 
 
 def test_pair_gemm_chunked_launches_are_bit_identical(dev):
-    """cim_gemm_pair_limit(n): a product goes out as consecutive launches of at most n workgroups (the MaskFuse weight gradients
-    beside the backbone backward) - same tiles, same arithmetic, same bits, for a batched product (>= 8 slices: the XCD-slice work
-    order), a split-K product and a plain one; the limit is per thread and 0 restores one launch."""
+    """max_workgroups = n of cim_gemm_pair*: a product goes out as consecutive launches of at most n workgroups (the MaskFuse
+    weight gradients beside the backbone backward) - same tiles, same arithmetic, same bits, for a batched product (>= 8 slices: the
+    XCD-slice work order), a split-K product and a plain one; the cap is an ARGUMENT of the call (no library state), 0 = one launch."""
     from cim_amd import _lib
     from cim_amd.ops import pair
     g = torch.Generator().manual_seed(11)
@@ -206,16 +206,12 @@ def test_pair_gemm_chunked_launches_are_bit_identical(dev):
     ref = (pair.gemm(pa, pb, M, N, K, False, False), pair.gemm(px, pw, 300, 264, 8192, False, True),
            pair.gemm(pa, pa, K, K, pair.pad32(M), True, False))
     for limit in (1, 5, 7, 100000):
-        _lib.call("cim_gemm_pair_limit", limit)
-        try:
-            got = (pair.gemm(pa, pb, M, N, K, False, False), pair.gemm(px, pw, 300, 264, 8192, False, True),
-                   pair.gemm(pa, pa, K, K, pair.pad32(M), True, False))
-        finally:
-            _lib.call("cim_gemm_pair_limit", 0)
+        got = (pair.gemm(pa, pb, M, N, K, False, False, limit=limit), pair.gemm(px, pw, 300, 264, 8192, False, True, limit=limit),
+               pair.gemm(pa, pa, K, K, pair.pad32(M), True, False, limit=limit))
         for a, b in zip(ref, got):
             assert torch.equal(a, b), limit
     with pytest.raises(_lib.CimHipError):
-        _lib.call("cim_gemm_pair_limit", -1)
+        pair.gemm(px, pw, 300, 264, 8192, False, True, limit=-1)
 
 
 @pytest.mark.parametrize("K", [2048, 50176])
@@ -232,14 +228,11 @@ def test_pair_engine_error_class(dev, K):
         scale = A.double().abs() @ B.double().abs()
         c = _pair_gemm(dev, A, B, 0, 0)
         err_pair = float(((c.cpu().double() - ref).abs() / scale).max())
-        saved = _lib.call("cim_gemm_get_engine")
-        _lib.call("cim_gemm_set_engine", 0)
         c32 = torch.empty(M, N, device=dev)
-        splits = _lib.call("cim_gemm_f32_splits", M, N, K)
+        splits = _lib.call("cim_gemm_f32_splits", M, N, K, 0)
         ws = torch.empty(splits * M * N, device=dev)
         _lib.call("cim_gemm_f32", A.to(dev).data_ptr(), B.to(dev).data_ptr(), c32.data_ptr(), None, M, N, K, K, N, N, 0, 0, 0,
-                  splits, ws.data_ptr(), _lib.stream_ptr())
-        _lib.call("cim_gemm_set_engine", saved)
+                  splits, ws.data_ptr(), 0, _lib.stream_ptr())
         err_f32 = float(((c32.cpu().double() - ref).abs() / scale).max())
         assert err_pair < 2e-6 and err_pair < 2.0 * err_f32 + 1e-7, (spread, err_pair, err_f32)
 

@@ -123,16 +123,14 @@ def test_roi_align_batches_groups_and_channel_chunks(dev, B, C, H, W, K):
     np.testing.assert_allclose(x.grad.cpu().numpy(), gref, rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("B,C,H,W,K,gs", [(2, 8, 13, 17, 300, None), (1, 516, 33, 43, 200, None), (1, 256, 25, 30, 700, "128")])
-def test_roi_align_backward_forms_agree_with_oracle(dev, B, C, H, W, K, gs, monkeypatch):
+@pytest.mark.parametrize("B,C,H,W,K", [(2, 8, 13, 17, 300), (1, 516, 33, 43, 200), (1, 512, 37, 49, 1900)])
+def test_roi_align_backward_forms_agree_with_oracle(dev, B, C, H, W, K):
     """The backward behind cim_roi_align(_maskcat)_bwd_ws - region form with partial maps (interleaved entry order) - and the
     entry points WITHOUT partial-map scratch (cim_roi_align_maskcat_bwd: the ROI groups then meet through atomics) against the
-    fp64 oracle, with several images, several ROI groups (128-ROI groups in the last case: the size the launcher picks when 64
-    would make too many workgroups) and a channel count that is not a multiple of the slice."""
+    fp64 oracle, with several images, several ROI groups (128-ROI groups in the last case: 30 x 16 x 2 = 960 workgroups of 64 ROIs
+    are more than the launcher's limit of 900) and a channel count that is not a multiple of the slice."""
     from cim_amd import _lib
     from cim_amd.ops import roi_align_maskcat
-    if gs:
-        monkeypatch.setenv("CIM_ROI_RG_GS", gs)
     from oracle import roi_align as oracle
     _, rois = _roi_case(B * 31 + K, C, H, W, K)
     rng = np.random.RandomState(K)
@@ -435,6 +433,21 @@ def test_backbone_hip_graph_replay_matches_eager(dev, config, monkeypatch):
         for n in eager[2]:
             d, ref = (got[2][n] - eager[2][n]).norm(), eager[2][n].norm()
             assert float(d) <= 2e-3 * float(ref) + 1e-7 * eager[2][n].numel() ** 0.5, n
+    # An optimizer step BETWEEN replays: the captured backward must see the new weights (a prefetched weight transpose baked
+    # into the graph would keep the capture-time weights: ADVICE round 4, ops/conv3x3.py: _transposed).
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                p.add_(p.grad, alpha=-0.05 / (float(p.grad.abs().max()) + 1e-12) * float(p.abs().max()))
+    after = step(data)                                               # replay on the updated weights
+    monkeypatch.setattr(model_builder, "GRAPH_BACKBONE", False)
+    ref_after = step(data)                                           # eager, same weights
+    assert any(float((after[2][n] - replay[2][n]).norm()) > 1e-3 * float(replay[2][n].norm()) for n in after[2]), \
+        "the update did not change the gradients: vacuous check"
+    torch.testing.assert_close(after[1], ref_after[1], rtol=1e-4, atol=1e-4)
+    for n in ref_after[2]:
+        d, ref = (after[2][n] - ref_after[2][n]).norm(), ref_after[2][n].norm()
+        assert float(d) <= 2e-3 * float(ref) + 1e-7 * ref_after[2][n].numel() ** 0.5, n
 
 
 # ------------------------------------------------------------------ fused HIP losses (csrc/losses.hip)

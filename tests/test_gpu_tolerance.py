@@ -31,7 +31,6 @@ def _set(monkeypatch, engine, algo):
     monkeypatch.setattr(gemm, "ENGINE", "f16x2" if engine == "f16x2p" else engine)
     monkeypatch.setattr(gemm, "CONV_ALGO", algo)
     gemm.forget_weight_scales()
-    _lib.call("cim_gemm_set_engine", 0 if engine == "fp32" else 1)
 
 
 def _step(model, batch, seed):

@@ -278,3 +278,23 @@ def test_mining_reads_score_blocks_in_place():
     assert ld == 5 and t.is_contiguous() and torch.equal(t, base.t())
     t, ld = _rows_in_place(blk.double())
     assert ld == 4 and t.dtype == torch.float32
+
+
+def test_library_sources_keep_no_state():
+    """include/cim_hip.h's contract (no allocation, no sync, no global state; re-entrant), checked on the sources: no
+    device allocation, no library-made events / streams, no process-wide or per-thread switches, no environment reads.  The only
+    per-thread datum is the message behind cim_last_error() (csrc/common.cpp)."""
+    import glob
+    banned = re.compile(r"hipMalloc|hipFree|hipEventCreate|hipStreamCreate|hipDeviceSynchronize|hipStreamSynchronize|"
+                        r"\bthread_local\b|\bgetenv\b|std::mutex|^\s*static\s+(?!const)[^()\n]*\[\d+\]\s*(=|;)|^\s*(static\s+)?int\s+g_[a-z_]+\s*=", re.M)
+    for path in sorted(glob.glob(os.path.join(REPO, "cim_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "cim_amd", "csrc", "*.cpp"))
+                       + glob.glob(os.path.join(REPO, "cim_amd", "csrc", "*.h"))):
+        src = open(path).read()
+        if os.path.basename(path) == "common.cpp":
+            src = src.replace('static thread_local char g_err[512] = "";', "")
+        hits = [m.group(0).strip() for m in banned.finditer(src)]
+        assert not hits, (os.path.basename(path), hits)
+    header = open(os.path.join(REPO, "include", "cim_hip.h")).read()
+    for gone in ("cim_gemm_set_engine", "cim_gemm_get_engine", "cim_gemm_pair_limit"):
+        assert gone + "(" not in header
+    assert "cim_mining_sync_bytes" in header and "fork_event" in header and "max_workgroups" in header

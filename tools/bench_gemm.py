@@ -50,16 +50,17 @@ def main():
     dx = torch.empty(N, 7, 7, 2 * C, device=dev)
     dwh = torch.empty(3, 3, 2 * C, C, device=dev)
     st = _lib.stream_ptr()
+    import cim_amd.ops.gemm as GG0
     fl = 2.0 * 49 * N * 18 * C * C
-    t = timeit(lambda: _lib.call("cim_conv3x3_f32", xp.data_ptr(), whwio.data_ptr(), b.data_ptr(), y.data_ptr(), N, 7, 2 * C, C, 1, st))
+    t = timeit(lambda: _lib.call("cim_conv3x3_f32", xp.data_ptr(), whwio.data_ptr(), b.data_ptr(), y.data_ptr(), N, 7, 2 * C, C, 1, GG0.engine_code(), st))
     res["conv_fwd_cim_ms"], res["conv_fwd_cim_tf"] = t, fl / t / 1e9
     t = timeit(lambda: F.conv2d(x, w, b, padding=1))
     res["conv_fwd_torch_ms"], res["conv_fwd_torch_tf"] = t, fl / t / 1e9
-    t = timeit(lambda: _lib.call("cim_conv3x3_f32", dy.data_ptr(), w2.data_ptr(), None, dx.data_ptr(), N, 7, C, 2 * C, 0, st))
+    t = timeit(lambda: _lib.call("cim_conv3x3_f32", dy.data_ptr(), w2.data_ptr(), None, dx.data_ptr(), N, 7, C, 2 * C, 0, GG0.engine_code(), st))
     res["conv_dgrad_cim_ms"], res["conv_dgrad_cim_tf"] = t, fl / t / 1e9
-    sp = _lib.call("cim_gemm_f32_splits", 18 * C, C, 49 * N)
+    sp = _lib.call("cim_gemm_f32_splits", 18 * C, C, 49 * N, GG0.engine_code())
     ws = torch.empty(max(sp, 1) * 18 * C * C, device=dev)
-    t = timeit(lambda: _lib.call("cim_conv3x3_wgrad_f32", xp.data_ptr(), dy.data_ptr(), dwh.data_ptr(), N, 7, 2 * C, C, sp, ws.data_ptr(), st))
+    t = timeit(lambda: _lib.call("cim_conv3x3_wgrad_f32", xp.data_ptr(), dy.data_ptr(), dwh.data_ptr(), N, 7, 2 * C, C, sp, ws.data_ptr(), GG0.engine_code(), st))
     res["conv_wgrad_cim_ms"], res["conv_wgrad_cim_tf"], res["conv_wgrad_splits"] = t, fl / t / 1e9, sp
     # Winograd F(2x2,3x3) pipeline (autograd wrapper: fwd, and fwd+bwd)
     from cim_amd.ops import conv3x3

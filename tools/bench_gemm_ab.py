@@ -42,9 +42,7 @@ ws = torch.empty(4 * 4096 * 50176, device=dev)     # 3.3 GB: up to 4 splits of t
 
 
 ENGINE = os.environ.get("CIM_AB_ENGINE", "f16x2")
-if ENGINE != "f16x2":
-    for l_ in libs.values():
-        l_.cim_gemm_set_engine(0 if ENGINE == "fp32" else 1)
+ENG = 0 if ENGINE == "fp32" else 1          # `engine` argument of the cim_gemm_f32* entry points
 
 
 def _amax(x, rows, cols, ld, want_rows, want_cols, batch=1, bs=0):
@@ -82,13 +80,13 @@ def cases_f16x2(lib):
 def cases(lib):
     if ENGINE == "f16x2":
         return cases_f16x2(lib)
-    sp = lambda m, n, k: min(lib.cim_gemm_f32_splits(m, n, k), (4 * 4096 * 50176) // (m * n))
+    sp = lambda m, n, k: min(lib.cim_gemm_f32_splits(m, n, k, ENG), (4 * 4096 * 50176) // (m * n))
     return {
-        "wino_fwd": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), U.data_ptr(), M.data_ptr(), mt, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, mt * 2 * C, 2 * C * C, mt * C, st), NPOS * 2.0 * mt * 2 * C * C),
-        "wino_wgrad": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), D.data_ptr(), dU.data_ptr(), 2 * C, C, mt, 2 * C, C, C, 1, 0, NPOS, mt * 2 * C, mt * C, 2 * C * C, st), NPOS * 2.0 * mt * 2 * C * C),
-        "fc1_fwd": (lambda: lib.cim_gemm_f32(xf.data_ptr(), w1.data_ptr(), y1.data_ptr(), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), ws.data_ptr(), st), 2.0 * N * K1 * 4096),
-        "fc1_dgrad": (lambda: lib.cim_gemm_f32(dyf.data_ptr(), w1.data_ptr(), dx1.data_ptr(), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, sp(N, K1, 4096), ws.data_ptr(), st), 2.0 * N * K1 * 4096),
-        "fc1_wgrad": (lambda: lib.cim_gemm_f32(dyf.data_ptr(), xf.data_ptr(), dw1.data_ptr(), None, 4096, K1, N, 4096, K1, K1, 1, 0, 0, sp(4096, K1, N), ws.data_ptr(), st), 2.0 * N * K1 * 4096),
+        "wino_fwd": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), U.data_ptr(), M.data_ptr(), mt, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, mt * 2 * C, 2 * C * C, mt * C, ENG, st), NPOS * 2.0 * mt * 2 * C * C),
+        "wino_wgrad": (lambda: lib.cim_gemm_f32_batched(V.data_ptr(), D.data_ptr(), dU.data_ptr(), 2 * C, C, mt, 2 * C, C, C, 1, 0, NPOS, mt * 2 * C, mt * C, 2 * C * C, ENG, st), NPOS * 2.0 * mt * 2 * C * C),
+        "fc1_fwd": (lambda: lib.cim_gemm_f32(xf.data_ptr(), w1.data_ptr(), y1.data_ptr(), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), ws.data_ptr(), ENG, st), 2.0 * N * K1 * 4096),
+        "fc1_dgrad": (lambda: lib.cim_gemm_f32(dyf.data_ptr(), w1.data_ptr(), dx1.data_ptr(), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, sp(N, K1, 4096), ws.data_ptr(), ENG, st), 2.0 * N * K1 * 4096),
+        "fc1_wgrad": (lambda: lib.cim_gemm_f32(dyf.data_ptr(), xf.data_ptr(), dw1.data_ptr(), None, 4096, K1, N, 4096, K1, K1, 1, 0, 0, sp(4096, K1, N), ws.data_ptr(), ENG, st), 2.0 * N * K1 * 4096),
     }
 
 

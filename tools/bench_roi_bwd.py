@@ -40,11 +40,7 @@ for cfgname, n, target in (("resnet50_voc", None, None), ("resnet50_voc", 800, 5
     nbytes = 4.0 * (C * H * W + 5 * K + 49 * K) + 4.0 * K * 2 * C * 49
     t_region = timeit(bwd)
     sweep = {}
-    for gs in ("64", "128"):
-        os.environ["CIM_ROI_RG_GS"] = gs
-        sc2 = torch.empty(_lib.call("cim_roi_align_bwd_scratch", K, 1, C, H, W) // 4 + 1, device=dev)
-        sweep[gs] = timeit(lambda: _lib.call("cim_roi_align_maskcat_bwd_ws", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), 0, sc2.data_ptr(), st))
-    os.environ.pop("CIM_ROI_RG_GS", None)
+    # (the ROI-group size is the launcher's own choice: the CIM_ROI_RG_GS sweep switch went with the library's getenv reads)
     import ctypes, glob
     alts = {}
     for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):     # ablation builds

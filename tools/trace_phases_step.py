@@ -32,7 +32,7 @@ marks = [("optimizer", 0, 0)]
 i_tab = first("roi_tables")
 i_fwd = last("roi_align_fwd")
 i_loss = first("losses_kernel")
-i_seed = first("asy_flag")
+i_seed = first("step_mine_kernel")
 i_rb0 = first("roi_align_bwd")
 i_rb1 = last("roi_partial_reduce") or last("roi_align_bwd")
 pts = [("optimizer launch", ms(step[0]["Start_Timestamp"]), ms(step[0]["End_Timestamp"])),
