@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256) void asy_flag_kernel(const uint16_t* __restric
     if (lane == 0) flag[row] = ((double)cnt < limit) ? 1 : 0;
 }
 
-// The containment map transposed (asy_t[j][i] = asy[i][j]): the mining reads COLUMNS of the map (every proposal against one
-// seed, heads.py:386) - in the transposed copy such a column is one contiguous 2N-byte row.  64 x 64 tiles through LDS, both
-// global sides in 128-byte runs.
-__global__ __launch_bounds__(256) void transpose_f16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int N) {
+// The containment map transposed (asy_t[j][i] = asy[i][j], rows padded to ldt = 8 ceil(N / 8) entries: 16-byte aligned rows): the
+// mining reads COLUMNS of the map (every proposal against one seed, heads.py:386) - in the transposed copy such a column is
+// one contiguous row.  64 x 64 tiles through LDS, both global sides in 128-byte runs; the pad entries are written as zero.
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int N, int ldt) {
     __shared__ uint16_t tile[64][66];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void transpose_f16_kernel(const uint16_t* __re
 #pragma unroll 4
     for (int k = ty; k < 64; k += 4) {
         const int r = c0 + k, c = r0 + tx;          // row of dst = column of src
-        if (r < N && c < N) dst[(size_t)r * N + c] = tile[tx][k];
+        if (r < N && c < ldt) dst[(size_t)r * ldt + c] = c < N ? tile[tx][k] : (uint16_t)0;
     }
 }
 
@@ -134,8 +134,9 @@ struct SeedLayout {
 // Top-K by RADIX SELECT (the reference takes argsort(descending)[:K], heads.py:354: only K = ceil(0.1 N) of the N keys are
 // wanted in order): four 8-bit histogram passes over the orderable score bits find the K-th largest value T and how many
 // keys equal to T belong to the top K (ties: the lowest proposal indices - a stable descending sort, App. B item 4); the K
-// survivors are ranked among themselves by counting (K^2 / 1024 compares per lane).  Round 4 sorted all N keys (bitonic,
-// 55 exchange stages): 12.5 of the kernel's 37 us.
+// survivors are compacted by wave ballots and ranked among themselves by counting (K^2 / 1024 compares per lane).  One
+// barrier per pass: the histograms of all four passes are cleared up front and every wave scans a pass's 256 bins for
+// itself.  Round 4 sorted all N keys (bitonic, 55 exchange stages): 12.5 of the kernel's 37 us.
 template <int MAXR>
 __device__ __forceinline__ void seed_topk_select(const float* __restrict__ score, int score_ld, int col, int N, int K,
                                                  unsigned* __restrict__ hist, unsigned long long* __restrict__ cand,
@@ -154,58 +155,70 @@ __device__ __forceinline__ void seed_topk_select(const float* __restrict__ score
             valid |= 1u << r;
         }
     }
+    hist[tid] = 0;                                   // the four passes' histograms (4 x 256 words), cleared once
+    if (tid == 0) s_misc[2] = 0;                     // (the compaction counter below)
+    __syncthreads();
     unsigned prefix = 0, pmask = 0;
-    int need = K;
+    int need = K, tot_eq = 0;
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < 4; ++pass) {           // ONE barrier per pass: every wave scans the histogram for itself
         const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
-        if (tid == 0) s_misc[2] = 0;                 // (the compaction counter below)
-        __syncthreads();
+        unsigned* __restrict__ h = hist + 256 * pass;
 #pragma unroll
         for (int r = 0; r < MAXR; ++r)
-            if (((valid >> r) & 1u) && (key[r] & pmask) == prefix) atomicAdd(&hist[(key[r] >> shift) & 255u], 1u);
+            if (((valid >> r) & 1u) && (key[r] & pmask) == prefix) atomicAdd(&h[(key[r] >> shift) & 255u], 1u);
         __syncthreads();
-        if (tid < 64) {                              // lane holds the bins 4 lane .. 4 lane + 3; suffix sums from the top bin down
-            const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];
-            const int cnt[4] = {(int)h.x, (int)h.y, (int)h.z, (int)h.w};
-            const int s4 = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-            int suf = s4;
+        // lane holds the bins 4 lane .. 4 lane + 3; suffix sums from the top bin down
+        const uint4 hv = reinterpret_cast<const uint4*>(h)[lane];
+        const int cnt[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
+        const int s4 = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        int suf = s4;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int x = __shfl_down(suf, o);
-                if (lane + o < 64) suf += x;
-            }
-            int above = suf - s4;                    // keys in the bins of higher lanes
-#pragma unroll
-            for (int b = 3; b >= 0; --b) {
-                if (above < need && need <= above + cnt[b]) {
-                    s_misc[0] = 4 * lane + b;        // the bin that holds the need-th largest key
-                    s_misc[1] = need - above;
-                }
-                above += cnt[b];
-            }
+        for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_down(suf, o);
+            if (lane + o < 64) suf += x;
         }
-        __syncthreads();
-        prefix |= (unsigned)s_misc[0] << shift;
-        pmask |= 255u << shift;
-        need = s_misc[1];
-    }
-    // T = prefix: `need` of the keys equal to T are in, in proposal order
-    int tie = 0;
+        int above = suf - s4;                        // keys in the bins of higher lanes
+        int found = -1, left = 0, inbin = 0;
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r) tie += (((valid >> r) & 1u) && key[r] == prefix) ? 1 : 0;
-    int tie_total;
-    int tie_before = block_exclusive_scan(tie, s_part, &tie_total);
+        for (int b = 3; b >= 0; --b) {
+            if (above < need && need <= above + cnt[b]) {
+                found = 4 * lane + b;                // the bin that holds the need-th largest key
+                left = need - above;
+                inbin = cnt[b];
+            }
+            above += cnt[b];
+        }
+        const int src = __builtin_ctzll(__ballot(found >= 0));              // exactly one lane found it
+        prefix |= (unsigned)__shfl(found, src) << shift;
+        pmask |= 255u << shift;
+        need = __shfl(left, src);
+        tot_eq = __shfl(inbin, src);
+    }
+    // T = prefix: `need` of the tot_eq keys equal to T are in - the lowest proposal indices (only when the boundary value is
+    // duplicated does the order among the ties matter)
+    int tie_before = 0;
+    if (tot_eq > need) {                             // (uniform)
+        int tie = 0;
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) tie += (((valid >> r) & 1u) && key[r] == prefix) ? 1 : 0;
+        int tie_total;
+        tie_before = block_exclusive_scan(tie, s_part, &tie_total);
+    }
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
-        if (!((valid >> r) & 1u)) continue;
-        bool take = key[r] > prefix;
-        if (key[r] == prefix) take = tie_before++ < need;
-        if (take) {
-            const int at = atomicAdd(&s_misc[2], 1);
-            cand[at] = ((unsigned long long)(~key[r]) << 32) | (unsigned)(tid * Rk + r);     // (descending score, ascending index)
+        if (r >= Rk) break;                          // (uniform)
+        bool take = false;
+        if ((valid >> r) & 1u) {
+            take = key[r] > prefix;
+            if (key[r] == prefix) take = tie_before++ < need;
         }
+        const unsigned long long m = __ballot(take);                         // one LDS atomic per wave
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_misc[2], __popcll(m));
+        base = __shfl(base, 0);
+        if (take) cand[base + __popcll(m & ((1ull << lane) - 1ull))] =
+            ((unsigned long long)(~key[r]) << 32) | (unsigned)(tid * Rk + r);     // (descending score, ascending index)
     }
     __syncthreads();
     // rank of each survivor among the K: G lanes per survivor count a share of the list each
@@ -226,7 +239,6 @@ __device__ __forceinline__ void seed_topk_select(const float* __restrict__ score
         kidx[cnt] = id;
         topk_out[cnt] = id;
     }
-    (void)lane;
     __syncthreads();
 }
 
@@ -264,20 +276,22 @@ __device__ __forceinline__ void seed_phase(const cim_mining_args& a, const SeedL
     // Suppression bit-matrix over the K x K gathered sub-block of the mask-IoU map:
     // bit (i, j) set <=> NOT (iou[idx_i, idx_j] < nms_thr)   (heads.py:250-254, fp16 compare).
     const float nms_thr = L.nms_thr;
-    for (int t0 = wave; t0 < K * KW; t0 += 16 * 8) {                     // 8 gathers in flight per wave (latency-bound: the
-        uint16_t v[8];                                                   // map is L2-resident, each gather a round trip)
+    constexpr int GU = 13;                                               // gathers in flight per wave (latency-bound: the map is
+    for (int t0 = wave; t0 < K * KW; t0 += 16 * GU) {                    // L2-resident, each gather a round trip; K = 100: one round)
+        uint16_t v[GU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < GU; ++u) {
             const int t = t0 + 16 * u;
-            const int i = t / KW, j = (t % KW) * 64 + lane;
-            v[u] = (t < K * KW && j < K) ? a.iou[(size_t)kidx[i] * N + kidx[j]] : (uint16_t)0;
+            const int i = t / KW, w = t % KW, j = w * 64 + lane;
+            // (the greedy scan only looks at candidates behind row i: the words below its own 64-block stay zero)
+            v[u] = (t < K * KW && j < K && w >= (i >> 6)) ? a.iou[(size_t)kidx[i] * N + kidx[j]] : (uint16_t)0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < GU; ++u) {
             const int t = t0 + 16 * u;
             if (t >= K * KW) break;
-            const int j = (t % KW) * 64 + lane;
-            const unsigned long long word = __ballot(j < K && !(h2f(v[u]) < nms_thr));
+            const int i = t / KW, w = t % KW, j = w * 64 + lane;
+            const unsigned long long word = __ballot(j < K && w >= (i >> 6) && !(h2f(v[u]) < nms_thr));
             if (lane == 0) sup[t] = word;
         }
     }
@@ -285,9 +299,9 @@ __device__ __forceinline__ void seed_phase(const cim_mining_args& a, const SeedL
     MCLK(0, wg_act, 2);
 
     // Greedy scan in score order by one wave; lane w owns word w of the "removed" set.  The scan is sequential in the
-    // candidates, so it walks them 64 at a time: the block's own 64 x 64 suppression bits sit one row per lane in
-    // registers and the keep / drop decisions inside the block are readlane + scalar bit operations (no LDS on the serial
-    // chain); the rows of the kept candidates are then OR-ed into the later words with independent LDS reads.
+    // KEPT candidates, 64 candidates at a time: the block's own 64 x 64 suppression bits sit one row per lane in
+    // registers, the next kept candidate is a count-trailing-zeros on the scalar "removed" word and its row a readlane (no LDS
+    // on the serial chain); the rows of the kept candidates are then OR-ed into the later words with independent LDS reads.
     if (wave == 0) {
         int cnt = 0;
         unsigned long long removed = 0ull;  // lane l holds word l (l < KW <= 64)
@@ -301,12 +315,17 @@ __device__ __forceinline__ void seed_phase(const cim_mining_args& a, const SeedL
             unsigned long long rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(r0 >> 32)) << 32) |
                                      (unsigned)__builtin_amdgcn_readfirstlane((int)r0);
             unsigned long long kept = 0ull;
-            for (int t = 0; t < nb; ++t) {
+            // walk the ALIVE candidates only: the next one is the lowest clear bit of `rem` (a kept candidate's row always has
+            // its own bit set - iou(i, i) is 1 or NaN, neither is < nms_thr - and is cleared explicitly as well)
+            const unsigned long long inblk = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+            unsigned long long alive = ~rem & inblk;
+            while (alive) {
+                const int t = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
                 const unsigned long long row = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(rhi, t) << 32) |
                                                (unsigned)__builtin_amdgcn_readlane(rlo, t);          // (readlane returns int)
-                const bool alive = !((rem >> t) & 1ull);
-                kept |= alive ? (1ull << t) : 0ull;
-                rem |= alive ? row : 0ull;
+                kept |= 1ull << t;
+                rem |= row | (1ull << t);
+                alive = ~rem & inblk & (t == 63 ? 0ull : (~0ull << (t + 1)));
             }
             if ((kept >> lane) & 1ull) {
                 const int at = cnt + __popcll(kept & ((1ull << lane) - 1ull));
@@ -343,41 +362,76 @@ __device__ __forceinline__ void seed_phase(const cim_mining_args& a, const SeedL
     const int n_seeds = s_misc[3];
     const float thr = L.con_thr;
     int32_t* __restrict__ res = L.res + (size_t)c * K;
-    for (int s = wave; s < K; s += 16) {
-        if (s >= n_seeds) {
-            if (lane == 0) res[s] = -1;
-            continue;
-        }
-        const int seed = sseed[s];
-        float best = -INFINITY;
-        int besti = INT_MAX;
-        int any = 0;
-        if (a.asy_t != nullptr) {
-            const uint16_t* __restrict__ colp = a.asy_t + (size_t)seed * N;      // column `seed` of the map, contiguous
-            if (lay.det_lds) {
-#pragma unroll 4
-                for (int i = lane; i < N; i += 64) {
-                    const bool cond = (h2f(colp[i]) > thr) && sflag[i];
-                    any |= cond;
-                    const float v = cond ? sdet[i] : 0.0f;               // heads.py:393
-                    if (v > best) {  // ascending i per lane: strict '>' keeps the first maximum
-                        best = v;
-                        besti = i;
+    if (a.asy_t != nullptr) {
+        // Two seeds per wave and round, a lane takes 8 consecutive proposals per 512-proposal chunk: one 16-byte load per seed and
+        // chunk from the seed's row of the transposed map (rows padded to 8 entries: 16-byte aligned), all of a round's loads in
+        // flight before the first compare.
+        const int ldt = (N + 7) & ~7;
+        for (int s0 = wave * 2; s0 < K; s0 += 32) {
+            const bool on0 = s0 < n_seeds, on1 = s0 + 1 < n_seeds;       // (uniform per wave)
+            if (!on0) {
+                if (lane == 0) res[s0] = -1;
+                if (lane == 1 && s0 + 1 < K) res[s0 + 1] = -1;
+                continue;
+            }
+            const uint4* __restrict__ row0 = reinterpret_cast<const uint4*>(a.asy_t + (size_t)sseed[s0] * ldt);
+            const uint4* __restrict__ row1 = reinterpret_cast<const uint4*>(a.asy_t + (size_t)sseed[on1 ? s0 + 1 : s0] * ldt);
+            float best0 = -INFINITY, best1 = -INFINITY;
+            int bi0 = INT_MAX, bi1 = INT_MAX, any0 = 0, any1 = 0;
+            for (int i0 = lane * 8; i0 < ldt; i0 += 512) {
+                const uint4 v0 = row0[i0 >> 3], v1 = row1[i0 >> 3];
+                float d[8];
+                unsigned fl = 0;
+                if (lay.det_lds) {
+                    const float4 da = *reinterpret_cast<const float4*>(sdet + i0), db = *reinterpret_cast<const float4*>(sdet + i0 + 4);
+                    const uint2 fb = *reinterpret_cast<const uint2*>(sflag + i0);
+                    d[0] = da.x; d[1] = da.y; d[2] = da.z; d[3] = da.w; d[4] = db.x; d[5] = db.y; d[6] = db.z; d[7] = db.w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fl |= ((((e < 4 ? fb.x : fb.y) >> (8 * (e & 3))) & 0xffu) ? 1u : 0u) << e;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int i = i0 + e;
+                        d[e] = i < N ? L.det[(size_t)i * L.det_ld + L.det_off + c * L.det_cs] : 0.0f;
+                        fl |= (i < N && flag[i] ? 1u : 0u) << e;
                     }
                 }
-            } else {
-#pragma unroll 4
-                for (int i = lane; i < N; i += 64) {
-                    const bool cond = (h2f(colp[i]) > thr) && flag[i];
-                    any |= cond;
-                    const float v = cond ? L.det[(size_t)i * L.det_ld + L.det_off + c * L.det_cs] : 0.0f;
-                    if (v > best) {
-                        best = v;
-                        besti = i;
-                    }
+                const unsigned w0[4] = {v0.x, v0.y, v0.z, v0.w}, w1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = i0 + e;
+                    const bool in = i < N && ((fl >> e) & 1u);
+                    const bool c0 = in && h2f((uint16_t)(w0[e >> 1] >> (16 * (e & 1)))) > thr;
+                    const bool c1 = in && h2f((uint16_t)(w1[e >> 1] >> (16 * (e & 1)))) > thr;
+                    any0 |= c0;
+                    any1 |= c1;
+                    const float x0 = c0 ? d[e] : 0.0f, x1 = c1 ? d[e] : 0.0f;        // heads.py:393
+                    if (i < N && x0 > best0) { best0 = x0; bi0 = i; }                 // ascending i per lane: strict '>' keeps the first maximum
+                    if (i < N && x1 > best1) { best1 = x1; bi1 = i; }
                 }
             }
-        } else {                                                         // no transposed copy: strided reads of the map's column
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov0 = __shfl_xor(best0, o), ov1 = __shfl_xor(best1, o);
+                const int oi0 = __shfl_xor(bi0, o), oi1 = __shfl_xor(bi1, o);
+                if (ov0 > best0 || (ov0 == best0 && oi0 < bi0)) { best0 = ov0; bi0 = oi0; }
+                if (ov1 > best1 || (ov1 == best1 && oi1 < bi1)) { best1 = ov1; bi1 = oi1; }
+            }
+            any0 = __any(any0);
+            any1 = __any(any1);
+            if (lane == 0) res[s0] = any0 ? bi0 : -1;
+            if (lane == 1 && s0 + 1 < K) res[s0 + 1] = (on1 && any1) ? bi1 : -1;
+        }
+    } else {
+        for (int s = wave; s < K; s += 16) {                             // no transposed copy: strided reads of the map's column
+            if (s >= n_seeds) {
+                if (lane == 0) res[s] = -1;
+                continue;
+            }
+            const int seed = sseed[s];
+            float best = -INFINITY;
+            int besti = INT_MAX;
+            int any = 0;
 #pragma unroll 4
             for (int i = lane; i < N; i += 64) {
                 const bool cond = (h2f(a.asy[(size_t)i * N + seed]) > thr) && flag[i];
@@ -388,18 +442,18 @@ __device__ __forceinline__ void seed_phase(const cim_mining_args& a, const SeedL
                     besti = i;
                 }
             }
-        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o);
-            const int oi = __shfl_xor(besti, o);
-            if (ov > best || (ov == best && oi < besti)) {
-                best = ov;
-                besti = oi;
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o);
+                const int oi = __shfl_xor(besti, o);
+                if (ov > best || (ov == best && oi < besti)) {
+                    best = ov;
+                    besti = oi;
+                }
             }
+            any = __any(any);
+            if (lane == 0) res[s] = any ? besti : -1;
         }
-        any = __any(any);
-        if (lane == 0) res[s] = any ? besti : -1;
     }
     MCLK(0, wg_act, 4);
 }
@@ -459,7 +513,8 @@ __device__ float np_pairwise_sum(const float* a, int n) {
 // layers' list lengths (np.random.choice draws one double per class member, every member of the list belongs to exactly one
 // class).  Each arbitrator publishes its G_l in sync->gword[l] and reads the earlier layers' words: at most R <= 4 workgroups
 // ever wait, on workgroups that are running or will be dispatched whatever the waiters hold, and layer 0 waits for nobody.
-__device__ void arbitrate_phase(const cim_mining_args& a, MiningSync* __restrict__ sync, unsigned char* smem, int l) {
+__device__ void arbitrate_phase(const cim_mining_args& a, MiningSync* __restrict__ sync, unsigned char* smem, int l, int n_act,
+                                const int16_t* __restrict__ s_act) {
 #pragma clang fp contract(off)                      // the sums below restate NumPy's: no fused multiply-adds
     const int N = a.N, K = a.K, C = a.C, tid = threadIdx.x;
     // LDS: cdf f64 [K] | part i32 [1024] | prob f32 [K] | pos i32 [K] | gclass i32 [N] | gweight f32 [N] | mark u8 [N]
@@ -479,14 +534,8 @@ __device__ void arbitrate_phase(const cim_mining_args& a, MiningSync* __restrict
 
     MCLK(1, l, 0);
     if (tid == 0) s_err = 0;
-    // the image's classes, ascending (labels[] is read once; the class loops below walk this list)
-    __shared__ int16_t s_act[1024];
-    int n_act;
-    {
-        const int on = (tid < C && a.labels[tid] != 0.0f) ? 1 : 0;
-        const int at = block_exclusive_scan(on, part, &n_act);
-        if (on) s_act[at] = (int16_t)tid;
-    }
+    // (s_act[0 .. n_act): the image's classes, ascending - listed once at the start of the launch; the class loops below walk it)
+    (void)C;
     // ---- arbitration (heads.py:397-405 / 306-314): the reference applies the image's classes one after the other in ascending
     // order, `w > gt_weight` (strict) deciding - per proposal that is: the largest weight among the classes that list it, the
     // LOWEST class on equal weights, and nothing unless w > -1 (heads.py:336).  All (class, candidate) pairs go through one
@@ -585,6 +634,10 @@ __device__ void arbitrate_phase(const cim_mining_args& a, MiningSync* __restrict
                 __syncthreads();
                 continue;
             }
+            // this class's uniforms: the load flies under the sums below
+            const int ubase = s_used;
+            const bool u_ok = ubase + Gc <= a.max_uniforms;
+            const double u_first = (u_ok && tid < Gc) ? a.uniforms[ubase + tid] : 0.0;
             for (int i = lo, j = p0; i < hi; ++i) {
                 const int gc = gclass[i];
                 if (gc == c + 1) {
@@ -624,12 +677,12 @@ __device__ void arbitrate_phase(const cim_mining_args& a, MiningSync* __restrict
             }
             __syncthreads();
             const double last = cdf[Gc - 1];
-            const int base = s_used;
-            if (base + Gc > a.max_uniforms) {                            // the host drew too few (cannot happen: bound = R * min(N, classes * K))
+            const int base = ubase;
+            if (!u_ok) {                                                 // the host drew too few (cannot happen: bound = R * min(N, classes * K))
                 if (tid == 0) s_err |= 2;
             } else {
                 for (int j = tid; j < Gc; j += 1024) {
-                    const double u = a.uniforms[base + j];
+                    const double u = j == tid ? u_first : a.uniforms[base + j];
                     int b = 0, e = Gc;                                   // searchsorted(cdf / cdf[-1], u, side='right'): first index with cdf > u
                     while (b < e) {
                         const int mid = (b + e) >> 1;
@@ -697,9 +750,15 @@ __global__ __launch_bounds__(1024) void step_mine_kernel(const cim_mining_args a
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_misc[8];
     __shared__ int s_part[16];
+    __shared__ int16_t s_act[1024];                                      // the image's classes, ascending
     const int c = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
     const cim_mining_layer& L = a.layer[l];
-    const int n_act = __syncthreads_count(tid < a.C && a.labels[tid] != 0.0f);
+    int n_act;
+    {
+        const int on = (tid < a.C && a.labels[tid] != 0.0f) ? 1 : 0;
+        const int at = block_exclusive_scan(on, s_part, &n_act);
+        if (on) s_act[at] = (int16_t)tid;
+    }
     if (a.labels[c] == 0.0f) {                                           // heads.py:340: only the image's classes
         if (tid == 0) L.n_seeds[c] = 0;
         if (n_act != 0 || c != 0) return;
@@ -716,7 +775,7 @@ __global__ __launch_bounds__(1024) void step_mine_kernel(const cim_mining_args a
         if (!s_misc[4]) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // the other classes' lists
     }
-    arbitrate_phase(a, sync, smem, l);
+    arbitrate_phase(a, sync, smem, l, n_act, s_act);
 }
 
 // ================================================================== the assignment launch (heads.py:435,477-501)
@@ -790,7 +849,7 @@ SeedLayout seed_layout(int N, int K) {
     const long long KW = (K + 63) / 64;
     auto up16 = [](long long v) { return (v + 15) & ~15ll; };
     SeedLayout s{};
-    long long o = 1024;                                                  // the 256-bin histogram
+    long long o = 4096;                                                  // the four passes' 256-bin histograms
     s.off_cand = (int)o; o = up16(o + (long long)K * 8);
     s.off_sup = (int)o;  o = up16(o + (long long)K * KW * 8);
     s.off_kidx = (int)o; o = up16(o + (long long)K * 4);
@@ -830,7 +889,7 @@ extern "C" int cim_asy_prep(const uint16_t* asy_f16, int N, const float* con_thr
     }
     if (asy_t != nullptr) {
         const unsigned t = (unsigned)((N + 63) / 64);
-        hipLaunchKernelGGL(transpose_f16_kernel, dim3(t, t), dim3(256), 0, cim::as_stream(stream), asy_f16, asy_t, N);
+        hipLaunchKernelGGL(transpose_f16_kernel, dim3(t, t), dim3(256), 0, cim::as_stream(stream), asy_f16, asy_t, N, (N + 7) & ~7);
     }
     CIM_CHECK_LAUNCH();
     return 0;

@@ -631,7 +631,7 @@ def prepare_containment(layers, asy_iou_map, using_CIM=None, ahead=True):
 
     def launch():
         prep.flags = torch.empty((len(slots), n), dtype=torch.uint8, device=dev)
-        prep.asy_t = torch.empty((n, n), dtype=torch.float16, device=dev)
+        prep.asy_t = torch.empty((n, (n + 7) & ~7), dtype=torch.float16, device=dev)      # rows padded to 16 bytes
         _lib.call("cim_asy_prep", asy.data_ptr(), n, thr, len(slots), prep.flags.data_ptr(), prep.asy_t.data_ptr(), _lib.stream_ptr())
 
     if side is None:

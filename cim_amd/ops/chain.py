@@ -21,10 +21,11 @@ Protocol (host side, per backward pass; everything hangs off P's own `state` dic
     was accumulated with another one: x had a second consumer after all) raises - it cannot be repaired silently.  A mark that is
     never taken (P's backward did not run) dies with P's state.
   * Someone who looks AT x's gradient would see dconv_P instead (the chain rewrites what flows along that edge).  So Q checks, at
-    its backward, that x is still private (still_private): no tensor hook, no retain_grad() on x, and P's node is part of the
-    running backward pass (torch.autograd.grad(loss, [x]) stops at x: P's backward never runs).  If not, Q computes the plain data
-    gradient and P its own BatchNorm backward - the ordinary autograd path, correct for every observer.  What cannot be seen from
-    here - torch.autograd.grad with x AND something upstream of P among its inputs - is documented in INTEGRATION.md section 4.
+    its backward, that x is still private (still_private): no tensor hook, no retain_grad() on x, and the running pass is a complete
+    .backward() - not torch.autograd.grad(...) / .backward(inputs=...), which stop at (or capture) tensors inside the graph:
+    restricted_pass() asks the engine whether Q's own parameters are accumulated into by this pass.  If not, Q computes the plain
+    data gradient and P its own BatchNorm backward - the ordinary autograd path, correct for every observer.  What cannot be seen
+    from here - torch.autograd.grad whose inputs hold x AND every parameter of Q - is documented in INTEGRATION.md section 4.
 """
 import collections
 
@@ -62,11 +63,30 @@ def node_runs(fn):
         return True
 
 
-def still_private(x, in_bn):
+def restricted_pass(node, indices=(1, 3, 4)):
+    """Is the running backward pass known NOT to be a complete .backward()?  torch.autograd.grad(outputs, inputs) and
+    .backward(inputs=...) only run the nodes between their ends and CAPTURE gradients at tensors inside the graph - there the
+    bypasses of this package (deferred weight gradients, chained BatchNorm backward, branch hand-over) must step aside.  The engine
+    tells whether a node runs (or is captured); a complete pass accumulates into every trainable leaf, so a parameter of `node`
+    (the Function's ctx; `indices`: its parameter inputs) whose AccumulateGrad node neither runs nor is captured gives a
+    restricted pass away.  (A captured leaf reads as "runs": all parameters are looked at, not the first.)"""
+    try:
+        nf = node.next_functions
+    except AttributeError:
+        return False
+    for i in indices:
+        fn = nf[i][0] if i < len(nf) else None
+        if fn is not None and type(fn).__name__ == "AccumulateGrad" and not node_runs(fn):
+            return True
+    return False
+
+
+def still_private(x, in_bn, node=None):
     """Q's backward: may x's incoming gradient still be rewritten into the gradient of P's convolution output?  Not when somebody
-    observes x's gradient (hook, retain_grad) or P's backward is not part of this pass - then the chain is undone for this pass."""
+    observes x's gradient (hook, retain_grad) or the pass is not a complete one - then the chain is undone for this pass."""
     ok = (not getattr(x, "retains_grad", False) and not getattr(x, "_backward_hooks", None)
-          and not getattr(x, "_post_accumulate_grad_hooks", None) and node_runs(x.grad_fn))
+          and not getattr(x, "_post_accumulate_grad_hooks", None) and node_runs(x.grad_fn)
+          and not (node is not None and restricted_pass(node)))
     if not ok:
         in_bn.state["taken"] = False             # P sees an ordinary gradient and runs its own BatchNorm backward
     return ok

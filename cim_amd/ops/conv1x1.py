@@ -85,16 +85,16 @@ class Conv1x1BnActFunction(Function):
         dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=dev) if need_w else None
         ws = torch.empty(_lib.call("cim_conv1x1_bwd_workspace", B, cin, cout, hw) // 4, dtype=torch.float32, device=dev)
         in_bn = ctx.in_bn if need_x else None
-        if in_bn is not None and not chain.still_private(x, in_bn):
+        if in_bn is not None and not chain.still_private(x, in_bn, ctx):
             in_bn = None                         # somebody looks at x's gradient / the producer's backward is not in this pass
         in_part = torch.empty((B, 2, (hw + 31) // 32, cin), dtype=torch.float32, device=dev) if in_bn is not None and in_bn.affine else None
-        side, ev_fork, ev_join, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
+        side, ev_fork, ev_join, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None, ctx)
         _lib.call("cim_conv1x1_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w2.data_ptr(),
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres),
                   _lib.ptr(None if chained else dgamma), _lib.ptr(None if chained else dbeta), _lib.ptr(dx), _lib.ptr(dw),
                   B, cin, cout, hw, ws.data_ptr(), _lib.stream_ptr(), side, ev_fork, ev_join, join, int(is_dconv), *chain.c_args(in_bn, in_part),
                   _lib.ptr(dx_add), dx_add_w)
-        if ctx.send_dx is not None and dx is not None and _receiver_runs(ctx.send_dx):
+        if ctx.send_dx is not None and dx is not None and _receiver_runs(ctx.send_dx, ctx):
             # a downsample layer: its data gradient is the SECOND gradient of the block's input - handed to the block's first layer
             # (whose backward runs later: checked) instead of autograd, which would scatter a stride-2 layer's into a zero-filled
             # tensor through two slice nodes (two fills + two copies) and add the two gradients with a launch of its own
@@ -104,7 +104,7 @@ class Conv1x1BnActFunction(Function):
             tok["sent"] = tok.get("sent", 0) + 1
             tok["dres"] = dx
             dx = None
-        if ctx.send is not None and dres is not None and _receiver_runs(ctx.send):
+        if ctx.send is not None and dres is not None and _receiver_runs(ctx.send, ctx):
             # hand the identity path's gradient to the block's FIRST layer instead of autograd (which would add it to that layer's
             # data gradient with a launch of its own); that layer's backward runs after this one (later nodes first) - checked
             if ctx.send.get("sent", 0) != ctx.send.get("received", 0):
@@ -124,12 +124,12 @@ class Conv1x1BnActFunction(Function):
             dmean, None, None, None, None, None, None, None, None
 
 
-def _receiver_runs(tok):
+def _receiver_runs(tok, node):
     """Branch hand-over: the block's first layer takes the second gradient of the block's input in its data-gradient epilogue - only
-    if its backward is part of the running pass (torch.autograd.grad towards this layer's weight alone never reaches it); else the
-    gradient goes back to autograd as usual."""
+    in a complete .backward() pass in which its node runs (torch.autograd.grad towards this layer's weight alone never reaches
+    it); else the gradient goes back to autograd as usual."""
     r = tok.get("recv_node")
-    return chain.node_runs(r() if r is not None else None)
+    return chain.node_runs(r() if r is not None else None) and not chain.restricted_pass(node)
 
 
 class _BnPartDesc(ctypes.Structure):          # cim_bn_part_desc of include/cim_hip.h
@@ -167,7 +167,8 @@ def affine_outputs(ctx, is_dconv, dy_part, need_affine, B, cout, hw, dev):
         _, _, _, _, gamma, mean, var = ctx.saved_tensors
         rec = (dy_part, var, ctx.cfg[5], g, b)
         if (_gemm_mod.DEFER_DW and not torch.cuda.is_current_stream_capturing()
-                and all(q is None or isinstance(q, torch.nn.Parameter) for q in (g, b))):
+                and all(q is None or isinstance(q, torch.nn.Parameter) for q in (g, b))
+                and not chain.restricted_pass(ctx)):
             _gemm_mod.defer_finisher(dev, finish_affine, rec, [q for q in (g, b) if q is not None])
             return None, None, True
         got = dict((id(q), t) for q, t in finish_affine([rec]))

@@ -120,10 +120,10 @@ class Conv3x3BnActFunction(Function):
         dw = torch.empty_like(w) if need_w else None
         ws = torch.empty(_lib.call("cim_conv3x3_nchw_bwd_workspace", B, cin, cout, H, W, stride) // 4, dtype=torch.float32, device=dev)
         in_bn = ctx.in_bn if need_x else None
-        if in_bn is not None and not chain.still_private(x, in_bn):
+        if in_bn is not None and not chain.still_private(x, in_bn, ctx):
             in_bn = None                         # somebody looks at x's gradient / the producer's backward is not in this pass
         in_part = torch.empty((B, 2, (H * W + 31) // 32, cin), dtype=torch.float32, device=dev) if in_bn is not None and in_bn.affine else None
-        side, ev_fork, ev_join, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None)
+        side, ev_fork, ev_join, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None, ctx)
         wt = _transposed(ctx.param) if (need_x and ctx.param is not None) else None
         _lib.call("cim_conv3x3_nchw_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w.data_ptr(),
                   gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, int(relu), _lib.ptr(dres),

@@ -14,6 +14,7 @@ from torch.autograd import Function
 
 from .. import _lib
 from ..utils import engine
+from . import chain
 
 
 def _ws(m, n, splits, like):
@@ -214,12 +215,16 @@ def fork_event(dev):
     return ent[1][ent[0]][1]
 
 
-def side_stream_for_backward(dev, param):
+def side_stream_for_backward(dev, param, node=None):
     """(side stream pointer or None, fork event, join event, join flag) for a backbone layer's backward whose weight is `param`:
     deferred to the side stream (the caller joins later: no join event), or - HIP-graph capture, CIM_DEFER_DW=0, a weight that is
-    not a Parameter - everything on the caller's stream (a fork / join inside every layer measured SLOWER than that: 17.0-17.1 vs
+    not a Parameter, a pass that is not a complete .backward() (torch.autograd.grad captures the gradient the node RETURNS: a
+    deferred one, installed as .grad at the end of the pass, would be lost; `node` = the layer's ctx, ops/chain.py:
+    restricted_pass) - everything on the caller's stream (a fork / join inside every layer measured SLOWER than that: 17.0-17.1 vs
     16.8 ms per step)."""
     if not DEFER_DW or param is None or torch.cuda.is_current_stream_capturing():
+        return None, None, None, 1
+    if node is not None and chain.restricted_pass(node):
         return None, None, None, 1
     return _body_stream(dev).cuda_stream, fork_event(dev), None, 0
 

@@ -22,6 +22,7 @@ from torch.autograd import Function
 _os_env = os.environ
 
 from .. import _lib
+from . import chain
 from . import gemm as G
 from . import pair
 
@@ -211,8 +212,12 @@ class MaskFusePairFunction(Function):
 
         published = []
         publisher = G.publisher_for(ctx.weights[1])      # several ranks: this model's nn.DataParallel wrapper takes the big gradients early
+        if publisher is not None and chain.restricted_pass(ctx, (1, 3, 5)):
+            publisher = None                             # (torch.autograd.grad towards the weights: through autograd)
         late = []               # (slot, weight, closure) of the weight gradients launched at the end (DW_WGS > 0)
-        run_late = overlap and DEFER_DW and G.DEFER_DW and DW_WGS > 0
+        # (a pass that does not accumulate into the weights - torch.autograd.grad towards them - returns the gradients through autograd)
+        run_late = (overlap and DEFER_DW and G.DEFER_DW and DW_WGS > 0
+                    and not chain.restricted_pass(ctx, (1, 3, 5)))
 
         def side_grad(slot, w, fn):
             if run_late:

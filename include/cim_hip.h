@@ -116,8 +116,9 @@ int cim_asy_flag(const uint16_t* asy_f16, int N, float con_thr, uint8_t* flag, v
 
 /* Everything the mining needs from the containment map ALONE (an input of the step: the host runs this on a side stream under
  * the backbone forward): flags [n_slots, N] = cim_asy_flag for each of the n_slots distinct con_thr values (con_thr_host: HOST
- * array), and asy_t [N,N] = the map transposed (may be NULL) - the containment step reads whole COLUMNS of the map
- * (heads.py:386: every proposal against one seed), contiguous rows of the transposed copy. */
+ * array), and asy_t [N, ldt] = the map transposed, rows padded to ldt = 8 ceil(N / 8) entries (16-byte aligned rows, pad entries
+ * zero; may be NULL) - the containment step reads whole COLUMNS of the map (heads.py:386: every proposal against one seed),
+ * contiguous rows of the transposed copy. */
 int cim_asy_prep(const uint16_t* asy_f16, int N, const float* con_thr_host, int n_slots, uint8_t* flags, uint16_t* asy_t,
                  void* stream);
 
@@ -173,7 +174,7 @@ typedef struct cim_mining_args {
     const float* labels;             /* [C] image labels */
     const uint16_t* iou;             /* [N,N] binary16 mask-IoU map */
     const uint16_t* asy;             /* [N,N] binary16 containment map */
-    const uint16_t* asy_t;           /* [N,N] its transpose from cim_asy_prep (NULL: the map's columns are read with strided loads) */
+    const uint16_t* asy_t;           /* [N, 8 ceil(N/8)] its transpose from cim_asy_prep (NULL: the map's columns are read with strided loads) */
     const uint8_t* flags;            /* [n_slots, N] from cim_asy_flag */
     const double* uniforms;          /* [max_uniforms] */
     int32_t max_uniforms, reserved_;

@@ -13,7 +13,7 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (2 * 8 * 16))()
 assert lib.cim_debug_mining_clocks(buf) == 0
 a = np.array(buf, dtype=np.uint64).reshape(2, 8, 16).astype(np.int64)
-for k, n in ((0, 4), (1, 9)):
+for k, n in ((0, 5), (1, 9)):
     for wg in range(8):
         st = a[k, wg, :n]
         if st[0] == 0:
