@@ -22,6 +22,8 @@
 #include <limits.h>
 
 using cim::h2f;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 #ifndef CIM_MINING_CLOCKS
 #define CIM_MINING_CLOCKS 0          // 1: phase stamps (100 MHz wall clock) of the mining launch -> cim_debug_mining_clocks (tools only)
@@ -125,8 +127,9 @@ struct MiningSync {
 
 // LDS layout of the seed phase (byte offsets; the arbitration phase re-uses the array from offset 0)
 struct SeedLayout {
-    int off_cand, off_sup, off_kidx, off_seed, off_det, off_flag;
+    int off_cand, off_sup, off_kidx, off_seed, off_det, off_flag, off_row;
     int det_lds;                                     // the layer's detector column and the flags staged in LDS (else read from memory)
+    int row_lds, row_halves;                         // the NMS matrix from whole map rows streamed through 16 wave-private LDS rows
     int total;
 };
 
@@ -138,12 +141,12 @@ struct SeedLayout {
 // barrier per pass: the histograms of all four passes are cleared up front and every wave scans a pass's 256 bins for
 // itself.  Round 4 sorted all N keys (bitonic, 55 exchange stages): 12.5 of the kernel's 37 us.
 template <int MAXR>
-__device__ __forceinline__ void seed_topk_select(const float* __restrict__ score, int score_ld, int col, int N, int K,
+__device__ __forceinline__ void seed_topk_select(const float (&sc)[MAXR], int N, int K,
                                                  unsigned* __restrict__ hist, unsigned long long* __restrict__ cand,
                                                  int32_t* __restrict__ kidx, int32_t* __restrict__ topk_out, int* s_misc,
                                                  int* s_part, int tid) {
     const int lane = tid & 63;
-    const int Rk = (N + 1023) >> 10;                 // keys per lane: lane t owns the proposals [t Rk, t Rk + Rk)
+    const int Rk = (N + 1023) >> 10;                 // keys per lane: lane t owns the proposals [t Rk, t Rk + Rk) (scores in sc[])
     unsigned key[MAXR];
     unsigned valid = 0;
 #pragma unroll
@@ -151,7 +154,7 @@ __device__ __forceinline__ void seed_topk_select(const float* __restrict__ score
         key[r] = 0;
         const int i = tid * Rk + r;
         if (r < Rk && i < N) {
-            key[r] = orderable(score[(size_t)i * score_ld + col]);
+            key[r] = orderable(sc[r]);
             valid |= 1u << r;
         }
     }
@@ -264,35 +267,117 @@ __device__ __forceinline__ void seed_phase(const cim_mining_args& a, const SeedL
     [[maybe_unused]] const int wg_act = (int)(l * 2 + (c & 1));          // (debug stamps only)
     MCLK(0, wg_act, 0);
     const uint8_t* __restrict__ flag = L.using_cim ? a.flags + (size_t)L.flag_slot * N : nullptr;
-    if (L.using_cim && lay.det_lds) {                                    // staged first: the loads fly under the select passes
-        for (int i = tid; i < N; i += 1024) {
-            sdet[i] = L.det[(size_t)i * L.det_ld + L.det_off + c * L.det_cs];
-            sflag[i] = flag[i];
+    // ONE round trip for everything this phase reads per proposal: lane t owns the proposals [t Rk, t Rk + Rk) - their seed
+    // scores stay in registers (the select's keys), their detector scores and flags go to LDS for the containment step
+    constexpr int MAXR = 8;
+    const int Rk = (N + 1023) >> 10;
+    float sc[MAXR];
+    {
+        const float* __restrict__ score = L.seed_score;
+        const int score_ld = L.seed_ld, col = L.seed_off + c;
+        const bool stage = L.using_cim && lay.det_lds;
+        float dv[MAXR];
+        uint8_t fv[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const int i = tid * Rk + r;
+            const bool in = r < Rk && i < N;
+            sc[r] = in ? score[(size_t)i * score_ld + col] : 0.0f;
+            dv[r] = (in && stage) ? L.det[(size_t)i * L.det_ld + L.det_off + c * L.det_cs] : 0.0f;
+            fv[r] = (in && stage) ? flag[i] : (uint8_t)0;
+        }
+        if (stage) {
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                const int i = tid * Rk + r;
+                if (r < Rk && i < N) {
+                    sdet[i] = dv[r];
+                    sflag[i] = fv[r];
+                }
+            }
         }
     }
     // key = (descending score, ascending index): a total order -> the stable descending argsort of heads.py:354 (App. B item 4)
-    seed_topk_select<8>(L.seed_score, L.seed_ld, L.seed_off + c, N, K, hist, cand, kidx, topk_out, s_misc, s_part, tid);
+    seed_topk_select<MAXR>(sc, N, K, hist, cand, kidx, topk_out, s_misc, s_part, tid);
     MCLK(0, wg_act, 1);
     // Suppression bit-matrix over the K x K gathered sub-block of the mask-IoU map:
     // bit (i, j) set <=> NOT (iou[idx_i, idx_j] < nms_thr)   (heads.py:250-254, fp16 compare).
     const float nms_thr = L.nms_thr;
-    constexpr int GU = 13;                                               // gathers in flight per wave (latency-bound: the map is
-    for (int t0 = wave; t0 < K * KW; t0 += 16 * GU) {                    // L2-resident, each gather a round trip; K = 100: one round)
-        uint16_t v[GU];
+    if (lay.row_lds) {
+        // ROW STREAMING: one wave per candidate row reads the candidate's WHOLE row of the map in 16-byte pieces (coalesced; the K
+        // wanted columns - a tenth of the row, scattered - touch nearly every 64-byte line of it anyway: gathering them one by one
+        // moved 3x the bytes through this CU's L1, 24 of the phase's 52 us at 2000 proposals), parks it in a wave-private LDS
+        // row and picks its K columns from there (one 2-byte LDS read per candidate and 64-candidate word, a ballot per word).
+        // Rows start at any 2-byte offset: the pieces are loaded from the 16-byte boundary below through a buffer resource over
+        // the map (reads behind its end return 0), the columns are shifted accordingly.  The next row's pieces are in flight
+        // while this one is picked apart.
+        const rsrc_t R = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.iou), 0, (int)(2u * (unsigned)N * (unsigned)N), 0x00020000);
+        uint16_t* __restrict__ myrow = reinterpret_cast<uint16_t*>(smem + lay.off_row) + (size_t)wave * lay.row_halves;
+        const int nch = lay.row_halves >> 3;                             // 16-byte pieces per row (<= 4 per lane)
+        int cj[4];
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int t = t0 + 16 * u;
-            const int i = t / KW, w = t % KW, j = w * 64 + lane;
-            // (the greedy scan only looks at candidates behind row i: the words below its own 64-block stay zero)
-            v[u] = (t < K * KW && j < K && w >= (i >> 6)) ? a.iou[(size_t)kidx[i] * N + kidx[j]] : (uint16_t)0;
+        for (int w = 0; w < 4; ++w) {
+            const int j = w * 64 + lane;
+            cj[w] = (w < KW && j < K) ? kidx[j] : -1;
         }
+        u32x4 cur[4], nxt[4];
+        int sh_c = 0, sh_n = 0;
+        auto issue = [&](int i, u32x4 (&buf)[4], int& shift) {
+            const unsigned b = 2u * (unsigned)kidx[i] * (unsigned)N;
+            shift = (int)((b & 15u) >> 1);
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int t = t0 + 16 * u;
-            if (t >= K * KW) break;
-            const int i = t / KW, w = t % KW, j = w * 64 + lane;
-            const unsigned long long word = __ballot(j < K && w >= (i >> 6) && !(h2f(v[u]) < nms_thr));
-            if (lane == 0) sup[t] = word;
+            for (int k = 0; k < 4; ++k) {
+                const int ch = lane + 64 * k;
+                buf[k] = ch < nch ? __builtin_amdgcn_raw_buffer_load_b128(R, (b & ~15u) + 16u * (unsigned)ch, 0, 0) : u32x4{0, 0, 0, 0};
+            }
+        };
+        int i = wave;
+        if (i < K) issue(i, cur, sh_c);
+        for (; i < K; i += 16) {
+            if (i + 16 < K) issue(i + 16, nxt, sh_n);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ch = lane + 64 * k;
+                if (ch < nch) *reinterpret_cast<u32x4*>(myrow + ch * 8) = cur[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (LDS operations of a wave execute in order: no wait needed,
+            __builtin_amdgcn_wave_barrier();                             // only the compiler must keep the writes above the reads)
+            const int w_lo = i >> 6;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w >= KW) break;
+                unsigned long long word = 0ull;
+                if (w >= w_lo) {                                         // (the greedy scan only looks at candidates behind row i)
+                    const uint16_t v = cj[w] >= 0 ? myrow[cj[w] + sh_c] : (uint16_t)0;
+                    word = __ballot(cj[w] >= 0 && !(h2f(v) < nms_thr));
+                }
+                if (lane == 0) sup[(size_t)i * KW + w] = word;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+            sh_c = sh_n;
+        }
+    } else {
+        constexpr int GU = 13;                                               // gathers in flight per wave (latency-bound: the map is
+        for (int t0 = wave; t0 < K * KW; t0 += 16 * GU) {                    // L2-resident, each gather a round trip; K = 100: one round)
+            uint16_t v[GU];
+    #pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int t = t0 + 16 * u;
+                const int i = t / KW, w = t % KW, j = w * 64 + lane;
+                // (the greedy scan only looks at candidates behind row i: the words below its own 64-block stay zero)
+                v[u] = (t < K * KW && j < K && w >= (i >> 6)) ? a.iou[(size_t)kidx[i] * N + kidx[j]] : (uint16_t)0;
+            }
+    #pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int t = t0 + 16 * u;
+                if (t >= K * KW) break;
+                const int i = t / KW, w = t % KW, j = w * 64 + lane;
+                const unsigned long long word = __ballot(j < K && w >= (i >> 6) && !(h2f(v[u]) < nms_thr));
+                if (lane == 0) sup[t] = word;
+            }
         }
     }
     __syncthreads();
@@ -859,6 +944,12 @@ SeedLayout seed_layout(int N, int K) {
     s.off_det = (int)o;
     s.off_flag = (int)(o + up16((long long)N * 4));
     if (s.det_lds) o += det;
+    // whole-row streaming of the NMS matrix: <= 4 sixteen-byte pieces per lane (N <= 2040), <= 4 words per row (K <= 256)
+    const long long pieces = (2ll * N + 14 + 15) / 16;
+    s.row_halves = (int)(pieces * 8);
+    s.off_row = (int)o;
+    s.row_lds = (pieces <= 256 && KW <= 4 && o + 16 * pieces * 16 <= 156 * 1024) ? 1 : 0;
+    if (s.row_lds) o += 16 * pieces * 16;
     const long long arb = arbitrate_lds_bytes(N, K);
     s.total = (int)(o > arb ? o : arb);
     return s;
@@ -925,7 +1016,7 @@ extern "C" int cim_mining_step(const cim_mining_args* args, void* sync, void* st
     CIM_CHECK_ARG(!any_cim || ((a.asy || a.asy_t) && a.flags));          // MIST-only steps never touch the containment map
     hipStream_t st = cim::as_stream(stream);
     const SeedLayout lay = seed_layout(N, K);
-    CIM_CHECK_ARG(lay.total <= 160 * 1024);
+    CIM_CHECK_ARG(lay.total <= 156 * 1024);               // (+ ~2.5 KB of static LDS)
     if (lay.total > 64 * 1024)
         CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(step_mine_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lay.total));

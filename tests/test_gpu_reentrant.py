@@ -24,7 +24,7 @@ def dev():
 def _mining_reference(inp, seed):
     from oracle import mining as om
     np.random.seed(seed)
-    cls, det = inp["layers"][0]
+    cls, det, _ = inp["layers"][0]
     return om.cim_layer_forward(cls, det, inp["labels"], inp["iou"], inp["asy"], cls_thr=0.25, iou_thr=0.5,
                                 anti_noise_sampling=False)
 
@@ -36,7 +36,7 @@ def test_two_threads_two_streams_mining_and_pair_gemm(dev):
     inp = case_inputs(MINING_CASES["n300_c20_k2"])
     ref = _mining_reference(inp, 1)
     t = lambda a: torch.from_numpy(a).to(dev)
-    cls, det = (t(x) for x in inp["layers"][0])
+    cls, det = (t(x) for x in inp["layers"][0][:2])
     labels, iou, asy = t(inp["labels"]), t(inp["iou"]), t(inp["asy"])
     layer = heads.CIM_layer(0.1, 0.25, 0.5, 0.85, Anti_noise_sampling=False)
     g = torch.Generator().manual_seed(5)
