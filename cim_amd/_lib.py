@@ -15,6 +15,7 @@ SIGNATURES = {
     "cim_roi_align_fwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
     "cim_roi_align_fwd_ws": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
     "cim_roi_align_maskcat_fwd_ws": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
+    "cim_roi_align_wino7_pair_fwd": [_P, _P, _P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, _P],
     "cim_roi_align_bwd_ws": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, c_int, _P, _P],
     "cim_roi_align_maskcat_bwd_ws": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, c_int, _P, _P],
     "cim_roi_align_bwd_workspace": [c_int, c_int, c_int, c_int],

@@ -563,6 +563,210 @@ __global__ __launch_bounds__(256) void roi_align_fwd_rowsum2_kernel(const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// Forward, fused with the MaskFuse prologue AND the Winograd input transform of MaskFuse's convolution (round 5):
+//   feat --ROIAlign--> box [7][7][C] --(box, box * mask)--> cat [7][7][2C] --B^T d B per tile--> V' [121][Rs][2C] pair image
+// for /root/reference/lib/modeling/resnet50.py:121-135 (roi_xform -> mask multiply -> concat -> mask_branch's 3 x 3 convolution in
+// the mixed 4 + 3 Winograd tiling of csrc/winograd.hip).  `cat` never exists: the two-kernel path wrote its 401 MB (cfg2), read
+// them back in wino7_input_pair_kernel (0.288 ms) and wrote the 991 MB image; here the image is the only output.
+// Workgroup = (ROI r, 256-channel slice), four waves.  Phase A: wave w computes the bin rows 2w, 2w + 1 of the ROI for the lane's
+// 4 channels with the row-sum arithmetic of roi_align_fwd_rowsum2_kernel (the same operations in the same order: the values are
+// the bits that kernel writes) into an LDS patch [49][256].  Phase B: wave t transforms tile type t (36 / 30 / 30 / 25 positions)
+// of the patch - once as it is, once multiplied by the ROI's 7 x 7 mask - with the arithmetic of w7_input_tile and stores the
+// split (h, l) fp16 chunks (w7_store_pair's protocol: lane pairs exchange halves, 16 bytes per lane).  Rows r >= K (the pad up
+// to a multiple of 32 rows the GEMM wants) are zero-filled.  The image is bit-identical to the two-kernel path's.
+#include "wino43_mats.h"
+namespace w7f {
+constexpr int NP[2] = {6, 5}, IN0[2] = {-1, 3}, QOFF[4] = {0, 36, 66, 96};
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned swap1(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ void store_pair(float* p, const float4& v, float s) {         // (= w7_store_pair of winograd.hip)
+    unsigned h0, l0, h1, l1;
+    cim::pair_split2(v.x * s, v.y * s, h0, l0);
+    cim::pair_split2(v.z * s, v.w * s, h1, l1);
+    const bool odd = (threadIdx.x & 1) != 0;
+    const unsigned r0 = swap1(odd ? h0 : l0), r1 = swap1(odd ? h1 : l1);
+    const u4 o = odd ? u4{r0, r1, l0, l1} : u4{h0, h1, r0, r1};
+    __builtin_nontemporal_store(o, reinterpret_cast<u4*>(p));
+}
+__device__ __forceinline__ void fma4(float4& a, float s, const float4& v) {
+    a.x = fmaf(s, v.x, a.x); a.y = fmaf(s, v.y, a.y); a.z = fmaf(s, v.z, a.z); a.w = fmaf(s, v.w, a.w);
+}
+// one tile type of the patch: d = patch (x mask when MASKED) -> B^T d B -> pair image positions Q0 .. Q0 + NA NB
+template <int KA, int KB, bool MASKED>
+__device__ __forceinline__ void tile(const float4* __restrict__ patch, const float* __restrict__ mask49, float* __restrict__ V,
+                                     size_t MC, size_t off, const float* __restrict__ scale, int lane) {
+    constexpr int NA = NP[KA], NB = NP[KB], P = 7, Q0 = QOFF[KA * 2 + KB];
+    float4 d[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int iy = IN0[KA] + i;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int ix = IN0[KB] + j;
+            if ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) {
+                d[i][j] = patch[(iy * P + ix) * 64 + lane];
+                if (MASKED) { const float m = mask49[iy * P + ix]; d[i][j] = make_float4(m * d[i][j].x, m * d[i][j].y, m * d[i][j].z, m * d[i][j].w); }
+            } else {
+                d[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        float4 trow[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            trow[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < NA; ++k)
+                if (W7_BT[KA][i][k] != 0.0f) fma4(trow[j], W7_BT[KA][i][k], d[k][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (W7_BT[KB][j][k] != 0.0f) fma4(v, W7_BT[KB][j][k], trow[k]);
+            store_pair(V + (size_t)(Q0 + i * NB + j) * MC + off, v, scale[Q0 + i * NB + j]);
+        }
+    }
+}
+}  // namespace w7f
+
+__global__ __launch_bounds__(256) void roi_align_wino7_pair_kernel(const float* __restrict__ feat, const float* __restrict__ masks,
+                                                                   float* __restrict__ V, int C, int H, int W, int K, int Rs,
+                                                                   const float* __restrict__ rec_all,
+                                                                   const float* __restrict__ scale) {
+    constexpr int P = 7;
+    __shared__ __attribute__((aligned(16))) float4 s_patch[49 * 64];                    // [bin][lane]: 49 KB
+    __shared__ __attribute__((aligned(16))) float s_wx[RS_MAXD][8];
+    __shared__ float s_wa[4][RS_MAXD], s_wb[4][RS_MAXD];
+    __shared__ int s_rows[4][RS_MAXD];
+    __shared__ float s_mask[49];
+    const int r = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = slice * 256 + lane * 4;
+    const size_t C2 = 2 * (size_t)C, MC = (size_t)Rs * C2;
+    if (r >= K) {                                                                        // pad rows: zero
+        if (c < C)
+            for (int q = wave; q < 121; q += 4) {
+                float* dst = V + (size_t)q * MC + (size_t)r * C2 + c;
+                __builtin_nontemporal_store(w7f::u4{0, 0, 0, 0}, reinterpret_cast<w7f::u4*>(dst));
+                __builtin_nontemporal_store(w7f::u4{0, 0, 0, 0}, reinterpret_cast<w7f::u4*>(dst + C));
+            }
+        return;
+    }
+    const int k = r;
+    const float* rec = rec_all + (size_t)k * roi_rec_words(P, H, W);
+    const float* wx = rec + P * H;
+    const int* box = reinterpret_cast<const int*>(rec + (P + 1) * (H + W));
+    const int ylo = box[0], yhi = box[1], xlo = box[2], xhi = box[3];
+    const float inv_count = 1.0f / reinterpret_cast<const float*>(box)[4];
+    const float* __restrict__ fb = feat + (size_t)box[5] * H * W * C;
+    const int ncols = max(xhi - xlo + 1, 0);
+    // ---- phase A: bin rows ph0, ph0 + 1 of this wave (rowsum2's arithmetic)
+    const int ph0 = wave * 2;
+    const bool two = ph0 + 1 < P;
+    const float* wy0 = rec + ph0 * H;
+    const float* wy1 = wy0 + H;
+    int nrows;
+    {
+        // the rows of the map with a non-zero weight in bin row ph0 or ph0 + 1, ascending (a wave-wide compaction of the loop
+        // rowsum2's thread 0 runs: same list, same order)
+        const int y = ylo + lane;
+        float a = 0.0f, b = 0.0f;
+        if (y <= yhi) { a = wy0[y]; b = two ? wy1[y] : 0.0f; }
+        const bool on = y <= yhi && (a != 0.0f || b != 0.0f);
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int n = __popcll(m & ((1ull << lane) - 1ull));
+            s_rows[wave][n] = y * W; s_wa[wave][n] = a * inv_count; s_wb[wave][n] = b * inv_count;
+        }
+        nrows = __popcll(m);
+    }
+    for (int e = tid; e < ncols * 8; e += 256) {
+        const int xi = e >> 3, pw = e & 7;
+        s_wx[xi][pw] = pw < P ? wx[pw * W + xlo + xi] : 0.0f;
+    }
+    if (tid < 49) s_mask[tid] = masks[(size_t)k * 49 + tid];
+    __syncthreads();
+    if (c < C) {
+        const int* __restrict__ rows = s_rows[wave];
+        const float* __restrict__ rwa = s_wa[wave];
+        const float* __restrict__ rwb = s_wb[wave];
+        const float* __restrict__ fc = fb + c;
+        ga_f2 al[7], ah[7], bl[7], bh[7];
+#pragma unroll
+        for (int pw = 0; pw < 7; ++pw) al[pw] = ah[pw] = bl[pw] = bh[pw] = ga_f2{0.f, 0.f};
+        for (int xi = 0; xi < ncols; xi += 2) {
+            const bool pair = xi + 1 < ncols;            // wave-uniform; the odd last column is loaded twice, weight 0
+            const int x0 = (xlo + xi) * C, dx1 = pair ? C : 0;
+            ga_f2 ta0l = {0.f, 0.f}, ta0h = {0.f, 0.f}, ta1l = {0.f, 0.f}, ta1h = {0.f, 0.f};
+            ga_f2 tb0l = {0.f, 0.f}, tb0h = {0.f, 0.f}, tb1l = {0.f, 0.f}, tb1h = {0.f, 0.f};
+            int rr = 0;
+            for (; rr + 4 <= nrows; rr += 4) {
+                float4 v0[4], v1[4];
+                float wa[4], wb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* src = fc + (size_t)rows[rr + j] * C + x0;
+                    v0[j] = *reinterpret_cast<const float4*>(src);
+                    v1[j] = *reinterpret_cast<const float4*>(src + dx1);
+                    wa[j] = rwa[rr + j];
+                    wb[j] = rwb[rr + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ta0l = ga_fma(wa[j], ga_lo(v0[j]), ta0l); ta0h = ga_fma(wa[j], ga_hi(v0[j]), ta0h);
+                    ta1l = ga_fma(wa[j], ga_lo(v1[j]), ta1l); ta1h = ga_fma(wa[j], ga_hi(v1[j]), ta1h);
+                    tb0l = ga_fma(wb[j], ga_lo(v0[j]), tb0l); tb0h = ga_fma(wb[j], ga_hi(v0[j]), tb0h);
+                    tb1l = ga_fma(wb[j], ga_lo(v1[j]), tb1l); tb1h = ga_fma(wb[j], ga_hi(v1[j]), tb1h);
+                }
+            }
+            for (; rr < nrows; ++rr) {
+                const float* src = fc + (size_t)rows[rr] * C + x0;
+                const float4 v0 = *reinterpret_cast<const float4*>(src);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + dx1);
+                const float wa = rwa[rr], wb = rwb[rr];
+                ta0l = ga_fma(wa, ga_lo(v0), ta0l); ta0h = ga_fma(wa, ga_hi(v0), ta0h);
+                ta1l = ga_fma(wa, ga_lo(v1), ta1l); ta1h = ga_fma(wa, ga_hi(v1), ta1h);
+                tb0l = ga_fma(wb, ga_lo(v0), tb0l); tb0h = ga_fma(wb, ga_hi(v0), tb0h);
+                tb1l = ga_fma(wb, ga_lo(v1), tb1l); tb1h = ga_fma(wb, ga_hi(v1), tb1h);
+            }
+            const int xj = pair ? xi + 1 : xi;
+            const float4 wa0 = *reinterpret_cast<const float4*>(&s_wx[xi][0]), wb0 = *reinterpret_cast<const float4*>(&s_wx[xi][4]);
+            const float4 wa1 = *reinterpret_cast<const float4*>(&s_wx[xj][0]), wb1 = *reinterpret_cast<const float4*>(&s_wx[xj][4]);
+            const float m1 = pair ? 1.0f : 0.0f;
+            const float w0[7] = {wa0.x, wa0.y, wa0.z, wa0.w, wb0.x, wb0.y, wb0.z};
+            const float w1[7] = {m1 * wa1.x, m1 * wa1.y, m1 * wa1.z, m1 * wa1.w, m1 * wb1.x, m1 * wb1.y, m1 * wb1.z};
+#pragma unroll
+            for (int pw = 0; pw < 7; ++pw) {
+                al[pw] = ga_fma(w0[pw], ta0l, al[pw]); ah[pw] = ga_fma(w0[pw], ta0h, ah[pw]);
+                al[pw] = ga_fma(w1[pw], ta1l, al[pw]); ah[pw] = ga_fma(w1[pw], ta1h, ah[pw]);
+                bl[pw] = ga_fma(w0[pw], tb0l, bl[pw]); bh[pw] = ga_fma(w0[pw], tb0h, bh[pw]);
+                bl[pw] = ga_fma(w1[pw], tb1l, bl[pw]); bh[pw] = ga_fma(w1[pw], tb1h, bh[pw]);
+            }
+        }
+#pragma unroll
+        for (int pw = 0; pw < 7; ++pw) {
+            s_patch[(ph0 * P + pw) * 64 + lane] = make_float4(al[pw].x, al[pw].y, ah[pw].x, ah[pw].y);
+            if (two) s_patch[((ph0 + 1) * P + pw) * 64 + lane] = make_float4(bl[pw].x, bl[pw].y, bh[pw].x, bh[pw].y);
+        }
+    }
+    __syncthreads();
+    // ---- phase B: tile type `wave` of the patch -> pair image, both halves of the channel concat
+    if (c >= C) return;
+    const size_t off = (size_t)r * C2 + c;
+    switch (wave) {
+        case 0: w7f::tile<0, 0, false>(s_patch, s_mask, V, MC, off, scale, lane); w7f::tile<0, 0, true>(s_patch, s_mask, V, MC, off + C, scale, lane); break;
+        case 1: w7f::tile<0, 1, false>(s_patch, s_mask, V, MC, off, scale, lane); w7f::tile<0, 1, true>(s_patch, s_mask, V, MC, off + C, scale, lane); break;
+        case 2: w7f::tile<1, 0, false>(s_patch, s_mask, V, MC, off, scale, lane); w7f::tile<1, 0, true>(s_patch, s_mask, V, MC, off + C, scale, lane); break;
+        default: w7f::tile<1, 1, false>(s_patch, s_mask, V, MC, off, scale, lane); w7f::tile<1, 1, true>(s_patch, s_mask, V, MC, off + C, scale, lane); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward, region form (default).
 //
 // What bounds the gather kernel is that every gradient vector is re-read by each of the ~3.7 pixel blocks its bin
@@ -1082,6 +1286,21 @@ extern "C" int cim_roi_align_fwd_ws(const float* feat, const float* rois, float*
     int rc = launch_fwd<false>(feat, rois, nullptr, out, B, C, H, W, K, P, spatial_scale, sampling_ratio, aligned,
                                cim::as_stream(stream), workspace);
     if (rc) return rc;
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_roi_align_wino7_pair_fwd(const float* feat, const float* rois, const float* masks, void* V, const float* scale,
+                                           int B, int C, int H, int W, int K, int Rs, int P, float spatial_scale,
+                                           int sampling_ratio, int aligned, float* workspace, void* stream) {
+    CIM_CHECK_ARG(feat && rois && masks && V && scale && workspace);
+    CIM_CHECK_ARG(B > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0 && K > 0 && Rs >= K && P == 7);
+    CIM_CHECK_ARG(H <= 64 && W <= RS_MAXD && (long long)H * W * C < (1ll << 30));
+    hipStream_t st = cim::as_stream(stream);
+    hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), sizeof(float) * roi_rec_words(P, H, W), st, rois, workspace, K, P, H, W,
+                       spatial_scale, sampling_ratio, aligned);
+    hipLaunchKernelGGL(roi_align_wino7_pair_kernel, dim3((unsigned)Rs, (unsigned)((C + 255) / 256)), dim3(256), 0, st, feat, masks,
+                       (float*)V, C, H, W, K, Rs, workspace, scale);
     CIM_CHECK_LAUNCH();
     return 0;
 }

@@ -16,6 +16,12 @@ from ..core.config import cfg
 from ..ops import conv3x3, gemm, linear, maskfuse_pair, pair, roi_align_maskcat
 
 
+# The box head as ONE autograd node whose first launch writes the convolution's Winograd input image straight from the feature map
+# (ops/maskfuse_pair.py: MaskFuseRoiPairFunction).  False: ROIAlign (+ mask multiply + concat) and the head as two nodes with the
+# `cat` tensor in between - same bits (tests/test_gpu_gemm_pair.py), kept for shapes the fused launch does not take.
+FUSE_ROI_WINO = True
+
+
 class MaskFuse(nn.Module):
     def __init__(self, dim_in, roi_xform_func, spatial_scale):
         super().__init__()
@@ -42,12 +48,22 @@ class MaskFuse(nn.Module):
         method = cfg.FAST_RCNN.ROI_XFORM_METHOD
         if method != "RoIAlign":
             raise NotImplementedError("MaskFuse: only ROI_XFORM_METHOD=RoIAlign is on the CIM path (got %s)" % method)
-        cat = roi_align_maskcat(x, rois, masks, cfg.FAST_RCNN.ROI_XFORM_RESOLUTION, self.spatial_scale,
-                                cfg.FAST_RCNN.ROI_XFORM_SAMPLING_RATIO, aligned=True)
-        # exact-fp32 MFMA contractions (cim_amd/csrc/gemm_f32.hip); the nn.Conv2d / nn.Linear
-        # modules only hold the parameters (reference names and layouts)
+        # the nn.Conv2d / nn.Linear modules only hold the parameters (reference names and layouts)
         conv = self.mask_branch[0]
         fc1, fc2 = self.seg_fc[0], self.seg_fc[2]
+        res, sr = cfg.FAST_RCNN.ROI_XFORM_RESOLUTION, cfg.FAST_RCNN.ROI_XFORM_SAMPLING_RATIO
+        import sys
+        if (FUSE_ROI_WINO and gemm.PAIR and not sys.modules["cim_amd.ops.roi_align"].EXACT
+                and maskfuse_pair.roi_supported(x, conv.weight, fc1.weight, fc2.weight, res)):
+            # ONE autograd node for the whole box head: ROIAlign + mask multiply + concat + the convolution's Winograd input
+            # transform in one launch (the conv input `cat` is never stored), then conv -> flatten -> fc1 -> fc2 on pair images.
+            # ROIAlign averages feature pixels and the masks are {0, 1}: max |cat| <= max |x| max(1, max |mask|)
+            xd = x.detach()
+            if not (xd.is_contiguous() or xd.is_contiguous(memory_format=torch.channels_last)):
+                xd = xd.contiguous()
+            fa = (pair.amax_of(xd).view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
+            return maskfuse_pair.maskfuse_roi_head(x, rois, masks.detach(), conv, fc1, fc2, fa, self.spatial_scale, sr)
+        cat = roi_align_maskcat(x, rois, masks, res, self.spatial_scale, sr, aligned=True)
         if gemm.PAIR and maskfuse_pair.supported(cat, conv.weight, fc1.weight, fc2.weight):
             # f16x2p engine: conv -> flatten -> fc1 -> fc2 on pair images (one scale per matrix).  ROIAlign averages feature
             # pixels and the masks are {0, 1}: max |cat| <= max |x| max(1, max |mask|) - a 6 MB pass instead of one over cat

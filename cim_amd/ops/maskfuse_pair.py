@@ -143,41 +143,103 @@ def _i32(dev):
     return torch.zeros(1, dtype=torch.int32, device=dev)
 
 
+def _head_forward(ctx, V, r, cin, p, wc, bc, w1, b1, w2, b2):
+    """conv (Winograd-domain product of V' with the filter image) -> flatten -> fc1 -> fc2 from the input image V'; saves what the
+    backward needs on ctx."""
+    cout, h1, h2 = wc.shape[0], w1.shape[0], w2.shape[0]
+    dev, rp = V.buf.device, pair.pad32(r)
+    st = _lib.stream_ptr()
+    Up, W1p, W2p = weight_image(wc, conv=True), weight_image(w1), weight_image(w2)
+    M = pair.gemm(V, Up, r, cout, cin, False, True)
+    y = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
+    am = torch.zeros(2, dtype=torch.int32, device=dev)
+    _lib.call("cim_wino7_output_amax", M.data_ptr(), _lib.ptr(bc), y.data_ptr(), r, cout, 1, am[0:1].data_ptr(), st)
+    del M
+    # flatten -> X' ; fc1 ; fc2
+    Xp = pair.Pair(torch.empty((1, rp, cout * p * p), dtype=torch.int32, device=dev), r, cout * p * p, 1,
+                   pair.scales_from(am[0:1], 1))
+    _lib.call("cim_flatten_chw_pair", y.data_ptr(), Xp.buf.data_ptr(), Xp.scale.data_ptr(), r, rp, p * p, cout, st)
+    Y1 = pair.gemm(Xp, W1p, r, h1, cout * p * p, False, True, bias=b1, relu=True, c_amax=am[1:2])
+    Y1p = pair.split(Y1, r, h1, h1, scale=pair.scales_from(am[1:2], 1))
+    Y2 = pair.gemm(Y1p, W2p, r, h2, h1, False, True, bias=b2, relu=True)
+    ctx.save_for_backward(y, Y1, Y2, V.buf, V.scale, Up.buf, Up.scale, W1p.buf, W1p.scale, W2p.buf, W2p.scale,
+                          Xp.buf, Xp.scale, Y1p.buf, Y1p.scale)
+    ctx.dims = (r, cin, cout, h1, h2, p)
+    ctx.has_bias = (bc is not None, b1 is not None, b2 is not None)
+    ctx.weights = (wc, w1, w2)           # the Parameter objects: big gradients may be published early (see backward)
+    return Y2
+
+
+def _input_scales(feat_amax, dev):
+    sV = torch.empty(NPOS, dtype=torch.float32, device=dev)
+    _lib.call("cim_wino7_pair_scales", feat_amax.data_ptr(), 0, sV.data_ptr(), _lib.stream_ptr())
+    return sV
+
+
 class MaskFusePairFunction(Function):
+    """(cat, weights) -> seg_x: the head on a materialised `cat` = [box_x, box_x * mask] tensor (ops.roi_align_maskcat)."""
+    arg_ofs = 0
+
     @staticmethod
     def forward(ctx, cat, wc, bc, w1, b1, w2, b2, feat_amax):
         cat = cat.contiguous(memory_format=torch.channels_last)
         r, cin, p, _ = cat.shape
-        cout, h1, h2 = wc.shape[0], w1.shape[0], w2.shape[0]
         dev, rp = cat.device, pair.pad32(r)
-        st = _lib.stream_ptr()
-        Up, W1p, W2p = weight_image(wc, conv=True), weight_image(w1), weight_image(w2)
-        # conv: V' -> M -> y (+bias, ReLU, max |y|)
-        sV = torch.empty(NPOS, dtype=torch.float32, device=dev)
-        _lib.call("cim_wino7_pair_scales", feat_amax.data_ptr(), 0, sV.data_ptr(), st)
+        sV = _input_scales(feat_amax, dev)
         V = pair.Pair(torch.empty((NPOS, rp, cin), dtype=torch.int32, device=dev), r, cin, NPOS, sV)
-        _lib.call("cim_wino7_input_pair", cat.data_ptr(), V.buf.data_ptr(), sV.data_ptr(), r, rp, cin, st)
-        M = pair.gemm(V, Up, r, cout, cin, False, True)
-        y = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
-        am = torch.zeros(2, dtype=torch.int32, device=dev)
-        _lib.call("cim_wino7_output_amax", M.data_ptr(), _lib.ptr(bc), y.data_ptr(), r, cout, 1, am[0:1].data_ptr(), st)
-        del M
-        # flatten -> X' ; fc1 ; fc2
-        Xp = pair.Pair(torch.empty((1, rp, cout * p * p), dtype=torch.int32, device=dev), r, cout * p * p, 1,
-                       pair.scales_from(am[0:1], 1))
-        _lib.call("cim_flatten_chw_pair", y.data_ptr(), Xp.buf.data_ptr(), Xp.scale.data_ptr(), r, rp, p * p, cout, st)
-        Y1 = pair.gemm(Xp, W1p, r, h1, cout * p * p, False, True, bias=b1, relu=True, c_amax=am[1:2])
-        Y1p = pair.split(Y1, r, h1, h1, scale=pair.scales_from(am[1:2], 1))
-        Y2 = pair.gemm(Y1p, W2p, r, h2, h1, False, True, bias=b2, relu=True)
-        ctx.save_for_backward(y, Y1, Y2, V.buf, V.scale, Up.buf, Up.scale, W1p.buf, W1p.scale, W2p.buf, W2p.scale,
-                              Xp.buf, Xp.scale, Y1p.buf, Y1p.scale)
-        ctx.dims = (r, cin, cout, h1, h2, p)
-        ctx.has_bias = (bc is not None, b1 is not None, b2 is not None)
-        ctx.weights = (wc, w1, w2)           # the Parameter objects: big gradients may be published early (see backward)
-        return Y2
+        _lib.call("cim_wino7_input_pair", cat.data_ptr(), V.buf.data_ptr(), sV.data_ptr(), r, rp, cin, _lib.stream_ptr())
+        return _head_forward(ctx, V, r, cin, p, wc, bc, w1, b1, w2, b2)
 
     @staticmethod
     def backward(ctx, dY2):
+        return _head_backward(ctx, dY2, 0) + (None,)
+
+
+class MaskFuseRoiPairFunction(Function):
+    """(feature map, rois, masks, weights) -> seg_x: ROIAlign, mask multiply, channel concat AND the Winograd input transform of the
+    convolution in ONE launch (csrc/roi_align.hip: roi_align_wino7_pair_kernel) - `cat` is never stored; the backward ends with the
+    ROIAlign backward on the head's input gradient.  /root/reference/lib/modeling/resnet50.py:120-138 as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, masks, wc, bc, w1, b1, w2, b2, feat_amax, spatial_scale, sampling_ratio):
+        from . import roi_align as RA
+        RA._check(feat, rois)
+        feat = RA._nhwc(feat)
+        rois = rois.to(torch.float32).contiguous()
+        masks = masks.to(torch.float32).contiguous()
+        B, C, H, W = feat.shape
+        K, P = rois.size(0), 7
+        if tuple(masks.shape) != (K, P, P):
+            raise ValueError("maskfuse: masks must be [K,7,7]")
+        dev, rp = feat.device, pair.pad32(K)
+        sV = _input_scales(feat_amax, dev)
+        V = pair.Pair(torch.empty((NPOS, rp, 2 * C), dtype=torch.int32, device=dev), K, 2 * C, NPOS, sV)
+        tables = RA._workspace(K, P, H, W, dev)
+        _lib.call("cim_roi_align_wino7_pair_fwd", feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), V.buf.data_ptr(), sV.data_ptr(),
+                  B, C, H, W, K, rp, P, float(spatial_scale), int(sampling_ratio), 1, tables.data_ptr(), _lib.stream_ptr())
+        ctx.roi = (rois, masks, tables, (B, C, H, W, K, P, float(spatial_scale), int(sampling_ratio), 1))
+        return _head_forward(ctx, V, K, 2 * C, P, wc, bc, w1, b1, w2, b2)
+
+    @staticmethod
+    def backward(ctx, dY2):
+        from . import roi_align as RA
+        dcat, dwc, dbc, dw1, db1, dw2, db2 = _head_backward(ctx, dY2, 2)
+        dfeat = None
+        if dcat is not None:
+            rois, masks, tables, (B, C, H, W, K, P, scale, sr, aligned) = ctx.roi
+            gcat = dcat.permute(0, 2, 3, 1)                  # the head's [K,7,7,2C] buffer (channels-last)
+            assert gcat.is_contiguous()
+            dfeat = RA._empty_nhwc(B, C, H, W, gcat)
+            _lib.call("cim_roi_align_maskcat_bwd_ws", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), dfeat.data_ptr(),
+                      B, C, H, W, K, P, scale, sr, aligned, tables.data_ptr(), 1,
+                      _lib.ptr(RA._scratch(K, B, C, H, W, gcat.device)), _lib.stream_ptr())
+            G.run_postponed(gcat.device)         # this node's late weight gradients start behind the ROIAlign backward
+        return dfeat, None, None, dwc, dbc, dw1, db1, dw2, db2, None, None, None
+
+
+def _head_backward(ctx, dY2, ofs):
+    """-> (d input, dwc, dbc, dw1, db1, dw2, db2); `ofs`: position of wc among the Function's inputs minus 1."""
+    if True:
         (y, Y1, Y2, Vb, Vs, Ub, Us, W1b, W1s, W2b, W2s, Xb, Xs, Y1b, Y1s) = ctx.saved_tensors
         r, cin, cout, h1, h2, p = ctx.dims
         dev, rp = y.device, pair.pad32(r)
@@ -185,7 +247,7 @@ class MaskFusePairFunction(Function):
         Up = pair.Pair(Ub, cout, cin, NPOS, Us)
         W1p, W2p = pair.Pair(W1b, h1, cout * p * p, 1, W1s), pair.Pair(W2b, h2, h1, 1, W2s)
         Xp, Y1p = pair.Pair(Xb, r, cout * p * p, 1, Xs), pair.Pair(Y1b, r, h1, 1, Y1s)
-        need_x, need_wc, need_w1, need_w2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[3], ctx.needs_input_grad[5]
+        need_x, need_wc, need_w1, need_w2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1 + ofs], ctx.needs_input_grad[3 + ofs], ctx.needs_input_grad[5 + ofs]
         cur, side = torch.cuda.current_stream(dev), G._side_stream(dev)
         overlap = G.OVERLAP and not torch.cuda.is_current_stream_capturing()
 
@@ -212,12 +274,12 @@ class MaskFusePairFunction(Function):
 
         published = []
         publisher = G.publisher_for(ctx.weights[1])      # several ranks: this model's nn.DataParallel wrapper takes the big gradients early
-        if publisher is not None and chain.restricted_pass(ctx, (1, 3, 5)):
+        if publisher is not None and chain.restricted_pass(ctx, (1 + ofs, 3 + ofs, 5 + ofs)):
             publisher = None                             # (torch.autograd.grad towards the weights: through autograd)
         late = []               # (slot, weight, closure) of the weight gradients launched at the end (DW_WGS > 0)
         # (a pass that does not accumulate into the weights - torch.autograd.grad towards them - returns the gradients through autograd)
         run_late = (overlap and DEFER_DW and G.DEFER_DW and DW_WGS > 0
-                    and not chain.restricted_pass(ctx, (1, 3, 5)))
+                    and not chain.restricted_pass(ctx, (1 + ofs, 3 + ofs, 5 + ofs)))
 
         def side_grad(slot, w, fn):
             if run_late:
@@ -231,22 +293,22 @@ class MaskFusePairFunction(Function):
         # ---- fc2
         # (the ReLU mask is applied by the split; one launch gives max |dz| and the bias gradient's partial sums)
         dY2 = dY2.contiguous()
-        db2 = pair.masked_stats(dY2, Y2, am[0:1], ctx.has_bias[2] and ctx.needs_input_grad[6])
+        db2 = pair.masked_stats(dY2, Y2, am[0:1], ctx.has_bias[2] and ctx.needs_input_grad[6 + ofs])
         dY2p = pair.split(dY2, r, h2, h2, scale=pair.scales_from(am[0:1], 1), relu_y=Y2)
         if need_w2:
             dw2 = side_grad(2, w2_p, lambda limit=0: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False, limit=limit))
         dY1 = pair.gemm(dY2p, W2p, r, h1, h2, False, False)
         # ---- fc1
-        db1 = pair.masked_stats(dY1, Y1, am[1:2], ctx.has_bias[1] and ctx.needs_input_grad[4])
+        db1 = pair.masked_stats(dY1, Y1, am[1:2], ctx.has_bias[1] and ctx.needs_input_grad[4 + ofs])
         dY1p = pair.split(dY1, r, h1, h1, scale=pair.scales_from(am[1:2], 1), relu_y=Y1)
         if need_w1:
             dw1 = side_grad(1, w1_p, lambda limit=0: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False, limit=limit))
-        if need_x or need_wc or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
+        if need_x or need_wc or (ctx.has_bias[0] and ctx.needs_input_grad[2 + ofs]):
             dX = pair.gemm(dY1p, W1p, r, cout * p * p, h1, False, False, c_amax=am[2:3], balance=True)
             # ---- flatten backward + ReLU mask of the conv; conv gradients
             st = _lib.stream_ptr()
             dy = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
-            want_dbc = ctx.has_bias[0] and ctx.needs_input_grad[2]
+            want_dbc = ctx.has_bias[0] and ctx.needs_input_grad[2 + ofs]
             bpart = torch.empty((r, cout), dtype=torch.float32, device=dev) if want_dbc else None
             _lib.call("cim_flatten_chw_bwd_bias", dX.data_ptr(), y.data_ptr(), dy.data_ptr(), _lib.ptr(bpart), r, p * p, cout, st)
             del dX
@@ -331,8 +393,22 @@ class MaskFusePairFunction(Function):
                 for t in (dw2, dw1, dwc):
                     if t is not None:
                         t.record_stream(cur)
-        return dcat, dwc, dbc, dw1, db1, dw2, db2, None
+        return dcat, dwc, dbc, dw1, db1, dw2, db2
 
 
 def maskfuse_head(cat, conv, fc1, fc2, feat_amax):
     return MaskFusePairFunction.apply(cat, conv.weight, conv.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, feat_amax)
+
+
+def roi_supported(x, conv_w, fc1_w, fc2_w, resolution):
+    """Shapes the fused ROIAlign -> Winograd-image launch takes (else: roi_align_maskcat + maskfuse_head)."""
+    c, h, w = x.shape[1], x.shape[2], x.shape[3]
+    cout = conv_w.shape[0]
+    return (x.is_cuda and x.dtype == torch.float32 and resolution == 7 and c % 32 == 0 and h <= 64 and w <= 64 and h * w * c < (1 << 30)
+            and cout % 64 == 0 and conv_w.shape[1] == 2 * c and fc1_w.shape[1] == cout * 49 and fc1_w.shape[0] % 32 == 0
+            and fc2_w.shape[1] == fc1_w.shape[0] and fc2_w.shape[0] % 32 == 0 and G.CONV_ALGO == "winograd7")
+
+
+def maskfuse_roi_head(x, rois, masks, conv, fc1, fc2, feat_amax, spatial_scale, sampling_ratio):
+    return MaskFuseRoiPairFunction.apply(x, rois, masks, conv.weight, conv.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias,
+                                         feat_amax, spatial_scale, sampling_ratio)

@@ -88,6 +88,18 @@ int cim_roi_align_maskcat_fwd(const float* feat, const float* rois, const float*
                               int B, int C, int H, int W, int K, int P,
                               float spatial_scale, int sampling_ratio, int aligned, void* stream);
 
+/* ROIAlign + mask multiply + channel concat + the Winograd INPUT TRANSFORM of MaskFuse.mask_branch's 3 x 3 convolution in one
+ * launch (+ the table launch): lib/modeling/resnet50.py:121-135 up to the convolution's contraction.  Writes the pair image
+ *   V [121][Rs][2C]  (mixed 4 + 3 tiling of the 7 x 7 map, cim_wino7_input_pair's layout; rows K .. Rs-1 zero; `scale` [121] from
+ *   cim_wino7_pair_scales(kind 0))
+ * that cim_gemm_pair_batched contracts with the filter image - `cat` is never stored (the two calls cim_roi_align_maskcat_fwd_ws
+ * + cim_wino7_input_pair wrote and re-read its 4 * K * 49 * 2C bytes).  Bit-identical to those two calls.  P == 7, C % 8 == 0,
+ * H, W <= 64; workspace: cim_roi_align_bwd_workspace(K,P,H,W) bytes, left holding the tables for cim_roi_align_maskcat_bwd_ws
+ * (tables_ready = 1). */
+int cim_roi_align_wino7_pair_fwd(const float* feat, const float* rois, const float* masks, void* V, const float* scale,
+                                 int B, int C, int H, int W, int K, int Rs, int P, float spatial_scale, int sampling_ratio,
+                                 int aligned, float* workspace, void* stream);
+
 int cim_roi_align_maskcat_bwd(const float* grad_cat, const float* rois, const float* masks, float* grad_in,
                               int B, int C, int H, int W, int K, int P,
                               float spatial_scale, int sampling_ratio, int aligned, float* workspace, void* stream);

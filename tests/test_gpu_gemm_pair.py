@@ -399,3 +399,65 @@ def test_maskfuse_pair_function_vs_per_layer_path(dev, r):
     assert float((out - ref).abs().max() / ref.abs().max()) < 2e-5
     for a, b, name in zip(gout, gref, ["cat", "wc", "bc", "w1", "b1", "w2", "b2"]):
         assert float((a - b).norm() / b.norm()) < 2e-5, name
+
+
+@pytest.mark.parametrize("C,H,W,K", [(256, 33, 43, 70), (64, 20, 25, 33), (512, 45, 60, 40)])
+def test_roi_align_wino7_pair_image_is_bit_identical_to_the_two_kernel_path(dev, C, H, W, K):
+    """cim_roi_align_wino7_pair_fwd (round 5: ROIAlign + mask multiply + concat + the Winograd 4 + 3 input transform in one launch,
+    lib/modeling/resnet50.py:121-135) writes the very pair image cim_roi_align_maskcat_fwd_ws + cim_wino7_input_pair write -
+    every byte, pad rows included - and, as one autograd node with the head, gives the same outputs and gradients as the two
+    nodes with the `cat` tensor in between (task 3)."""
+    from cim_amd import _lib
+    from cim_amd.ops import maskfuse_pair, pair, roi_align_maskcat
+    from cim_amd.ops import roi_align as _  # noqa: F401
+    import sys
+    RA = sys.modules["cim_amd.ops.roi_align"]
+    rng = np.random.RandomState(C + K)
+    feat = torch.from_numpy(rng.randn(2, C, H, W).astype(np.float32)).to(dev).contiguous(memory_format=torch.channels_last)
+    x1 = rng.uniform(-20, W * 16 * 0.8, K); y1 = rng.uniform(-20, H * 16 * 0.8, K)
+    rois = np.stack([rng.randint(0, 2, K), x1, y1, x1 + rng.uniform(1, W * 16, K), y1 + rng.uniform(1, H * 16, K)], 1).astype(np.float32)
+    rois[0, 1:] = (0, 0, W * 16, H * 16)
+    rois[1, 1:] = (40, 40, 40.5, 40.25)
+    rois[2, 1:] = (W * 16 + 500, 10, W * 16 + 900, 200)
+    rois_d = torch.from_numpy(rois).to(dev)
+    masks = torch.from_numpy((rng.rand(K, 7, 7) > 0.4).astype(np.float32)).to(dev)
+    st = _lib.stream_ptr()
+    fa = (pair.amax_of(feat).view(torch.float32) * 1.0).view(torch.int32)
+    sV = maskfuse_pair._input_scales(fa, dev)
+    rp = pair.pad32(K)
+    # two kernels
+    cat = roi_align_maskcat(feat, rois_d, masks, 7, 1 / 16.0, 0, True).contiguous(memory_format=torch.channels_last)
+    V0 = torch.full((121, rp, 2 * C), 0x7fff7fff, dtype=torch.int32, device=dev)
+    _lib.call("cim_wino7_input_pair", cat.data_ptr(), V0.data_ptr(), sV.data_ptr(), K, rp, 2 * C, st)
+    # one kernel
+    V1 = torch.full((121, rp, 2 * C), 0x7fff7fff, dtype=torch.int32, device=dev)
+    ws = RA._workspace(K, 7, H, W, dev)
+    _lib.call("cim_roi_align_wino7_pair_fwd", feat.data_ptr(), rois_d.data_ptr(), masks.data_ptr(), V1.data_ptr(), sV.data_ptr(),
+              2, C, H, W, K, rp, 7, 1 / 16.0, 0, 1, ws.data_ptr(), st)
+    assert torch.equal(V0, V1)
+    if C % 32:
+        return
+    # the whole box head: one node against two
+    torch.manual_seed(C)
+    conv = torch.nn.Conv2d(2 * C, 64, 3, padding=1).to(dev)
+    fc1, fc2 = torch.nn.Linear(64 * 49, 128).to(dev), torch.nn.Linear(128, 96).to(dev)
+    params = [conv.weight, conv.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias]
+    dy = torch.randn(K, 96, device=dev)
+    assert maskfuse_pair.roi_supported(feat, conv.weight, fc1.weight, fc2.weight, 7)
+
+    def run(fused):
+        x = feat.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+        for t in params:
+            t.grad = None
+        if fused:
+            out = maskfuse_pair.maskfuse_roi_head(x, rois_d, masks, conv, fc1, fc2, fa, 1 / 16.0, 0)
+        else:
+            out = maskfuse_pair.maskfuse_head(roi_align_maskcat(x, rois_d, masks, 7, 1 / 16.0, 0, True), conv, fc1, fc2, fa)
+        out.backward(dy)
+        from cim_amd.ops import gemm
+        gemm.join_side()
+        torch.cuda.synchronize()
+        return [out.detach()] + [x.grad] + [t.grad for t in params]
+
+    for a, b, name in zip(run(True), run(False), ["seg_x", "dfeat", "wc", "bc", "w1", "b1", "w2", "b2"]):
+        assert torch.equal(a, b), name
