@@ -402,10 +402,11 @@ def instrument(_lib, timer):
 
     def call(name, *args):
         if name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_fwd_ws", "cim_roi_align_maskcat_bwd",
-                    "cim_roi_align_maskcat_bwd_ws"):
+                    "cim_roi_align_maskcat_bwd_ws", "cim_roi_align_wino7_pair_fwd"):
             if "bwd" not in name:
                 state["conv"] = state["bg"] = 0
-            with timer.span("cim_roi_align_maskcat_bwd" if "bwd" in name else "cim_roi_align_maskcat_fwd"):
+            with timer.span("cim_roi_align_maskcat_bwd" if "bwd" in name else
+                            "cim_roi_align_wino7_pair_fwd" if "wino7" in name else "cim_roi_align_maskcat_fwd"):
                 return orig_call(name, *args)
         if name == "cim_conv3x3_f32":       # per image: 1st launch = forward, 2nd = data gradient
             state["conv"] += 1
@@ -519,6 +520,26 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
         n = infos[j]["n"]
         return 4.0 * (Cf * Hf * Wf + 5 * n + 49 * n) + 4.0 * n * 2 * Cf * 49
 
+    def ra_wino_bytes(j):          # the fused forward's own traffic: the map in, the Winograd input pair image out (no `cat`)
+        Hf, Wf = feat[j]
+        n = infos[j]["n"]
+        return 4.0 * (Cf * Hf * Wf + 5 * n + 49 * n) + 4.0 * 121 * ((n + 31) // 32 * 32) * 2 * Cf
+
+    ls = timer.launches("cim_roi_align_wino7_pair_fwd")
+    if ls:
+        tot_b = float(np.sum([ra_wino_bytes(j) for _, j in ls]))
+        tot_8d = float(np.sum([ra_bytes(j) for _, j in ls]))
+        tot_ms = float(np.sum([m for m, _ in ls]))
+        ach = tot_b / (tot_ms * 1e-3) / 1e9
+        hbm.append(dict(kernel="cim_roi_align_wino7_pair_fwd (ROIAlign + mask multiply + concat + Winograd 4+3 input transform: the conv "
+                               "input `cat` is never stored; replaces cim_roi_align_maskcat_fwd_ws + cim_wino7_input_pair)",
+                        bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, ms=tot_ms / len(ls),
+                        launches=len(ls), algorithmic_bytes=tot_b / len(ls), traffic=None,
+                        algorithmic_bytes_note="feature map + rois + masks in, pair image [121][N padded to 32][2 Cf] x 4 B out",
+                        survey_8d=dict(algorithmic_bytes=tot_8d / len(ls), frac=tot_8d / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       note="SURVEY.md 8(d)'s formula prices an operator that writes `cat` (4 N 2Cf 49 bytes); this "
+                                            "launch writes the 2.47x larger Winograd image instead and the separate transform launch "
+                                            "(round 4: 0.288 ms for 401 MB in + 991 MB out) is gone")))
     for name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_bwd"):
         ls = timer.launches(name)
         if ls:
@@ -546,11 +567,14 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
         step_ms = float(np.sum([m for m, _ in ls[1::len(MINING_CALLS)]]))
         hbm.append(dict(kernel="mining + sampling + assignment (cim_asy_prep: flags + transposed containment map, on the side stream under "
                                "the backbone forward; cim_mining_step: 2 launches on the step's stream; no host round trip)",
-                        bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                        ms=tot_ms / n_img, ms_on_step_stream=step_ms / n_img, ms_prep_side_stream=(tot_ms - step_ms) / n_img,
+                        bound="hbm", achieved=tot_b / (step_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=tot_b / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        ms=step_ms / n_img, ms_prep_side_stream=(tot_ms - step_ms) / n_img, ms_both_calls=tot_ms / n_img,
                         algorithmic_bytes=tot_b / n_img, traffic=None, kernel_launches_per_image=4,
-                        note="latency-bound: 2 dependent launches over a few MB per image on the step's stream (SURVEY.md 8d); "
-                             "`ms` sums both calls (the prep overlaps the backbone: it costs kernel time, not step time)"))
+                        note="latency-bound: 2 dependent launches over a few MB per image on the step's stream (SURVEY.md 8d).  `ms` = "
+                             "cim_mining_step on the step's stream (what the step waits for); the input-only prep (2 launches: flags + "
+                             "transposed map) runs on the side stream under the backbone forward - its HIP-event time there "
+                             "(ms_prep_side_stream, mostly launch latency of an idle stream) costs no step time; ms_both_calls sums them"))
     metric = "images/sec training step (ResNet-50 VOC, ~1k proposals/img) at 1/2/4/8 GPU" \
         if args.config == "resnet50_voc" else "images/sec training step (%s)" % args.config      # BASELINE.json
     ns = [i["n"] for i in infos]

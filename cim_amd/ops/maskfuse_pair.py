@@ -170,6 +170,11 @@ def _head_forward(ctx, V, r, cin, p, wc, bc, w1, b1, w2, b2):
     return Y2
 
 
+def _roi_align_module():
+    import importlib
+    return importlib.import_module(__package__ + ".roi_align")      # (the package attribute `roi_align` is the function)
+
+
 def _input_scales(feat_amax, dev):
     sV = torch.empty(NPOS, dtype=torch.float32, device=dev)
     _lib.call("cim_wino7_pair_scales", feat_amax.data_ptr(), 0, sV.data_ptr(), _lib.stream_ptr())
@@ -202,7 +207,7 @@ class MaskFuseRoiPairFunction(Function):
 
     @staticmethod
     def forward(ctx, feat, rois, masks, wc, bc, w1, b1, w2, b2, feat_amax, spatial_scale, sampling_ratio):
-        from . import roi_align as RA
+        RA = _roi_align_module()
         RA._check(feat, rois)
         feat = RA._nhwc(feat)
         rois = rois.to(torch.float32).contiguous()
@@ -222,7 +227,7 @@ class MaskFuseRoiPairFunction(Function):
 
     @staticmethod
     def backward(ctx, dY2):
-        from . import roi_align as RA
+        RA = _roi_align_module()
         dcat, dwc, dbc, dw1, db1, dw2, db2 = _head_backward(ctx, dY2, 2)
         dfeat = None
         if dcat is not None:
