@@ -57,9 +57,9 @@ SIGNATURES = {
     "cim_gemm_f16x2_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
                                _P, _P, _P],
     "cim_gemm_pair_splits": [c_int, c_int, c_int],
-    "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P],
+    "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P],
     "cim_gemm_pair_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
-                              _P, _P, c_int, _P],
+                              _P, _P, c_int, c_int, _P],
     "cim_pair_scales": [_P, c_int, _P, _P, c_int, _P],
     "cim_pair_split": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, _P, _P, _P],
     "cim_pair_amax": [_P, c_longlong, _P, _P],
@@ -89,7 +89,7 @@ SIGNATURES = {
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }
 
-ABI_VERSION = 11         # cim_abi_version() of include/cim_hip.h this binding was written against
+ABI_VERSION = 12         # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 

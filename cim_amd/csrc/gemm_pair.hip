@@ -230,7 +230,12 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return v;
 }
 
-template <int AL, int BL>
+// ONEP: the h * h product ALONE (one MFMA product per multiply-add instead of three): operands carry 11 significant bits - fp16
+// inputs with fp32 accumulation, the arithmetic class of TF32 (10 bits), which is what the reference's conv / matmul run in on
+// its own hardware (torch 1.10 defaults, tools/train.py:153-154 sets only cudnn.deterministic / benchmark).  An explicit
+// argument of the entry points (products = 1); the step's default is the fp32-class three-product evaluation.  The l halves of
+// the images are still moved (they are interleaved with the h halves in memory) and ignored.
+template <int AL, int BL, bool ONEP>
 __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -340,10 +345,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
 #define PAIR_READ(AH, AL_, BH, BL_, BUF, KS)                                                   \
     _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                           \
         BH[j] = fb.read((BUF) + OPER, j, KS, 0);                                               \
-        BL_[j] = fb.read((BUF) + OPER, j, KS, 1);                                              \
+        if constexpr (!ONEP) BL_[j] = fb.read((BUF) + OPER, j, KS, 1);                         \
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < MIV; ++i) {                                          \
-        AL_[i] = fa.read((BUF), i, KS, 1);                                                     \
+        if constexpr (!ONEP) AL_[i] = fa.read((BUF), i, KS, 1);                                \
         AH[i] = fa.read((BUF), i, KS, 0);                                                      \
     }
 #define PAIR_MMA(AF, BF)                                                                       \
@@ -383,8 +388,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
         PAIR_READ_L(ah1, al1, bh1, bl1, cur, 1)
         PAIR_FENCE();
         PAIR_PRIO(1);
-        PAIR_MMA(al0, bh0);
-        PAIR_MMA(ah0, bl0);
+        if constexpr (!ONEP) {
+            PAIR_MMA(al0, bh0);
+            PAIR_MMA(ah0, bl0);
+        }
         PAIR_MMA(ah0, bh0);
         PAIR_PRIO(0);
         PAIR_FENCE();
@@ -398,8 +405,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
         }
         PAIR_FENCE();
         PAIR_PRIO(1);
-        PAIR_MMA(al1, bh1);
-        PAIR_MMA(ah1, bl1);
+        if constexpr (!ONEP) {
+            PAIR_MMA(al1, bh1);
+            PAIR_MMA(ah1, bl1);
+        }
         PAIR_MMA(ah1, bh1);
         PAIR_PRIO(0);
         PAIR_FENCE();
@@ -605,9 +614,9 @@ __global__ __launch_bounds__(256) void pair_amax_kernel(const float* __restrict_
 }
 
 template <int AL, int BL>
-int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st, int max_workgroups) {
+int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st, int max_workgroups, int products) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
-    auto kern = gemm_pair_kernel<AL, BL>;
+    auto kern = products == 1 ? gemm_pair_kernel<AL, BL, true> : gemm_pair_kernel<AL, BL, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     const int slabs = g.K / BK;
@@ -646,11 +655,12 @@ int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st, int ma
     return 0;
 }
 
-int dispatch_pair(const PairArgs& g, int a_mcontig, int b_kcontig, int splits, float* workspace, hipStream_t st, int max_workgroups) {
-    if (!a_mcontig && !b_kcontig) return launch_pair<L_KC, L_MC>(g, splits, workspace, st, max_workgroups);
-    if (!a_mcontig && b_kcontig) return launch_pair<L_KC, L_KC>(g, splits, workspace, st, max_workgroups);
-    if (a_mcontig && !b_kcontig) return launch_pair<L_MC, L_MC>(g, splits, workspace, st, max_workgroups);
-    return launch_pair<L_MC, L_KC>(g, splits, workspace, st, max_workgroups);
+int dispatch_pair(const PairArgs& g, int a_mcontig, int b_kcontig, int splits, float* workspace, hipStream_t st, int max_workgroups,
+                  int products) {
+    if (!a_mcontig && !b_kcontig) return launch_pair<L_KC, L_MC>(g, splits, workspace, st, max_workgroups, products);
+    if (!a_mcontig && b_kcontig) return launch_pair<L_KC, L_KC>(g, splits, workspace, st, max_workgroups, products);
+    if (a_mcontig && !b_kcontig) return launch_pair<L_MC, L_MC>(g, splits, workspace, st, max_workgroups, products);
+    return launch_pair<L_MC, L_KC>(g, splits, workspace, st, max_workgroups, products);
 }
 
 }  // namespace
@@ -688,12 +698,13 @@ extern "C" int cim_gemm_pair_splits(int M, int N, int K) {
 
 extern "C" int cim_gemm_pair(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda,
                              int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
-                             const float* a_scale, const float* b_scale, uint32_t* c_amax, int max_workgroups, void* stream) {
-    CIM_CHECK_ARG(A && B && C && a_scale && b_scale && max_workgroups >= 0);
+                             const float* a_scale, const float* b_scale, uint32_t* c_amax, int max_workgroups, int products,
+                             void* stream) {
+    CIM_CHECK_ARG(A && B && C && a_scale && b_scale && max_workgroups >= 0 && (products == 3 || products == 1));
     CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
     CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
     PairArgs g{(const char*)A, (const char*)B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 1, 0, 0, 0, a_scale, b_scale, c_amax, 0, 0, 0, 0};
-    int rc = dispatch_pair(g, a_mcontig, b_kcontig, splits, workspace, cim::as_stream(stream), max_workgroups);
+    int rc = dispatch_pair(g, a_mcontig, b_kcontig, splits, workspace, cim::as_stream(stream), max_workgroups, products);
     if (rc) { cim::set_error("cim_gemm_pair: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;
@@ -701,12 +712,13 @@ extern "C" int cim_gemm_pair(const void* A, const void* B, float* C, const float
 
 extern "C" int cim_gemm_pair_batched(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb,
                                      int ldc, int a_mcontig, int b_kcontig, int batch, long long a_bs, long long b_bs,
-                                     long long c_bs, const float* a_scale, const float* b_scale, int max_workgroups, void* stream) {
-    CIM_CHECK_ARG(A && B && C && a_scale && b_scale && batch > 0 && batch <= 65535 && max_workgroups >= 0);
+                                     long long c_bs, const float* a_scale, const float* b_scale, int max_workgroups, int products,
+                                     void* stream) {
+    CIM_CHECK_ARG(A && B && C && a_scale && b_scale && batch > 0 && batch <= 65535 && max_workgroups >= 0 && (products == 3 || products == 1));
     CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
     CIM_CHECK_ARG(a_bs % 8 == 0 && b_bs % 8 == 0 && c_bs % 4 == 0);
     PairArgs g{(const char*)A, (const char*)B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, batch, a_bs, b_bs, c_bs, a_scale, b_scale, nullptr, 0, 0, 0, 0};
-    int rc = dispatch_pair(g, a_mcontig, b_kcontig, 1, nullptr, cim::as_stream(stream), max_workgroups);
+    int rc = dispatch_pair(g, a_mcontig, b_kcontig, 1, nullptr, cim::as_stream(stream), max_workgroups, products);
     if (rc) { cim::set_error("cim_gemm_pair_batched: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;

@@ -418,14 +418,18 @@ int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int 
  * of at most that many workgroups.  A workgroup of this engine owns its CU (128 KB of LDS), so a capped product never holds
  * more CUs than that and leaves the rest of the chip to concurrent streams - used for the MaskFuse weight-gradient products
  * that run beside the backbone's backward (cim_amd/ops/maskfuse_pair.py).  Same tiles, same arithmetic, same bits. */
+/* products: 3 = the fp32-class evaluation h*l + l*h + h*h (the training step's arithmetic); 1 = the h*h product alone - operands
+ * with 11 significant bits, fp32 accumulation: the arithmetic class of TF32, which the reference's own convolutions / matmuls
+ * run in on its hardware (torch 1.10 defaults; tools/train.py:153-154 touches cudnn.deterministic / benchmark only).  Reported
+ * beside the headline as bench.py's extra.tf32_class, never used by default. */
 int cim_gemm_pair_splits(int M, int N, int K);
 int cim_gemm_pair(const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
                   int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
-                  const float* a_scale, const float* b_scale, uint32_t* c_amax, int max_workgroups, void* stream);
+                  const float* a_scale, const float* b_scale, uint32_t* c_amax, int max_workgroups, int products, void* stream);
 int cim_gemm_pair_batched(const void* A, const void* B, float* C, int M, int N, int K,
                           int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
                           int batch, long long a_bs, long long b_bs, long long c_bs,
-                          const float* a_scale, const float* b_scale, int max_workgroups, void* stream);
+                          const float* a_scale, const float* b_scale, int max_workgroups, int products, void* stream);
 int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float* scale, int n, void* stream);
 int cim_pair_split(const float* X, void* P, int rows, int rows_pad, int cols, int ld, int ldp, int batch,
                    long long x_bs, long long p_bs, const float* scale, const float* relu_y, void* stream);
