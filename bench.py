@@ -535,10 +535,10 @@ def instrument(_lib, timer):
 
     def call(name, *args):
         if name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_fwd_ws", "cim_roi_align_maskcat_bwd",
-                    "cim_roi_align_maskcat_bwd_ws", "cim_roi_align_wino7_pair_fwd"):
+                    "cim_roi_align_maskcat_bwd_ws", "cim_roi_align_wino7_pair_fwd", "cim_roi_align_bwd_ws"):
             if "bwd" not in name:
                 state["conv"] = state["bg"] = 0
-            with timer.span("cim_roi_align_maskcat_bwd" if "bwd" in name else
+            with timer.span("cim_roi_align_bwd" if name == "cim_roi_align_bwd_ws" else "cim_roi_align_maskcat_bwd" if "bwd" in name else
                             "cim_roi_align_wino7_pair_fwd" if "wino7" in name else "cim_roi_align_maskcat_fwd"):
                 return orig_call(name, *args)
         if name == "cim_conv3x3_f32":       # per image: 1st launch = forward, 2nd = data gradient
@@ -673,6 +673,23 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
                                        note="SURVEY.md 8(d)'s formula prices an operator that writes `cat` (4 N 2Cf 49 bytes); this "
                                             "launch writes the 2.47x larger Winograd image instead and the separate transform launch "
                                             "(round 4: 0.288 ms for 401 MB in + 991 MB out) is gone")))
+    ls = timer.launches("cim_roi_align_bwd")
+    if ls:      # the plain ROIAlign backward on dbox = dcat_lo + mask * dcat_hi (the fold happens in the convolution's last backward stage)
+        def rb_bytes(j):
+            Hf, Wf = feat[j]
+            n = infos[j]["n"]
+            return 4.0 * (Cf * Hf * Wf + 5 * n) + 4.0 * n * Cf * 49
+        tot_b = float(np.sum([rb_bytes(j) for _, j in ls]))
+        tot_8d = float(np.sum([ra_bytes(j) for _, j in ls]))
+        tot_ms = float(np.sum([m for m, _ in ls]))
+        ach = tot_b / (tot_ms * 1e-3) / 1e9
+        hbm.append(dict(kernel="cim_roi_align_bwd_ws (ROIAlign backward on dbox [N,7,7,Cf]: the mask multiply + concat backward is folded into "
+                               "cim_wino7_dx_maskfold, which writes dbox instead of dcat [N,7,7,2Cf])",
+                        bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, ms=tot_ms / len(ls),
+                        launches=len(ls), algorithmic_bytes=tot_b / len(ls), traffic=None,
+                        survey_8d=dict(algorithmic_bytes=tot_8d / len(ls), frac=tot_8d / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       note="SURVEY.md 8(d)'s backward reads dcat (4 N 2Cf 49 bytes); this launch reads half of that - the "
+                                            "same gradient, combined upstream - so its own algorithmic bytes are 4 (Cf Hf Wf + 5N + 49 N Cf)")))
     for name in ("cim_roi_align_maskcat_fwd", "cim_roi_align_maskcat_bwd"):
         ls = timer.launches(name)
         if ls:

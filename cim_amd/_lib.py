@@ -77,6 +77,7 @@ SIGNATURES = {
     "cim_wino_scale_bounds": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_dy_adjoint_transform": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_dx_adjoint_output": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "cim_wino7_dx_maskfold": [_P, _P, _P, c_int, c_int, _P],
     "cim_wino_filter_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_output_transform": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "cim_wino_dy_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],

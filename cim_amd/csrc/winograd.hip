@@ -982,6 +982,50 @@ __global__ __launch_bounds__(256) void wino7_dx_kernel(const float* __restrict__
     }
 }
 
+// The same stage with MaskFuse's prologue folded back in (round 5): Md holds the gradient of cat = [box, box * mask] (2 Cb channels);
+// what the ROIAlign backward needs is  dbox = dcat[:, :Cb] + mask * dcat[:, Cb:]  (lib/modeling/resnet50.py:131-134 differentiated).
+// A lane transforms channel c of the MASKED half first (all four tile types into the 49 accumulators), scales by the ROI's 7 x 7
+// mask, then accumulates the plain half on top: dbox [R,7,7,Cb] is written instead of dcat [R,7,7,2Cb] - half the bytes out of
+// this launch and half the bytes into the ROIAlign backward (which re-reads them 1.5x).  grid = (R, chunks); block = 256.
+__global__ __launch_bounds__(256) void wino7_dx_maskfold_kernel(const float* __restrict__ M, const float* __restrict__ masks,
+                                                                float* __restrict__ dbox, int R, int Cb) {
+    constexpr int VW = CIM_W7_VDX;
+    typedef typename w7_vec<VW>::T VT;
+    const int r = blockIdx.x;
+    const size_t C2 = 2 * (size_t)Cb, MC = (size_t)R * C2;
+    const float* __restrict__ mk = masks + (size_t)r * 49;
+    for (int c = (blockIdx.y * 256 + threadIdx.x) * VW; c < Cb; c += gridDim.y * 256 * VW) {
+        VT acc[7][7];
+#pragma unroll
+        for (int y = 0; y < 7; ++y)
+#pragma unroll
+            for (int x = 0; x < 7; ++x) vzero(acc[y][x]);
+        const size_t rc = (size_t)r * C2 + c;
+        w7_dx_tile<0, 0, VT>(M, MC, rc + Cb, acc);
+        w7_dx_tile<0, 1, VT>(M, MC, rc + Cb, acc);
+        w7_dx_tile<1, 0, VT>(M, MC, rc + Cb, acc);
+        w7_dx_tile<1, 1, VT>(M, MC, rc + Cb, acc);
+#pragma unroll
+        for (int y = 0; y < 7; ++y)
+#pragma unroll
+            for (int x = 0; x < 7; ++x) {
+                const float m = mk[y * 7 + x];
+                VT z;
+                vzero(z);
+                vfma(z, m, acc[y][x]);
+                acc[y][x] = z;
+            }
+        w7_dx_tile<0, 0, VT>(M, MC, rc, acc);
+        w7_dx_tile<0, 1, VT>(M, MC, rc, acc);
+        w7_dx_tile<1, 0, VT>(M, MC, rc, acc);
+        w7_dx_tile<1, 1, VT>(M, MC, rc, acc);
+#pragma unroll
+        for (int y = 0; y < 7; ++y)
+#pragma unroll
+            for (int x = 0; x < 7; ++x) w7_store(dbox + (((size_t)r * 7 + y) * 7 + x) * Cb + c, acc[y][x]);
+    }
+}
+
 template <int KA, int KB, typename VT>
 __device__ __forceinline__ void w7_wgrad_tile(const float* __restrict__ dU, size_t KN, size_t idx, VT (&acc)[3][3]) {
     constexpr int NA = W7::NP[KA], NB = W7::NP[KB], Q0 = W7::QOFF[KA * 2 + KB];
@@ -1258,6 +1302,15 @@ extern "C" int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int 
     int chunks = (C + 256 * CIM_W7_VDX - 1) / (256 * CIM_W7_VDX);
     if (chunks > 4) chunks = 4;
     hipLaunchKernelGGL(wino7_dx_kernel, dim3(R, chunks), dim3(256), 0, cim::as_stream(stream), M, dx, R, C);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino7_dx_maskfold(const float* M, const float* masks, float* dbox, int R, int Cb, void* stream) {
+    CIM_CHECK_ARG(M && masks && dbox && R > 0 && Cb > 0 && Cb % 4 == 0);
+    int chunks = (Cb + 256 * CIM_W7_VDX - 1) / (256 * CIM_W7_VDX);
+    if (chunks > 4) chunks = 4;
+    hipLaunchKernelGGL(wino7_dx_maskfold_kernel, dim3(R, chunks), dim3(256), 0, cim::as_stream(stream), M, masks, dbox, R, Cb);
     CIM_CHECK_LAUNCH();
     return 0;
 }

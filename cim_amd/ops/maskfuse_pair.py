@@ -228,22 +228,24 @@ class MaskFuseRoiPairFunction(Function):
     @staticmethod
     def backward(ctx, dY2):
         RA = _roi_align_module()
-        dcat, dwc, dbc, dw1, db1, dw2, db2 = _head_backward(ctx, dY2, 2)
+        rois, masks, tables, (B, C, H, W, K, P, scale, sr, aligned) = ctx.roi
+        dbox, dwc, dbc, dw1, db1, dw2, db2 = _head_backward(ctx, dY2, 2, fold_masks=masks)
         dfeat = None
-        if dcat is not None:
-            rois, masks, tables, (B, C, H, W, K, P, scale, sr, aligned) = ctx.roi
-            gcat = dcat.permute(0, 2, 3, 1)                  # the head's [K,7,7,2C] buffer (channels-last)
+        if dbox is not None:
+            gcat = dbox.permute(0, 2, 3, 1)                  # [K,7,7,C] (channels-last): dcat's halves already combined with the masks
             assert gcat.is_contiguous()
             dfeat = RA._empty_nhwc(B, C, H, W, gcat)
-            _lib.call("cim_roi_align_maskcat_bwd_ws", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), dfeat.data_ptr(),
+            _lib.call("cim_roi_align_bwd_ws", gcat.data_ptr(), rois.data_ptr(), dfeat.data_ptr(),
                       B, C, H, W, K, P, scale, sr, aligned, tables.data_ptr(), 1,
                       _lib.ptr(RA._scratch(K, B, C, H, W, gcat.device)), _lib.stream_ptr())
             G.run_postponed(gcat.device)         # this node's late weight gradients start behind the ROIAlign backward
         return dfeat, None, None, dwc, dbc, dw1, db1, dw2, db2, None, None, None
 
 
-def _head_backward(ctx, dY2, ofs):
-    """-> (d input, dwc, dbc, dw1, db1, dw2, db2); `ofs`: position of wc among the Function's inputs minus 1."""
+def _head_backward(ctx, dY2, ofs, fold_masks=None):
+    """-> (d input, dwc, dbc, dw1, db1, dw2, db2); `ofs`: position of wc among the Function's inputs minus 1.
+    fold_masks ([r,7,7] masks): the input gradient is returned as  dbox = dcat[:, :C] + mask * dcat[:, C:]  ([r,C,7,7], half the
+    channels: the backward of the mask multiply + concat folded into the convolution's last backward stage)."""
     if True:
         (y, Y1, Y2, Vb, Vs, Ub, Us, W1b, W1s, W2b, W2s, Xb, Xs, Y1b, Y1s) = ctx.saved_tensors
         r, cin, cout, h1, h2, p = ctx.dims
@@ -337,8 +339,12 @@ def _head_backward(ctx, dY2, ofs):
                 E = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sE)
                 _lib.call("cim_wino7_dy_pair", dy.data_ptr(), E.buf.data_ptr(), sE.data_ptr(), r, rp, cout, 1, st)
                 M2 = pair.gemm(E, Up, r, cin, cout, False, False, balance=True)
-                dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
-                _lib.call("cim_wino_dx_adjoint_output", M2.data_ptr(), dxp.data_ptr(), r, p, cin, 7, st)
+                if fold_masks is None:
+                    dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
+                    _lib.call("cim_wino_dx_adjoint_output", M2.data_ptr(), dxp.data_ptr(), r, p, cin, 7, st)
+                else:
+                    dxp = torch.empty((r, p, p, cin // 2), dtype=torch.float32, device=dev)
+                    _lib.call("cim_wino7_dx_maskfold", M2.data_ptr(), fold_masks.data_ptr(), dxp.data_ptr(), r, cin // 2, st)
                 dcat = dxp.permute(0, 3, 1, 2)
             dy_conv = dy
             if overlap:

@@ -488,6 +488,10 @@ int cim_wino_scale_bounds(const uint32_t* amax_in, uint32_t* bounds, int n, int 
  * 121 GEMMs Md[pos] = E[pos] . U[pos]^T (U [121][Cin][Cout] read K-contiguously), dx = overlap-add of B Md B^T
  * (cim_wino_dx_adjoint_output).  E [121][R][Cout], Md [121][R][Cin], dx [R,7,7,Cin]. */
 int cim_wino_dy_adjoint_transform(const float* dy, float* E, uint32_t* row_amax, int R, int P, int C, int tile, void* stream);
+/* cim_wino_dx_adjoint_output (tile = 7) with the backward of MaskFuse's prologue folded in: Md [121][R][2 Cb] is the Winograd-domain
+ * gradient of cat = [box, box * mask] (lib/modeling/resnet50.py:131-134); written is  dbox [R,7,7,Cb] = dcat[..., :Cb] + mask *
+ * dcat[..., Cb:]  (masks [R,7,7]) - the input of the plain ROIAlign backward (cim_roi_align_bwd_ws), half the bytes of dcat. */
+int cim_wino7_dx_maskfold(const float* M, const float* masks, float* dbox, int R, int Cb, void* stream);
 int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int P, int C, int tile, void* stream);
 int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, int tile, void* stream);
 int cim_wino_output_transform(const float* M, const float* bias, float* y, int R, int P, int C, int relu, int tile, void* stream);

