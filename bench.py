@@ -103,7 +103,7 @@ def run(args):
     # right before the next step's draw instead of at the end of backward (cim_amd/modeling/heads.py: LAZY_SETTLE) - the same
     # stream position, but the host's wait for the step's mining launches no longer caps its lead over the GPU at half a step
     # (with an 8 ms host hiccup every fourth step: 14.19 vs 14.46 ms per step; none on a quiet box: 13.95 vs 13.95).
-    heads.LAZY_SETTLE = os.environ.get("CIM_LAZY_SETTLE", "1") == "1"
+    heads.LAZY_SETTLE = True
     if os.environ.get("CIM_BENCH_WATCHDOG"):        # debugging aid: dump all thread stacks if a phase stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["CIM_BENCH_WATCHDOG"]), repeat=True)
@@ -541,16 +541,9 @@ def instrument(_lib, timer):
             with timer.span("cim_roi_align_bwd" if name == "cim_roi_align_bwd_ws" else "cim_roi_align_maskcat_bwd" if "bwd" in name else
                             "cim_roi_align_wino7_pair_fwd" if "wino7" in name else "cim_roi_align_maskcat_fwd"):
                 return orig_call(name, *args)
-        if name == "cim_conv3x3_f32":       # per image: 1st launch = forward, 2nd = data gradient
-            state["conv"] += 1
-            with timer.span("maskfuse_conv_fwd" if state["conv"] == 1 else "maskfuse_conv_dgrad"):
-                return orig_call(name, *args)
-        if name in ("cim_gemm_f32_batched", "cim_gemm_f16x2_batched", "cim_gemm_pair_batched"):  # Winograd-domain GEMMs, per image: forward, data grad, weight grad
+        if name == "cim_gemm_pair_batched":  # Winograd-domain GEMMs, per image: forward, data grad, weight grad
             state["bg"] += 1
             with timer.span(("wino_gemm_fwd", "wino_gemm_dgrad", "wino_gemm_wgrad")[min(state["bg"], 3) - 1]):
-                return orig_call(name, *args)
-        if name == "cim_conv3x3_wgrad_f32":
-            with timer.span("maskfuse_conv_wgrad"):
                 return orig_call(name, *args)
         if name in MINING_CALLS:            # a-4 ... a-6: every mining / sampling / assignment launch of the three CIM layers
             with timer.span("mining"):
@@ -578,7 +571,7 @@ def pmc_traffic(config):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs of this
     script, tools/pmc_traffic.py).  Only a profile of THIS workload counts: files are named per config and record the
     image mix they were taken on; anything else -> {} and `traffic: null`."""
-    for rnd in ("r4", "r3"):                       # the newest committed profile of this configuration
+    for rnd in ("r5", "r4"):                       # the newest committed profile of this configuration
         path = os.path.join(REPO, "profiles", rnd, "pmc_traffic_%s.json" % config)
         if os.path.exists(path):
             with open(path) as f:
@@ -601,44 +594,26 @@ def make_optimizer(model, torch):
 
 
 def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, np):
-    engine = "f16x2p" if getattr(gemm_mod, "PAIR", False) else gemm_mod.ENGINE
-    products = {"f16x2p": 3.0, "f16x2": 3.0, "bf16x3": 6.0, "fp32": 1.0}[engine]
-    kern = {"f16x2p": "gemm_pair_kernel", "f16x2": "gemm_f16x2_kernel", "bf16x3": "gemm_bf16x3_kernel", "fp32": "gemm_f32_kernel"}[engine]
-    # dominant kernel: the MFMA GEMM of the MaskFuse 3x3 conv forward (a-2).  Algorithmic flops of ONE launch on image j:
-    #   Winograd 4+3 mixed tiling (CIM_CONV_ALGO=winograd7, default): 121 batched GEMMs [N_j x 2Cf] x [2Cf x Cf]
-    #   Winograd F(4x4,3x3) / F(2x2,3x3): 36 x [4N x 2Cf] / 16 x [16N x 2Cf];  direct: 2 * 49N * 18Cf * Cf   
+    engine, conv_algo, products = "f16x2p", "winograd7", 3.0     # the product's ONE engine / algorithm (ops/maskfuse_pair.py)
+    # dominant kernel: the MFMA GEMM of the MaskFuse 3x3 conv forward (a-2).  Algorithmic flops of ONE launch on image j: the mixed
+    # 4 + 3 Winograd tiling's 121 batched GEMMs [N_j x 2Cf] x [2Cf x Cf]                                          
     wino = timer.launches("wino_gemm_fwd")
-    if wino:
-        ms = [m for m, _ in wino]
-        flops = []
-        for _, j in wino:
-            _, npos, rows = gemm_mod._wino_geometry(gemm_mod.CONV_ALGO, 7, infos[j]["n"])
-            flops.append(2.0 * npos * rows * (2 * Cf) * Cf)
-        what = {"winograd7": "Winograd 4+3 mixed tiling", "winograd4": "Winograd F(4x4,3x3)", "winograd": "Winograd F(2x2,3x3)"}
-        kname = "%s<%s> x%d (MaskFuse conv3x3 fwd, %s domain)" % (kern, "L_KC,L_KC" if engine == "f16x2p" else "A_KCONTIG,B_NCONTIG", npos,
-                                                                   what.get(gemm_mod.CONV_ALGO, gemm_mod.CONV_ALGO))
-    else:
-        direct = timer.launches("maskfuse_conv_fwd")
-        ms = [m for m, _ in direct]
-        flops = [2.0 * 49 * infos[j]["n"] * (2 * Cf * 9) * Cf for _, j in direct]
-        kname = "%s<A_CONV_K,B_NCONTIG> (MaskFuse conv3x3 fwd, implicit GEMM)" % kern
-    # split engines: every algorithmic fp32 multiply-add is executed as several half-precision MFMA products with fp32
-    # accumulation, so the kernel is priced against the bf16/f16 MFMA peak with achieved = products x algorithmic flops / time
-    # (f16x2: 3 products, bf16x3: 6; fp32: v_mfma_f32_32x32x2_f32 against its own peak).
+    ms = [m for m, _ in wino]
+    flops = [2.0 * 121 * infos[j]["n"] * (2 * Cf) * Cf for _, j in wino]
+    kname = "gemm_pair_kernel<L_KC,L_KC> x121 (MaskFuse conv3x3 fwd, Winograd 4+3 mixed tiling domain)"
+    # every algorithmic fp32 multiply-add is executed as three fp16 MFMA products with fp32 accumulation, so the kernel is priced
+    # against the f16 MFMA peak with achieved = 3 x algorithmic flops / time
     conv_ms = float(np.mean(ms))
     alg_tf = float(np.sum(flops)) / (float(np.sum(ms)) * 1e-3) / 1e12
-    roofline = dict(bound="mfma", kernel=kname, achieved=products * alg_tf,
-                    peak=FP32_MFMA_PEAK_TF if engine == "fp32" else BF16_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None,
+    roofline = dict(bound="mfma", kernel=kname, achieved=products * alg_tf, peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", traffic=None,
                     ms=conv_ms, launches=len(ms), algorithmic_flops_per_launch=float(np.mean(flops)),
-                    engine={"f16x2p": "f16x2p: 3 f16 MFMA products per fp32 multiply-add on operands pre-split by their producers (two fp16 terms, one power-of-two scale per matrix), LDS-DMA staging, fp32 accumulate",
-                            "f16x2": "f16x2: 3 f16 MFMA products per fp32 multiply-add (scaled two-term split), fp32 accumulate",
-                            "bf16x3": "bf16x3: 6 bf16 MFMA products per fp32 multiply-add, fp32 accumulate",
-                            "fp32": "fp32: v_mfma_f32_32x32x2_f32"}[engine],
+                    engine="f16x2p: 3 f16 MFMA products per fp32 multiply-add on operands pre-split by their producers (two fp16 terms, "
+                           "one power-of-two scale per matrix), LDS-DMA staging, fp32 accumulate",
                     algorithmic_tflops=alg_tf, fp32_mfma_peak=FP32_MFMA_PEAK_TF)
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
     pmc = pmc_traffic(args.config)
     mix_tag = "fixed" if args.fixed_image else "mix%d" % len(infos)
-    pmc_ok = pmc.get("_workload") == mix_tag and pmc.get("_conv_algo") == gemm_mod.CONV_ALGO and pmc.get("_engine") == engine
+    pmc_ok = pmc.get("_workload") == mix_tag and pmc.get("_conv_algo") == conv_algo and pmc.get("_engine") == engine
     # `traffic` is NOT measured by this run: it is the calibrated FETCH_SIZE + WRITE_SIZE of the same launch from the committed
     # rocprofv3 --pmc passes of this command (two separate profiler runs), replayed here when workload, algorithm and engine match
     if pmc_ok and wino and pmc.get("wino_gemm_fwd"):
@@ -734,17 +709,10 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
     return dict(metric=metric, value=images / elapsed, unit="images/s", n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
                 scaling="weak", vs_baseline=None, dtype="fp32", data="synthetic",
-                dtype_note={"f16x2p": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
-                                      "two-term fp16 operand split written by the operands' producers (3 MFMA products, dropped "
-                                      "term <= 2^-22, one power-of-two scale per matrix) - measured deviation of losses / "
-                                      "gradients from the reference in tests/test_gpu_tolerance.py (profiles/r4/parity_deviation.json)",
-                            "f16x2": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled "
-                                     "two-term fp16 operand split (3 MFMA products, dropped term <= 2^-22, rms 2^-25.6) - "
-                                     "measured error vs fp64 in the class of the f32-multiply engine (CIM_GEMM_ENGINE=fp32)",
-                            "bf16x3": "fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated as an exact "
-                                      "3 x bf16 operand split (6 MFMA products, dropped terms < 2^-23) - measured error vs fp64 "
-                                      "below the f32-multiply engine's (CIM_GEMM_ENGINE=fp32)",
-                            "fp32": "fp32 multiplies and accumulation"}[engine],
+                dtype_note="fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled two-term fp16 operand "
+                           "split written by the operands' producers (3 MFMA products, dropped term <= 2^-22, one power-of-two scale per "
+                           "matrix) - measured deviation of losses / gradients from the reference in tests/test_gpu_tolerance.py "
+                           "(profiles/r5/parity_deviation.json); the TF32-class single-product line: extra.tf32_class",
                 config=dict(workload=workload, parallelism="dp%d" % world, inputs="resident in HBM (extra.with_h2d_upload: "
                             "uploaded from pinned host memory inside every step)"),
                 roofline=roofline, roofline_hbm=hbm)

@@ -46,16 +46,6 @@ SIGNATURES = {
     "cim_bn_act_bwd_chunks": [c_int, c_int, c_int],
     "cim_bn_act_bwd": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_sgd_multi": [_P, _P, c_int, c_float, _P],
-    "cim_gemm_f32_splits": [c_int, c_int, c_int, c_int],
-    "cim_gemm_f32": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, c_int, _P],
-    "cim_conv3x3_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
-    "cim_conv3x3_wgrad_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
-    "cim_gemm_f32_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_int, _P],
-    "cim_gemm_f16x2_splits": [c_int, c_int, c_int],
-    "cim_amax_rowcol": [_P, c_int, c_int, c_int, c_int, c_longlong, _P, _P, _P],
-    "cim_gemm_f16x2": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P],
-    "cim_gemm_f16x2_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
-                               _P, _P, _P],
     "cim_gemm_pair_splits": [c_int, c_int, c_int],
     "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P],
     "cim_gemm_pair_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
@@ -71,16 +61,8 @@ SIGNATURES = {
     "cim_wino7_output_amax": [_P, _P, _P, c_int, c_int, c_int, _P, _P],
     "cim_flatten_chw_pair": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_flatten_chw_bwd_bias": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
-    "cim_wino_input_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
-    "cim_flatten_chw": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
-    "cim_wino_input_transform_amax": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
-    "cim_wino_scale_bounds": [_P, _P, c_int, c_int, c_int, c_int, _P],
-    "cim_wino_dy_adjoint_transform": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_dx_adjoint_output": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino7_dx_maskfold": [_P, _P, _P, c_int, c_int, _P],
-    "cim_wino_filter_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
-    "cim_wino_output_transform": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
-    "cim_wino_dy_transform": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_wino_wgrad_output": [_P, _P, c_int, c_int, c_int, _P],
     "cim_losses_fwd": [_P, _P],
     "cim_linear_bias_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
@@ -125,7 +107,7 @@ def load():
     return lib
 
 
-VALUE_RETURNING = {"cim_mining_sync_bytes", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_f32_splits", "cim_gemm_f16x2_splits", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch"}      # return a count, not a status
+VALUE_RETURNING = {"cim_mining_sync_bytes", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch"}      # return a count, not a status
 
 
 # split counts / workspace sizes of the body's layers: pure functions of their integer arguments (their tuning switches are read

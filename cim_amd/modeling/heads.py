@@ -480,7 +480,7 @@ class _RngLedger:
                 and re-draws exactly `used` doubles: the generator ends where the reference's would.
 
     settle() runs automatically at the end of the backward pass (FusedLossFunction.backward queues it as an
-    autograd-engine callback) and before the next draw(); `settle_rng()` does it on demand; CIM_MINING_SYNC=1
+    autograd-engine callback) and before the next draw(); `settle_rng()` does it on demand; MINING_SYNC = True
     settles inside the forward (one stall per step, the round-1 behaviour)."""
 
     def __init__(self):
@@ -518,7 +518,7 @@ class _RngLedger:
                 if used > 0:
                     np.random.random_sample(used)
             else:       # the caller re-seeded / used the generator in between: its state wins, nothing to rewind
-                if STRICT_RNG:
+                if _strict():
                     raise _lib.CimHipError("np.random was re-seeded or used between a training forward and the end of its "
                                            "backward pass: the run has left the reference's NumPy stream (CIM_STRICT=1; call "
                                            "cim_amd.modeling.heads.settle_rng() right after the forward)")
@@ -529,16 +529,22 @@ class _RngLedger:
 
 
 _rng = _RngLedger()
-MINING_SYNC = os.environ.get("CIM_MINING_SYNC", "0") == "1" or not engine.HAS_ENGINE_CALLBACK
-# Opt-in (CIM_LAZY_SETTLE=1 or heads.LAZY_SETTLE = True): do NOT settle at the end of the backward pass - the generator is settled
+
+
+def _strict():
+    from ..ops import fallback
+    return fallback.strict()
+
+
+MINING_SYNC = not engine.HAS_ENGINE_CALLBACK        # (True: settle inside the forward, one stall per step - the round-1 behaviour)
+# Opt-in (heads.LAZY_SETTLE = True): do NOT settle at the end of the backward pass - the generator is settled
 # right before the NEXT step's draw (always) or by settle_rng().  The settle waits for the step's mining launches to have run on
 # the GPU: at the end of backward that caps the host's lead over the GPU at about half a step; one step later the wait is never
 # felt.  Valid only when nothing in this process draws from np.random between a backward pass and the next forward without
 # calling settle_rng() first (the reference's epoch sampler does draw there, lib/roi_data/loader.py:94: a training loop calls
 # settle_rng() before it asks the sampler for a new epoch, or leaves this off).
-LAZY_SETTLE = os.environ.get("CIM_LAZY_SETTLE", "0") == "1"
-# CIM_STRICT=1 (the test suite sets it): leaving the reference's NumPy stream is an error, not a warning
-STRICT_RNG = os.environ.get("CIM_STRICT", "0") == "1"
+LAZY_SETTLE = False
+# (CIM_STRICT=1 - the test suite sets it - makes leaving the reference's NumPy stream an error, not a warning: ops/fallback.py)
 
 
 def settle_rng():

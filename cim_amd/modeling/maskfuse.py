@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from ..core.config import cfg
-from ..ops import conv3x3, gemm, linear, maskfuse_pair, pair, roi_align_maskcat
+from ..ops import maskfuse_pair, pair, roi_align_maskcat
 
 
 # The box head as ONE autograd node whose first launch writes the convolution's Winograd input image straight from the feature map
@@ -39,10 +39,8 @@ class MaskFuse(nn.Module):
 
     def prefetch(self):
         """Weight-only work of the forward, launched ahead on the side stream (called before the backbone forward)."""
-        if gemm.PAIR and cfg.FAST_RCNN.ROI_XFORM_RESOLUTION == 7 and gemm.CONV_ALGO == "winograd7":
+        if cfg.FAST_RCNN.ROI_XFORM_RESOLUTION == 7:
             maskfuse_pair.prefetch_weight_images(self.mask_branch[0].weight, self.seg_fc[0].weight, self.seg_fc[2].weight)
-        else:
-            gemm.prefetch_filter_transform(self.mask_branch[0].weight, cfg.FAST_RCNN.ROI_XFORM_RESOLUTION)
 
     def forward(self, x, rois, masks):
         method = cfg.FAST_RCNN.ROI_XFORM_METHOD
@@ -53,7 +51,7 @@ class MaskFuse(nn.Module):
         fc1, fc2 = self.seg_fc[0], self.seg_fc[2]
         res, sr = cfg.FAST_RCNN.ROI_XFORM_RESOLUTION, cfg.FAST_RCNN.ROI_XFORM_SAMPLING_RATIO
         import sys
-        if (FUSE_ROI_WINO and gemm.PAIR and not sys.modules["cim_amd.ops.roi_align"].EXACT
+        if (FUSE_ROI_WINO and not sys.modules["cim_amd.ops.roi_align"].EXACT
                 and maskfuse_pair.roi_supported(x, conv.weight, fc1.weight, fc2.weight, res)):
             # ONE autograd node for the whole box head: ROIAlign + mask multiply + concat + the convolution's Winograd input
             # transform in one launch (the conv input `cat` is never stored), then conv -> flatten -> fc1 -> fc2 on pair images.
@@ -64,23 +62,17 @@ class MaskFuse(nn.Module):
             fa = (pair.amax_of(xd).view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
             return maskfuse_pair.maskfuse_roi_head(x, rois, masks.detach(), conv, fc1, fc2, fa, self.spatial_scale, sr)
         cat = roi_align_maskcat(x, rois, masks, res, self.spatial_scale, sr, aligned=True)
-        if gemm.PAIR and maskfuse_pair.supported(cat, conv.weight, fc1.weight, fc2.weight):
-            # f16x2p engine: conv -> flatten -> fc1 -> fc2 on pair images (one scale per matrix).  ROIAlign averages feature
-            # pixels and the masks are {0, 1}: max |cat| <= max |x| max(1, max |mask|) - a 6 MB pass instead of one over cat
-            xd = x.detach()
-            if not (xd.is_contiguous() or xd.is_contiguous(memory_format=torch.channels_last)):
-                xd = xd.contiguous()
-            fa = (pair.amax_of(xd).view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
-            return maskfuse_pair.maskfuse_head(cat, conv, fc1, fc2, fa)
-        # ROIAlign averages feature pixels, so per channel max |box_x| <= max |x| over the map and
-        # max |box_x * mask| <= that times max |mask| ({0,1} masks: 1): a 6 MB pass instead of one over the
-        # 400 MB cat tensor for the conv's weight-gradient operand scales (f16x2 engine)
-        xc = None
-        if gemm.ENGINE == "f16x2" and gemm.CONV_ALGO in ("winograd4", "winograd7"):
-            xn = x.detach().contiguous(memory_format=torch.channels_last)
-            fa = gemm.amax(xn, xn.size(0) * xn.size(2) * xn.size(3), xn.size(1), xn.size(1), want_cols=True)[1]
-            fm = (fa.view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
-            xc = torch.cat([fa, fm])
-        # (c, h, w) flatten order of the reference's `.view(batch, -1)` on an NCHW tensor, fused into the conv op
-        y = conv3x3(cat, conv.weight, conv.bias, relu=True, x_col_amax=xc, flatten_chw=True)
-        return linear(linear(y, fc1.weight, fc1.bias, relu=True), fc2.weight, fc2.bias, relu=True)
+        if not maskfuse_pair.supported(cat, conv.weight, fc1.weight, fc2.weight):
+            # ONE engine, ONE algorithm: every configuration of the reference (512 / 1024 / 2048 feature channels, 7 x 7 ROI maps,
+            # 4096-wide fully connected layers) qualifies; anything else fails loudly instead of taking a second code path
+            raise NotImplementedError(
+                "MaskFuse: the MI355X contraction engine takes 7 x 7 ROI maps, dim_in a multiple of 16 (conv output channels a multiple "
+                "of 64) and fully connected widths that are multiples of 32 - got cat %s, conv %s, fc %s / %s"
+                % (tuple(cat.shape), tuple(conv.weight.shape), tuple(fc1.weight.shape), tuple(fc2.weight.shape)))
+        # conv -> flatten -> fc1 -> fc2 on pair images (one scale per matrix).  ROIAlign averages feature pixels and the masks are
+        # {0, 1}: max |cat| <= max |x| max(1, max |mask|) - a 6 MB pass instead of one over cat
+        xd = x.detach()
+        if not (xd.is_contiguous() or xd.is_contiguous(memory_format=torch.channels_last)):
+            xd = xd.contiguous()
+        fa = (pair.amax_of(xd).view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
+        return maskfuse_pair.maskfuse_head(cat, conv, fc1, fc2, fa)

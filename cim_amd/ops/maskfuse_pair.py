@@ -2,8 +2,8 @@
 ONE autograd Function whose intermediate operands are pair images written by their producers.
 
 Replaces the `mask_branch` / `seg_fc` part of MaskFuse.forward, /root/reference/lib/modeling/resnet50.py:104-110,131-137,
-and its autograd backward.  Same values as cim_amd.ops.gemm's per-layer Functions (which stay for the other engines /
-shapes); what changes is who splits the operands (cim_amd/csrc/gemm_pair.hip header):
+and its autograd backward - the ONE engine and ONE algorithm of the product (the per-layer Functions on the superseded engines are
+test infrastructure: experiments/engines.py).  Every operand is split by its producer (cim_amd/csrc/gemm_pair.hip header):
 
   forward   cat --wino7_input_pair--> V'   (scale per position from max |feature map|)
             w   --wino7_filter_pair--> U'  (side stream, under the backbone forward; scale from max |w|)
@@ -16,10 +16,8 @@ shapes); what changes is who splits the operands (cim_amd/csrc/gemm_pair.hip hea
             dU = V'^T . D' -> dW  |  Md = E' . U' -> dcat      (weight gradients on the side stream)
 Every image is written once and read by two products (contracted over its columns by one, over its rows by the other).
 """
-import os
 import torch
 from torch.autograd import Function
-_os_env = os.environ
 
 from .. import _lib
 from . import chain
@@ -27,7 +25,7 @@ from . import gemm as G
 from . import pair
 
 NPOS = 121
-# OPT-IN experiment (CIM_DEFER_MASKFUSE_DW=1, with CIM_HIGH_PRIO=1): the node's weight-gradient GEMMs (fc2, fc1, conv: ~2.5 ms of MFMA
+# Measured experiment (DEFER_DW with gemm.HIGH_PRIO, both module attributes): the node's weight-gradient GEMMs (fc2, fc1, conv: ~2.5 ms of MFMA
 # work at cfg2) are only needed by the optimizer, so they can be joined once, at the end of the backward pass (ops/gemm.py:
 # defer_side_join), and keep running on the normal-priority side stream while a high-priority main chain
 # (model_builder.Generalized_RCNN.forward) goes on to the ROIAlign and backbone backward.  Measured at cfg2 (same box, interleaved,
@@ -37,7 +35,7 @@ NPOS = 121
 # allocator, weights went NaN, and NaN operands draw less power and run the MFMAs at a higher clock.  The lifetimes are recorded now
 # (record_stream below) and tests/test_gpu_parity.py::test_stream_scheduling_does_not_change_a_training_run runs 40 optimizer steps
 # with the options on and off, bit-equal.)
-DEFER_DW = _os_env.get("CIM_DEFER_MASKFUSE_DW", "1") == "1"
+DEFER_DW = True
 # With the deferred join: the three weight-gradient products are LAUNCHED at the end of this node's backward (behind its
 # data-gradient chain, not beside it) in consecutive launches of DW_WGS workgroups (the `max_workgroups` argument of cim_gemm_pair*; a workgroup owns its
 # CU) - they then run beside the ROIAlign and backbone backward, whose small kernels get on the chip between two launches instead
@@ -46,7 +44,7 @@ DEFER_DW = _os_env.get("CIM_DEFER_MASKFUSE_DW", "1") == "1"
 # 14.19; late as whole products 14.44 / 14.62 / 14.31; late in launches of 96 / 128 / 192 / 224 (part of the chip left free):
 # 16.9 / 15.8 / 15.1 / 14.9 - the products are MFMA-bound, CUs withheld from them are simply lost.
 # 0: launched where their operands are ready, uncapped (beside the data-gradient products).
-DW_WGS = int(_os_env.get("CIM_MASKFUSE_DW_WGS", "256"))
+DW_WGS = 256
 # which schedule the backward passes of this process took (counts per pass; bench.py prints it in extra.comm, the 2-rank tests
 # assert on it): the single-process schedule (late launches of DW_WGS workgroups, postponed behind the ROIAlign backward) and the
 # multi-rank one (whole products, handed to nn.DataParallel as soon as they are enqueued) are different code paths
@@ -58,8 +56,7 @@ def supported(cat, wc, w1, w2):
     r, cin, p, q = cat.shape
     cout = wc.shape[0]
     return (cat.is_cuda and p == 7 and q == 7 and cin % 32 == 0 and cout % 64 == 0 and wc.shape[1] == cin
-            and w1.shape[1] == cout * 49 and w1.shape[0] % 32 == 0 and w2.shape[1] == w1.shape[0] and w2.shape[0] % 32 == 0
-            and G.CONV_ALGO == "winograd7")
+            and w1.shape[1] == cout * 49 and w1.shape[0] % 32 == 0 and w2.shape[1] == w1.shape[0] and w2.shape[0] % 32 == 0)
 
 
 def _weight_amax(w, rows, cols):
@@ -79,8 +76,7 @@ def _store(w, img, ev):
     _IMAGES[key] = (w._version, w.data_ptr(), img, ev, _weakref.ref(w, lambda _r, key=key: _IMAGES.pop(key, None)))
 
 
-import os as _os
-_STALE_FC = _os.environ.get("CIM_DEBUG_STALE_FC_IMAGES", "0") == "1"      # measurement aid: never refresh the fc weights' images
+_STALE_FC = False      # measurement aid (tools set it): never refresh the fc weights' images
 
 
 def _cached(w):
@@ -120,10 +116,13 @@ def weight_image(w, conv=False):
     return img
 
 
+PREFETCH = True        # the weights' pair images on the side stream, under the backbone forward
+
+
 def prefetch_weight_images(wc, w1, w2):
     """Build the three weights' pair images on the SIDE stream now (they depend on the weights only): called before the
     backbone forward, whose small latency-bound kernels leave most of the chip idle."""
-    if not (G.OVERLAP and G.PREFETCH_U and wc.is_cuda) or torch.cuda.is_current_stream_capturing():
+    if not (G.OVERLAP and PREFETCH and wc.is_cuda) or torch.cuda.is_current_stream_capturing():
         return
     todo = [(w, c) for w, c in ((wc, True), (w1, False), (w2, False)) if _cached(w) is None and w.is_contiguous()]
     if not todo:
@@ -417,7 +416,7 @@ def roi_supported(x, conv_w, fc1_w, fc2_w, resolution):
     cout = conv_w.shape[0]
     return (x.is_cuda and x.dtype == torch.float32 and resolution == 7 and c % 32 == 0 and h <= 64 and w <= 64 and h * w * c < (1 << 30)
             and cout % 64 == 0 and conv_w.shape[1] == 2 * c and fc1_w.shape[1] == cout * 49 and fc1_w.shape[0] % 32 == 0
-            and fc2_w.shape[1] == fc1_w.shape[0] and fc2_w.shape[0] % 32 == 0 and G.CONV_ALGO == "winograd7")
+            and fc2_w.shape[1] == fc1_w.shape[0] and fc2_w.shape[0] % 32 == 0)
 
 
 def maskfuse_roi_head(x, rois, masks, conv, fc1, fc2, feat_amax, spatial_scale, sampling_ratio):

@@ -20,8 +20,8 @@ def _engine():
     return getattr(getattr(torch.autograd, "Variable", None), "_execution_engine", None)
 
 
-HAS_ENGINE_CALLBACK = (os.environ.get("CIM_NO_ENGINE_CALLBACK", "0") != "1"
-                       and callable(getattr(_engine(), "queue_callback", None)))
+_FAST_PATHS = os.environ.get("CIM_NO_ENGINE_CALLBACK", "0") != "1"      # (=1: the fallbacks for a torch build without the private hooks)
+HAS_ENGINE_CALLBACK = _FAST_PATHS and callable(getattr(_engine(), "queue_callback", None))
 
 
 def queue_callback(fn):
@@ -35,7 +35,7 @@ def queue_callback(fn):
 def broadcast_coalesced(tensors, src=0, group=None, buffer_bytes=256 << 20):
     import torch.distributed as dist
     fn = getattr(dist, "_broadcast_coalesced", None)
-    if fn is not None and os.environ.get("CIM_NO_ENGINE_CALLBACK", "0") != "1":
+    if fn is not None and _FAST_PATHS:
         pg = group if group is not None else dist.group.WORLD
         by_dtype = {}
         for t in tensors:

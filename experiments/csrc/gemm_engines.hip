@@ -23,6 +23,7 @@
 //   B: N-contiguous rows ([K,N]) or K-contiguous rows ([N,K], nn.Linear weights)
 #include "common.h"
 #include "../../include/cim_hip.h"
+#include "../include/cim_exp.h"
 
 namespace {
 

@@ -1,27 +1,448 @@
-// Winograd-domain stages of the MaskFuse 3 x 3 convolution on R x 7 x 7 ROI maps in the MIXED 4 + 3 tiling, and the (c, h, w)
-// flatten in front of seg_fc.0 - the producers and consumers of the pair engine's operands (gemm_pair.hip).
+// Winograd F(2x2, 3x3) transforms for the MaskFuse 3x3 convolution on R x P x P ROI maps (P = 7).
 //
-// Replaces (together with cim_gemm_pair_batched) the evaluation of nn.Conv2d(2C, C, 3, padding=1) of
-// /root/reference/lib/modeling/resnet50.py:104 and its two gradients:
-//   forward        :  y  = A^T [ (G g G^T) . (B^T d B) ] A          per tile (Lavin & Gray), 121 multiplies per 49 outputs
-//   data gradient  :  dx = overlap-add of B [ (A dy A^T) . U^T ] B^T   (the ADJOINT of the forward: reuses the forward's U)
-//   weight gradient:  dW = AW [ (B^T d B)^T . (GD dy GD^T) ] AW^T
-// Layouts: activations channels-last [R,7,7,C]; transformed operands position-major, [121][rows][C], as pair images (written by
-// the transforms here, or by csrc/roi_align.hip's fused forward); GEMM results fp32.  HBM-bound kernels: lanes along C, 16 bytes
-// per lane.  The superseded F(2x2,3x3) / F(4x4,3x3) algorithms and the fp32 / bf16x3 / f16x2 engines they fed are test
-// infrastructure (experiments/csrc/winograd_all.hip, round 5).
+// Replaces (together with the batched fp32 MFMA GEMM of gemm_f32.hip) the direct evaluation of
+// nn.Conv2d(2C, C, 3, padding=1) of /root/reference/lib/modeling/resnet50.py:104 and its two
+// gradients: 16 multiplies per 2x2 output tile instead of 36, i.e. 1.07 instead of 1.85 TFLOP per
+// contraction at cfg2 (7x7 outputs are covered by 4x4 tiles of 2x2; 49/64 of the tile grid is used).
+// All arithmetic is fp32; the transform matrices contain only 0, +-1, +-1/2, so the result differs
+// from the direct fp32 sum by ~2e-6 relative (measured; the direct fp32 sum itself is at 6e-7).
+//
+//   forward / data gradient:  Y = A^T [ (G g G^T) . (B^T d B) ] A          (Lavin & Gray F(2x2,3x3))
+//   weight gradient        :  dW = A3^T [ (B^T d B) . (G2 dy G2^T) ] A3    (F(3x3,2x2), SAME B^T:
+//                              the transformed input V is computed once in forward and reused)
+//
+// Layouts (all fp32): activations NHWC [R,P,P,C]; transformed operands are position-major so that
+// each of the 16 positions is one plain GEMM:  V [16][R*T*T][C],  U [16][Cin][Cout],
+// M [16][R*T*T][Cout]  (T = ceil(P/2) tiles per side).  Memory-bound kernels: one lane = one
+// (tile, 4 channels), every access a 16 B/lane contiguous run along C.
 #include "common.h"
 #include "../../include/cim_hip.h"
-#include "wino43_mats.h"
+#include "../include/cim_exp.h"
 
 namespace {
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+// V[pos][m][c] = (B^T d B)[pos],  d = 4x4 input patch of tile m (zero outside the map).
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int R, int P,
+                                                         int T, int C) {
+    const int m = blockIdx.x;                  // tile index: (r, ty, tx)
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
+        float4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = 2 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ix = 2 * tx - 1 + j;
+                d[i][j] = ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P)
+                              ? *reinterpret_cast<const float4*>(x + (((size_t)r * P + iy) * P + ix) * C + c)
+                              : f4(0.f);
+            }
+        }
+        float4 u[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // rows: B^T d
+            u[0][j] = d[0][j] - d[2][j];
+            u[1][j] = d[1][j] + d[2][j];
+            u[2][j] = d[2][j] - d[1][j];
+            u[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {          // columns: (.) B
+            const float4 v0 = u[i][0] - u[i][2], v1 = u[i][1] + u[i][2], v2 = u[i][2] - u[i][1], v3 = u[i][1] - u[i][3];
+            float* dst = V + (size_t)(i * 4) * MC + (size_t)m * C + c;
+            *reinterpret_cast<float4*>(dst) = v0;
+            *reinterpret_cast<float4*>(dst + MC) = v1;
+            *reinterpret_cast<float4*>(dst + 2 * MC) = v2;
+            *reinterpret_cast<float4*>(dst + 3 * MC) = v3;
+        }
+    }
+}
+
+// U[pos][k][n] = (G g G^T)[pos].  mode 0 (forward): k = ci, n = co, g = W[co][ci][:, :]
+//                                 mode 1 (data gradient): k = co, n = ci, g = W[co][ci] rotated by 180 degrees
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
+                                                          int Cin, int mode) {
+    const int Kd = mode ? Cout : Cin, Nd = mode ? Cin : Cout;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)Kd * Nd) return;
+    const int k = (int)(idx / Nd), n = (int)(idx % Nd);
+    const int co = mode ? k : n, ci = mode ? n : k;
+    const float* g = W + ((size_t)co * Cin + ci) * 9;
+    float w[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) w[a][b] = mode ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = w[0][b];
+        t[1][b] = 0.5f * (w[0][b] + w[1][b] + w[2][b]);
+        t[2][b] = 0.5f * (w[0][b] - w[1][b] + w[2][b]);
+        t[3][b] = w[2][b];
+    }
+    const size_t KN = (size_t)Kd * Nd;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float* dst = U + (size_t)(a * 4) * KN + idx;
+        dst[0] = t[a][0];
+        dst[KN] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        dst[2 * KN] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        dst[3 * KN] = t[a][2];
+    }
+}
+
+// y[r, 2ty+a, 2tx+b, c] = (A^T M A)[a][b] + bias[c], optional ReLU; rows / columns >= P are dropped.
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int R, int P, int T, int C, int relu) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
+        float4 q[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[i][j] = *reinterpret_cast<const float4*>(M + (size_t)(i * 4 + j) * MC + (size_t)m * C + c);
+        float4 s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = q[0][j] + q[1][j] + q[2][j];
+            s[1][j] = q[1][j] - q[2][j] - q[3][j];
+        }
+        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c) : f4(0.f);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = 2 * ty + a;
+            if (oy >= P) continue;
+            float4 o[2];
+            o[0] = s[a][0] + s[a][1] + s[a][2] + bv;
+            o[1] = s[a][1] - s[a][2] - s[a][3] + bv;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ox = 2 * tx + b;
+                if (ox >= P) continue;
+                float4 v = o[b];
+                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                *reinterpret_cast<float4*>(y + (((size_t)r * P + oy) * P + ox) * C + c) = v;
+            }
+        }
+    }
+}
+
+// D[pos][m][c] = (G2 dy G2^T)[pos], dy = the tile's 2x2 output-gradient patch (zero past the map),
+// G2 = [[1,0],[1/2,1/2],[1/2,-1/2],[0,-1]]   (F(3x3,2x2) with the forward's B^T).
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int P,
+                                                      int T, int C) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
+        float4 d[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int oy = 2 * ty + a, ox = 2 * tx + b;
+                d[a][b] = (oy < P && ox < P) ? *reinterpret_cast<const float4*>(dy + (((size_t)r * P + oy) * P + ox) * C + c) : f4(0.f);
+            }
+        float4 u[4][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            u[0][b] = d[0][b];
+            u[1][b] = 0.5f * (d[0][b] + d[1][b]);
+            u[2][b] = 0.5f * (d[0][b] - d[1][b]);
+            u[3][b] = f4(0.f) - d[1][b];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* dst = D + (size_t)(i * 4) * MC + (size_t)m * C + c;
+            *reinterpret_cast<float4*>(dst) = u[i][0];
+            *reinterpret_cast<float4*>(dst + MC) = 0.5f * (u[i][0] + u[i][1]);
+            *reinterpret_cast<float4*>(dst + 2 * MC) = 0.5f * (u[i][0] - u[i][1]);
+            *reinterpret_cast<float4*>(dst + 3 * MC) = f4(0.f) - u[i][1];
+        }
+    }
+}
+
+// dW[co][ci][3][3] = A3^T dU A3,  dU[pos][ci][co],  A3^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]].
+__global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dW, int Cout,
+                                                             int Cin) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;     // (ci, co), co fastest
+    const size_t KN = (size_t)Cin * Cout;
+    if (idx >= KN) return;
+    const int ci = (int)(idx / Cout), co = (int)(idx % Cout);
+    float q[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[i][j] = dU[(size_t)(i * 4 + j) * KN + idx];
+    float s[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = q[0][j] + q[1][j] + q[2][j];
+        s[1][j] = q[1][j] - q[2][j];
+        s[2][j] = q[1][j] + q[2][j] + q[3][j];
+    }
+    float* dst = dW + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        dst[a * 3 + 0] = s[a][0] + s[a][1] + s[a][2];
+        dst[a * 3 + 1] = s[a][1] - s[a][2];
+        dst[a * 3 + 2] = s[a][1] + s[a][2] + s[a][3];
+    }
+}
+
+
+// =============================================================================================
+// F(4x4, 3x3) / F(3x3, 4x4) on the point set {0, 1, -1, 2, -1/2, inf} (wino43_mats.h, generated and
+// verified in rational arithmetic by tools/gen_winograd.py): 36 multiplies per 4x4 output tile
+// instead of 144, i.e. 0.60 TFLOP per contraction at cfg2 (P = 7 -> 2x2 tiles, 49/64 used).
+// fp32 throughout; measured error 7e-6 (F(2x2,3x3): 1.2e-6, direct: 6e-7) - selected with
+// CIM_CONV_ALGO=winograd4.  Same kernel structure as above; lanes own 2 channels (float2) so the
+// 6x6 patch fits in registers, and the matrix products are unrolled against the constexpr tables
+// (zero entries vanish at compile time).
+#include "wino43_mats.h"
+
 __device__ __forceinline__ float2 f2(float v) { return make_float2(v, v); }
 __device__ __forceinline__ void fma2(float2& a, float s, float2 v) { a.x = fmaf(s, v.x, a.x); a.y = fmaf(s, v.y, a.y); }
 __device__ __forceinline__ void fma4(float4& a, float s, float4 v) {
     a.x = fmaf(s, v.x, a.x); a.y = fmaf(s, v.y, a.y); a.z = fmaf(s, v.z, a.z); a.w = fmaf(s, v.w, a.w);
 }
+
+// AMAX: also emit row_amax[pos][m], an UPPER BOUND of max |V[pos][m][:]| as IEEE bit patterns (the f16x2 GEMM engine's
+// per-row operand scales, cim_hip.h): |(B^T d B)[i][j]| <= (sum_k |B^T[i][k]|)(sum_k |B^T[j][k]|) max|d| with max|d| over
+// the tile's 6 x 6 patch and all channels - ONE running maximum per lane, one block reduction, plain stores (no atomics,
+// no zero-fill).  (Tracking the 36 exact row maxima costs 130 more VGPRs and half the occupancy of this HBM-streaming
+// kernel: 0.75 instead of 0.43 ms per step; the bound costs fp16 head-room at the small end only, as for the columns.)
+template <bool AMAX>
+__global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int R, int P,
+                                                           int T, int C, unsigned* __restrict__ row_amax) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    float dmax = 0.0f;
+    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
+        float2 d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int iy = 4 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ix = 4 * tx - 1 + j;
+                d[i][j] = ((unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P)
+                              ? *reinterpret_cast<const float2*>(x + (((size_t)r * P + iy) * P + ix) * C + c)
+                              : f2(0.f);
+                if constexpr (AMAX) dmax = fmaxf(dmax, fmaxf(fabsf(d[i][j].x), fabsf(d[i][j].y)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float2 trow[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                trow[j] = f2(0.f);
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (W43_BT[i][k] != 0.0f) fma2(trow[j], W43_BT[i][k], d[k][j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float2 v = f2(0.f);
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (W43_BT[j][k] != 0.0f) fma2(v, W43_BT[j][k], trow[k]);
+                *reinterpret_cast<float2*>(V + (size_t)(i * 6 + j) * MC + (size_t)m * C + c) = v;
+            }
+        }
+    }
+    if constexpr (AMAX) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmax;
+        __syncthreads();
+        if (threadIdx.x < 36) {
+            const float tile_max = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            float fi = 0.0f, fj = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sum += fabsf(W43_BT[p][k]);
+                if (p == (int)threadIdx.x / 6) fi = sum;
+                if (p == (int)threadIdx.x % 6) fj = sum;
+            }
+            row_amax[(size_t)threadIdx.x * ((size_t)R * T * T) + m] = __float_as_uint(fi * fj * tile_max * 1.0001f);
+        }
+    }
+}
+
+// Column-scale bounds of a Winograd-domain operand from the |max| of the untransformed tensor:
+//   |(L d L^T)[i][j]| <= (sum_k |L[i][k]|) (sum_k |L[j][k]|) max|d|      (L = B^T, G or G4)
+// out[pos][n] = bits(f_pos * max_{t < group} float(in[n * group + t])).  The bound exceeds the true column
+// maximum by a small factor only (<= 49, typically ~5): the f16x2 engine needs an UPPER bound within a few bits.
+__global__ __launch_bounds__(256) void wino43_bound_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n,
+                                                           int group, int kind) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.0f;
+    for (int t = 0; t < group; ++t) a = fmaxf(a, __uint_as_float(in[(size_t)i * group + t]));
+    float f[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        float sum = 0.0f;
+        if (kind == 0) { for (int k = 0; k < 6; ++k) sum += fabsf(W43_BT[p][k]); }
+        else if (kind == 1) { for (int k = 0; k < 3; ++k) sum += fabsf(W43_G[p][k]); }
+        else { for (int k = 0; k < 4; ++k) sum += fabsf(W43_G4[p][k]); }
+        f[p] = sum;
+    }
+#pragma unroll
+    for (int p = 0; p < 36; ++p) out[(size_t)p * n + i] = __float_as_uint(f[p / 6] * f[p % 6] * a * 1.0001f);
+}
+
+__global__ __launch_bounds__(256) void wino43_filter_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
+                                                            int Cin, int mode) {
+    const int Kd = mode ? Cout : Cin, Nd = mode ? Cin : Cout;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)Kd * Nd) return;
+    const int k = (int)(idx / Nd), n = (int)(idx % Nd);
+    const int co = mode ? k : n, ci = mode ? n : k;
+    const float* g = W + ((size_t)co * Cin + ci) * 9;
+    float w[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) w[a][b] = mode ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
+    float t[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) t[i][b] = W43_G[i][0] * w[0][b] + W43_G[i][1] * w[1][b] + W43_G[i][2] * w[2][b];
+    const size_t KN = (size_t)Kd * Nd;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            U[(size_t)(i * 6 + j) * KN + idx] = t[i][0] * W43_G[j][0] + t[i][1] * W43_G[j][1] + t[i][2] * W43_G[j][2];
+}
+
+__global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int R, int P, int T, int C, int relu) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
+        float2 s[4][6];                                   // AT . q, accumulated row by row of q
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s[a][j] = f2(0.f);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float2 q = *reinterpret_cast<const float2*>(M + (size_t)(i * 6 + j) * MC + (size_t)m * C + c);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (W43_AT[a][i] != 0.0f) fma2(s[a][j], W43_AT[a][i], q);
+            }
+        const float2 bv = bias ? *reinterpret_cast<const float2*>(bias + c) : f2(0.f);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oy = 4 * ty + a;
+            if (oy >= P) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ox = 4 * tx + b;
+                if (ox >= P) continue;
+                float2 v = bv;
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (W43_AT[b][j] != 0.0f) fma2(v, W43_AT[b][j], s[a][j]);
+                if (relu) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
+                *reinterpret_cast<float2*>(y + (((size_t)r * P + oy) * P + ox) * C + c) = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino43_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int P,
+                                                        int T, int C) {
+    const int m = blockIdx.x;
+    const int r = m / (T * T), t = m % (T * T), ty = t / T, tx = t % T;
+    const size_t MC = (size_t)R * T * T * C;
+    for (int c = threadIdx.x * 2; c < C; c += 256 * 2) {
+        float2 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int oy = 4 * ty + a, ox = 4 * tx + b;
+                d[a][b] = (oy < P && ox < P) ? *reinterpret_cast<const float2*>(dy + (((size_t)r * P + oy) * P + ox) * C + c) : f2(0.f);
+            }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float2 trow[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                trow[b] = f2(0.f);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (W43_G4[i][a] != 0.0f) fma2(trow[b], W43_G4[i][a], d[a][b]);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float2 v = f2(0.f);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (W43_G4[j][b] != 0.0f) fma2(v, W43_G4[j][b], trow[b]);
+                *reinterpret_cast<float2*>(D + (size_t)(i * 6 + j) * MC + (size_t)m * C + c) = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino43_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dW, int Cout,
+                                                               int Cin) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;     // (ci, co), co fastest
+    const size_t KN = (size_t)Cin * Cout;
+    if (idx >= KN) return;
+    const int ci = (int)(idx / Cout), co = (int)(idx % Cout);
+    float s[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s[a][j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float q = dU[(size_t)(i * 6 + j) * KN + idx];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if (W43_A3T[a][i] != 0.0f) s[a][j] += W43_A3T[a][i] * q;
+        }
+    float* dst = dW + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (W43_A3T[b][j] != 0.0f) v += W43_A3T[b][j] * s[a][j];
+            dst[a * 3 + b] = v;
+        }
+}
+
 
 // =============================================================================================
 // Mixed tiling of the 7 x 7 ROI map: one 4-wide and one 3-wide tile per axis (4 + 3 = 7) instead of two 4-wide tiles
@@ -769,13 +1190,109 @@ __global__ __launch_bounds__(256) void flatten_chw_pair_kernel(const float* __re
 
 #define WINO_GEOM_OK() CIM_CHECK_ARG(R > 0 && P > 0 && P <= 64 && C > 0 && C % 4 == 0)
 
+#define WINO_TILE_OK() CIM_CHECK_ARG(tile == 2 || tile == 4 || (tile == 7 && P == 7))
+
+extern "C" int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, int tile, void* stream) {
+    WINO_GEOM_OK();
+    WINO_TILE_OK();
+    CIM_CHECK_ARG(x && V);
+    const int T = (P + tile - 1) / tile;
+    if (tile == 7) hipLaunchKernelGGL(wino7_input_kernel<false>, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), x, V, R, C, (unsigned*)nullptr);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_input_kernel<false>, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C, (unsigned*)nullptr);
+    else hipLaunchKernelGGL(wino_input_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_input_transform_amax(const float* x, float* V, uint32_t* row_amax, int R, int P, int C, int tile,
+                                             void* stream) {
+    WINO_GEOM_OK();
+    CIM_CHECK_ARG(x && V && row_amax && (tile == 4 || (tile == 7 && P == 7)));
+    const int T = (P + 3) / 4;
+    if (tile == 7) hipLaunchKernelGGL(wino7_input_kernel<true>, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), x, V, R, C, row_amax);
+    else hipLaunchKernelGGL(wino43_input_kernel<true>, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), x, V, R, P, T, C, row_amax);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_scale_bounds(const uint32_t* amax_in, uint32_t* bounds, int n, int group, int kind, int tile,
+                                     void* stream) {
+    CIM_CHECK_ARG(amax_in && bounds && n > 0 && group > 0 && kind >= 0 && kind <= 2 && (tile == 4 || tile == 7));
+    if (tile == 7) hipLaunchKernelGGL(wino7_bound_kernel, dim3((n + 255) / 256, 121), dim3(256), 0, cim::as_stream(stream), amax_in, bounds, n, group, kind);
+    else hipLaunchKernelGGL(wino43_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax_in, bounds, n,
+                       group, kind);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, int tile, void* stream) {
+    CIM_CHECK_ARG(W && U && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1));
+    CIM_CHECK_ARG(tile == 2 || tile == 4 || tile == 7);
+    const size_t n = (size_t)Cout * Cin;
+    if (tile == 7) hipLaunchKernelGGL(wino7_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U, Cout, Cin, mode);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U, Cout, Cin, mode);
+    else hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W, U,
+                       Cout, Cin, mode);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_output_transform(const float* M, const float* bias, float* y, int R, int P, int C, int relu,
+                                         int tile, void* stream) {
+    WINO_GEOM_OK();
+    WINO_TILE_OK();
+    CIM_CHECK_ARG(M && y);
+    const int T = (P + tile - 1) / tile;
+    if (tile == 7) hipLaunchKernelGGL(wino7_output_kernel, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, C, relu, (unsigned*)nullptr);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C, relu);
+    else hipLaunchKernelGGL(wino_output_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, P, T, C,
+                       relu);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_dy_transform(const float* dy, float* D, int R, int P, int C, int tile, void* stream) {
+    WINO_GEOM_OK();
+    WINO_TILE_OK();
+    CIM_CHECK_ARG(dy && D);
+    const int T = (P + tile - 1) / tile;
+    if (tile == 7) hipLaunchKernelGGL((wino7_dy_kernel<false, false>), dim3(R, 4), dim3(256), 0, cim::as_stream(stream), dy, D, R, C, (unsigned*)nullptr);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
+    else hipLaunchKernelGGL(wino_dy_kernel, dim3(R * T * T), dim3(256), 0, cim::as_stream(stream), dy, D, R, P, T, C);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, int tile, void* stream) {
     CIM_CHECK_ARG(dU && dW && Cout > 0 && Cin > 0);
-    CIM_CHECK_ARG(tile == 7);         // (the F(2x2,3x3) / F(4x4,3x3) stages are test infrastructure: experiments/csrc/winograd_all.hip)
+    CIM_CHECK_ARG(tile == 2 || tile == 4 || tile == 7);
     const size_t n = (size_t)Cout * Cin;
-    if (CIM_W7_VWG == 4 && Cout % 4 == 0)
+    if (tile == 7 && CIM_W7_VWG == 4 && Cout % 4 == 0)
         hipLaunchKernelGGL(wino7_wgrad_out_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
-    else hipLaunchKernelGGL(wino7_wgrad_out_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
+    else if (tile == 7) hipLaunchKernelGGL(wino7_wgrad_out_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
+    else if (tile == 4) hipLaunchKernelGGL(wino43_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
+    else hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU,
+                       dW, Cout, Cin);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_flatten_chw(const float* src, const float* relu_y, float* dst, int R, int PP, int C, int backward,
+                               void* stream) {
+    CIM_CHECK_ARG(src && dst && R > 0 && PP > 0 && PP <= 64 && C > 0 && C % 64 == 0 && R <= 2147483647 / 1 && C / 64 <= 65535);
+    CIM_CHECK_ARG(backward || relu_y == nullptr);
+    if (backward) hipLaunchKernelGGL(flatten_chw_kernel<false>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C, (float*)nullptr);
+    else hipLaunchKernelGGL(flatten_chw_kernel<true>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C, (float*)nullptr);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino_dy_adjoint_transform(const float* dy, float* E, uint32_t* row_amax, int R, int P, int C, int tile,
+                                             void* stream) {
+    WINO_GEOM_OK();
+    CIM_CHECK_ARG(dy && E && tile == 7 && P == 7);
+    if (row_amax) hipLaunchKernelGGL((wino7_dy_kernel<true, true>), dim3(R, 4), dim3(256), 0, cim::as_stream(stream), dy, E, R, C, row_amax);
+    else hipLaunchKernelGGL((wino7_dy_kernel<true, false>), dim3(R, 4), dim3(256), 0, cim::as_stream(stream), dy, E, R, C, (unsigned*)nullptr);
     CIM_CHECK_LAUNCH();
     return 0;
 }

@@ -337,71 +337,20 @@ int cim_bn_act_bwd(const float* dy, const float* y, const float* x, const float*
                    int N, int C, int HW, int relu, void* stream);
 
 /* ------------------------------------------------------------------ MaskFuse contractions (a-2)
- * fp32-in / fp32-out MFMA GEMMs replacing the ATen/cuDNN calls behind MaskFuse,
- * lib/modeling/resnet50.py:104-110,135-136 (Conv2d(2C,C,3,pad=1), Linear(49C,4096),
- * Linear(4096,4096)) and their autograd backward.  Two arithmetic engines, same results class:
- *   engine 1 (default): every fp32 operand is split exactly into three bf16 terms in the kernel and the
- *     product evaluated as six v_mfma_f32_32x32x16_bf16 products with fp32 accumulation
- *     (dropped terms < 2^-23 |a*b|: two orders below the fp32 accumulation rounding itself);
- *   engine 0: v_mfma_f32_32x32x2_f32 (f32 multiplies).
- * `engine` is an ARGUMENT of every such call (0 or 1): the library keeps no engine switch.
- *
- * C[M,N] = A . B (+ bias[N]) (ReLU optional), row-major C with leading dimension ldc.
- *   a_mcontig = 0: A element (m,k) at A[m*lda + k];  1: at A[k*lda + m]
- *   b_kcontig = 0: B element (k,n) at B[k*ldb + n];  1: at B[n*ldb + k]   (nn.Linear weight)
- * splits > 1: split-K through `workspace` (splits*M*N floats), reduced in a fixed order
- * (deterministic).  cim_gemm_f32_splits() returns the split count the library would choose. */
-int cim_gemm_f32_splits(int M, int N, int K, int engine);
-int cim_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
-                 int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu,
-                 int splits, float* workspace, int engine, void* stream);
-
-/* 3x3 / stride 1 / pad 1 convolution on R independent P x P maps as an implicit GEMM
- * (no im2col buffer): X [R,P,P,Cin] (NHWC), Whwio [3,3,Cin,Cout], Y [R,P,P,Cout].
- * The data gradient is the same call on dY with the spatially flipped, in/out-swapped weights. */
-int cim_conv3x3_f32(const float* X, const float* Whwio, const float* bias, float* Y,
-                    int R, int P, int Cin, int Cout, int relu, int engine, void* stream);
-
-/* Weight gradient: dWhwio [3,3,Cin,Cout] = im2col(X)^T . dY, dY [R,P,P,Cout]. */
-int cim_conv3x3_wgrad_f32(const float* X, const float* dY, float* dWhwio,
-                          int R, int P, int Cin, int Cout, int splits, float* workspace, int engine, void* stream);
-
-/* `batch` independent GEMMs of identical shape in one launch (strides in elements between
- * consecutive problems); used for the 16 positions of the Winograd-domain convolution. */
-int cim_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K,
-                         int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
-                         int batch, long long a_bs, long long b_bs, long long c_bs, int engine, void* stream);
-
-/* f16x2 engine (the host's default, CIM_GEMM_ENGINE=f16x2): the same contractions as cim_gemm_f32 /
- * cim_gemm_f32_batched with every fp32 operand scaled by a power of two per A row / per B column and split
- * into TWO fp16 terms (x*s = h + l, 23 significant bits), evaluated as the three products hl + lh + hh on
- * v_mfma_f32_32x32x16_f16 with fp32 accumulation and rescaled exactly in the epilogue.  Error bound of an
- * fp32 GEMM relative to |a_row|*|b_col| (dropped l*l term <= 2^-22, rms 2^-25.6, per product); half the MFMA
- * work of the bf16x3 engine.
- *
- * cim_amax_rowcol: X is a stored [batch][rows][ld] fp32 matrix (cols used).  row_amax [batch*rows] /
- * col_amax [batch*cols] (either may be NULL) receive max |x| as IEEE bit patterns through atomicMax, so the
- * CALLER ZEROES them first.  One pass over X serves both orientations of the operand.
- * a_amax [batch][M]: the row array of a K-contiguous A, the column array of the stored matrix of an
- * M-contiguous A;  b_amax [batch][N]: the column array of an N-contiguous B, the row array of a K-contiguous B. */
-int cim_amax_rowcol(const float* X, int rows, int cols, int ld, int batch, long long bs,
-                    uint32_t* row_amax, uint32_t* col_amax, void* stream);
-int cim_gemm_f16x2_splits(int M, int N, int K);
-int cim_gemm_f16x2(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
-                   int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu,
-                   int splits, float* workspace, const uint32_t* a_amax, const uint32_t* b_amax, void* stream);
-int cim_gemm_f16x2_batched(const float* A, const float* B, float* C, int M, int N, int K,
-                           int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
-                           int batch, long long a_bs, long long b_bs, long long c_bs,
-                           const uint32_t* a_amax, const uint32_t* b_amax, void* stream);
-
-/* f16x2p engine (CIM_GEMM_ENGINE=f16x2p, the host's default): the f16x2 arithmetic on operands that were split by
+ * The dense contractions behind MaskFuse, lib/modeling/resnet50.py:104-110,135-136 (Conv2d(2C,C,3,pad=1) in the mixed 4 + 3
+ * Winograd tiling of the 7 x 7 ROI map, Linear(49C,4096), Linear(4096,4096)) and their autograd backward: fp32 in, fp32 out, on
+ * ONE arithmetic engine and ONE convolution algorithm.  (Rounds 1-3 carried four engines and four algorithms behind environment
+ * switches; the superseded ones are test infrastructure now: experiments/include/cim_exp.h.)
+ */
+/* The pair engine ("f16x2p"): every fp32 operand x is scaled by ONE power of two per matrix and split into two fp16 terms,
+ * x * s = h + l (22 significant bits); a product is evaluated as h*l + l*h + h*h on v_mfma_f32_32x32x16_f16 with fp32
+ * accumulation and rescaled exactly in the epilogue (error class of an fp32 GEMM, tests/test_gpu_gemm_pair.py).  The operands were split by
  * their PRODUCERS.  A "pair image" of a logical fp32 matrix [rows][cols] is [rows][ld / 8][h: 8 x f16 | l: 8 x f16]
  * (ld logical elements per row, a multiple of 8; 4 bytes per element) with x * s = h + l for ONE power-of-two scale s per
  * matrix (per batch entry).  The same image serves the product that contracts over its columns (K-contiguous use) and the
  * one that contracts over its rows (through the hardware transpose read of LDS), so it is written once.  The GEMM moves
  * 16-byte chunks HBM -> LDS by LDS-DMA; its loop holds MFMAs and LDS reads only.
- *   cim_gemm_pair[_batched]: C[M,N] = A . B * 1 / (a_scale * b_scale) (+ bias)(ReLU), fp32 C.  Layout flags as cim_gemm_f32;
+ *   cim_gemm_pair[_batched]: C[M,N] = A . B * 1 / (a_scale * b_scale) (+ bias)(ReLU), fp32 C.  a_mcontig = 0: A element (m,k) at A[m*lda + k], 1: at A[k*lda + m]; b_kcontig = 0: B element (k,n) at B[k*ldb + n], 1: at B[n*ldb + k];
  *     K % 32 == 0 (zero-filled rows / columns pad the images), lda / ldb % 8 == 0, an M-contiguous A needs M % 8 == 0, an
  *     N-contiguous B needs N % 8 == 0.  a_scale / b_scale: [batch] device floats, the scales the images were written with.
  *     c_amax (optional): receives max |C| as an IEEE bit pattern through atomicMax (caller zeroes) - the scale source
@@ -436,67 +385,36 @@ int cim_pair_split(const float* X, void* P, int rows, int rows_pad, int cols, in
 int cim_pair_amax(const float* X, long long n, uint32_t* amax, void* stream);
 int cim_pair_masked_stats(const float* dy, const float* y, int rows, int cols, float* part, uint32_t* amax, void* stream);
 
-/* Producers of pair images for the MaskFuse convolution in the mixed 4 + 3 Winograd tiling (121 positions, P = 7; the
- * fp32 stages are cim_wino_* with tile = 7 below) and for seg_fc.0's input:
+/* Producers of pair images for the MaskFuse convolution in the mixed 4 + 3 Winograd tiling (121 positions, P = 7) and for seg_fc.0's input:
  *   cim_wino7_pair_scales: scale[121] from ONE max |d| bit pattern of the untransformed tensor: per position the bound
  *        (abs row sum)_i (abs row sum)_j max|d| of the transform.  kind 0: input (B^T), 1: filter (G), 2: dy for the weight
  *        gradient (GD), 3: dy for the adjoint data gradient (A)
  *   cim_wino7_input_pair : x [R,7,7,C] fp32 -> V [121][Rs][C] pair image (Rs >= R rows per position, rows >= R zeroed)
  *   cim_wino7_filter_pair: W [Cout,Cin,3,3] -> U' [121][Cout][Cin] pair image (ci contiguous)
  *   cim_wino7_dy_pair    : dy [R,7,7,C] -> D (adjoint = 0: GD dy GD^T) or E (adjoint = 1: A dy A^T) [121][Rs][C]
- *   cim_wino7_output_amax: cim_wino_output_transform(tile = 7) that also reports max |y| (atomicMax, caller zeroes)
- *   cim_flatten_chw_pair : cim_flatten_chw forward into a pair image [Rs][C*PP] (lib/modeling/resnet50.py:135) */
+ *   cim_wino7_output_amax: M [121][R][C] -> y [R,7,7,C] = A^T m A per tile (+ bias, ReLU); also reports max |y| (atomicMax, caller zeroes)
+ *   cim_flatten_chw_pair : the (c, h, w) flatten of the NCHW `.view(N, -1)` on channels-last data, into a pair image [Rs][C*PP] (lib/modeling/resnet50.py:135) */
 int cim_wino7_pair_scales(const uint32_t* amax, int kind, float* scale, void* stream);
 int cim_wino7_input_pair(const float* x, void* V, const float* scale, int R, int Rs, int C, void* stream);
 int cim_wino7_filter_pair(const float* W, void* U, const float* scale, int Cout, int Cin, void* stream);
 int cim_wino7_dy_pair(const float* dy, void* D, const float* scale, int R, int Rs, int C, int adjoint, void* stream);
 int cim_wino7_output_amax(const float* M, const float* bias, float* y, int R, int C, int relu, uint32_t* y_amax, void* stream);
 int cim_flatten_chw_pair(const float* src, void* dst, const float* scale, int R, int Rs, int PP, int C, void* stream);
-/* cim_flatten_chw(backward = 1) that also writes bias_partial [R][C] = sum over the PP pixels of the masked gradient (the
+/* the flatten's backward: src [R][C][PP] -> dst [R][PP][C], zeroed where relu_y [R][PP][C] <= 0 (the conv's ReLU mask); also writes bias_partial [R][C] = sum over the PP pixels of the masked gradient (the
  * conv's bias gradient is its sum over R); bias_partial may be NULL */
 int cim_flatten_chw_bwd_bias(const float* src, const float* relu_y, float* dst, float* bias_partial, int R, int PP, int C,
                              void* stream);
 
-/* Winograd F(2x2,3x3) evaluation of the same 3x3 / stride 1 / pad 1 convolution (fp32 throughout,
- * 1.72x fewer multiplies at P = 7): T = ceil(P/2) tiles per side, 16 transform positions.
- *   cim_wino_input_transform : x [R,P,P,C]            -> V [16][R*T*T][C]       (B^T d B)
- *   cim_wino_filter_transform: W [Cout,Cin,3,3]       -> U [16][K][N]           (G g G^T)
- *        mode 0: K = Cin, N = Cout (forward);  mode 1: K = Cout, N = Cin, taps rotated (data gradient)
- *   (16 GEMMs  M[pos] = V[pos] . U[pos]  through cim_gemm_f32_batched)
- *   cim_wino_output_transform: M [16][R*T*T][C], bias -> y [R,P,P,C]            (A^T m A, +bias, ReLU)
- *   weight gradient: cim_wino_dy_transform: dy [R,P,P,C] -> D [16][R*T*T][C]    (G2 dy G2^T)
- *        16 GEMMs dU[pos] = V[pos]^T . D[pos];  cim_wino_wgrad_output: dU [16][Cin][Cout] -> dW [Cout,Cin,3,3]
- * `tile` = 2: F(2x2,3x3), 16 positions (default);  `tile` = 4: F(4x4,3x3) on the points {0,1,-1,2,-1/2,inf},
- * 36 positions, T = ceil(P/4), 3.1x fewer multiplies than direct at P = 7, fp32 error ~7e-6. */
-int cim_wino_input_transform(const float* x, float* V, int R, int P, int C, int tile, void* stream);
-/* (c, h, w) flatten between the conv and seg_fc.0 (resnet50.py:135, `.view(N, -1)` of an NCHW tensor) on channels-last
- * data.  backward = 0: src [R][PP][C] -> dst [R][C][PP].  backward = 1: src [R][C][PP] -> dst [R][PP][C], zeroed where
- * relu_y [R][PP][C] <= 0 (the conv's ReLU mask; NULL = no mask).  PP <= 64, C % 64 == 0. */
-int cim_flatten_chw(const float* src, const float* relu_y, float* dst, int R, int PP, int C, int backward, void* stream);
 
-/* f16x2 engine helpers (tile = 4 only):
- * cim_wino_input_transform_amax: the input transform that also stores row_amax [36][R*T*T], an upper bound of
- *   max |V[pos][m][:]| (bit patterns; f_pos * max |x| over the tile's patch and all channels; plain stores, nothing
- *   to zero) - the per-row operand scales of the forward / data-gradient GEMMs.
- * cim_wino_scale_bounds: per-column scale BOUNDS of a transformed operand from the |max| of the untransformed
- *   tensor, bounds [36][n] = f_pos * max_{t<group} amax_in[n*group + t], f_pos = product of the absolute row sums
- *   of the transform matrix (kind 0: B^T (input), 1: G (filter), 2: G4 (output gradient)). */
-int cim_wino_input_transform_amax(const float* x, float* V, uint32_t* row_amax, int R, int P, int C, int tile, void* stream);
-int cim_wino_scale_bounds(const uint32_t* amax_in, uint32_t* bounds, int n, int group, int kind, int tile, void* stream);
-/* Data gradient of the mixed tiling (tile = 7) as the ADJOINT of the forward - reuses the forward's U, no transform of a
- * rotated filter:  E = A dy A^T per tile (cim_wino_dy_adjoint_transform; row_amax [121][R] optional: row-scale bounds of E),
- * 121 GEMMs Md[pos] = E[pos] . U[pos]^T (U [121][Cin][Cout] read K-contiguously), dx = overlap-add of B Md B^T
- * (cim_wino_dx_adjoint_output).  E [121][R][Cout], Md [121][R][Cin], dx [R,7,7,Cin]. */
-int cim_wino_dy_adjoint_transform(const float* dy, float* E, uint32_t* row_amax, int R, int P, int C, int tile, void* stream);
+/* fp32 stages of the same tiling that the pair engine's results pass through (tile must be 7):
+ *   cim_wino_wgrad_output     : dU [121][Cin][Cout] (fp32, from cim_gemm_pair_batched) -> dW [Cout,Cin,3,3]
+ *   cim_wino_dx_adjoint_output: Md [121][R][Cin] -> dx [R,7,7,Cin]   (overlap-add of B Md B^T: the adjoint of the forward) */
+int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, int tile, void* stream);
+int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int P, int C, int tile, void* stream);
 /* cim_wino_dx_adjoint_output (tile = 7) with the backward of MaskFuse's prologue folded in: Md [121][R][2 Cb] is the Winograd-domain
  * gradient of cat = [box, box * mask] (lib/modeling/resnet50.py:131-134); written is  dbox [R,7,7,Cb] = dcat[..., :Cb] + mask *
  * dcat[..., Cb:]  (masks [R,7,7]) - the input of the plain ROIAlign backward (cim_roi_align_bwd_ws), half the bytes of dcat. */
 int cim_wino7_dx_maskfold(const float* M, const float* masks, float* dbox, int R, int Cb, void* stream);
-int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int P, int C, int tile, void* stream);
-int cim_wino_filter_transform(const float* W, float* U, int Cout, int Cin, int mode, int tile, void* stream);
-int cim_wino_output_transform(const float* M, const float* bias, float* y, int R, int P, int C, int relu, int tile, void* stream);
-int cim_wino_dy_transform(const float* dy, float* D, int R, int P, int C, int tile, void* stream);
-int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int Cin, int tile, void* stream);
 
 /* ------------------------------------------------------------------ losses (a-8, a-9, a-10)
  * Replaces cls_iou_loss + loss_weight_bag_loss (per refinement layer), mil_bag_loss and PCL_loss,

@@ -228,11 +228,11 @@ def test_pair_engine_error_class(dev, K):
         scale = A.double().abs() @ B.double().abs()
         c = _pair_gemm(dev, A, B, 0, 0)
         err_pair = float(((c.cpu().double() - ref).abs() / scale).max())
-        c32 = torch.empty(M, N, device=dev)
-        splits = _lib.call("cim_gemm_f32_splits", M, N, K, 0)
+        c32 = torch.empty(M, N, device=dev)          # the true-fp32 MFMA comparator: v_mfma_f32_32x32x2_f32 (csrc/conv1x1.hip)
+        splits = _lib.call("cim_gemm_small_splits", M, N, K)
         ws = torch.empty(splits * M * N, device=dev)
-        _lib.call("cim_gemm_f32", A.to(dev).data_ptr(), B.to(dev).data_ptr(), c32.data_ptr(), None, M, N, K, K, N, N, 0, 0, 0,
-                  splits, ws.data_ptr(), 0, _lib.stream_ptr())
+        _lib.call("cim_gemm_small_f32", A.to(dev).data_ptr(), B.to(dev).data_ptr(), c32.data_ptr(), M, N, K, K, N, N, 0, 0,
+                  None, None, None, None, None, 0.0, None, 0, splits, ws.data_ptr(), _lib.stream_ptr())
         err_f32 = float(((c32.cpu().double() - ref).abs() / scale).max())
         assert err_pair < 2e-6 and err_pair < 2.0 * err_f32 + 1e-7, (spread, err_pair, err_f32)
 
@@ -352,7 +352,8 @@ def test_maskfuse_pair_function_vs_per_layer_path(dev, r):
     its norm (a 3 x 3 window of one proposal over all input channels) - a property of ReLU, not of either path.  With
     unseeded module parameters this test failed in ~8 % of its runs for exactly that reason (round 4: 600 draws, every
     failure was one flipped mask with |pre-activation| <= 1.4e-6; none with the masks taken from the path under test)."""
-    from cim_amd.ops import conv3x3, linear, maskfuse_pair, pair
+    from cim_amd.ops import maskfuse_pair, pair
+    from experiments.engines import conv3x3, linear        # the per-layer f16x2 Functions: the comparator
     cin, cout, h = 128, 64, 256
     lin = torch.nn.functional.linear
     for seed in range(r, r + 64):

@@ -763,7 +763,8 @@ def test_fused_sgd_matrix_mode_hands_scales_to_the_contractions(dev):
     """Weights of >= 2^20 elements take the SGD kernel's matrix mode: same update as torch.optim.SGD, and the row / column
     max |w_new| it registers are exactly what cim_amax_rowcol computes - valid for this version of the weight only."""
     from cim_amd.optim import SGD
-    from cim_amd.ops import gemm as G, linear
+    from cim_amd.ops import gemm as G
+    from experiments import engines as X            # cim_amax_rowcol / the f16x2 engine's linear: the consumers these scales were made for
     g = torch.Generator().manual_seed(5)
     rows, cols = 1036, 1028                                  # ragged against the 64 x 1024 tiles (and the 4-row unroll)
     w0 = torch.randn(rows, cols, generator=g)
@@ -782,14 +783,14 @@ def test_fused_sgd_matrix_mode_hands_scales_to_the_contractions(dev):
     torch.testing.assert_close(hp[1].detach().cpu(), rp[1].detach(), rtol=1e-5, atol=1e-6)
     reg = G._registered_scales(hp[0], rows, cols)
     assert reg is not None
-    ra, ca = G.amax(hp[0].detach(), rows, cols, cols, True, True)
+    ra, ca = X.amax(hp[0].detach(), rows, cols, cols, True, True)
     assert torch.equal(reg[0], ra) and torch.equal(reg[1], ca)
     x = torch.randn(50, cols, generator=g).to(dev)
-    y_reg = linear(x, hp[0])                                 # uses the registered scales
+    y_reg = X.linear(x, hp[0])                               # uses the registered scales
     with torch.no_grad():
         hp[0].mul_(1.0)                                      # any other in-place change invalidates them
     assert G._registered_scales(hp[0], rows, cols) is None
-    y_own = linear(x, hp[0])
+    y_own = X.linear(x, hp[0])
     assert torch.equal(y_reg, y_own)
 
 

@@ -2,7 +2,8 @@
 
 north_star: "within stated fp tolerance on losses/logits".  The build's stated tolerance (README):
 relative deviation of each of the four losses <= 1e-5, of every parameter gradient (||g - g_ref|| / ||g_ref||) <= 6e-3,
-against the fp32 CPU reference.  This test RECORDS the deviation for every CIM_GEMM_ENGINE x CIM_CONV_ALGO combination
+against the fp32 CPU reference.  This test RECORDS the deviation for every engine x algorithm combination (the product's pair engine
+and the superseded ones of experiments/)
  - against the reference's own whole-step golden (cfg1, tests/golden/e2e_vgg16_voc.npz: the REFERENCE code ran it) and
  - against the fp32/direct run of the same step at cfg2 full size (1000 proposals, 516 x 688 image),
 prints the table (profiles/r2/parity_deviation.json is a copy of one run) and asserts 3x-margin bounds per engine."""
@@ -25,12 +26,19 @@ GRAD_TOL = GRAD_RTOL          # 5e-4 per parameter; gradients that cancel to not
 
 
 def _set(monkeypatch, engine, algo):
-    from cim_amd import _lib
+    """f16x2p + winograd7 = the product as it is.  Every other combination routes MaskFuse.forward through the superseded engines of
+    experiments/ (test infrastructure: the product has one engine and one algorithm)."""
+    from cim_amd.modeling import maskfuse
     from cim_amd.ops import gemm
-    monkeypatch.setattr(gemm, "PAIR", engine == "f16x2p")      # pre-split pair images (MaskFuse's fused head Function)
-    monkeypatch.setattr(gemm, "ENGINE", "f16x2" if engine == "f16x2p" else engine)
-    monkeypatch.setattr(gemm, "CONV_ALGO", algo)
+    from experiments import engines
     gemm.forget_weight_scales()
+    monkeypatch.undo()
+    if engine == "f16x2p":
+        assert algo == "winograd7"
+        return
+    monkeypatch.setattr(engines, "ENGINE", engine)
+    monkeypatch.setattr(engines, "CONV_ALGO", algo)
+    monkeypatch.setattr(maskfuse.MaskFuse, "forward", lambda self, x, rois, masks: engines.maskfuse_forward(self, x, rois, masks))
 
 
 def _step(model, batch, seed):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Loss trajectory of a short training run on one synthetic image (bench.py's model, optimizer and inputs), printed every
-10 steps: run it twice, e.g. with CIM_DEFER_DW=1 and =0 (or CIM_GEMM_OVERLAP=0), to see that a scheduling option does not
-change what is learned.  Runs are not bit-reproducible (float atomics in the wide BatchNorm-backward reductions)."""
+10 steps: run it twice, e.g. with and without --no-defer (ops.gemm.DEFER_DW = False) or --no-overlap (ops.gemm.OVERLAP = False), to
+see that a scheduling option does not change what is learned.  Runs are not bit-reproducible (float atomics in the wide
+BatchNorm-backward reductions)."""
 import os
 import sys
 
@@ -15,7 +16,13 @@ from cim_amd.core.config import cfg  # noqa: E402
 from cim_amd.core.presets import apply_preset  # noqa: E402
 from cim_amd.modeling.model_builder import Generalized_RCNN  # noqa: E402
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+from cim_amd.ops import gemm as _gemm  # noqa: E402
+if "--no-defer" in sys.argv:
+    _gemm.DEFER_DW = False
+if "--no-overlap" in sys.argv:
+    _gemm.OVERLAP = _gemm.DEFER_DW = False
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+steps = int(_args[0]) if _args else 60
 dev = torch.device("cuda:0")
 apply_preset("resnet50_voc")
 torch.manual_seed(cfg.RNG_SEED)
