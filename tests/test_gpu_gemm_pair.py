@@ -271,6 +271,7 @@ def _close_to(d, ref, floor):
 def test_wino7_pair_producers_match_fp32_transforms(dev):
     from cim_amd import _lib
     from cim_amd.ops import pair
+    from experiments import _lib as _xlib           # the fp32 stages of the same tiling: the comparator (test infrastructure)
     st = _lib.stream_ptr()
     g = torch.Generator().manual_seed(11)
     R, C, Co = 37, 64, 128
@@ -279,7 +280,7 @@ def test_wino7_pair_producers_match_fp32_transforms(dev):
     amax = x.abs().max().reshape(1).view(torch.int32)
     # input transform
     V = torch.empty(121, R, C, device=dev)
-    _lib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), R, 7, C, 7, st)
+    _xlib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), R, 7, C, 7, st)
     sc = torch.empty(121, device=dev)
     _lib.call("cim_wino7_pair_scales", amax.data_ptr(), 0, sc.data_ptr(), st)
     Vp = pair.Pair(torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev), R, C, 121, sc)
@@ -293,9 +294,9 @@ def test_wino7_pair_producers_match_fp32_transforms(dev):
     for adj, kind in ((0, 2), (1, 3)):
         D = torch.empty(121, R, C, device=dev)
         if adj:
-            _lib.call("cim_wino_dy_adjoint_transform", x.data_ptr(), D.data_ptr(), None, R, 7, C, 7, st)
+            _xlib.call("cim_wino_dy_adjoint_transform", x.data_ptr(), D.data_ptr(), None, R, 7, C, 7, st)
         else:
-            _lib.call("cim_wino_dy_transform", x.data_ptr(), D.data_ptr(), R, 7, C, 7, st)
+            _xlib.call("cim_wino_dy_transform", x.data_ptr(), D.data_ptr(), R, 7, C, 7, st)
         _lib.call("cim_wino7_pair_scales", amax.data_ptr(), kind, sc.data_ptr(), st)
         Dp = pair.Pair(torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev), R, C, 121, sc)
         _lib.call("cim_wino7_dy_pair", x.data_ptr(), Dp.buf.data_ptr(), sc.data_ptr(), R, Rs, C, adj, st)
@@ -307,7 +308,7 @@ def test_wino7_pair_producers_match_fp32_transforms(dev):
     # filter transform: U' [121][Cout][Cin] = U [121][Cin][Cout] transposed
     w = torch.randn(Co, C, 3, 3, generator=g).to(dev)
     U = torch.empty(121, C, Co, device=dev)
-    _lib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), Co, C, 0, 7, st)
+    _xlib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), Co, C, 0, 7, st)
     wamax = w.abs().max().reshape(1).view(torch.int32)
     _lib.call("cim_wino7_pair_scales", wamax.data_ptr(), 1, sc.data_ptr(), st)
     Up = pair.Pair(torch.empty((121, Co, C), dtype=torch.int32, device=dev), Co, C, 121, sc)
@@ -320,6 +321,7 @@ def test_wino7_pair_producers_match_fp32_transforms(dev):
 def test_output_amax_and_flatten_pair(dev):
     from cim_amd import _lib
     from cim_amd.ops import pair
+    from experiments import _lib as _xlib           # the fp32 stages of the same tiling: the comparator (test infrastructure)
     st = _lib.stream_ptr()
     g = torch.Generator().manual_seed(12)
     R, C = 21, 128
@@ -329,7 +331,7 @@ def test_output_amax_and_flatten_pair(dev):
     y0 = torch.empty(R, 7, 7, C, device=dev)
     y1 = torch.empty(R, 7, 7, C, device=dev)
     am = torch.zeros(1, dtype=torch.int32, device=dev)
-    _lib.call("cim_wino_output_transform", M.data_ptr(), bias.data_ptr(), y0.data_ptr(), R, 7, C, 1, 7, st)
+    _xlib.call("cim_wino_output_transform", M.data_ptr(), bias.data_ptr(), y0.data_ptr(), R, 7, C, 1, 7, st)
     _lib.call("cim_wino7_output_amax", M.data_ptr(), bias.data_ptr(), y1.data_ptr(), R, C, 1, am.data_ptr(), st)
     assert torch.equal(y0, y1)
     assert float(am.view(torch.float32)) == float(y0.max())
