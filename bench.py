@@ -700,6 +700,20 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
                              "cim_mining_step on the step's stream (what the step waits for); the input-only prep (2 launches: flags + "
                              "transposed map) runs on the side stream under the backbone forward - its HIP-event time there "
                              "(ms_prep_side_stream, mostly launch latency of an idle stream) costs no step time; ms_both_calls sums them"))
+    # ROIAlign + mining together (north_star: ">= 40 % of the HBM roofline on ROIAlign + mining"): all three calls' algorithmic bytes
+    # over the sum of their times - once with the launches' OWN bytes (the forward writes the Winograd image, the backward reads the
+    # folded gradient), once with SURVEY.md 8(d)'s formulas for an operator pair that moves `cat` both ways
+    trio = [h for h in hbm if h["kernel"].startswith(("cim_roi_align", "mining"))]
+    if len(trio) >= 3:
+        tms = sum(h["ms"] for h in trio)
+        own = sum(h["algorithmic_bytes"] for h in trio)
+        s8d = sum(h.get("survey_8d", {}).get("algorithmic_bytes", h["algorithmic_bytes"]) for h in trio)
+        hbm.append(dict(kernel="ROIAlign forward + backward + mining (sum of the three calls above)", bound="hbm", ms=tms,
+                        algorithmic_bytes=own, achieved=own / (tms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=own / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                        survey_8d=dict(algorithmic_bytes=s8d, frac=s8d / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       note="round 4, two more launches on the same data (cat written + re-read by the Winograd input "
+                                            "transform: 0.288 ms; dcat written in full): 0.131 + 0.208 + 0.090 ms = 23.9 %")))
     metric = "images/sec training step (ResNet-50 VOC, ~1k proposals/img) at 1/2/4/8 GPU" \
         if args.config == "resnet50_voc" else "images/sec training step (%s)" % args.config      # BASELINE.json
     ns = [i["n"] for i in infos]
