@@ -41,6 +41,12 @@ for cfgname, n, target in (("resnet50_voc", None, None), ("resnet50_voc", 800, 5
     t_region = timeit(bwd)
     sweep = {}
     # (the ROI-group size is the launcher's own choice: the CIM_ROI_RG_GS sweep switch went with the library's getenv reads)
+    # the PLAIN backward (cim_roi_align_bwd_ws on dbox [K,7,7,C]: what the step runs since round 5 - the mask multiply + concat
+    # backward is folded into cim_wino7_dx_maskfold)
+    gbox = torch.randn(K, 7, 7, C, device=dev)
+    plain = lambda lib_call: lib_call("cim_roi_align_bwd_ws", gbox.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), 0, scratch.data_ptr(), st)
+    t_plain = timeit(lambda: plain(_lib.call))
+    plain_bytes = 4.0 * (C * H * W + 5 * K) + 4.0 * K * C * 49
     import ctypes, glob
     alts = {}
     for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):     # ablation builds
@@ -50,6 +56,9 @@ for cfgname, n, target in (("resnet50_voc", None, None), ("resnet50_voc", 800, 5
         sc = torch.empty(alt.cim_roi_align_bwd_scratch(K, 1, C, H, W) // 4 + 1, device=dev)
         f = lambda: alt.cim_roi_align_maskcat_bwd_ws(gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), 0, sc.data_ptr(), st)
         alts[os.path.basename(path)] = timeit(f)
-    out.append(dict(alts=alts, config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, region_ms=t_region,
+        alt.cim_roi_align_bwd_ws.argtypes = _lib.SIGNATURES["cim_roi_align_bwd_ws"]
+        alts[os.path.basename(path) + " plain"] = timeit(lambda: alt.cim_roi_align_bwd_ws(gbox.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), 0, sc.data_ptr(), st))
+    out.append(dict(alts=alts, config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, plain_ms=t_plain, plain_alg_MB=plain_bytes / 1e6,
+                    plain_frac=plain_bytes / t_plain / 1e6 / 8000, region_ms=t_region,
                     region_frac=nbytes / t_region / 1e6 / 8000, group_size_sweep_ms=sweep))
     print(json.dumps(out[-1]))
