@@ -810,18 +810,8 @@ static inline int rg_group_size(int K, int B, int C, int H, int W) {
 constexpr int RG_REC = 36;                                              // words per entry record: off, m, touch, pad, wy[16], wx[16]
 constexpr int RG_MAXREG = 256;
 struct RegionOrder { unsigned char o[RG_MAXREG]; };
-// Plain (not mask-cat) backward: the gradient has half the channels per entry, so a window of the SAME bytes holds 64 entries -
-// the stream is paced by round trips per window, not by bytes (CIM_ROI_RG_WIN2 = 64; 32 = the mask-cat geometry)
-#ifndef CIM_ROI_RG_WIN2
-#define CIM_ROI_RG_WIN2 32
-#endif
-template <bool MASKCAT> struct RgGeom {
-    static constexpr int WIN = MASKCAT ? RG_WIN : CIM_ROI_RG_WIN2;
-    static constexpr int MAXE = (MASKCAT || CIM_ROI_RG_WIN2 == RG_WIN) ? RG_MAXE : 128;
-};
-template <bool MASKCAT>
 static inline size_t rg_lds_bytes(int GS, int P) {     // staging windows + entry records + entry map
-    return sizeof(float) * (2 * RgGeom<MASKCAT>::WIN * 256 + RgGeom<MASKCAT>::MAXE * RG_REC) + sizeof(unsigned short) * ((size_t)GS * P * P + 8);
+    return sizeof(float) * (2 * RG_WIN * 256 + RG_MAXE * RG_REC) + sizeof(unsigned short) * ((size_t)GS * P * P + 8);
 }
 
 template <bool MASKCAT, int RG_GS>
@@ -833,11 +823,9 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
                                                                      const RegionOrder region_order, int n_regions,
                                                                      int regions_x, int n_slices, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float rg_smem[];
-    constexpr int WIN = RgGeom<MASKCAT>::WIN, MAXE = RgGeom<MASKCAT>::MAXE;
-    constexpr bool WIDE = WIN == 64;               // (plain backward: a thread stages two float4 of entry le AND two of entry le + 32)
-    float (*stage)[WIN][256] = reinterpret_cast<float (*)[WIN][256]>(rg_smem);        // [2][WIN][256]
-    float* erec = rg_smem + 2 * WIN * 256;                                            // [MAXE][REC]
-    unsigned short* emap = reinterpret_cast<unsigned short*>(erec + MAXE * RG_REC);   // [GS * P * P]: entry -> ROI | ph << 7 | pw << 11
+    float (*stage)[RG_WIN][256] = reinterpret_cast<float (*)[RG_WIN][256]>(rg_smem);   // [2][32][256]: 64 KB
+    float* erec = rg_smem + 2 * RG_WIN * 256;                                         // [MAXE][REC]: 36 KB
+    unsigned short* emap = reinterpret_cast<unsigned short*>(erec + RG_MAXE * RG_REC);   // [GS * P * P]: entry -> ROI | ph << 7 | pw << 11
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // work order: region (centre first) slowest, then ROI group, then channel slice
@@ -950,19 +938,19 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
     const int total = (CIM_ROI_RG_EXP == 6) ? 0 : d_base[RG_GS];
 
     // loader role of this thread inside a staging window: entry le = tid / 32, two float4 of the slice's 64
-    const int le = WIN != 16 ? tid >> 5 : tid >> 6, lq = WIN != 16 ? (tid & 31) * 2 : (tid & 63);
+    const int le = RG_WIN == 32 ? tid >> 5 : tid >> 6, lq = RG_WIN == 32 ? (tid & 31) * 2 : (tid & 63);
     const int cbase = slice * 256;
     // consumer role: lane's 4 channels of the slice
     const int my_touch = (7 << (RG_SBH * wr)) | ((15 << (RG_SBW * wc)) << 16);
 
-    for (int w0 = 0; w0 < total; w0 += MAXE) {
+    for (int w0 = 0; w0 < total; w0 += RG_MAXE) {
         __syncthreads();                                   // previous super-window fully consumed
         // ---- entry records of [w0, w0 + MAXE): 4 threads per entry, each 3 rows of wy and 4 columns of wx
         {
             const int e = tid >> 2, part = tid & 3;
             const int ge = w0 + e;
             int rm = 0, cm = 0;
-            if (ge < total && e < MAXE) {
+            if (ge < total) {
                 const int code = emap[ge];
                 const int lo = code & 127, ph = (code >> 7) & 15, pw = code >> 11;
                 const int k = kgroup * RG_GS + lo;
@@ -992,34 +980,29 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
             }
             rm |= __shfl_xor(rm, 1); rm |= __shfl_xor(rm, 2);
             cm |= __shfl_xor(cm, 1); cm |= __shfl_xor(cm, 2);
-            if (ge < total && e < MAXE && part == 0) reinterpret_cast<int*>(erec + e * RG_REC)[2] = rm | (cm << 16);
+            if (ge < total && part == 0) reinterpret_cast<int*>(erec + e * RG_REC)[2] = rm | (cm << 16);
         }
         __syncthreads();
-        const int n = min(MAXE, total - w0);
-        const int nwin = (CIM_ROI_RG_EXP == 3 || CIM_ROI_RG_EXP == 5) ? 0 : (n + WIN - 1) / WIN;
+        const int n = min(RG_MAXE, total - w0);
+        const int nwin = (CIM_ROI_RG_EXP == 3 || CIM_ROI_RG_EXP == 5) ? 0 : (n + RG_WIN - 1) / RG_WIN;
         // ---- software pipeline over the staging windows: the next window's loads are in flight while this one is consumed
         // (two windows in flight - a second register set - measured no faster: 0.213 vs 0.207 ms)
         struct Regs { float4 r0, r1, h0, h1; float m; };
         auto gload = [&](Regs& R, int win) {
-            const int e = win * WIN + le;
+            const int e = win * RG_WIN + le;
             R.r0 = R.r1 = R.h0 = R.h1 = make_float4(0.f, 0.f, 0.f, 0.f);
             R.m = 0.0f;
-            const int c0 = min(cbase + lq * 4, C - 4), c1 = min(cbase + lq * 4 + 4, C - 4);
             if (e < n && CIM_ROI_RG_EXP != 2) {
                 const float* rr = erec + e * RG_REC;
                 const int off = reinterpret_cast<const int*>(rr)[0];
+                const int c0 = min(cbase + lq * 4, C - 4), c1 = min(cbase + lq * 4 + 4, C - 4);
                 R.r0 = *reinterpret_cast<const float4*>(grad_out + off + c0);
-                if (WIN != 16) R.r1 = *reinterpret_cast<const float4*>(grad_out + off + c1);
+                if (RG_WIN == 32) R.r1 = *reinterpret_cast<const float4*>(grad_out + off + c1);
                 if (MASKCAT) {
                     R.h0 = *reinterpret_cast<const float4*>(grad_out + off + C + c0);
-                    if (WIN != 16) R.h1 = *reinterpret_cast<const float4*>(grad_out + off + C + c1);
+                    if (RG_WIN == 32) R.h1 = *reinterpret_cast<const float4*>(grad_out + off + C + c1);
                     R.m = rr[1];
                 }
-            }
-            if (WIDE && !MASKCAT && e + 32 < n && CIM_ROI_RG_EXP != 2) {       // the window's second half: entry le + 32 in the h registers
-                const int off = reinterpret_cast<const int*>(erec + (e + 32) * RG_REC)[0];
-                R.h0 = *reinterpret_cast<const float4*>(grad_out + off + c0);
-                R.h1 = *reinterpret_cast<const float4*>(grad_out + off + c1);
             }
         };
         auto put = [&](const Regs& R, int buf) {
@@ -1030,18 +1013,13 @@ __global__ __launch_bounds__(RG_NT) void roi_align_bwd_region_kernel(const float
             }
             float* sb = &stage[buf][le][lq * 4];
             *reinterpret_cast<float4*>(sb) = a;
-            if (WIN != 16) *reinterpret_cast<float4*>(sb + 4) = c;
-            if (WIDE && !MASKCAT) {
-                float* sb2 = &stage[buf][(le + 32) % WIN][lq * 4];
-                *reinterpret_cast<float4*>(sb2) = R.h0;
-                *reinterpret_cast<float4*>(sb2 + 4) = R.h1;
-            }
+            if (RG_WIN == 32) *reinterpret_cast<float4*>(sb + 4) = c;
         };
         auto consume = [&](int buf, int win) {
             // entries of the window whose bin touches this wave's sub-block
-            const int e0 = win * WIN;
+            const int e0 = win * RG_WIN;
             int t = 0;
-            if (lane < WIN && e0 + lane < n) t = reinterpret_cast<const int*>(erec + (e0 + lane) * RG_REC)[2];
+            if (lane < RG_WIN && e0 + lane < n) t = reinterpret_cast<const int*>(erec + (e0 + lane) * RG_REC)[2];
             const bool hit = ((t & my_touch & 0xffff) != 0) && (((t & my_touch) >> 16) != 0);
             unsigned long long todo = __ballot(hit);
             if (CIM_ROI_RG_EXP == 1) todo = 0;
@@ -1245,7 +1223,7 @@ static int launch_bwd_region(const float* go, const float* rois, const float* ma
         if (e != hipSuccess) return (int)e;
     }
     auto kern = GS == 128 ? roi_align_bwd_region_kernel<MASKCAT, 128> : roi_align_bwd_region_kernel<MASKCAT, 64>;
-    const size_t lds = rg_lds_bytes<MASKCAT>(GS, P);
+    const size_t lds = rg_lds_bytes(GS, P);
     hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) return (int)ea;
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_slices * B * groups * n_regions)), dim3(RG_NT), lds, st, go, masks, gin, C, H, W, K, P, B,
@@ -1265,7 +1243,7 @@ int launch_bwd(const float* go, const float* rois, const float* masks, float* gi
     // (With several ROI groups and no partial-map scratch the groups meet through atomicAdd: slow, but every entry point works.)
     if (K > 0 && ws != nullptr && C % 4 == 0 && P <= 16 && H < 256 && W < 256 &&
         (long long)K * P * P * (MASKCAT ? 2 : 1) * C < (1ll << 31) &&
-        rg_lds_bytes<MASKCAT>(rg_group_size(K, B, C, H, W), P) <= 158 * 1024 && ((H + RG_RH - 1) / RG_RH) * ((W + RG_RW - 1) / RG_RW) <= RG_MAXREG &&
+        rg_lds_bytes(rg_group_size(K, B, C, H, W), P) <= 158 * 1024 && ((H + RG_RH - 1) / RG_RH) * ((W + RG_RW - 1) / RG_RW) <= RG_MAXREG &&
         (long long)B * ((K + 63) / 64) * ((C + 255) / 256) * RG_MAXREG < (1ll << 31))
         return launch_bwd_region<MASKCAT>(go, rois, masks, gin, B, C, H, W, K, P, scale, sr, aligned, ws, st, tables_ready, scratch);
     // generic form (odd channel counts, no workspace, maps beyond the region form's limits): one thread per output element,
