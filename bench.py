@@ -642,7 +642,9 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
         hbm.append(dict(kernel="cim_roi_align_wino7_pair_fwd (ROIAlign + mask multiply + concat + Winograd 4+3 input transform: the conv "
                                "input `cat` is never stored; replaces cim_roi_align_maskcat_fwd_ws + cim_wino7_input_pair)",
                         bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, ms=tot_ms / len(ls),
-                        launches=len(ls), algorithmic_bytes=tot_b / len(ls), traffic=None,
+                        launches=len(ls), algorithmic_bytes=tot_b / len(ls),
+                        traffic=(pmc["cim_roi_align_wino7_pair_fwd"]["hbm_bytes_mean"] if pmc_ok and pmc.get("cim_roi_align_wino7_pair_fwd") else None),
+                        traffic_source=(pmc["_source"] if pmc_ok and pmc.get("cim_roi_align_wino7_pair_fwd") else None),
                         algorithmic_bytes_note="feature map + rois + masks in, pair image [121][N padded to 32][2 Cf] x 4 B out",
                         survey_8d=dict(algorithmic_bytes=tot_8d / len(ls), frac=tot_8d / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        note="SURVEY.md 8(d)'s formula prices an operator that writes `cat` (4 N 2Cf 49 bytes); this "
@@ -661,7 +663,10 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
         hbm.append(dict(kernel="cim_roi_align_bwd_ws (ROIAlign backward on dbox [N,7,7,Cf]: the mask multiply + concat backward is folded into "
                                "cim_wino7_dx_maskfold, which writes dbox instead of dcat [N,7,7,2Cf])",
                         bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, ms=tot_ms / len(ls),
-                        launches=len(ls), algorithmic_bytes=tot_b / len(ls), traffic=None,
+                        launches=len(ls), algorithmic_bytes=tot_b / len(ls),
+                        traffic=(pmc["cim_roi_align_bwd"]["hbm_bytes_mean"] + pmc.get("roi_partial_reduce", {}).get("hbm_bytes_mean", 0.0)
+                                 if pmc_ok and pmc.get("cim_roi_align_bwd") else None),
+                        traffic_source=(pmc["_source"] if pmc_ok and pmc.get("cim_roi_align_bwd") else None),
                         survey_8d=dict(algorithmic_bytes=tot_8d / len(ls), frac=tot_8d / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        note="SURVEY.md 8(d)'s backward reads dcat (4 N 2Cf 49 bytes); this launch reads half of that - the "
                                             "same gradient, combined upstream - so its own algorithmic bytes are 4 (Cf Hf Wf + 5N + 49 N Cf)")))

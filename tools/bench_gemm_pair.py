@@ -80,10 +80,16 @@ def zi(n):
     return torch.zeros(n, dtype=torch.int32, device=dev)
 
 
+def xlib():
+    """the superseded f16x2 engine (experiments/libcim_exp.so): the comparison rows of this table"""
+    from experiments import _lib as _x
+    return _x.load()
+
+
 def _amax(x, rows, cols, ld, want_rows, want_cols, batch=1, bs=0):
     ra = zi(batch * rows) if want_rows else None
     ca = zi(batch * cols) if want_cols else None
-    assert lib.cim_amax_rowcol(P(x), rows, cols, ld, batch, bs, _lib.ptr(ra), _lib.ptr(ca), st) == 0
+    assert xlib().cim_amax_rowcol(P(x), rows, cols, ld, batch, bs, _lib.ptr(ra), _lib.ptr(ca), st) == 0
     return ra, ca
 
 
@@ -112,13 +118,13 @@ if not args.no_old:
     xr, xc = _amax(xf, NP, K1, K1, True, True)
     wr, wc = _amax(w1, 4096, K1, K1, True, True)
     dr, dc = _amax(dyf, NP, 4096, 4096, True, True)
-    so = lambda m, n, k: min(lib.cim_gemm_f16x2_splits(m, n, k), 16)
-    cases["f16x2 wino_fwd"] = (lambda: lib.cim_gemm_f16x2_batched(P(V), P(U), P(M), N, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, NP * 2 * C, 2 * C * C, N * C, P(Vr), P(Uc), st), fl_conv)
-    cases["f16x2 wino_dgrad"] = (lambda: lib.cim_gemm_f16x2_batched(P(D), P(U), P(M2), N, 2 * C, C, C, C, 2 * C, 0, 1, NPOS, NP * C, 2 * C * C, N * 2 * C, P(Dr), P(Ur), st), fl_conv)
-    cases["f16x2 wino_wgrad"] = (lambda: lib.cim_gemm_f16x2_batched(P(V), P(D), P(dU), 2 * C, C, N, 2 * C, C, C, 1, 0, NPOS, NP * 2 * C, NP * C, 2 * C * C, P(Vc), P(Dc), st), fl_conv)
-    cases["f16x2 fc1_fwd"] = (lambda: lib.cim_gemm_f16x2(P(xf), P(w1), P(y1), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, so(N, 4096, K1), P(ws), P(xr), P(wr), st), fl_fc)
-    cases["f16x2 fc1_dgrad"] = (lambda: lib.cim_gemm_f16x2(P(dyf), P(w1), P(dx1), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, 1, None, P(dr), P(wc), st), fl_fc)
-    cases["f16x2 fc1_wgrad"] = (lambda: lib.cim_gemm_f16x2(P(dyf), P(xf), P(dw1), None, 4096, K1, N, 4096, K1, K1, 1, 0, 0, 1, None, P(dc), P(xc), st), fl_fc)
+    so = lambda m, n, k: min(xlib().cim_gemm_f16x2_splits(m, n, k), 16)
+    cases["f16x2 wino_fwd"] = (lambda: xlib().cim_gemm_f16x2_batched(P(V), P(U), P(M), N, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, NP * 2 * C, 2 * C * C, N * C, P(Vr), P(Uc), st), fl_conv)
+    cases["f16x2 wino_dgrad"] = (lambda: xlib().cim_gemm_f16x2_batched(P(D), P(U), P(M2), N, 2 * C, C, C, C, 2 * C, 0, 1, NPOS, NP * C, 2 * C * C, N * 2 * C, P(Dr), P(Ur), st), fl_conv)
+    cases["f16x2 wino_wgrad"] = (lambda: xlib().cim_gemm_f16x2_batched(P(V), P(D), P(dU), 2 * C, C, N, 2 * C, C, C, 1, 0, NPOS, NP * 2 * C, NP * C, 2 * C * C, P(Vc), P(Dc), st), fl_conv)
+    cases["f16x2 fc1_fwd"] = (lambda: xlib().cim_gemm_f16x2(P(xf), P(w1), P(y1), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, so(N, 4096, K1), P(ws), P(xr), P(wr), st), fl_fc)
+    cases["f16x2 fc1_dgrad"] = (lambda: xlib().cim_gemm_f16x2(P(dyf), P(w1), P(dx1), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, 1, None, P(dr), P(wc), st), fl_fc)
+    cases["f16x2 fc1_wgrad"] = (lambda: xlib().cim_gemm_f16x2(P(dyf), P(xf), P(dw1), None, 4096, K1, N, 4096, K1, K1, 1, 0, 0, 1, None, P(dc), P(xc), st), fl_fc)
 if args.only:
     keep = args.only.split(",")
     cases = {k: v for k, v in cases.items() if any(s in k for s in keep)}

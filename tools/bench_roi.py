@@ -42,6 +42,18 @@ fwd = lambda: _lib.call("cim_roi_align_maskcat_fwd_ws", feat.data_ptr(), rois.da
 bwd = lambda: _lib.call("cim_roi_align_maskcat_bwd", gcat.data_ptr(), rois.data_ptr(), masks.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
 nbytes = 4.0 * (C * H * W + 5 * K + 49 * K) + 4.0 * K * 2 * C * 49
 tf, tb = timeit(fwd), timeit(bwd)
+# what the training step runs since round 5: the forward that writes the Winograd input pair image, the plain backward on dbox
+from cim_amd.ops import maskfuse_pair, pair  # noqa: E402
+rp = pair.pad32(K)
+sV = maskfuse_pair._input_scales(pair.amax_of(feat), dev)
+V = torch.empty(121, rp, 2 * C, dtype=torch.int32, device=dev)
+gbox = torch.randn(K, 7, 7, C, device=dev)
+scratch = torch.empty(_lib.call("cim_roi_align_bwd_scratch", K, 1, C, H, W) // 4 + 1, device=dev)
+fwdw = lambda: _lib.call("cim_roi_align_wino7_pair_fwd", feat.data_ptr(), rois.data_ptr(), masks.data_ptr(), V.data_ptr(), sV.data_ptr(), 1, C, H, W, K, rp, 7, 1.0 / stride, 0, 1, ws.data_ptr(), st)
+bwdp = lambda: _lib.call("cim_roi_align_bwd_ws", gbox.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, C, H, W, K, 7, 1.0 / stride, 0, 1, ws.data_ptr(), 0, scratch.data_ptr(), st)
+tfw, tbp = timeit(fwdw), timeit(bwdp)
+wbytes = 4.0 * (C * H * W + 5 * K + 49 * K) + 4.0 * 121 * rp * 2 * C
+pbytes = 4.0 * (C * H * W + 5 * K) + 4.0 * K * C * 49
 import ctypes, glob
 for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):     # ALT builds (ablations)
     alt = ctypes.CDLL(path)
@@ -53,4 +65,6 @@ for path in sorted(glob.glob(os.path.join(_lib.HERE, "libcim_hip_alt*.so"))):   
     f(); torch.cuda.synchronize()
     print(os.path.basename(path), "fwd_ms %.4f bwd_ms %.4f  max |fwd - base| %.3g" % (timeit(f), timeit(bw), float((cat - ref_cat).abs().max())))
 print(json.dumps(dict(config=cfgname, K=K, C=C, H=H, W=W, alg_MB=nbytes / 1e6, fwd_ms=tf, fwd_frac=nbytes / tf / 1e6 / 8000,
-                      bwd_ms=tb, bwd_frac=nbytes / tb / 1e6 / 8000)))
+                      bwd_ms=tb, bwd_frac=nbytes / tb / 1e6 / 8000,
+                      wino7_pair_fwd_ms=tfw, wino7_pair_fwd_alg_MB=wbytes / 1e6, wino7_pair_fwd_frac=wbytes / tfw / 1e6 / 8000,
+                      plain_bwd_ms=tbp, plain_bwd_alg_MB=pbytes / 1e6, plain_bwd_frac=pbytes / tbp / 1e6 / 8000)))

@@ -17,9 +17,10 @@ import json
 import sys
 
 # product kernels -> the key bench.py looks up
-KEYS = (("gemm_pair_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_f16x2_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_bf16x3_kernel<0, 0>", "wino_gemm_fwd"), ("gemm_f32_kernel<0, 0>", "wino_gemm_fwd"),
+KEYS = (("gemm_pair_kernel<0, 0, false>", "wino_gemm_fwd"), ("gemm_pair_kernel<0, 0>", "wino_gemm_fwd"),
+        ("roi_align_wino7_pair", "cim_roi_align_wino7_pair_fwd"), ("wino7_dx_maskfold", "wino7_dx_maskfold"),
         ("roi_align_fwd_rowsum", "cim_roi_align_maskcat_fwd"), ("roi_align_fwd_agg", "cim_roi_align_maskcat_fwd"),
-        ("roi_align_bwd_region", "cim_roi_align_maskcat_bwd"), ("roi_align_bwd_gather", "cim_roi_align_maskcat_bwd"),
+        ("roi_align_bwd_region_kernel<false", "cim_roi_align_bwd"), ("roi_align_bwd_region", "cim_roi_align_maskcat_bwd"),
         ("roi_partial_reduce", "roi_partial_reduce"), ("mask_iou_pair", "mask_iou_pair"), ("mask_pack", "mask_pack"),
         ("sgd_multi", "sgd_multi"), ("gemm_small_kernel", "backbone_conv1x1"))
 

@@ -27,7 +27,7 @@ rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d /tmp/pmc_mfma -o r -- 
 python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_mfma gemm_pair_kernel > "$OUT/pmc_mfma_gemm_pair.json"
 SQR="SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE"
 rocprofv3 --kernel-trace --pmc $SQR --output-format csv -d /tmp/pmc_roi -o r -- python3 "$ROOT/tools/bench_roi.py" > "$OUT/pmc_roi.log" 2>&1
-python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_roi roi_align roi_partial roi_tables > "$OUT/pmc_sq_roi_align.json"
+python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_roi roi_align roi_partial roi_tables wino7 > "$OUT/pmc_sq_roi_align.json"
 rocprofv3 --kernel-trace --pmc $SQR --output-format csv -d /tmp/pmc_roib -o r -- python3 "$ROOT/tools/bench_roi_bwd.py" > "$OUT/pmc_roib.log" 2>&1
 python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_roib roi_align_bwd roi_partial > "$OUT/pmc_sq_roi_align_bwd.json"
 python3 "$ROOT/tools/bench_gemm_pair.py" --no-old --json "$OUT/gemm_pair_ablation.json" > "$OUT/gemm_pair_ablation.txt" 2>&1
@@ -37,6 +37,8 @@ done > "$OUT/bench_other_configs.json"
 python3 "$ROOT/bench.py" --fixed-image --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > "$OUT/bench_fixed_image.json"
 python3 "$ROOT/tools/bench_roi_bwd.py" 2>/dev/null | grep "^{" > "$OUT/bench_roi_bwd.json"
 python3 "$ROOT/tools/bench_roi.py" 2>/dev/null | tail -1 > "$OUT/bench_roi.json"
+python3 "$ROOT/tools/bench_mining.py" > "$OUT/bench_mining.txt" 2>&1
+python3 "$ROOT/tools/bench_mining.py" --config resnet50_coco2017 >> "$OUT/bench_mining.txt" 2>&1
 python3 "$ROOT/tools/bench_conv3x3.py" 2>/dev/null | grep "^{" > "$OUT/bench_conv3x3.json"
 python3 "$ROOT/tools/bench_gemm_small.py" 2>/dev/null | grep "^{" > "$OUT/bench_gemm_small.json"
 (cd "$ROOT" && python3 -m pytest tests/test_gpu_tolerance.py tests/test_gpu_fullsize.py -q -m gpu > "$OUT/parity_tests.log" 2>&1; cp gpurun_out/parity_deviation.json "$OUT/parity_deviation.json" 2>/dev/null)
