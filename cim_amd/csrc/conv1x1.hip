@@ -595,7 +595,13 @@ extern "C" int cim_gemm_small_splits(int M, int N, int K) {
     const long long tiles = (long long)((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
     // (sweep, tools/bench_gemm_small.py, us over 7 layer shapes forward / dX / dW: 157 / 136 / 182 with these limits; 2 slabs
     // per workgroup or up to 768-1024 workgroups: 188 / 178 / 219 - more partial products than the latency chain gains)
-    constexpr int min_k = 4 * SBK, want = 512;
+#ifndef CIM_SMALL_WGS
+#define CIM_SMALL_WGS 512          // (compile-time sweep switch, tools/build_alt.sh)
+#endif
+#ifndef CIM_SMALL_MINSLABS
+#define CIM_SMALL_MINSLABS 4
+#endif
+    constexpr int min_k = CIM_SMALL_MINSLABS * SBK, want = CIM_SMALL_WGS;
     int s = 1;
     while (tiles * s < want && K / (s * 2) >= min_k && s < 64) s *= 2;
     return s;

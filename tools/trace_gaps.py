@@ -16,7 +16,7 @@ path = sys.argv[1]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "roi_align_fwd" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if ("roi_align_fwd" in r["Kernel_Name"] or "roi_align_wino7_pair" in r["Kernel_Name"])]
 # one full step: from the optimizer launch before the second-last ROIAlign forward to the one before the last
 opt = [i for i, r in enumerate(rows) if "sgd_multi_kernel" in r["Kernel_Name"] or "multi_tensor_apply" in r["Kernel_Name"]]
 a = max(i for i in opt if i < marks[-2])

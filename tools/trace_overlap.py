@@ -9,7 +9,7 @@ import sys
 path, pat = sys.argv[1], sys.argv[2]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "roi_align_fwd" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if ("roi_align_fwd" in r["Kernel_Name"] or "roi_align_wino7_pair" in r["Kernel_Name"])]
 sel = rows[marks[-1]:]
 t0 = int(sel[0]["Start_Timestamp"])
 for r in sel:

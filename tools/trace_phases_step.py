@@ -30,7 +30,7 @@ def last(pat):
 
 marks = [("optimizer", 0, 0)]
 i_tab = first("roi_tables")
-i_fwd = last("roi_align_fwd")
+i_fwd = last("roi_align_wino7_pair") if last("roi_align_wino7_pair") is not None else last("roi_align_fwd")
 i_loss = first("losses_kernel")
 i_seed = first("step_mine_kernel")
 i_rb0 = first("roi_align_bwd")

@@ -28,7 +28,7 @@ def product_name(r):
         wgs = g // max(w, 1)
     if wgs % 121 == 0:
         per = wgs // 121
-        tag = "Winograd forward" if "<0, 0>" in name else "Winograd data gradient" if "<0, 1>" in name else "Winograd weight gradient"
+        tag = "Winograd forward" if "<0, 0" in name else "Winograd data gradient" if "<0, 1" in name else "Winograd weight gradient"
         return "%s [%s GEMM: 121 x %d tiles]" % (name, tag, per)
     if wgs == 256:
         return "%s [late weight-gradient chunk: 256 workgroups]" % name
@@ -39,7 +39,7 @@ def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "roi_align_fwd" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if ("roi_align_fwd" in r["Kernel_Name"] or "roi_align_wino7_pair" in r["Kernel_Name"])]
     assert len(marks) >= steps, "fewer ROIAlign forwards than steps in the trace"
     # the backbone forward precedes ROIAlign inside a step: start at the end of the previous step's last kernel,
     # i.e. right after the optimizer's last dispatch before the first timed ROIAlign -> use the previous ROIAlign
