@@ -23,6 +23,11 @@ the only collective is the gradient all-reduce:
     with gradient accumulation (`--iter_size k`, train.py:420) set `iter_size=k` (or CIM_ITER_SIZE=k) and only the
     k-th backward after `zero_grad()` communicates (leaving it at 1 is still correct - averaging is linear - but
     reduces k times);
+  * gradients that do NOT come through autograd - the backbone's convolution weights (side stream, ops/gemm.py) and the gamma /
+    beta of chained BatchNorm layers (bn1 / bn2 of a bottleneck, finished by ONE launch at the end of the pass, ops/chain.py) -
+    fire no hook: the buckets that hold them go out at the forced flush at the end of backward.  Every backbone bucket holds
+    deferred convolution weights, and the backbone's buckets are the LAST ones in the strict issue order, so the affine
+    parameters hold nothing back that was not waiting already (tests/test_gpu_dp.py checks each of them is the ranks' mean);
   * construction broadcasts rank 0's parameters and buffers (a per-rank checkpoint load or a nondeterministic
     initialisation cannot make the replicas diverge silently).
 """

@@ -158,7 +158,7 @@ def _worker(rank, world, port, backend, out):
     for (n, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
         assert torch.equal(a, b), "parameter %s was not broadcast from rank 0" % n
     assert any("tensor" in b for b in dp.buckets) and len(dp.buckets) > 3
-    checks = []
+    checks, affine = [], []
     for step in range(2):                                # two steps: a different image per rank AND per step
         batch = _small_batch(10 * step + rank, n=40 + 8 * rank, dev=dev)
         # local gradient of this rank's image on an unwrapped copy
@@ -177,9 +177,26 @@ def _worker(rank, world, port, backend, out):
         got = _flat_grads(model)
         torch.cuda.synchronize()
         checks.append((float((got - mean).norm() / mean.norm()), float((local - mean).norm() / mean.norm())))
+        # the gamma / beta gradients of chained BatchNorm layers (bn1, bn2 of a bottleneck) do not come through autograd: they
+        # are installed at the end of the backward pass (ops/conv1x1.py: finish_affine) like the deferred weight gradients, and
+        # go out with the backbone's bucket at the forced flush - each of them must be the MEAN over the ranks, on every rank
+        off = 0
+        for (name, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            if not p.requires_grad:
+                continue
+            n = p.numel()
+            if (".bn1." in name or ".bn2." in name) and name.startswith("Conv_Body.res"):
+                m, l, g = mean[off:off + n], local[off:off + n], got[off:off + n]
+                affine.append((name, float((g - m).abs().max() / m.abs().max().clamp(min=1e-20)),
+                               float((l - m).abs().max() / m.abs().max().clamp(min=1e-20))))
+            off += n
+        mine = got.cpu() if backend == "gloo" else got
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert torch.equal(both[0], both[1]), "the ranks hold different gradients after the reduction"
         heads.settle_rng()
     if rank == 0:
-        torch.save(checks, out)
+        torch.save(dict(checks=checks, affine=affine), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -190,9 +207,15 @@ def test_two_ranks_real_model(tmp_path, backend):
         pytest.skip("RCCL test needs >= 2 GPUs (this box has %d)" % torch.cuda.device_count())
     out = str(tmp_path / "checks.pt")
     mp.spawn(_worker, args=(2, _free_port(), backend, out), nprocs=2, join=True)
-    for err, spread in torch.load(out):
+    r = torch.load(out)
+    for err, spread in r["checks"]:
         assert spread > 1e-2, "the two ranks' gradients should differ (different images)"
         assert err < 2e-3, "all-reduced gradient differs from the mean of the per-rank gradients: %.3g" % err
+    # chained BatchNorm affine gradients (installed at the end of the pass, not by autograd) are all-reduced too
+    assert len(r["affine"]) >= 2 * 2 * (4 + 6), len(r["affine"])          # 2 steps x (bn1, bn2) x (weight, bias) x res3 + res4 blocks
+    for name, err, spread in r["affine"]:
+        assert err < 5e-3, "%s: all-reduced gradient is not the mean of the ranks' gradients (%.3g)" % (name, err)
+    assert max(sp for _, _, sp in r["affine"]) > 1e-2, "the ranks' BatchNorm affine gradients should differ before the reduction"
 
 
 def _schedule_worker(rank, world, port, ref_path, out):
