@@ -87,6 +87,13 @@ __device__ __forceinline__ void w7_store_pair(float*, float, float) {}
 #ifndef CIM_W7_VOUT
 #define CIM_W7_VOUT 4           // output transform M -> y      (2 | 4)
 #endif
+#ifndef CIM_W7_VMF
+#define CIM_W7_VMF 1            // mask-folding adjoint output   Md -> dbox    (1 | 2): one channel per lane keeps both halves'
+                                // transforms at ~120 VGPRs (two per lane: 314, one wave per SIMD - 0.266 vs 0.235 ms at cfg2)
+#endif
+#ifndef CIM_W7_MF_WAVES
+#define CIM_W7_MF_WAVES 1       // register cap of that kernel: waves per SIMD the compiler must allow
+#endif
 #ifndef CIM_W7_VDX
 #define CIM_W7_VDX 2            // adjoint output   Md -> dx    (1 | 2 | 4)
 #endif
@@ -202,19 +209,6 @@ __device__ __forceinline__ void w7_input_tile(const float* __restrict__ x, float
     }
 }
 
-// grid = (R, 4 tile types); block = 256 (CIM_W7_VIN channels per lane)
-template <bool AMAX>
-__global__ __launch_bounds__(256) void wino7_input_kernel(const float* __restrict__ x, float* __restrict__ V, int R, int C,
-                                                          unsigned* __restrict__ row_amax) {
-    const int r = blockIdx.x;
-    switch (blockIdx.y) {
-        case 0: w7_input_tile<0, 0, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
-        case 1: w7_input_tile<0, 1, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
-        case 2: w7_input_tile<1, 0, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
-        default: w7_input_tile<1, 1, AMAX, CIM_W7_VIN>(x, V, r, R, C, row_amax); break;
-    }
-}
-
 // zero rows of a pair image: positions [q0, q0 + nq) of row r (the rows that pad R up to a multiple of 32)
 __device__ __forceinline__ void w7_zero_rows(float* __restrict__ V, int q0, int nq, int r, int Rs, int C) {
     for (int q = q0; q < q0 + nq; ++q)
@@ -286,41 +280,6 @@ __global__ __launch_bounds__(256) void wino7_filter_pair_kernel(const float* __r
     w7_filter_pair_tile<0, 1>(w, U, KN, idx, scale, src_a, src_b, j < 4);
     w7_filter_pair_tile<1, 0>(w, U, KN, idx, scale, src_a, src_b, j < 4);
     w7_filter_pair_tile<1, 1>(w, U, KN, idx, scale, src_a, src_b, j < 4);
-}
-
-template <int KA, int KB>
-__device__ __forceinline__ void w7_filter_tile(const float (&w)[3][3], float* __restrict__ U, size_t KN, size_t idx) {
-    constexpr int NA = W7::NP[KA], NB = W7::NP[KB], Q0 = W7::QOFF[KA * 2 + KB];
-    float t[NA][3];
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) t[i][b] = W7_G[KA][i][0] * w[0][b] + W7_G[KA][i][1] * w[1][b] + W7_G[KA][i][2] * w[2][b];
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            w7_store(U + (size_t)(Q0 + i * NB + j) * KN + idx, t[i][0] * W7_G[KB][j][0] + t[i][1] * W7_G[KB][j][1] + t[i][2] * W7_G[KB][j][2]);
-}
-
-__global__ __launch_bounds__(256) void wino7_filter_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout,
-                                                           int Cin, int mode) {
-    const int Kd = mode ? Cout : Cin, Nd = mode ? Cin : Cout;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)Kd * Nd) return;
-    const int k = (int)(idx / Nd), n = (int)(idx % Nd);
-    const int co = mode ? k : n, ci = mode ? n : k;
-    const float* g = W + ((size_t)co * Cin + ci) * 9;
-    float w[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) w[a][b] = mode ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
-    const size_t KN = (size_t)Kd * Nd;
-    w7_filter_tile<0, 0>(w, U, KN, idx);
-    w7_filter_tile<0, 1>(w, U, KN, idx);
-    w7_filter_tile<1, 0>(w, U, KN, idx);
-    w7_filter_tile<1, 1>(w, U, KN, idx);
 }
 
 template <int KA, int KB, int VW>
@@ -454,18 +413,6 @@ __device__ __forceinline__ void w7_dy_tile(const float* __restrict__ dy, float* 
     }
 }
 
-template <bool ADJ, bool AMAX>
-__global__ __launch_bounds__(256) void wino7_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int C,
-                                                       unsigned* __restrict__ row_amax) {
-    const int r = blockIdx.x;
-    switch (blockIdx.y) {
-        case 0: w7_dy_tile<0, 0, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
-        case 1: w7_dy_tile<0, 1, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
-        case 2: w7_dy_tile<1, 0, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
-        default: w7_dy_tile<1, 1, ADJ, AMAX>(dy, D, r, R, C, row_amax); break;
-    }
-}
-
 // dy [R][7][7][C] fp32 -> pair image D / E [121][Rs][C]; grid = (Rs, 4)
 template <bool ADJ>
 __global__ __launch_bounds__(256) void wino7_dy_pair_kernel(const float* __restrict__ dy, float* __restrict__ D, int R, int Rs,
@@ -567,9 +514,9 @@ __global__ __launch_bounds__(256) void wino7_dx_kernel(const float* __restrict__
 // A lane transforms channel c of the MASKED half first (all four tile types into the 49 accumulators), scales by the ROI's 7 x 7
 // mask, then accumulates the plain half on top: dbox [R,7,7,Cb] is written instead of dcat [R,7,7,2Cb] - half the bytes out of
 // this launch and half the bytes into the ROIAlign backward (which re-reads them 1.5x).  grid = (R, chunks); block = 256.
-__global__ __launch_bounds__(256) void wino7_dx_maskfold_kernel(const float* __restrict__ M, const float* __restrict__ masks,
+__global__ __launch_bounds__(256, CIM_W7_MF_WAVES) void wino7_dx_maskfold_kernel(const float* __restrict__ M, const float* __restrict__ masks,
                                                                 float* __restrict__ dbox, int R, int Cb) {
-    constexpr int VW = CIM_W7_VDX;
+    constexpr int VW = CIM_W7_VMF;
     typedef typename w7_vec<VW>::T VT;
     const int r = blockIdx.x;
     const size_t C2 = 2 * (size_t)Cb, MC = (size_t)R * C2;
@@ -658,26 +605,6 @@ __global__ __launch_bounds__(256) void wino7_wgrad_out_kernel(const float* __res
 #pragma unroll
             for (int b = 0; b < 3; ++b) dst[a * 3 + b] = vget(acc[a][b], l);
     }
-}
-
-// column-scale bounds for the 121 positions (see wino43_bound_kernel): kind 0: B^T (input), 1: G (filter), 2: GD (dy).
-// grid = (ceil(n / 256), 121): one thread per (column, position)
-__global__ __launch_bounds__(256) void wino7_bound_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n,
-                                                          int group, int kind) {
-    const int i = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
-    if (i >= n) return;
-    const int type = q < 36 ? 0 : q < 66 ? 1 : q < 96 ? 2 : 3;
-    const int ka = type >> 1, kb = type & 1, nb = kb ? 5 : 6, pl = q - W7::QOFF[type];
-    const int pi = pl / nb, pj = pl % nb;
-    float fa = 0.0f, fb = 0.0f;
-    const int len = kind == 0 ? 6 : kind == 1 ? 3 : 4;
-    for (int t = 0; t < len; ++t) {
-        fa += fabsf(kind == 0 ? W7_BT[ka][pi][t] : kind == 1 ? W7_G[ka][pi][t % 3] : W7_GD[ka][pi][t % 4]);
-        fb += fabsf(kind == 0 ? W7_BT[kb][pj][t] : kind == 1 ? W7_G[kb][pj][t % 3] : W7_GD[kb][pj][t % 4]);
-    }
-    float a = 0.0f;
-    for (int t = 0; t < group; ++t) a = fmaxf(a, __uint_as_float(in[(size_t)i * group + t]));
-    out[(size_t)q * n + i] = __float_as_uint(fa * fb * a * 1.0001f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -792,7 +719,7 @@ extern "C" int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int 
 
 extern "C" int cim_wino7_dx_maskfold(const float* M, const float* masks, float* dbox, int R, int Cb, void* stream) {
     CIM_CHECK_ARG(M && masks && dbox && R > 0 && Cb > 0 && Cb % 4 == 0);
-    int chunks = (Cb + 256 * CIM_W7_VDX - 1) / (256 * CIM_W7_VDX);
+    int chunks = (Cb + 256 * CIM_W7_VMF - 1) / (256 * CIM_W7_VMF);
     if (chunks > 4) chunks = 4;
     hipLaunchKernelGGL(wino7_dx_maskfold_kernel, dim3(R, chunks), dim3(256), 0, cim::as_stream(stream), M, masks, dbox, R, Cb);
     CIM_CHECK_LAUNCH();
