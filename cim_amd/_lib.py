@@ -23,6 +23,11 @@ SIGNATURES = {
     "cim_roi_align_bwd": [_P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
     "cim_roi_align_maskcat_fwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P],
     "cim_roi_align_maskcat_bwd": [_P, _P, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P, _P],
+    "cim_maxpool2d_out_size": [c_int, c_int, c_int, c_int],
+    "cim_maxpool2d_fwd": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "cim_maxpool2d_bwd": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "cim_upsample_nearest_fwd": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "cim_upsample_nearest_bwd": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_image_prep": [_P, c_int, c_int, _P, c_int, c_int, c_longlong, c_int, ctypes.c_double, c_int, _P, _P],
     "cim_mask_pack": [_P, _P, c_int, c_int, _P],
     "cim_mask_iou_pair": [_P, c_int, c_int, _P, _P, _P, _P],
@@ -50,11 +55,11 @@ SIGNATURES = {
     "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P],
     "cim_gemm_pair_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
                               _P, _P, c_int, c_int, _P],
-    "cim_pair_scales": [_P, c_int, _P, _P, c_int, _P],
+    "cim_pair_scales": [_P, c_int, _P, _P, c_int, c_int, _P],
     "cim_pair_split": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, _P, _P, _P],
     "cim_pair_amax": [_P, c_longlong, _P, _P],
     "cim_pair_masked_stats": [_P, _P, c_int, c_int, _P, _P, _P],
-    "cim_wino7_pair_scales": [_P, c_int, _P, _P],
+    "cim_wino7_pair_scales": [_P, c_int, _P, c_int, _P, _P],
     "cim_wino7_input_pair": [_P, _P, _P, c_int, c_int, c_int, _P],
     "cim_wino7_filter_pair": [_P, _P, _P, c_int, c_int, _P],
     "cim_wino7_dy_pair": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
@@ -72,7 +77,7 @@ SIGNATURES = {
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }
 
-ABI_VERSION = 12         # cim_abi_version() of include/cim_hip.h this binding was written against
+ABI_VERSION = 13         # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 
@@ -107,12 +112,12 @@ def load():
     return lib
 
 
-VALUE_RETURNING = {"cim_mining_sync_bytes", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch"}      # return a count, not a status
+VALUE_RETURNING = {"cim_maxpool2d_out_size", "cim_mining_sync_bytes", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch"}      # return a count, not a status
 
 
 # split counts / workspace sizes of the body's layers: pure functions of their integer arguments (their tuning switches are read
 # once per process), asked ~100 times per training step with the step's few dozen layer shapes
-PURE = {"cim_gemm_small_splits", "cim_conv3x3_nchw_splits", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace",
+PURE = {"cim_maxpool2d_out_size", "cim_gemm_small_splits", "cim_conv3x3_nchw_splits", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace",
         "cim_bn_act_bwd_chunks", "cim_gemm_pair_splits"}
 _PURE_VALUES = {}
 

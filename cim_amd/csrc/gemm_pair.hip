@@ -562,10 +562,15 @@ __global__ __launch_bounds__(256) void pair_masked_stats_kernel(const float* __r
     }
 }
 __global__ void pair_scales_kernel(const unsigned* __restrict__ amax, int n_amax, const float* __restrict__ factor,
-                                   float* __restrict__ scale, int n) {
+                                   float* __restrict__ scale, int n, int reduce_all) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned bits = 0;
+    if (reduce_all) {                       // one scale source: the maximum of all words (a wave-strided pass + wave maximum)
+        for (int t = threadIdx.x & 63; t < n_amax; t += 64) bits = max(bits, amax[t] & 0x7fffffffu);
+        bits = wave_max_u32(bits);
+    }
     if (i >= n) return;
-    float a = __uint_as_float(amax[min(i, n_amax - 1)]);
+    float a = __uint_as_float(reduce_all ? bits : amax[min(i, n_amax - 1)]);
     if (factor != nullptr) a *= factor[i];
     scale[i] = pair_scale_of(__float_as_uint(a));
 }
@@ -603,8 +608,9 @@ __global__ __launch_bounds__(256) void pair_split_kernel(const float* __restrict
 }
 
 // max |x| of a dense fp32 array as a bit pattern (atomicMax into a caller-zeroed word)
-__global__ __launch_bounds__(256) void pair_amax_kernel(const float* __restrict__ X, long long n4, unsigned* __restrict__ out) {
+__global__ __launch_bounds__(256) void pair_amax_kernel(const float* __restrict__ X, long long n4, int tail, unsigned* __restrict__ out) {
     unsigned m = 0;
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) m = __float_as_uint(X[n4 * 4 + threadIdx.x]) & 0x7fffffffu;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const uint4 v = *reinterpret_cast<const uint4*>(X + i * 4);
         m = max(m, max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
@@ -724,9 +730,10 @@ extern "C" int cim_gemm_pair_batched(const void* A, const void* B, float* C, int
     return 0;
 }
 
-extern "C" int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float* scale, int n, void* stream) {
+extern "C" int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float* scale, int n, int reduce_all, void* stream) {
     CIM_CHECK_ARG(amax && scale && n > 0 && n_amax > 0);
-    hipLaunchKernelGGL(pair_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax, n_amax, factor, scale, n);
+    hipLaunchKernelGGL(pair_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, cim::as_stream(stream), amax, n_amax, factor, scale, n,
+                       reduce_all);
     CIM_CHECK_LAUNCH();
     return 0;
 }
@@ -751,10 +758,10 @@ extern "C" int cim_pair_masked_stats(const float* dy, const float* y, int rows, 
 }
 
 extern "C" int cim_pair_amax(const float* X, long long n, uint32_t* amax, void* stream) {
-    CIM_CHECK_ARG(X && amax && n > 0 && n % 4 == 0);
+    CIM_CHECK_ARG(X && amax && n > 0 && ((size_t)X & 15) == 0);
     const long long n4 = n / 4;
     const unsigned blocks = (unsigned)((n4 + 256 * 8 - 1) / (256 * 8) < 2048 ? (n4 + 256 * 8 - 1) / (256 * 8) : 2048);
-    hipLaunchKernelGGL(pair_amax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, cim::as_stream(stream), X, n4, amax);
+    hipLaunchKernelGGL(pair_amax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, cim::as_stream(stream), X, n4, (int)(n - n4 * 4), amax);
     CIM_CHECK_LAUNCH();
     return 0;
 }

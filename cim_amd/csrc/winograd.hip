@@ -432,9 +432,14 @@ __global__ __launch_bounds__(256) void wino7_dy_pair_kernel(const float* __restr
 
 // scale[q] = 2^(14 - exponent(bound_q)), bound_q = (abs row sum)_i (abs row sum)_j max|d| 1.0001 >= max |transformed value| at
 // position q.  kind 0: B^T (input), 1: G (filter), 2: GD (dy, weight gradient), 3: A (dy, adjoint data gradient).
-__global__ void wino7_pair_scales_kernel(const unsigned* __restrict__ amax, int kind, float* __restrict__ scale) {
+__global__ void wino7_pair_scales_kernel(const unsigned* __restrict__ amax, int n_amax, const unsigned* __restrict__ amax_mul, int kind,
+                                         float* __restrict__ scale) {
     const int q = threadIdx.x;
     if (q >= 121) return;
+    unsigned mbits = 0;                     // (non-negative floats order like their bit patterns)
+    for (int t = 0; t < n_amax; ++t) mbits = max(mbits, amax[t] & 0x7fffffffu);
+    float dmax = __uint_as_float(mbits);
+    if (amax_mul != nullptr) dmax *= fmaxf(1.0f, __uint_as_float(amax_mul[0] & 0x7fffffffu));
     const int type = q < 36 ? 0 : q < 66 ? 1 : q < 96 ? 2 : 3;
     const int ka = type >> 1, kb = type & 1, nb = kb ? 5 : 6, pl = q - W7::QOFF[type];
     const int pi = pl / nb, pj = pl % nb;
@@ -448,7 +453,7 @@ __global__ void wino7_pair_scales_kernel(const unsigned* __restrict__ amax, int 
     } else {
         for (int t = 0; t < 4; ++t) { fa += fabsf(W7_AT[ka][t][pi]); fb += fabsf(W7_AT[kb][t][pj]); }
     }
-    scale[q] = cim::pair_scale_of(__float_as_uint(fa * fb * __uint_as_float(amax[0]) * 1.0001f));
+    scale[q] = cim::pair_scale_of(__float_as_uint(fa * fb * dmax * 1.0001f));
 }
 
 // Last stage of the adjoint data gradient: dx[r, y, x, c] = sum over the four tile types of (B M B^T)[y - y0][x - x0]
@@ -727,9 +732,9 @@ extern "C" int cim_wino7_dx_maskfold(const float* M, const float* masks, float* 
 }
 
 // ---- pair-image producers of the f16x2p engine (tile = 7 geometry: 121 positions) ---------------------------------------
-extern "C" int cim_wino7_pair_scales(const uint32_t* amax, int kind, float* scale, void* stream) {
-    CIM_CHECK_ARG(amax && scale && kind >= 0 && kind <= 3);
-    hipLaunchKernelGGL(wino7_pair_scales_kernel, dim3(1), dim3(128), 0, cim::as_stream(stream), amax, kind, scale);
+extern "C" int cim_wino7_pair_scales(const uint32_t* amax, int n_amax, const uint32_t* amax_mul, int kind, float* scale, void* stream) {
+    CIM_CHECK_ARG(amax && scale && kind >= 0 && kind <= 3 && n_amax >= 1 && n_amax <= 65536);
+    hipLaunchKernelGGL(wino7_pair_scales_kernel, dim3(1), dim3(128), 0, cim::as_stream(stream), amax, n_amax, amax_mul, kind, scale);
     CIM_CHECK_LAUNCH();
     return 0;
 }

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..core.config import cfg
-from ..ops import bn_act, conv1x1_bn_act, conv3x3_bn_act
+from ..ops import bn_act, conv1x1_bn_act, conv3x3_bn_act, upsample_nearest
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "HRNet.MaskFuse" by get_func)
 
 BN_MOMENTUM = 0.1
@@ -44,6 +44,15 @@ def _downsample(ds, x):
             return conv1x1_bn_act(x, ds[0], ds[1], relu=False)
         return conv3x3_bn_act(x, ds[0], ds[1], relu=False)      # (falls back to ATen + bn_act for other shapes)
     return ds(x)
+
+
+def _up(seq, x):
+    """A fuse layer's up path, nn.Sequential(1 x 1 conv, BN, nn.Upsample(nearest)) (HRNet.py:195-201): the projection with its
+    BatchNorm as one small-tile GEMM launch, the up-sampling on csrc/pool.hip."""
+    if len(seq) == 3 and isinstance(seq[0], nn.Conv2d) and seq[0].kernel_size == (1, 1) and isinstance(seq[1], nn.BatchNorm2d) \
+            and isinstance(seq[2], nn.Upsample):
+        return upsample_nearest(conv1x1_bn_act(x, seq[0], seq[1], relu=False), seq[2])
+    return seq(x)
 
 
 def _is_conv_bn(m):
@@ -155,7 +164,7 @@ class HighResolutionModule(nn.Module):
         for i, row in enumerate(self.fuse_layers):
             y = x[0] if i == 0 else _conv_bn_steps(row[0], x[0])
             for j in range(1, self.num_branches):
-                y = y + (x[j] if i == j else (_conv_bn_steps(row[j], x[j]) if j < i else row[j](x[j])))
+                y = y + (x[j] if i == j else (_conv_bn_steps(row[j], x[j]) if j < i else _up(row[j], x[j])))
             fused.append(self.relu(y))
         return fused
 

@@ -42,6 +42,18 @@ class MaskFuse(nn.Module):
         if cfg.FAST_RCNN.ROI_XFORM_RESOLUTION == 7:
             maskfuse_pair.prefetch_weight_images(self.mask_branch[0].weight, self.seg_fc[0].weight, self.seg_fc[2].weight)
 
+    @staticmethod
+    def _cat_amax(x, masks):
+        """int32[2] bit patterns (max |x|, max |mask|): the scale source of the convolution's input image.  ROIAlign averages feature
+        pixels and the masks multiply them: max |cat| <= max |x| max(1, max |mask|) - two small passes instead of one over cat."""
+        xd, md = x.detach(), masks.detach().to(torch.float32)
+        if not (xd.is_contiguous() or xd.is_contiguous(memory_format=torch.channels_last)):
+            xd = xd.contiguous()
+        fa = torch.zeros(2, dtype=torch.int32, device=x.device)
+        pair.amax_of(xd, out=fa[0:1])
+        pair.amax_of(md.contiguous(), out=fa[1:2])
+        return fa
+
     def forward(self, x, rois, masks):
         method = cfg.FAST_RCNN.ROI_XFORM_METHOD
         if method != "RoIAlign":
@@ -56,11 +68,7 @@ class MaskFuse(nn.Module):
             # ONE autograd node for the whole box head: ROIAlign + mask multiply + concat + the convolution's Winograd input
             # transform in one launch (the conv input `cat` is never stored), then conv -> flatten -> fc1 -> fc2 on pair images.
             # ROIAlign averages feature pixels and the masks are {0, 1}: max |cat| <= max |x| max(1, max |mask|)
-            xd = x.detach()
-            if not (xd.is_contiguous() or xd.is_contiguous(memory_format=torch.channels_last)):
-                xd = xd.contiguous()
-            fa = (pair.amax_of(xd).view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
-            return maskfuse_pair.maskfuse_roi_head(x, rois, masks.detach(), conv, fc1, fc2, fa, self.spatial_scale, sr)
+            return maskfuse_pair.maskfuse_roi_head(x, rois, masks.detach(), conv, fc1, fc2, self._cat_amax(x, masks), self.spatial_scale, sr)
         cat = roi_align_maskcat(x, rois, masks, res, self.spatial_scale, sr, aligned=True)
         if not maskfuse_pair.supported(cat, conv.weight, fc1.weight, fc2.weight):
             # ONE engine, ONE algorithm: every configuration of the reference (512 / 1024 / 2048 feature channels, 7 x 7 ROI maps,
@@ -71,8 +79,4 @@ class MaskFuse(nn.Module):
                 % (tuple(cat.shape), tuple(conv.weight.shape), tuple(fc1.weight.shape), tuple(fc2.weight.shape)))
         # conv -> flatten -> fc1 -> fc2 on pair images (one scale per matrix).  ROIAlign averages feature pixels and the masks are
         # {0, 1}: max |cat| <= max |x| max(1, max |mask|) - a 6 MB pass instead of one over cat
-        xd = x.detach()
-        if not (xd.is_contiguous() or xd.is_contiguous(memory_format=torch.channels_last)):
-            xd = xd.contiguous()
-        fa = (pair.amax_of(xd).view(torch.float32) * masks.detach().abs().max().clamp(min=1.0)).view(torch.int32)
-        return maskfuse_pair.maskfuse_head(cat, conv, fc1, fc2, fa)
+        return maskfuse_pair.maskfuse_head(cat, conv, fc1, fc2, self._cat_amax(x, masks))

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from ..core.config import cfg
-from ..ops import conv1x1_bn_act, conv3x3_bn_act, conv7x7_bn_act
+from ..ops import conv1x1_bn_act, conv3x3_bn_act, conv7x7_bn_act, max_pool2d
 from ..ops.conv3x3 import prefetch_transposed_weights
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "resnet50.MaskFuse" by get_func)
 
@@ -131,8 +131,8 @@ class resnet(nn.Module):
                                          for b in getattr(self, "res%d" % i)])
         for i in range(self.block_counts):
             m = getattr(self, "res%d" % (i + 1))
-            if i == 0:      # the stem: 7 x 7 convolution + BatchNorm + ReLU in one launch (frozen: forward only), then the max-pool
-                x = m[3](conv7x7_bn_act(x, m[0], m[1], relu=True))
+            if i == 0:      # the stem: 7 x 7 convolution + BatchNorm + ReLU in one launch (frozen: forward only), then the max-pool (csrc/pool.hip)
+                x = max_pool2d(conv7x7_bn_act(x, m[0], m[1], relu=True), m[3])
             else:
                 x = m(x)
         return x

@@ -4,7 +4,7 @@
 import torch.nn as nn
 
 from ..core.config import cfg
-from ..ops import conv3x3_bias_act
+from ..ops import conv3x3_bias_act, max_pool2d
 from .maskfuse import MaskFuse  # noqa: F401  (resolved as "vgg16.MaskFuse" by get_func)
 
 # (out_channels per conv, trailing max-pool, dilation)
@@ -48,7 +48,7 @@ class dilated_conv5_body(nn.Module):
 
     def forward(self, x):
         # every Conv2d + ReLU pair is one launch of the implicit-GEMM kernel (bias + ReLU in its epilogue, dilation 2 in conv5;
-        # cim_amd/csrc/conv1x1.hip); the max-pools stay ATen's own kernel.  CPU tensors take the modules as they are.
+        # cim_amd/csrc/conv1x1.hip), every max-pool one launch of csrc/pool.hip.  CPU tensors take the modules as they are.
         for i in range(1, 6):
             seq = getattr(self, "conv%d" % i)
             if not x.is_cuda:
@@ -61,6 +61,9 @@ class dilated_conv5_body(nn.Module):
                 if isinstance(m, nn.Conv2d) and k + 1 < len(mods) and isinstance(mods[k + 1], nn.ReLU):
                     x = conv3x3_bias_act(x, m, relu=True)
                     k += 2
+                elif isinstance(m, nn.MaxPool2d):
+                    x = max_pool2d(x, m)
+                    k += 1
                 else:
                     x = m(x)
                     k += 1

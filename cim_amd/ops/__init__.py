@@ -7,6 +7,7 @@ eval-only box ops) - SURVEY.md section 2.2."""
 from .bn_act import bn_act
 from .conv1x1 import conv1x1_bn_act
 from .conv3x3 import conv3x3_bias_act, conv3x3_bn_act, conv7x7_bn_act
+from .pool import max_pool2d, upsample_nearest
 from .roi_align import RoIAlign, roi_align, roi_align_maskcat
 
 
@@ -26,4 +27,4 @@ roi_pool = _out_of_scope("roi_pool")
 nms = _out_of_scope("nms")
 soft_nms = _out_of_scope("soft_nms")
 
-__all__ = ["RoIPool", "RoIAlign", "roi_pool", "roi_align", "nms", "soft_nms", "roi_align_maskcat", "bn_act", "conv1x1_bn_act", "conv3x3_bn_act", "conv3x3_bias_act", "conv7x7_bn_act"]
+__all__ = ["RoIPool", "RoIAlign", "roi_pool", "roi_align", "nms", "soft_nms", "roi_align_maskcat", "bn_act", "conv1x1_bn_act", "conv3x3_bn_act", "conv3x3_bias_act", "conv7x7_bn_act", "max_pool2d", "upsample_nearest"]

@@ -60,10 +60,11 @@ def supported(cat, wc, w1, w2):
 
 
 def _weight_amax(w, rows, cols):
-    """int32[1] bit pattern of max |w|: from the arrays the fused SGD kernel registered for this version of w, else one pass."""
+    """int32[n] bit patterns whose maximum is max |w|: the row maxima the fused SGD kernel registered for this version of w (the
+    scale kernels take their maximum themselves), else one pass (n = 1)."""
     reg = G._registered_scales(w, rows, cols)
-    if reg is not None and reg[0] is not None:
-        return reg[0].max().reshape(1)
+    if reg is not None and reg[0] is not None and reg[0].is_contiguous() and reg[0].numel() <= 65536:
+        return reg[0].reshape(-1)
     return pair.amax_of(w.detach())
 
 
@@ -90,7 +91,8 @@ def _conv_image(w):
     cout, cin = w.shape[0], w.shape[1]
     sc = torch.empty(NPOS, dtype=torch.float32, device=w.device)
     st = _lib.stream_ptr()
-    _lib.call("cim_wino7_pair_scales", _weight_amax(w, cout, cin * 9).data_ptr(), 1, sc.data_ptr(), st)
+    wa = _weight_amax(w, cout, cin * 9)
+    _lib.call("cim_wino7_pair_scales", wa.data_ptr(), wa.numel(), None, 1, sc.data_ptr(), st)
     U = pair.Pair(torch.empty((NPOS, cout, cin), dtype=torch.int32, device=w.device), cout, cin, NPOS, sc)
     _lib.call("cim_wino7_filter_pair", w.data_ptr(), U.buf.data_ptr(), sc.data_ptr(), cout, cin, st)
     return U
@@ -98,7 +100,7 @@ def _conv_image(w):
 
 def _fc_image(w):
     n, k = w.shape
-    return pair.split(w.detach(), n, k, k, scale=pair.scales_from(_weight_amax(w, n, k), 1))
+    return pair.split(w.detach(), n, k, k, scale=pair.scales_from(_weight_amax(w, n, k), 1, reduce_all=True))
 
 
 def weight_image(w, conv=False):
@@ -175,8 +177,11 @@ def _roi_align_module():
 
 
 def _input_scales(feat_amax, dev):
+    """Scales of the convolution's input image from max |feature map| (feat_amax[0], bit pattern); a second word, if given, is
+    max |mask|: ROIAlign averages feature pixels, so max |cat| <= max |x| max(1, max |mask|)."""
     sV = torch.empty(NPOS, dtype=torch.float32, device=dev)
-    _lib.call("cim_wino7_pair_scales", feat_amax.data_ptr(), 0, sV.data_ptr(), _lib.stream_ptr())
+    mul = feat_amax[1:2].data_ptr() if feat_amax.numel() > 1 else None
+    _lib.call("cim_wino7_pair_scales", feat_amax.data_ptr(), 1, mul, 0, sV.data_ptr(), _lib.stream_ptr())
     return sV
 
 
@@ -324,7 +329,7 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
                 def wgrad(limit=0):
                     st2 = _lib.stream_ptr()
                     sD = torch.empty(NPOS, dtype=torch.float32, device=dev)
-                    _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 2, sD.data_ptr(), st2)
+                    _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 1, None, 2, sD.data_ptr(), st2)
                     D = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sD)
                     _lib.call("cim_wino7_dy_pair", dy.data_ptr(), D.buf.data_ptr(), sD.data_ptr(), r, rp, cout, 0, st2)
                     dU = pair.gemm(V, D, cin, cout, rp, True, False, limit=limit)
@@ -334,7 +339,7 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
                 dwc = side_grad(0, wc_p, wgrad)
             if need_x:
                 sE = torch.empty(NPOS, dtype=torch.float32, device=dev)
-                _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 3, sE.data_ptr(), st)
+                _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 1, None, 3, sE.data_ptr(), st)
                 E = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sE)
                 _lib.call("cim_wino7_dy_pair", dy.data_ptr(), E.buf.data_ptr(), sE.data_ptr(), r, rp, cout, 1, st)
                 M2 = pair.gemm(E, Up, r, cin, cout, False, False, balance=True)

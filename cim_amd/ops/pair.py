@@ -42,6 +42,8 @@ def amax_of(x, out=None):
     """max |x| of a dense fp32 tensor as an int32[1] bit pattern (device)."""
     if out is None:
         out = torch.zeros(1, dtype=torch.int32, device=x.device)
+    if x.data_ptr() % 16:
+        x = x.clone()                    # (16-byte lanes)
     _lib.call("cim_pair_amax", x.data_ptr(), x.numel(), out.data_ptr(), _lib.stream_ptr())
     return out
 
@@ -55,10 +57,11 @@ def masked_stats(dy, y, amax, want_colsum):
     return part.sum(dim=0) if want_colsum else None
 
 
-def scales_from(amax, n=1, factor=None):
-    """float32[n] power-of-two scales 2^(14 - exponent(amax * factor[i])) (amax: int32 bit patterns, [1] or [n])."""
+def scales_from(amax, n=1, factor=None, reduce_all=False):
+    """float32[n] power-of-two scales 2^(14 - exponent(amax * factor[i])) (amax: int32 bit patterns, [1] or [n]); reduce_all: every
+    scale from the maximum of ALL words of `amax` (the row maxima of a weight -> the one scale of its image)."""
     s = torch.empty(n, dtype=torch.float32, device=amax.device)
-    _lib.call("cim_pair_scales", amax.data_ptr(), amax.numel(), _lib.ptr(factor), s.data_ptr(), n, _lib.stream_ptr())
+    _lib.call("cim_pair_scales", amax.data_ptr(), amax.numel(), _lib.ptr(factor), s.data_ptr(), n, int(reduce_all), _lib.stream_ptr())
     return s
 
 

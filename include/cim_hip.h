@@ -219,6 +219,22 @@ int cim_mining_step(const cim_mining_args* args, void* sync, void* stream);
 int cim_image_prep(const uint8_t* src_bgr, int h, int w, float* dst, int H, int W, long long plane_stride, int row_stride,
                    double inv_scale, int hflip, const float* mean_std6_host, void* stream);
 
+/* ------------------------------------------------------------------ max-pooling / nearest up-sampling of the bodies (a-11)
+ * Replaces nn.MaxPool2d(3, 2, 1) of the ResNet stem (lib/modeling/resnet50.py:29, torchvision resnet50.maxpool), nn.MaxPool2d(2, 2)
+ * of VGG16 (lib/modeling/vgg16.py:43,50,60) and nn.Upsample(scale_factor = 2^k, mode = 'nearest') of HRNet's fuse layers
+ * (lib/modeling/HRNet.py:201).  x: NC planes [H][W] fp32 (NCHW contiguous).  ATen semantics: floor output size
+ * (cim_maxpool2d_out_size), no dilation, the window is scanned rows first, the first maximum wins, NaN propagates.
+ *   cim_maxpool2d_fwd: y [NC][Ho][Wo]; idx (may be NULL: inference / frozen stem) receives the arg-max as h * W + w
+ *   cim_maxpool2d_bwd: dx [NC][H][W] = for every input pixel the sum of dy over the windows whose arg-max it is (a gather in
+ *                      window order: deterministic, no atomics)
+ *   cim_upsample_nearest_fwd: y [NC][H*scale][W*scale] = x[.., oh / scale, ow / scale]; accumulate != 0: y += ... (the fuse sum)
+ *   cim_upsample_nearest_bwd: dx [NC][H][W] = sum of the scale x scale block of dy, rows first */
+int cim_maxpool2d_out_size(int in, int k, int stride, int pad);
+int cim_maxpool2d_fwd(const float* x, float* y, int* idx, int NC, int H, int W, int k, int stride, int pad, void* stream);
+int cim_maxpool2d_bwd(const float* dy, const int* idx, float* dx, int NC, int H, int W, int k, int stride, int pad, void* stream);
+int cim_upsample_nearest_fwd(const float* x, float* y, int NC, int H, int W, int scale, int accumulate, void* stream);
+int cim_upsample_nearest_bwd(const float* dy, float* dx, int NC, int H, int W, int scale, void* stream);
+
 /* ------------------------------------------------------------------ backbone 1x1 convolutions (a-11)
  * The 1 x 1 convolutions of the ResNet bottlenecks (torchvision Bottleneck conv1 / conv3 / downsample.0 as wrapped by
  * lib/modeling/resnet50.py:17-91) and their backward products as small-tile fp32-MFMA GEMMs, C[M,N] = A . B:
@@ -355,10 +371,11 @@ int cim_bn_act_bwd(const float* dy, const float* y, const float* x, const float*
  *     N-contiguous B needs N % 8 == 0.  a_scale / b_scale: [batch] device floats, the scales the images were written with.
  *     c_amax (optional): receives max |C| as an IEEE bit pattern through atomicMax (caller zeroes) - the scale source
  *     of the next split.
- *   cim_pair_scales: scale[i] = 2^(14 - exponent(amax[min(i, n_amax - 1)] * factor[i]))  (factor may be NULL)
+ *   cim_pair_scales: scale[i] = 2^(14 - exponent(amax[min(i, n_amax - 1)] * factor[i]))  (factor may be NULL); reduce_all != 0:
+ *                    every scale from the MAXIMUM of the n_amax words (row / column maxima of a weight -> its one scale)
  *   cim_pair_split : fp32 X [batch][rows][ld] -> pair image [batch][rows_pad][ldp], rows >= `rows` zero-filled; relu_y
  *                    (optional, laid out as X): elements with relu_y <= 0 are written as 0 (a fused ReLU backward mask)
- *   cim_pair_amax  : max |x| bit pattern of n floats (atomicMax into a caller-zeroed word)
+ *   cim_pair_amax  : max |x| bit pattern of n floats (atomicMax into a caller-zeroed word; X 16-byte aligned, any n)
  *   cim_pair_masked_stats: the ReLU backward of a fully connected layer in front of its split, dz = y > 0 ? dy : 0 on [rows][cols]
  *                    (never stored: cim_pair_split applies the same mask): max |dz| as cim_pair_amax and, when `part`
  *                    ([ceil(rows / 64)][cols], may be NULL) is given, the bias gradient's partial sums over chunks of 64 rows, each
@@ -379,14 +396,15 @@ int cim_gemm_pair_batched(const void* A, const void* B, float* C, int M, int N, 
                           int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
                           int batch, long long a_bs, long long b_bs, long long c_bs,
                           const float* a_scale, const float* b_scale, int max_workgroups, int products, void* stream);
-int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float* scale, int n, void* stream);
+int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float* scale, int n, int reduce_all, void* stream);
 int cim_pair_split(const float* X, void* P, int rows, int rows_pad, int cols, int ld, int ldp, int batch,
                    long long x_bs, long long p_bs, const float* scale, const float* relu_y, void* stream);
 int cim_pair_amax(const float* X, long long n, uint32_t* amax, void* stream);
 int cim_pair_masked_stats(const float* dy, const float* y, int rows, int cols, float* part, uint32_t* amax, void* stream);
 
 /* Producers of pair images for the MaskFuse convolution in the mixed 4 + 3 Winograd tiling (121 positions, P = 7) and for seg_fc.0's input:
- *   cim_wino7_pair_scales: scale[121] from ONE max |d| bit pattern of the untransformed tensor: per position the bound
+ *   cim_wino7_pair_scales: scale[121] from max |d| of the untransformed tensor (the maximum of the n_amax bit patterns `amax`, times
+ *        max(1, amax_mul[0]) when amax_mul is given: the {0, 1} masks of MaskFuse's concat): per position the bound
  *        (abs row sum)_i (abs row sum)_j max|d| of the transform.  kind 0: input (B^T), 1: filter (G), 2: dy for the weight
  *        gradient (GD), 3: dy for the adjoint data gradient (A)
  *   cim_wino7_input_pair : x [R,7,7,C] fp32 -> V [121][Rs][C] pair image (Rs >= R rows per position, rows >= R zeroed)
@@ -394,7 +412,7 @@ int cim_pair_masked_stats(const float* dy, const float* y, int rows, int cols, f
  *   cim_wino7_dy_pair    : dy [R,7,7,C] -> D (adjoint = 0: GD dy GD^T) or E (adjoint = 1: A dy A^T) [121][Rs][C]
  *   cim_wino7_output_amax: M [121][R][C] -> y [R,7,7,C] = A^T m A per tile (+ bias, ReLU); also reports max |y| (atomicMax, caller zeroes)
  *   cim_flatten_chw_pair : the (c, h, w) flatten of the NCHW `.view(N, -1)` on channels-last data, into a pair image [Rs][C*PP] (lib/modeling/resnet50.py:135) */
-int cim_wino7_pair_scales(const uint32_t* amax, int kind, float* scale, void* stream);
+int cim_wino7_pair_scales(const uint32_t* amax, int n_amax, const uint32_t* amax_mul, int kind, float* scale, void* stream);
 int cim_wino7_input_pair(const float* x, void* V, const float* scale, int R, int Rs, int C, void* stream);
 int cim_wino7_filter_pair(const float* W, void* U, const float* scale, int Cout, int Cin, void* stream);
 int cim_wino7_dy_pair(const float* dy, void* D, const float* scale, int R, int Rs, int C, int adjoint, void* stream);

@@ -282,7 +282,7 @@ def test_wino7_pair_producers_match_fp32_transforms(dev):
     V = torch.empty(121, R, C, device=dev)
     _xlib.call("cim_wino_input_transform", x.data_ptr(), V.data_ptr(), R, 7, C, 7, st)
     sc = torch.empty(121, device=dev)
-    _lib.call("cim_wino7_pair_scales", amax.data_ptr(), 0, sc.data_ptr(), st)
+    _lib.call("cim_wino7_pair_scales", amax.data_ptr(), 1, None, 0, sc.data_ptr(), st)
     Vp = pair.Pair(torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev), R, C, 121, sc)
     _lib.call("cim_wino7_input_pair", x.data_ptr(), Vp.buf.data_ptr(), sc.data_ptr(), R, Rs, C, st)
     d = _decode(Vp)
@@ -297,7 +297,7 @@ def test_wino7_pair_producers_match_fp32_transforms(dev):
             _xlib.call("cim_wino_dy_adjoint_transform", x.data_ptr(), D.data_ptr(), None, R, 7, C, 7, st)
         else:
             _xlib.call("cim_wino_dy_transform", x.data_ptr(), D.data_ptr(), R, 7, C, 7, st)
-        _lib.call("cim_wino7_pair_scales", amax.data_ptr(), kind, sc.data_ptr(), st)
+        _lib.call("cim_wino7_pair_scales", amax.data_ptr(), 1, None, kind, sc.data_ptr(), st)
         Dp = pair.Pair(torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev), R, C, 121, sc)
         _lib.call("cim_wino7_dy_pair", x.data_ptr(), Dp.buf.data_ptr(), sc.data_ptr(), R, Rs, C, adj, st)
         d = _decode(Dp)
@@ -310,7 +310,7 @@ def test_wino7_pair_producers_match_fp32_transforms(dev):
     U = torch.empty(121, C, Co, device=dev)
     _xlib.call("cim_wino_filter_transform", w.data_ptr(), U.data_ptr(), Co, C, 0, 7, st)
     wamax = w.abs().max().reshape(1).view(torch.int32)
-    _lib.call("cim_wino7_pair_scales", wamax.data_ptr(), 1, sc.data_ptr(), st)
+    _lib.call("cim_wino7_pair_scales", wamax.data_ptr(), 1, None, 1, sc.data_ptr(), st)
     Up = pair.Pair(torch.empty((121, Co, C), dtype=torch.int32, device=dev), Co, C, 121, sc)
     _lib.call("cim_wino7_filter_pair", w.data_ptr(), Up.buf.data_ptr(), sc.data_ptr(), Co, C, st)
     assert float((U.abs().amax(dim=(1, 2)) * sc).max()) < 2.0 ** 15
