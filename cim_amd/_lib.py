@@ -59,6 +59,7 @@ SIGNATURES = {
     "cim_pair_split": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, _P, _P, _P],
     "cim_pair_amax": [_P, c_longlong, _P, _P],
     "cim_pair_masked_stats": [_P, _P, c_int, c_int, _P, _P, _P],
+    "cim_wino7_flatten_bwd_dy_pair": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cim_wino7_pair_scales": [_P, c_int, _P, c_int, _P, _P],
     "cim_wino7_input_pair": [_P, _P, _P, c_int, c_int, c_int, _P],
     "cim_wino7_filter_pair": [_P, _P, _P, c_int, c_int, _P],

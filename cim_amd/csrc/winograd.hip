@@ -430,6 +430,120 @@ __global__ __launch_bounds__(256) void wino7_dy_pair_kernel(const float* __restr
     }
 }
 
+// ---- flatten backward + ReLU mask + BOTH output-gradient transforms of the convolution in one launch -------------------------------
+// Replaces flatten_chw_kernel<false> + wino7_dy_pair_kernel<true> + wino7_dy_pair_kernel<false> (the backward of `.view(N, -1)`
+// and mask_branch's ReLU, /root/reference/lib/modeling/resnet50.py:135,104-105, in front of the convolution's two gradient products):
+// dX [R][C * 49] ((c, h, w) order, seg_fc.0's data gradient) is read ONCE, masked with the saved conv output, and leaves as the
+// pair images E = A dy A^T (adjoint data gradient) and D = GD dy GD^T (weight gradient) - the masked gradient dy [R,7,7,C] is
+// never stored (was: 200 MB written, read twice).  Workgroup = (ROI, 256-channel slice): the slice's 49 x 256 gradients are 12544
+// CONSECUTIVE floats of dX; they are transposed through LDS ([49][260] floats), masked in place (a lane owns 4 channels, a wave
+// every fourth pixel: the bias partial sums keep flatten_chw_kernel's order), then wave t transforms tile type t from LDS exactly as
+// w7_dy_tile does from memory - bit-identical images.  grid = (Rs, C / 256); rows R .. Rs-1 are zeroed.
+constexpr int W7_FB_LDW = 260;
+
+template <int KA, int KB, bool ADJ>
+__device__ __forceinline__ void w7_dy_regs_pair(const float4 (&d)[W7::OUT[KA]][W7::OUT[KB]], float* __restrict__ D, size_t MC, size_t rc,
+                                                const float* __restrict__ scale) {
+    constexpr int NA = W7::NP[KA], NB = W7::NP[KB], OA = W7::OUT[KA], OB = W7::OUT[KB], Q0 = W7::QOFF[KA * 2 + KB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        float4 trow[OB];
+#pragma unroll
+        for (int b = 0; b < OB; ++b) {
+            trow[b] = f4(0.f);
+#pragma unroll
+            for (int a = 0; a < OA; ++a) {
+                const float m = ADJ ? W7_AT[KA][a][i] : W7_GD[KA][i][a];
+                if (m != 0.0f) fma4(trow[b], m, d[a][b]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            float4 v = f4(0.f);
+#pragma unroll
+            for (int b = 0; b < OB; ++b) {
+                const float m = ADJ ? W7_AT[KB][b][j] : W7_GD[KB][j][b];
+                if (m != 0.0f) fma4(v, m, trow[b]);
+            }
+            w7_store_pair(D + (size_t)(Q0 + i * NB + j) * MC + rc, v, scale[Q0 + i * NB + j]);
+        }
+    }
+}
+
+template <int KA, int KB>
+__device__ __forceinline__ void w7_fb_tile(const float* __restrict__ s, int lane, float* __restrict__ E, float* __restrict__ D, size_t MC,
+                                           size_t rc, const float* __restrict__ sE, const float* __restrict__ sD) {
+    constexpr int OA = W7::OUT[KA], OB = W7::OUT[KB];
+    float4 d[OA][OB];
+#pragma unroll
+    for (int a = 0; a < OA; ++a)
+#pragma unroll
+        for (int b = 0; b < OB; ++b)
+            d[a][b] = *reinterpret_cast<const float4*>(s + ((W7::OUT0[KA] + a) * 7 + W7::OUT0[KB] + b) * W7_FB_LDW + 4 * lane);
+    if (E != nullptr) w7_dy_regs_pair<KA, KB, true>(d, E, MC, rc, sE);
+    if (D != nullptr) w7_dy_regs_pair<KA, KB, false>(d, D, MC, rc, sD);
+}
+
+__global__ __launch_bounds__(256) void wino7_flatten_bwd_dy_pair_kernel(const float* __restrict__ dX, const float* __restrict__ y,
+                                                                        float* __restrict__ E, float* __restrict__ D,
+                                                                        float* __restrict__ bsum, int R, int Rs, int C,
+                                                                        const float* __restrict__ sE, const float* __restrict__ sD) {
+    __shared__ __attribute__((aligned(16))) float s[49 * W7_FB_LDW];
+    __shared__ float4 red[3][64];          // (waves 1 .. 3; with the tile 54032 B: three workgroups per CU)
+    const int r = blockIdx.x, c0 = blockIdx.y * 256, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t MC = (size_t)Rs * C, rc = (size_t)r * C + c0 + 4 * lane;
+    if (r >= R) {                          // pad rows of both images
+        const w7_u4 z = {0u, 0u, 0u, 0u};
+        for (int q = w; q < 121; q += 4) {
+            if (E != nullptr) __builtin_nontemporal_store(z, reinterpret_cast<w7_u4*>(E + (size_t)q * MC + rc));
+            if (D != nullptr) __builtin_nontemporal_store(z, reinterpret_cast<w7_u4*>(D + (size_t)q * MC + rc));
+        }
+        return;
+    }
+    // the slice's (c, p) run of dX -> s[p][c]
+    const float4* __restrict__ src4 = reinterpret_cast<const float4*>(dX + ((size_t)r * C + c0) * 49);
+    for (int i = tid; i < 49 * 64; i += 256) {
+        const float4 v = vload_once<float4>(reinterpret_cast<const float*>(src4 + i));
+        int c = (4 * i) / 49, p = 4 * i - 49 * c;
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[p * W7_FB_LDW + c] = e[k];
+            if (++p == 49) { p = 0; ++c; }
+        }
+    }
+    __syncthreads();
+    // ReLU mask of the saved conv output, in place; per-channel sums over the ROI's pixels (the conv's bias gradient, partial)
+    float4 part = f4(0.f);
+    for (int p = w; p < 49; p += 4) {
+        float4* sp = reinterpret_cast<float4*>(s + p * W7_FB_LDW + 4 * lane);
+        float4 d = *sp;
+        if (y != nullptr) {
+            const float4 yv = *reinterpret_cast<const float4*>(y + ((size_t)r * 49 + p) * C + c0 + 4 * lane);
+            d.x = yv.x > 0.0f ? d.x : 0.0f;
+            d.y = yv.y > 0.0f ? d.y : 0.0f;
+            d.z = yv.z > 0.0f ? d.z : 0.0f;
+            d.w = yv.w > 0.0f ? d.w : 0.0f;
+            *sp = d;
+        }
+        part.x += d.x; part.y += d.y; part.z += d.z; part.w += d.w;
+    }
+    if (bsum != nullptr && w > 0) red[w - 1][lane] = part;
+    __syncthreads();
+    if (bsum != nullptr && w == 0) {
+        const float4 a = part, b = red[0][lane], c = red[1][lane], e = red[2][lane];
+        *reinterpret_cast<float4*>(bsum + rc) = make_float4((a.x + b.x) + (c.x + e.x), (a.y + b.y) + (c.y + e.y),
+                                                            (a.z + b.z) + (c.z + e.z), (a.w + b.w) + (c.w + e.w));
+    }
+    switch (w) {
+        case 0: w7_fb_tile<0, 0>(s, lane, E, D, MC, rc, sE, sD); break;
+        case 1: w7_fb_tile<0, 1>(s, lane, E, D, MC, rc, sE, sD); break;
+        case 2: w7_fb_tile<1, 0>(s, lane, E, D, MC, rc, sE, sD); break;
+        default: w7_fb_tile<1, 1>(s, lane, E, D, MC, rc, sE, sD); break;
+    }
+}
+
 // scale[q] = 2^(14 - exponent(bound_q)), bound_q = (abs row sum)_i (abs row sum)_j max|d| 1.0001 >= max |transformed value| at
 // position q.  kind 0: B^T (input), 1: G (filter), 2: GD (dy, weight gradient), 3: A (dy, adjoint data gradient).
 __global__ void wino7_pair_scales_kernel(const unsigned* __restrict__ amax, int n_amax, const unsigned* __restrict__ amax_mul, int kind,
@@ -759,6 +873,15 @@ extern "C" int cim_wino7_dy_pair(const float* dy, void* D, const float* scale, i
     CIM_CHECK_ARG(dy && D && scale && R > 0 && Rs >= R && C > 0 && C % 8 == 0);
     if (adjoint) hipLaunchKernelGGL(wino7_dy_pair_kernel<true>, dim3(Rs, 4), dim3(256), 0, cim::as_stream(stream), dy, (float*)D, R, Rs, C, scale);
     else hipLaunchKernelGGL(wino7_dy_pair_kernel<false>, dim3(Rs, 4), dim3(256), 0, cim::as_stream(stream), dy, (float*)D, R, Rs, C, scale);
+    CIM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cim_wino7_flatten_bwd_dy_pair(const float* dX, const float* relu_y, void* E, const float* scale_e, void* D,
+                                             const float* scale_d, float* bias_partial, int R, int Rs, int C, void* stream) {
+    CIM_CHECK_ARG(dX && (E || D) && (!E || scale_e) && (!D || scale_d) && R > 0 && Rs >= R && C > 0 && C % 256 == 0 && C / 256 <= 65535);
+    hipLaunchKernelGGL(wino7_flatten_bwd_dy_pair_kernel, dim3(Rs, C / 256), dim3(256), 0, cim::as_stream(stream), dX, relu_y, (float*)E,
+                       (float*)D, bias_partial, R, Rs, C, scale_e, scale_d);
     CIM_CHECK_LAUNCH();
     return 0;
 }

@@ -118,6 +118,7 @@ def weight_image(w, conv=False):
     return img
 
 
+FUSE_DY = True         # flatten backward + ReLU mask + both dy transforms of the convolution in one launch (else three)
 PREFETCH = True        # the weights' pair images on the side stream, under the backbone forward
 
 
@@ -299,7 +300,8 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
             return publish(w, on_side(fn))
 
         wc_p, w1_p, w2_p = ctx.weights
-        dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = dy_conv = None
+        dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = None
+        dy_keep = []
         am = torch.zeros(3, dtype=torch.int32, device=dev)
         # ---- fc2
         # (the ReLU mask is applied by the split; one launch gives max |dz| and the bias gradient's partial sums)
@@ -318,30 +320,53 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
             dX = pair.gemm(dY1p, W1p, r, cout * p * p, h1, False, False, c_amax=am[2:3], balance=True)
             # ---- flatten backward + ReLU mask of the conv; conv gradients
             st = _lib.stream_ptr()
-            dy = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
             want_dbc = ctx.has_bias[0] and ctx.needs_input_grad[2 + ofs]
             bpart = torch.empty((r, cout), dtype=torch.float32, device=dev) if want_dbc else None
-            _lib.call("cim_flatten_chw_bwd_bias", dX.data_ptr(), y.data_ptr(), dy.data_ptr(), _lib.ptr(bpart), r, p * p, cout, st)
+            fused = FUSE_DY and cout % 256 == 0 and p == 7
+            E = D = dy = None
+            if fused:
+                # ONE launch: dX -> (masked, transposed in LDS) -> the adjoint image E' and the weight-gradient image D'; the masked
+                # gradient dy [r,7,7,cout] is never stored (csrc/winograd.hip: wino7_flatten_bwd_dy_pair_kernel)
+                if need_x:
+                    sE = torch.empty(NPOS, dtype=torch.float32, device=dev)
+                    _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 1, None, 3, sE.data_ptr(), st)
+                    E = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sE)
+                if need_wc:
+                    sD = torch.empty(NPOS, dtype=torch.float32, device=dev)
+                    _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 1, None, 2, sD.data_ptr(), st)
+                    D = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sD)
+                if E is not None or D is not None:
+                    _lib.call("cim_wino7_flatten_bwd_dy_pair", dX.data_ptr(), y.data_ptr(), _lib.ptr(E.buf if E is not None else None),
+                              _lib.ptr(E.scale if E is not None else None), _lib.ptr(D.buf if D is not None else None),
+                              _lib.ptr(D.scale if D is not None else None),
+                              _lib.ptr(bpart), r, rp, cout, st)
+                else:
+                    fused = False
+            if not fused:
+                dy = torch.empty((r, p, p, cout), dtype=torch.float32, device=dev)
+                _lib.call("cim_flatten_chw_bwd_bias", dX.data_ptr(), y.data_ptr(), dy.data_ptr(), _lib.ptr(bpart), r, p * p, cout, st)
             del dX
             if want_dbc:
                 dbc = bpart.sum(dim=0)          # per-ROI partial sums from the flatten kernel: 4 MB instead of a pass over dy
             if need_wc:
-                def wgrad(limit=0):
+                def wgrad(limit=0, D=D):
                     st2 = _lib.stream_ptr()
-                    sD = torch.empty(NPOS, dtype=torch.float32, device=dev)
-                    _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 1, None, 2, sD.data_ptr(), st2)
-                    D = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sD)
-                    _lib.call("cim_wino7_dy_pair", dy.data_ptr(), D.buf.data_ptr(), sD.data_ptr(), r, rp, cout, 0, st2)
+                    if D is None:
+                        sD = torch.empty(NPOS, dtype=torch.float32, device=dev)
+                        _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 1, None, 2, sD.data_ptr(), st2)
+                        D = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sD)
+                        _lib.call("cim_wino7_dy_pair", dy.data_ptr(), D.buf.data_ptr(), sD.data_ptr(), r, rp, cout, 0, st2)
                     dU = pair.gemm(V, D, cin, cout, rp, True, False, limit=limit)
                     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
                     _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, 7, st2)
                     return dw
                 dwc = side_grad(0, wc_p, wgrad)
             if need_x:
-                sE = torch.empty(NPOS, dtype=torch.float32, device=dev)
-                _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 1, None, 3, sE.data_ptr(), st)
-                E = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sE)
-                _lib.call("cim_wino7_dy_pair", dy.data_ptr(), E.buf.data_ptr(), sE.data_ptr(), r, rp, cout, 1, st)
+                if E is None:
+                    sE = torch.empty(NPOS, dtype=torch.float32, device=dev)
+                    _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 1, None, 3, sE.data_ptr(), st)
+                    E = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sE)
+                    _lib.call("cim_wino7_dy_pair", dy.data_ptr(), E.buf.data_ptr(), sE.data_ptr(), r, rp, cout, 1, st)
                 M2 = pair.gemm(E, Up, r, cin, cout, False, False, balance=True)
                 if fold_masks is None:
                     dxp = torch.empty((r, p, p, cin), dtype=torch.float32, device=dev)
@@ -350,9 +375,10 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
                     dxp = torch.empty((r, p, p, cin // 2), dtype=torch.float32, device=dev)
                     _lib.call("cim_wino7_dx_maskfold", M2.data_ptr(), fold_masks.data_ptr(), dxp.data_ptr(), r, cin // 2, st)
                 dcat = dxp.permute(0, 3, 1, 2)
-            dy_conv = dy
+            dy_keep = [t for t in ((dy,) if D is None else (D.buf, D.scale)) if t is not None]   # what the late weight gradient reads
             if overlap:
-                dy.record_stream(side)
+                for t in dy_keep:
+                    t.record_stream(side)
         if late:
             # biggest first: with several ranks a gradient's all-reduce starts right behind its product (publish), and fc1's 822 MB
             # is the one that needs the rest of the backward pass to hide under
@@ -369,7 +395,7 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
                     got = {slot: publish(w, fn(limit)) for slot, w, fn in late}
                 if defer:           # (postponed: this node has returned - the join bookkeeping of the block below happens here)
                     keep = [t for t in (V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf,
-                                        dY1p.scale, dy_conv, am) if t is not None]
+                                        dY1p.scale, am) if t is not None] + dy_keep
                     for slot, w, _ in late:
                         if got[slot] is not None:
                             G.defer_side_join(dev, w, got[slot], *keep)
@@ -388,13 +414,13 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
         if overlap:
             # operands the side stream's GEMMs read: the allocator must not hand their memory out before that work is done,
             # whichever way (join here, deferred join, DataParallel's all-reduce) the weight gradients leave this node
-            for t in (V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf, dY1p.scale, dy_conv, am):
+            for t in [V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf, dY1p.scale, am] + dy_keep:
                 if t is not None:
                     t.record_stream(side)
             if DEFER_DW and G.DEFER_DW:
                 # the weight gradients keep running on the side stream while the main stream goes on to the ROIAlign and backbone
                 # backward: joined (and installed as .grad) once, at the end of the backward pass (ops/gemm.py: defer_side_join)
-                keep = [V.buf, Xp.buf, Y1p.buf, dY2p.buf, dY1p.buf, dy_conv]
+                keep = [V.buf, Xp.buf, Y1p.buf, dY2p.buf, dY1p.buf] + dy_keep
                 for w, t in ((w2_p, dw2), (w1_p, dw1), (wc_p, dwc)):
                     if t is not None and isinstance(w, torch.nn.Parameter):
                         G.defer_side_join(dev, w, t, *[k for k in keep if k is not None])

@@ -410,12 +410,18 @@ int cim_pair_masked_stats(const float* dy, const float* y, int rows, int cols, f
  *   cim_wino7_input_pair : x [R,7,7,C] fp32 -> V [121][Rs][C] pair image (Rs >= R rows per position, rows >= R zeroed)
  *   cim_wino7_filter_pair: W [Cout,Cin,3,3] -> U' [121][Cout][Cin] pair image (ci contiguous)
  *   cim_wino7_dy_pair    : dy [R,7,7,C] -> D (adjoint = 0: GD dy GD^T) or E (adjoint = 1: A dy A^T) [121][Rs][C]
+ *   cim_wino7_flatten_bwd_dy_pair: the backward of the (c, h, w) flatten + mask_branch's ReLU + BOTH transforms above in one launch:
+ *        dX [R][C*49] (seg_fc.0's data gradient), relu_y [R,7,7,C] (saved conv output; NULL: no mask) -> E (adjoint = 1 image, may be
+ *        NULL) and D (adjoint = 0 image, may be NULL), bit-identical to cim_flatten_chw_bwd_bias + cim_wino7_dy_pair x 2 without the
+ *        masked gradient ever being stored; bias_partial [R][C] (may be NULL) as cim_flatten_chw_bwd_bias.  C % 256 == 0
  *   cim_wino7_output_amax: M [121][R][C] -> y [R,7,7,C] = A^T m A per tile (+ bias, ReLU); also reports max |y| (atomicMax, caller zeroes)
  *   cim_flatten_chw_pair : the (c, h, w) flatten of the NCHW `.view(N, -1)` on channels-last data, into a pair image [Rs][C*PP] (lib/modeling/resnet50.py:135) */
 int cim_wino7_pair_scales(const uint32_t* amax, int n_amax, const uint32_t* amax_mul, int kind, float* scale, void* stream);
 int cim_wino7_input_pair(const float* x, void* V, const float* scale, int R, int Rs, int C, void* stream);
 int cim_wino7_filter_pair(const float* W, void* U, const float* scale, int Cout, int Cin, void* stream);
 int cim_wino7_dy_pair(const float* dy, void* D, const float* scale, int R, int Rs, int C, int adjoint, void* stream);
+int cim_wino7_flatten_bwd_dy_pair(const float* dX, const float* relu_y, void* E, const float* scale_e, void* D, const float* scale_d,
+                                  float* bias_partial, int R, int Rs, int C, void* stream);
 int cim_wino7_output_amax(const float* M, const float* bias, float* y, int R, int C, int relu, uint32_t* y_amax, void* stream);
 int cim_flatten_chw_pair(const float* src, void* dst, const float* scale, int R, int Rs, int PP, int C, void* stream);
 /* the flatten's backward: src [R][C][PP] -> dst [R][PP][C], zeroed where relu_y [R][PP][C] <= 0 (the conv's ReLU mask); also writes bias_partial [R][C] = sum over the PP pixels of the masked gradient (the

@@ -467,3 +467,71 @@ def test_roi_align_wino7_pair_image_is_bit_identical_to_the_two_kernel_path(dev,
             assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), name      # summation order than fma(mask, hi, lo) later)
         else:
             assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("R,C,mask", [(37, 256, True), (21, 512, True), (5, 256, False)])
+def test_flatten_backward_dy_images_in_one_launch_are_bit_identical(dev, R, C, mask):
+    """cim_wino7_flatten_bwd_dy_pair (round 5): the backward of the (c, h, w) flatten + the conv's ReLU mask + both output-gradient
+    transforms in ONE launch writes the very images (and bias partial sums) that cim_flatten_chw_bwd_bias + cim_wino7_dy_pair x 2
+    write - every byte, pad rows included - without storing the masked gradient (lib/modeling/resnet50.py:104-105,135 backward)."""
+    from cim_amd import _lib
+    from cim_amd.ops import pair
+    st = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(R + C)
+    Rs = pair.pad32(R)
+    dX = torch.randn(R, C * 49, generator=g).to(dev)
+    y = torch.randn(R, 7, 7, C, generator=g).to(dev) if mask else None
+    amax = dX.abs().max().reshape(1).view(torch.int32)
+    sE, sD = torch.empty(121, device=dev), torch.empty(121, device=dev)
+    _lib.call("cim_wino7_pair_scales", amax.data_ptr(), 1, None, 3, sE.data_ptr(), st)
+    _lib.call("cim_wino7_pair_scales", amax.data_ptr(), 1, None, 2, sD.data_ptr(), st)
+    # three launches
+    dy = torch.empty(R, 7, 7, C, device=dev)
+    b0 = torch.empty(R, C, device=dev)
+    _lib.call("cim_flatten_chw_bwd_bias", dX.data_ptr(), _lib.ptr(y), dy.data_ptr(), b0.data_ptr(), R, 49, C, st)
+    E0 = torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev)
+    D0 = torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev)
+    _lib.call("cim_wino7_dy_pair", dy.data_ptr(), E0.data_ptr(), sE.data_ptr(), R, Rs, C, 1, st)
+    _lib.call("cim_wino7_dy_pair", dy.data_ptr(), D0.data_ptr(), sD.data_ptr(), R, Rs, C, 0, st)
+    # one launch (both images; each alone)
+    for want_e, want_d in ((True, True), (True, False), (False, True)):
+        E1 = torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev)
+        D1 = torch.full((121, Rs, C), 0x7fff7fff, dtype=torch.int32, device=dev)
+        b1 = torch.full((R, C), float("nan"), device=dev)
+        _lib.call("cim_wino7_flatten_bwd_dy_pair", dX.data_ptr(), _lib.ptr(y), E1.data_ptr() if want_e else None,
+                  sE.data_ptr() if want_e else None, D1.data_ptr() if want_d else None, sD.data_ptr() if want_d else None,
+                  b1.data_ptr(), R, Rs, C, st)
+        if want_e:
+            assert torch.equal(E0, E1)
+        if want_d:
+            assert torch.equal(D0, D1)
+        assert torch.equal(b0, b1)
+
+
+def test_head_backward_with_and_without_the_fused_dy_launch_is_bit_identical(dev):
+    from cim_amd.ops import gemm, maskfuse_pair, pair
+    torch.manual_seed(3)
+    R, C = 45, 128
+    conv = torch.nn.Conv2d(2 * C, 256, 3, padding=1).to(dev)
+    fc1, fc2 = torch.nn.Linear(256 * 49, 128).to(dev), torch.nn.Linear(128, 96).to(dev)
+    params = [conv.weight, conv.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias]
+    cat0 = torch.randn(R, 2 * C, 7, 7, device=dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(R, 96, device=dev)
+    fa = pair.amax_of(cat0)
+
+    def run(fused):
+        maskfuse_pair.FUSE_DY = fused
+        try:
+            cat = cat0.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+            for t in params:
+                t.grad = None
+            out = maskfuse_pair.maskfuse_head(cat, conv, fc1, fc2, fa)
+            out.backward(dy)
+            gemm.join_side()
+            torch.cuda.synchronize()
+            return [out.detach(), cat.grad] + [t.grad for t in params]
+        finally:
+            maskfuse_pair.FUSE_DY = True
+
+    for a, b, name in zip(run(True), run(False), ["seg_x", "dcat", "wc", "bc", "w1", "b1", "w2", "b2"]):
+        assert torch.equal(a, b), name
