@@ -64,7 +64,8 @@ class DataParallel(nn.Module):
         self._next_bucket = 0
         self._force_flat = force_flat_grads
         self._big_bytes = big_bytes
-        self.iter_size = 1 if iter_size is None else int(iter_size)
+        # (the reference's driver builds the wrapper without this argument, tools/train.py:344: CIM_ITER_SIZE carries its --iter_size)
+        self.iter_size = int(os.environ.get("CIM_ITER_SIZE", "1")) if iter_size is None else int(iter_size)
         self._backwards = 0          # backward passes since zero_grad()
         self._cb_queued = False
         self._reduced_this_step = False     # this step's buckets are reduced: a second finish_gradient_sync() is a no-op

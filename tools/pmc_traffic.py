@@ -19,6 +19,7 @@ import sys
 # product kernels -> the key bench.py looks up
 KEYS = (("gemm_pair_kernel<0, 0, false>", "wino_gemm_fwd"), ("gemm_pair_kernel<0, 0>", "wino_gemm_fwd"),
         ("roi_align_wino7_pair", "cim_roi_align_wino7_pair_fwd"), ("wino7_dx_maskfold", "wino7_dx_maskfold"),
+        ("wino7_flatten_bwd_dy_pair", "wino7_flatten_bwd_dy_pair"), ("step_mine_kernel", "step_mine"),
         ("roi_align_fwd_rowsum", "cim_roi_align_maskcat_fwd"), ("roi_align_fwd_agg", "cim_roi_align_maskcat_fwd"),
         ("roi_align_bwd_region_kernel<false", "cim_roi_align_bwd"), ("roi_align_bwd_region", "cim_roi_align_maskcat_bwd"),
         ("roi_partial_reduce", "roi_partial_reduce"), ("mask_iou_pair", "mask_iou_pair"), ("mask_pack", "mask_pack"),
@@ -30,7 +31,11 @@ def per_kernel(d, counter, names=None):
     vals = collections.defaultdict(list)
     for r in rows:
         if r["Counter_Name"] == counter:
-            vals[r["Kernel_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+            try:
+                wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+            except (KeyError, ValueError):
+                wgs = 0
+            vals[r["Kernel_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), wgs))
     return vals
 
 
@@ -39,8 +44,8 @@ def calibrate(fdir, wdir):
     out = {}
     for tag, needle, nbytes in (("copy16", "vectorized_elementwise_kernel", float(1 << 30)), ("copy4", "elementwise_kernel", None)):
         pick = lambda k: needle in k and "FillFunctor" not in k and ("vectorized" in needle or "vectorized" not in k)
-        fk = [v for k, vs in f.items() if pick(k) for _, v in vs]
-        wk = [v for k, vs in w.items() if pick(k) for _, v in vs]
+        fk = [v[1] for k, vs in f.items() if pick(k) for v in vs]
+        wk = [v[1] for k, vs in w.items() if pick(k) for v in vs]
         if not fk or not wk:
             continue
         big_f, big_w = max(fk), max(wk)
@@ -65,14 +70,19 @@ def main():
             ff, wf = cal["copy16"]["fetch_factor"], cal["copy16"]["write_factor"]
     out["_applied_factors"] = dict(fetch=ff, write=wf)
     for needle, key in KEYS:
-        f = [v for k, vs in fetch.items() if needle in k for _, v in sorted(vs)]
-        w = [v for k, vs in write.items() if needle in k for _, v in sorted(vs)]
-        if not f or key in out:
+        fl = [v for k, vs in fetch.items() if needle in k for v in sorted(vs)]
+        wl = [v for k, vs in write.items() if needle in k for v in sorted(vs)]
+        if not fl or key in out:
             continue
         if key == "wino_gemm_fwd":
-            # this instantiation is launched three times per image, the Winograd-domain forward GEMM of the MaskFuse conv first
-            # (f16x2p: then fc1's and fc2's forward products; f16x2: then fc2's and fc1's data-gradient GEMMs)
-            f, w = f[0::3], w[0::3]
+            # this instantiation also runs fc products and late weight-gradient chunks: the Winograd-domain forward GEMM of the
+            # MaskFuse conv is the launch whose workgroup count is a multiple of the 121 positions (121 x 16 / 121 x 20 tiles)
+            if any(v[2] for v in fl):
+                fl = [v for v in fl if v[2] and v[2] % 121 == 0]
+                wl = [v for v in wl if v[2] and v[2] % 121 == 0]
+            else:
+                fl, wl = fl[0::3], wl[0::3]
+        f, w = [v[1] for v in fl], [v[1] for v in wl]
         # (the first launches of a run belong to the warm-up: same kernels, same sizes)
         out[key] = dict(kernel=needle, dispatches=len(f), fetch_kib_mean=sum(f) / len(f), write_kib_mean=(sum(w) / len(w)) if w else None,
                         hbm_bytes_mean=(sum(f) / len(f) / ff + ((sum(w) / len(w) / wf) if w else 0)) * 1024)
