@@ -1307,66 +1307,11 @@ extern "C" int cim_wino_dx_adjoint_output(const float* M, float* dx, int R, int 
     return 0;
 }
 
-extern "C" int cim_wino7_dx_maskfold(const float* M, const float* masks, float* dbox, int R, int Cb, void* stream) {
-    CIM_CHECK_ARG(M && masks && dbox && R > 0 && Cb > 0 && Cb % 4 == 0);
-    int chunks = (Cb + 256 * CIM_W7_VDX - 1) / (256 * CIM_W7_VDX);
-    if (chunks > 4) chunks = 4;
-    hipLaunchKernelGGL(wino7_dx_maskfold_kernel, dim3(R, chunks), dim3(256), 0, cim::as_stream(stream), M, masks, dbox, R, Cb);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
 
-// ---- pair-image producers of the f16x2p engine (tile = 7 geometry: 121 positions) ---------------------------------------
-extern "C" int cim_wino7_pair_scales(const uint32_t* amax, int kind, float* scale, void* stream) {
-    CIM_CHECK_ARG(amax && scale && kind >= 0 && kind <= 3);
-    hipLaunchKernelGGL(wino7_pair_scales_kernel, dim3(1), dim3(128), 0, cim::as_stream(stream), amax, kind, scale);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
+// (the pair-image producers' entry points live in the product library only: cim_amd/csrc/winograd.hip)
 
-extern "C" int cim_wino7_input_pair(const float* x, void* V, const float* scale, int R, int Rs, int C, void* stream) {
-    CIM_CHECK_ARG(x && V && scale && R > 0 && Rs >= R && C > 0 && C % 8 == 0);
-    hipLaunchKernelGGL(wino7_input_pair_kernel, dim3(Rs, 4), dim3(256), 0, cim::as_stream(stream), x, (float*)V, R, Rs, C, scale);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
 
-extern "C" int cim_wino7_filter_pair(const float* W, void* U, const float* scale, int Cout, int Cin, void* stream) {
-    CIM_CHECK_ARG(W && U && scale && Cout > 0 && Cin > 0 && Cin % 8 == 0);
-    const size_t n = (size_t)Cout * Cin;
-    hipLaunchKernelGGL(wino7_filter_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), W,
-                       (float*)U, Cout, Cin, scale);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
 
-extern "C" int cim_wino7_dy_pair(const float* dy, void* D, const float* scale, int R, int Rs, int C, int adjoint, void* stream) {
-    CIM_CHECK_ARG(dy && D && scale && R > 0 && Rs >= R && C > 0 && C % 8 == 0);
-    if (adjoint) hipLaunchKernelGGL(wino7_dy_pair_kernel<true>, dim3(Rs, 4), dim3(256), 0, cim::as_stream(stream), dy, (float*)D, R, Rs, C, scale);
-    else hipLaunchKernelGGL(wino7_dy_pair_kernel<false>, dim3(Rs, 4), dim3(256), 0, cim::as_stream(stream), dy, (float*)D, R, Rs, C, scale);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
 
-extern "C" int cim_wino7_output_amax(const float* M, const float* bias, float* y, int R, int C, int relu, uint32_t* y_amax,
-                                     void* stream) {
-    CIM_CHECK_ARG(M && y && R > 0 && C > 0 && C % 4 == 0);
-    hipLaunchKernelGGL(wino7_output_kernel, dim3(R, 4), dim3(256), 0, cim::as_stream(stream), M, bias, y, R, C, relu, y_amax);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
 
-extern "C" int cim_flatten_chw_pair(const float* src, void* dst, const float* scale, int R, int Rs, int PP, int C, void* stream) {
-    CIM_CHECK_ARG(src && dst && scale && R > 0 && Rs >= R && PP > 0 && PP <= 64 && C > 0 && C % 64 == 0 && C / 64 <= 65535);
-    hipLaunchKernelGGL(flatten_chw_pair_kernel, dim3(Rs, C / 64), dim3(256), 0, cim::as_stream(stream), src, (float*)dst, R, PP, C, scale);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}
 
-extern "C" int cim_flatten_chw_bwd_bias(const float* src, const float* relu_y, float* dst, float* bias_partial, int R, int PP,
-                                        int C, void* stream) {
-    CIM_CHECK_ARG(src && dst && R > 0 && PP > 0 && PP <= 64 && C > 0 && C % 64 == 0 && C / 64 <= 65535);
-    hipLaunchKernelGGL(flatten_chw_kernel<false>, dim3(R, C / 64), dim3(256), 0, cim::as_stream(stream), src, relu_y, dst, PP, C, bias_partial);
-    CIM_CHECK_LAUNCH();
-    return 0;
-}

@@ -26,6 +26,20 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().cim_abi_version() >= 1
 
 
+def test_experiments_library_builds_and_exports_only_its_own_header():
+    """experiments/ (superseded engines, test comparators) builds against the CURRENT product header - a changed product signature
+    must not break it - and exports what experiments/include/cim_exp.h declares, no product entry point besides the error pair."""
+    import subprocess
+    from experiments import build as xbuild
+    xbuild.build()
+    header = open(os.path.join(REPO, "experiments", "include", "cim_exp.h")).read()
+    declared = set(re.findall(r"\b(cim_[a-z0-9_]+)\s*\(", header))
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(REPO, "experiments", "libcim_exp.so")], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (cim_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    assert exported - declared <= {"cim_last_error", "cim_abi_version", "cim_set_last_error"}, exported - declared
+
+
 def test_no_cpu_fallback():
     from cim_amd import _lib
     from cim_amd.modeling import heads
@@ -298,3 +312,22 @@ def test_library_sources_keep_no_state():
     for gone in ("cim_gemm_set_engine", "cim_gemm_get_engine", "cim_gemm_pair_limit"):
         assert gone + "(" not in header
     assert "cim_mining_sync_bytes" in header and "fork_event" in header and "max_workgroups" in header
+
+
+def test_pool_wrappers_take_the_module_on_cpu_tensors_and_parse_geometry():
+    """ops/pool.py: CPU tensors run the nn module itself (host-side tests of the model code); the geometry the HIP kernels take is
+    read off the module the way torch stores it (ints or pairs)."""
+    import torch.nn as nn
+    from cim_amd.ops import max_pool2d, upsample_nearest
+    from cim_amd.ops.pool import _one
+    x = torch.randn(1, 3, 9, 11)
+    m = nn.MaxPool2d(3, 2, 1)
+    assert torch.equal(max_pool2d(x, m), m(x))
+    u = nn.Upsample(scale_factor=2, mode="nearest")
+    assert torch.equal(upsample_nearest(x, u), u(x))
+    assert _one(3) == 3 and _one((2, 2)) == 2 and _one((2, 3)) is None
+    from cim_amd import _lib
+    lib = _lib.load()
+    for n, k, s, p in ((258, 3, 2, 1), (7, 3, 2, 1), (33, 2, 2, 0), (5, 5, 3, 2)):
+        want = nn.MaxPool2d(k, s, p)(torch.zeros(1, 1, n, n)).shape[-1]
+        assert lib.cim_maxpool2d_out_size(n, k, s, p) == want
