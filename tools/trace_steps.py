@@ -15,7 +15,8 @@ import sys
 def product_name(r):
     """The pair GEMM serves nine products per step under three instantiations: one row per PRODUCT, told apart by the launch's
     workgroup count (batched Winograd products are multiples of the 121 positions: forward 4 N-tiles per M-tile, data gradient 8;
-    launches of exactly 256 workgroups are the chunked late weight gradients), so that the roofline's dominant launch - the
+    launches of exactly 256 workgroups of the M-contiguous-A instantiations are the chunked late weight gradients; fc1's forward
+    product at <= 1024 proposals also has 256 workgroups - 4 x 16 tiles x 4 K-splits - under <0, 0>), so that the roofline's dominant launch - the
     Winograd-domain forward GEMM - has its own average duration in this file."""
     name = r["Kernel_Name"]
     if "gemm_pair_kernel" not in name:
@@ -30,7 +31,7 @@ def product_name(r):
         per = wgs // 121
         tag = "Winograd forward" if "<0, 0" in name else "Winograd data gradient" if "<0, 1" in name else "Winograd weight gradient"
         return "%s [%s GEMM: 121 x %d tiles]" % (name, tag, per)
-    if wgs == 256:
+    if wgs == 256 and "<1, " in name:          # (weight gradients contract over the rows of both operands: M-contiguous A)
         return "%s [late weight-gradient chunk: 256 workgroups]" % name
     return "%s [fc product: %d workgroups]" % (name, wgs)
 
