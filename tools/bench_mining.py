@@ -71,7 +71,8 @@ def main():
             if ahead:
                 torch.cuda.current_stream().wait_event(prep.event)      # (in the step the backbone forward lies in between)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+            torch.cuda._sleep(3000000)      # ~1.4 ms of GPU spin in front: the host enqueues the calls meanwhile (as in the step, where it
+            a.record()                      # runs ahead of the GPU) - without it the span holds the host's ~0.25 ms of launch work
             res = heads.mine_step(layers, scores, labels, iou, asy, prep=prep)
             b.record()
             res.commit()
