@@ -484,7 +484,10 @@ __device__ __forceinline__ void w7_fb_tile(const float* __restrict__ s, int lane
     if (D != nullptr) w7_dy_regs_pair<KA, KB, false>(d, D, MC, rc, sD);
 }
 
-__global__ __launch_bounds__(256) void wino7_flatten_bwd_dy_pair_kernel(const float* __restrict__ dX, const float* __restrict__ y,
+#ifndef CIM_W7_FB_WAVES
+#define CIM_W7_FB_WAVES 3
+#endif
+__global__ __launch_bounds__(256, CIM_W7_FB_WAVES) void wino7_flatten_bwd_dy_pair_kernel(const float* __restrict__ dX, const float* __restrict__ y,
                                                                         float* __restrict__ E, float* __restrict__ D,
                                                                         float* __restrict__ bsum, int R, int Rs, int C,
                                                                         const float* __restrict__ sE, const float* __restrict__ sD) {
@@ -536,11 +539,13 @@ __global__ __launch_bounds__(256) void wino7_flatten_bwd_dy_pair_kernel(const fl
         *reinterpret_cast<float4*>(bsum + rc) = make_float4((a.x + b.x) + (c.x + e.x), (a.y + b.y) + (c.y + e.y),
                                                             (a.z + b.z) + (c.z + e.z), (a.w + b.w) + (c.w + e.w));
     }
+    // wave t: the adjoint image of tile type t and the weight-gradient image of tile type 3 - t (36 + 25, 30 + 30, 30 + 30, 25 + 36
+    // positions: the four waves carry the same number of stores)
     switch (w) {
-        case 0: w7_fb_tile<0, 0>(s, lane, E, D, MC, rc, sE, sD); break;
-        case 1: w7_fb_tile<0, 1>(s, lane, E, D, MC, rc, sE, sD); break;
-        case 2: w7_fb_tile<1, 0>(s, lane, E, D, MC, rc, sE, sD); break;
-        default: w7_fb_tile<1, 1>(s, lane, E, D, MC, rc, sE, sD); break;
+        case 0: w7_fb_tile<0, 0>(s, lane, E, nullptr, MC, rc, sE, sD); w7_fb_tile<1, 1>(s, lane, nullptr, D, MC, rc, sE, sD); break;
+        case 1: w7_fb_tile<0, 1>(s, lane, E, nullptr, MC, rc, sE, sD); w7_fb_tile<1, 0>(s, lane, nullptr, D, MC, rc, sE, sD); break;
+        case 2: w7_fb_tile<1, 0>(s, lane, E, nullptr, MC, rc, sE, sD); w7_fb_tile<0, 1>(s, lane, nullptr, D, MC, rc, sE, sD); break;
+        default: w7_fb_tile<1, 1>(s, lane, E, nullptr, MC, rc, sE, sD); w7_fb_tile<0, 0>(s, lane, nullptr, D, MC, rc, sE, sD); break;
     }
 }
 
