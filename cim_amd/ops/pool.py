@@ -21,7 +21,7 @@ class MaxPool2dFunction(Function):
         ho = _lib.call("cim_maxpool2d_out_size", h, k, s, p)
         wo = _lib.call("cim_maxpool2d_out_size", w, k, s, p)
         y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
-        idx = torch.empty((n, c, ho, wo), dtype=torch.int32, device=x.device) if x.requires_grad else None
+        idx = torch.empty((n, c, ho, wo), dtype=torch.int32, device=x.device) if ctx.needs_input_grad[0] else None
         _lib.call("cim_maxpool2d_fwd", x.data_ptr(), y.data_ptr(), _lib.ptr(idx), n * c, h, w, k, s, p, _lib.stream_ptr())
         ctx.geom = (n, c, h, w, k, s, p)
         if idx is not None:
