@@ -535,3 +535,40 @@ def test_head_backward_with_and_without_the_fused_dy_launch_is_bit_identical(dev
 
     for a, b, name in zip(run(True), run(False), ["seg_x", "dcat", "wc", "bc", "w1", "b1", "w2", "b2"]):
         assert torch.equal(a, b), name
+
+
+def test_scale_sources_of_abi_13(dev):
+    """cim_pair_amax takes any n (tail elements), cim_pair_scales(reduce_all) takes the maximum of all words (a weight's row maxima ->
+    its one scale), cim_wino7_pair_scales multiplies max |d| by max(1, max |mask|) (MaskFuse's concat: lib/modeling/resnet50.py:131-134)."""
+    from cim_amd import _lib
+    from cim_amd.ops import pair
+    st = _lib.stream_ptr()
+    g = torch.Generator().manual_seed(5)
+    for n in (49 * 850, 7, 4096 + 3):
+        x = torch.randn(n, generator=g).to(dev)
+        x[n - 1] = -37.5                                           # the maximum sits in the tail
+        got = pair.amax_of(x).view(torch.float32)
+        assert float(got) == 37.5, (n, float(got))
+    # reduce_all: one scale from the maximum of the row maxima
+    rows = (torch.rand(300, generator=g) * 3.0).to(dev)
+    rows[123] = 5.0
+    words = rows.view(torch.int32)
+    s_all = pair.scales_from(words, 1, reduce_all=True)
+    s_one = pair.scales_from(torch.tensor([5.0], device=dev).view(torch.int32), 1)
+    assert torch.equal(s_all, s_one) and float(s_one) == 2.0 ** (14 - 2)
+    # the Winograd scales with a mask maximum: equal to the scales of amax * max(1, max |mask|)
+    a = torch.tensor([3.0], device=dev).view(torch.int32)
+    for mmax, eff in ((0.5, 3.0), (1.0, 3.0), (2.5, 7.5)):
+        m = torch.tensor([mmax], device=dev).view(torch.int32)
+        e = torch.tensor([eff], device=dev).view(torch.int32)
+        s0, s1 = torch.empty(121, device=dev), torch.empty(121, device=dev)
+        _lib.call("cim_wino7_pair_scales", a.data_ptr(), 1, m.data_ptr(), 0, s0.data_ptr(), st)
+        _lib.call("cim_wino7_pair_scales", e.data_ptr(), 1, None, 0, s1.data_ptr(), st)
+        assert torch.equal(s0, s1), mmax
+    # several amax words: their maximum
+    many = torch.tensor([0.25, 3.0, 1.0], device=dev).view(torch.int32)
+    s2 = torch.empty(121, device=dev)
+    _lib.call("cim_wino7_pair_scales", many.data_ptr(), 3, None, 1, s2.data_ptr(), st)
+    s3 = torch.empty(121, device=dev)
+    _lib.call("cim_wino7_pair_scales", a.data_ptr(), 1, None, 1, s3.data_ptr(), st)
+    assert torch.equal(s2, s3)
