@@ -731,6 +731,42 @@ __global__ __launch_bounds__(256) void wino7_wgrad_out_kernel(const float* __res
     }
 }
 
+// The same transform with COALESCED stores: the lanes of a wave run along co (dU's contiguous index), but dW [Cout][Cin][3][3] keeps
+// co OUTERMOST - a lane's nine results are 36 bytes, the next lane's 73 KB away: 576 scattered 4-byte stores per wave cost half of
+// the kernel (0.213 ms; 0.104 with the stores removed).  Workgroup = 64 co x CIM_W7_WG_CI ci (wave w takes ci0 + w): the results of a
+// co row pass through LDS and leave as one run of 9 CIM_W7_WG_CI floats per row.  Bit-identical results.
+// grid = (Cout / 64, Cin / CIM_W7_WG_CI); block = 64 CIM_W7_WG_CI.
+#ifndef CIM_W7_WG_CI
+#define CIM_W7_WG_CI 4
+#endif
+__global__ __launch_bounds__(64 * CIM_W7_WG_CI) void wino7_wgrad_out_rows_kernel(const float* __restrict__ dU, float* __restrict__ dW,
+                                                                                 int Cout, int Cin) {
+    constexpr int NCI = CIM_W7_WG_CI, ROW = 9 * NCI;
+    __shared__ float t[64][ROW + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * NCI;
+    const size_t KN = (size_t)Cin * Cout;
+    const size_t idx = (size_t)(ci0 + w) * Cout + co0 + lane;
+    float acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = 0.0f;
+    w7_wgrad_tile<0, 0, float>(dU, KN, idx, acc);
+    w7_wgrad_tile<0, 1, float>(dU, KN, idx, acc);
+    w7_wgrad_tile<1, 0, float>(dU, KN, idx, acc);
+    w7_wgrad_tile<1, 1, float>(dU, KN, idx, acc);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) t[lane][w * 9 + a * 3 + b] = acc[a][b];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * ROW; e += 64 * NCI) {
+        const int row = e / ROW, col = e - row * ROW;
+        dW[((size_t)(co0 + row) * Cin + ci0) * 9 + col] = t[row][col];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // (c, h, w) flatten of the conv output and its adjoint, fused with the ReLU mask.
 // The reference flattens MaskFuse's NCHW conv output with .view(N, -1) (resnet50.py:135): seg_fc.0's weight columns
@@ -824,6 +860,12 @@ extern "C" int cim_wino_wgrad_output(const float* dU, float* dW, int Cout, int C
     CIM_CHECK_ARG(dU && dW && Cout > 0 && Cin > 0);
     CIM_CHECK_ARG(tile == 7);         // (the F(2x2,3x3) / F(4x4,3x3) stages are test infrastructure: experiments/csrc/winograd_all.hip)
     const size_t n = (size_t)Cout * Cin;
+    if (Cout % 64 == 0 && Cin % CIM_W7_WG_CI == 0 && Cin / CIM_W7_WG_CI <= 65535) {
+        hipLaunchKernelGGL(wino7_wgrad_out_rows_kernel, dim3(Cout / 64, Cin / CIM_W7_WG_CI), dim3(64 * CIM_W7_WG_CI), 0, cim::as_stream(stream),
+                           dU, dW, Cout, Cin);
+        CIM_CHECK_LAUNCH();
+        return 0;
+    }
     if (CIM_W7_VWG == 4 && Cout % 4 == 0)
         hipLaunchKernelGGL(wino7_wgrad_out_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
     else hipLaunchKernelGGL(wino7_wgrad_out_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cim::as_stream(stream), dU, dW, Cout, Cin);
