@@ -404,7 +404,7 @@ def test_maskfuse_pair_function_vs_per_layer_path(dev, r):
         assert float((a - b).norm() / b.norm()) < 2e-5, name
 
 
-@pytest.mark.parametrize("C,H,W,K", [(256, 33, 43, 70), (64, 20, 25, 33), (512, 45, 60, 40)])
+@pytest.mark.parametrize("C,H,W,K", [(256, 33, 43, 70), (64, 20, 25, 33), (512, 45, 60, 40), (256, 7, 9, 3), (1024, 64, 64, 32), (8, 33, 43, 65)])
 def test_roi_align_wino7_pair_image_is_bit_identical_to_the_two_kernel_path(dev, C, H, W, K):
     """cim_roi_align_wino7_pair_fwd (round 5: ROIAlign + mask multiply + concat + the Winograd 4 + 3 input transform in one launch,
     lib/modeling/resnet50.py:121-135) writes the very pair image cim_roi_align_maskcat_fwd_ws + cim_wino7_input_pair write -
