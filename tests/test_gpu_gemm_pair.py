@@ -469,7 +469,7 @@ def test_roi_align_wino7_pair_image_is_bit_identical_to_the_two_kernel_path(dev,
             assert torch.equal(a, b), name
 
 
-@pytest.mark.parametrize("R,C,mask", [(37, 256, True), (21, 512, True), (5, 256, False)])
+@pytest.mark.parametrize("R,C,mask", [(37, 256, True), (21, 512, True), (5, 256, False), (1, 256, True), (33, 2048, True)])
 def test_flatten_backward_dy_images_in_one_launch_are_bit_identical(dev, R, C, mask):
     """cim_wino7_flatten_bwd_dy_pair (round 5): the backward of the (c, h, w) flatten + the conv's ReLU mask + both output-gradient
     transforms in ONE launch writes the very images (and bias partial sums) that cim_flatten_chw_bwd_bias + cim_wino7_dy_pair x 2
