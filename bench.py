@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--sustained", type=float, default=5.0, help="seconds of the extra sustained loop (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra loops (sustained, iter_size=4, upload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--late-cus", type=int, default=None, help="A/B aid: CUs of the stream MaskFuse's late weight-gradient launches run on "
+                    "(cim_amd/ops/gemm.py: LATE_CUS; 0 = the whole chip); default: the package's setting")
     ap.add_argument("--phases", type=int, default=0, help="extra: N more steps with HIP events at the phase boundaries of the "
                     "step (main stream, no profiler attached) -> extra.phases")
     ap.add_argument("--cpu-sample", type=int, default=0, help="proposals in the CPU sample (0 = all)")
@@ -104,6 +106,8 @@ def run(args):
     # stream position, but the host's wait for the step's mining launches no longer caps its lead over the GPU at half a step
     # (with an 8 ms host hiccup every fourth step: 14.19 vs 14.46 ms per step; none on a quiet box: 13.95 vs 13.95).
     heads.LAZY_SETTLE = True
+    if args.late_cus is not None:
+        gemm_mod.LATE_CUS = args.late_cus
     if os.environ.get("CIM_BENCH_WATCHDOG"):        # debugging aid: dump all thread stacks if a phase stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["CIM_BENCH_WATCHDOG"]), repeat=True)
@@ -166,6 +170,10 @@ def run(args):
         infos.append(dict(n=n, H=H, W=W, n_cls=int((inp["labels"] > 0).sum())))
         del inp
     torch.cuda.synchronize()
+    if args.late_cus:
+        # hipExtStreamCreateWithCUMask only makes BLOCKING streams (they synchronise with the NULL stream, which is torch's default
+        # stream): the step then runs on a stream of its own
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     np.random.seed(cfg.RNG_SEED + rank)                        # the anti-noise sampling stream
     state = dict(i=0, feat={})
 

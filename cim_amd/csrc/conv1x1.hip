@@ -26,7 +26,7 @@ namespace {
 #define CIM_SMALL_BK 32
 #endif
 #ifndef CIM_SMALL_ABL
-#define CIM_SMALL_ABL 0          // ablation builds (tools/build_alt.sh): 1 one MFMA per slab, 2 no stores, 3 no global loads, 4 empty kernel
+#define CIM_SMALL_ABL 0          // ablation builds (tools/build_alt.sh): 1 one MFMA per slab, 2 no stores, 3 no global loads (3 x 3: no gathers), 4 empty kernel, 5 (3 x 3) gathers without address arithmetic
 #endif
 constexpr int SBM = 64, SBN = 64, SBK = CIM_SMALL_BK;
 constexpr int SLD = 68;                      // padded row stride of a k-major slab (floats); % 4 == 0 for b128 stores
@@ -308,137 +308,15 @@ __global__ __launch_bounds__(128 * WN) void gemm_small_kernel(const SmallArgs g)
 #endif
 }
 
-// Round 6: the TILE-WALKING form of gemm_small_kernel (64 x 64 tiles).  Measured on the kernel above (profiles/r6/
-// pmc_sq_backbone.json, tools/bench_gemm_small.py): a launch costs ~12 us whatever its K - res3.conv1 (704 workgroups x 4 slabs)
-// 16 us, res4.0.conv1 (704 x 8 slabs) 20 us: ~1 us per slab round (= the MFMA time of the ~2.75 co-resident workgroups of a CU:
-// the steady state IS MFMA-bound), the rest is every workgroup of the launch being in the same phase at the same time - all
-// waiting for their first operands, then all multiplying, then all storing.  Here a launch has `R` workgroups per CU (R x 256 in
-// all; the dynamic LDS request is padded so that exactly R fit) and a workgroup WALKS over work items (tile, split) b, b + G,
-// b + 2G, ... with the operand pipeline (two register sets of pieces in flight, two LDS buffers, one barrier per slab) running
-// ACROSS item boundaries: the first slabs of the next item are on their way while the last slabs of this one are multiplied and
-// its epilogue's stores drain under the next item's MFMAs.  Items, slab order inside an item and the epilogue are those of
-// gemm_small_kernel: results are bit-identical (tests/test_gpu_gemm.py: walk vs plain).
-// Three cursors move over the same item sequence: L (global loads, two slabs ahead), P (LDS stores, one ahead), C (MFMAs).
-template <bool AM, bool BKc>
-__global__ __launch_bounds__(256) void gemm_small_walk_kernel(const SmallArgs g, const int items, const int tiles) {
-    constexpr int NT = 256, BNT = 64;
-    constexpr int PA = SBM * 8 / NT, PB = BNT * 8 / NT;
-    extern __shared__ __attribute__((aligned(16))) float walk_smem[];
-    float* const As0 = walk_smem;
-    float* const As1 = walk_smem + SBK * SLD;
-    float* const Bs0 = walk_smem + 2 * SBK * SLD;
-    float* const Bs1 = walk_smem + 3 * SBK * SLD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (g.N + BNT - 1) / BNT;
-    const int kper = ((g.K + g.splits - 1) / g.splits + SBK - 1) / SBK * SBK;
-    const int G = gridDim.x;
-    const rsrc_t RA_ = make_rsrc(g.A, tile_extent(AM, g.M, g.K, g.lda)), RB_ = make_rsrc(g.B, tile_extent(!BKc, g.N, g.K, g.ldb));
-    const unsigned sa = (AM ? (unsigned)g.lda * SBK : (unsigned)SBK) * 4u, sb = (!BKc ? (unsigned)g.ldb * SBK : (unsigned)SBK) * 4u;
-
-    // item -> tile origin, split, first k, slabs (an empty split - the rounding of kper leaves some behind K - walks one slab of
-    // zeros: its partial tile must still be stored)
-    auto decode = [&](int item, int& m0, int& n0, int& split, int& kbeg) -> int {
-        split = item / tiles;
-        const int tile = item - split * tiles;
-        const int tm = tile / tiles_n;
-        m0 = tm * SBM;
-        n0 = (tile - tm * tiles_n) * BNT;
-        kbeg = split * kper;
-        const int kend = min(g.K, kbeg + kper);
-        return max(1, (kend - kbeg + SBK - 1) / SBK);
-    };
-    int itemL = blockIdx.x, slabL = 0, nslabL = 1 << 30;
-    unsigned oa[PA], ob[PB];
-    auto enterL = [&]() {
-        if (itemL < items) {
-            int m0, n0, sp, kb;
-            nslabL = decode(itemL, m0, n0, sp, kb);
-#pragma unroll
-            for (int i = 0; i < PA; ++i) oa[i] = tile_off<AM, SBM>(g.lda, m0, kb, tid + i * NT);
-#pragma unroll
-            for (int i = 0; i < PB; ++i) ob[i] = tile_off<!BKc, BNT>(g.ldb, n0, kb, tid + i * NT);
-        } else {                       // behind the last item: loads that touch no memory (offsets behind the operands)
-            nslabL = 1 << 30;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) oa[i] = OOB;
-#pragma unroll
-            for (int i = 0; i < PB; ++i) ob[i] = OOB;
-        }
-    };
-    int itemP = blockIdx.x, slabP = 0, nslabP = 1 << 30, kbegP = 0;
-    auto enterP = [&]() {
-        if (itemP < items) { int m0, n0, sp; nslabP = decode(itemP, m0, n0, sp, kbegP); }
-        else nslabP = 1 << 30;
-    };
-    int itemC = blockIdx.x, slabC = 0, nslabC = 1 << 30, m0C = 0, n0C = 0, splitC = 0;
-    auto enterC = [&]() {
-        if (itemC < items) { int kb; nslabC = decode(itemC, m0C, n0C, splitC, kb); }
-        else nslabC = 1 << 30;
-    };
-
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    float4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
-#define WK_GLOAD(RA, RB)                                                                                           \
-    {                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < PA; ++i) RA[i] = bld4(RA_, oa[i] + (unsigned)slabL * sa);             \
-        _Pragma("unroll") for (int i = 0; i < PB; ++i) RB[i] = bld4(RB_, ob[i] + (unsigned)slabL * sb);             \
-        if (++slabL == nslabL) { itemL += G; slabL = 0; enterL(); }                                                \
-    }
-#define WK_PUT(RA, RB, AS, BS)                                                                                     \
-    {                                                                                                              \
-        const int kp = kbegP + slabP * SBK;                                                                        \
-        _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                             \
-            tile_store<AM, SBM>(AS, tile_ktail<AM, SBM>(RA[i], g.K, kp, tid + i * NT), tid + i * NT);               \
-        _Pragma("unroll") for (int i = 0; i < PB; ++i)                                                             \
-            tile_store<!BKc, BNT>(BS, tile_ktail<!BKc, BNT>(RB[i], g.K, kp, tid + i * NT), tid + i * NT);           \
-        if (++slabP == nslabP) { itemP += G; slabP = 0; enterP(); }                                                \
-    }
-#define WK_MMA(AS, BS)                                                                                             \
-    {                                                                                                              \
-        const float* __restrict__ a = AS + (lane >> 5) * SLD + wm * 32 + (lane & 31);                              \
-        const float* __restrict__ b = BS + (lane >> 5) * SLD + wn * 32 + (lane & 31);                              \
-        float av[SBK / 2], bv[SBK / 2];                                                                            \
-        _Pragma("unroll") for (int t = 0; t < SBK / 2; ++t) { av[t] = a[2 * t * SLD]; bv[t] = b[2 * t * SLD]; }    \
-        _Pragma("unroll") for (int t = 0; t < SBK / 2; ++t)                                                        \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);                                \
-        asm volatile("" : "+a"(acc));                                                                              \
-    }
-    // one slab step: loads of slab t + 2 -> the register set slab t was stored from; MFMAs of slab t; slab t + 1 -> the other LDS
-    // buffer (its pieces were requested one step ago: the wait in front of these stores is exact, whichever path the steps in
-    // between took); the item's epilogue when this was its last slab; barrier
-#define WK_STEP(RAc, RBc, RAn, RBn, ASc, BSc, ASn, BSn)                                                            \
-    {                                                                                                              \
-        WK_GLOAD(RAc, RBc)                                                                                         \
-        WK_MMA(ASc, BSc)                                                                                           \
-        WK_PUT(RAn, RBn, ASn, BSn)                                                                                 \
-        if (++slabC == nslabC) {                                                                                   \
-            small_epilogue(g, acc, m0C + wm * 32, n0C + wn * 32, lane, splitC);                                    \
-            _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.0f;                                          \
-            asm volatile("" : "+a"(acc));                                                                          \
-            itemC += G; slabC = 0; enterC();                                                                       \
-        }                                                                                                          \
-        __syncthreads();                                                                                           \
-    }
-    enterL(); enterP(); enterC();
-    WK_GLOAD(ra0, rb0)
-    WK_GLOAD(ra1, rb1)
-    WK_PUT(ra0, rb0, As0, Bs0)
-    asm volatile("" : "+a"(acc));
-    __syncthreads();
-    while (itemC < items) {
-        WK_STEP(ra0, rb0, ra1, rb1, As0, Bs0, As1, Bs1)
-        if (itemC >= items) break;
-        WK_STEP(ra1, rb1, ra0, rb0, As1, Bs1, As0, Bs0)
-    }
-#undef WK_GLOAD
-#undef WK_PUT
-#undef WK_MMA
-#undef WK_STEP
-}
-
+// Round 6, measured and dropped: a TILE-WALKING form of this kernel - R workgroups per CU (the LDS request padded so that exactly R
+// fit) that walk over the (tile, split) items b, b + G, ... with the operand pipeline running across item boundaries (three cursors:
+// loads two slabs ahead, LDS stores one ahead, MFMAs), epilogue stores draining under the next item's MFMAs.  Bit-identical to this
+// kernel on every shape and epilogue, and SLOWER (tools/bench_gemm_small.py, 7 layer shapes, us forward / dX / dW): 205 / 159 / 153
+// at R = 1, 177 / 143 / 149 at R = 2, 169 / 137 / 148 at R = 4 against 160 / 130 / 148 - these launches live on the NUMBER of
+// workgroups a CU holds (memory operations in flight), not on a long pipeline per workgroup.  The phase ablations of the same
+// round (profiles/r6/gemm_small_ablation_kernel_trace.txt; res3.conv3 forward, 704 workgroups x 4 slabs, 17.8 us of GPU time):
+// without the stores 10.2 us, with one MFMA per slab instead of 16: 14.3 us, without the global loads 15.8 us - the output
+// (y + the convolution output the BatchNorm backward needs, 22.9 MB at ~3 TB/s) is the largest single part, the MFMAs the smallest.
 // Round 4, measured and dropped: a REGISTER-DIRECT form of this product - every wave fetches its MFMA operands straight from memory
 // (lane (r, h) takes the 16 k of its half of a slab: four 16-byte loads per K-contiguous row, 16 coalesced 4-byte loads per
 // row-contiguous one; no LDS staging, no barrier in the loop), one 32 x 32 tile per workgroup whose four waves split K and meet in
@@ -626,7 +504,14 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
                     }
                 }
             }
+#if CIM_SMALL_ABL == 3       /* ablation: no gather loads (the address arithmetic stays) */
+            asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]));
+#elif CIM_SMALL_ABL == 5     /* ablation: gather loads without their address arithmetic */
+            rb[i] = make_float4(bld1(RB_, (unsigned)(p * 16 + k0 * 64)), bld1(RB_, (unsigned)(p * 16 + k0 * 64 + 4)),
+                                bld1(RB_, (unsigned)(p * 16 + k0 * 64 + 8)), bld1(RB_, (unsigned)(p * 16 + k0 * 64 + 12)));
+#else
             rb[i] = make_float4(bld1(RB_, off[0]), bld1(RB_, off[1]), bld1(RB_, off[2]), bld1(RB_, off[3]));
+#endif
         }
     };
     auto load_a = [&](int s, float4 (&ra)[PA]) {
@@ -651,7 +536,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
         const float* __restrict__ b = Bs[BUF] + (lane >> 5) * SLD + wn * 32 + (lane & 31);                          \
         float av[CBK / 2], bv[CBK / 2];                                                                             \
         _Pragma("unroll") for (int t = 0; t < CBK / 2; ++t) { av[t] = a[2 * t * SLD]; bv[t] = b[2 * t * SLD]; }     \
-        _Pragma("unroll") for (int t = 0; t < CBK / 2; ++t)                                                         \
+        _Pragma("unroll") for (int t = 0; t < (CIM_SMALL_ABL == 1 ? 1 : CBK / 2); ++t)                              \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);                                 \
         asm volatile("" : "+a"(acc));                                                                               \
     }
@@ -677,6 +562,9 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
     }
 #undef C3_PUT
 #undef C3_MMA
+#if CIM_SMALL_ABL == 2
+    if (m0 + wm * 32 + lane < 0)
+#endif
     small_epilogue(g, acc, m0 + wm * 32, n0 + wn * 32, lane, split);
 }
 
@@ -726,39 +614,9 @@ static void launch_splitk_reduce(const SmallArgs& g, hipStream_t st) {
     }
 }
 
-#ifndef CIM_SMALL_WALK
-#define CIM_SMALL_WALK 1           // 0: every product on gemm_small_kernel (A/B builds, tools/build_alt.sh)
-#endif
-#ifndef CIM_WALK_MIN_ITEMS
-#define CIM_WALK_MIN_ITEMS 512     // fewer (tile, split) items than this: nothing to walk over - one workgroup per item
-#endif
-#ifndef CIM_WALK_R
-#define CIM_WALK_R 0               // workgroups per CU of a walking launch; 0: by the item count
-#endif
-// workgroups per CU of a walking launch and the dynamic LDS request that admits exactly that many (160 KiB per CU)
-static inline int walk_wgs_per_cu(long long items) {
-    if (CIM_WALK_R) return CIM_WALK_R;
-    return items >= 1024 ? 2 : 1;
-}
-static inline size_t walk_lds_bytes(int R, size_t need) {
-    const size_t want = R <= 1 ? 96 * 1024 : R == 2 ? 72 * 1024 : R == 3 ? 48 * 1024 : 0;
-    return want > need ? want : need;
-}
-
 template <bool AM, bool BKc>
 static void launch_small(const SmallArgs& g, int splits, hipStream_t st, bool narrow) {
     const long long tm = (g.M + SBM - 1) / SBM;
-    const long long tiles = tm * ((g.N + 63) / 64), items = tiles * splits;
-    if (CIM_SMALL_WALK && !narrow && items >= CIM_WALK_MIN_ITEMS) {
-        const int R = walk_wgs_per_cu(items);
-        const size_t lds = walk_lds_bytes(R, sizeof(float) * 4 * SBK * SLD);
-        auto kern = gemm_small_walk_kernel<AM, BKc>;
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        const long long G = items < 256ll * R ? items : 256ll * R;
-        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, st, g, (int)items, (int)tiles);
-        return;
-    }
     if (narrow)
         hipLaunchKernelGGL((gemm_small_kernel<AM, BKc, 1>), dim3((unsigned)(tm * ((g.N + 31) / 32)), (unsigned)splits), dim3(128), 0, st, g);
     else

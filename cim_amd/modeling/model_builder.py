@@ -134,7 +134,7 @@ class Generalized_RCNN(nn.Module):
 
     def forward(self, data, rois, masks, labels, gtrois=None, mat=None, path=None, index=None,
                 iou_map=None, asy_iou_map=None):
-        """model_builder.py:117-213.  With CIM_HIGH_PRIO=1 (opt-in experiment, no measured gain: ops/maskfuse_pair.py) the TRAINING step
+        """model_builder.py:117-213.  With `ops.gemm.HIGH_PRIO = True` (a module attribute; opt-in experiment, no measured gain: ops/maskfuse_pair.py) the TRAINING step
         runs on a high-priority HIP stream of its own (ops/gemm.py: main_stream_high_priority; its backward follows it there); the
         caller's stream is ordered before and after, so drivers see ordinary tensors."""
         if not (self.training and _gemm_ops.HIGH_PRIO and torch.is_tensor(data) and data.is_cuda) or torch.cuda.is_current_stream_capturing():

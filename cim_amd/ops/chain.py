@@ -24,7 +24,8 @@ Protocol (host side, per backward pass; everything hangs off P's own `state` dic
     its backward, that x is still private (still_private): no tensor hook, no retain_grad() on x, and the running pass is a complete
     .backward() - not torch.autograd.grad(...) / .backward(inputs=...), which stop at (or capture) tensors inside the graph:
     restricted_pass() asks the engine whether Q's own parameters are accumulated into by this pass.  If not, Q computes the plain
-    data gradient and P its own BatchNorm backward - the ordinary autograd path, correct for every observer.  What cannot be seen
+    data gradient and P its own BatchNorm backward - the ordinary autograd path, correct for every observer (the decision is per pass:
+    state["unchained_pass"], consumed by P's take(); the forward-time mark state["taken"] is never cleared).  What cannot be seen
     from here - torch.autograd.grad whose inputs hold x AND every parameter of Q - is documented in INTEGRATION.md section 4.
 """
 import collections
@@ -88,7 +89,9 @@ def still_private(x, in_bn, node=None):
           and not getattr(x, "_post_accumulate_grad_hooks", None) and node_runs(x.grad_fn)
           and not (node is not None and restricted_pass(node)))
     if not ok:
-        in_bn.state["taken"] = False             # P sees an ordinary gradient and runs its own BatchNorm backward
+        # P sees an ordinary gradient in THIS pass and runs its own BatchNorm backward.  The forward-time mark state["taken"] stays:
+        # a later complete pass over a retained graph chains again, and take()'s second-consumer check must still be armed for it.
+        in_bn.state["unchained_pass"] = True
     return ok
 
 
@@ -103,6 +106,7 @@ def c_args(in_bn, part):
 
 
 def hand_over(in_bn, dx, part=None):
+    in_bn.state.pop("unchained_pass", None)      # (a mark left by an earlier restricted pass in which P's backward never ran)
     in_bn.state["handed"] = (dx.data_ptr(), dx.numel(), part)
 
 
@@ -113,6 +117,8 @@ def take(dy, state):
     h = state.pop("handed", None)
     if h is not None and h[0] == dy.data_ptr() and h[1] == dy.numel():
         return True, h[2]
+    if state.pop("unchained_pass", False):       # Q stepped aside in this pass (still_private): an ordinary gradient
+        return False, None
     if state.get("taken"):
         raise RuntimeError("cim_amd: a layer whose BatchNorm backward was fused into its consumer's data gradient received a "
                            "different gradient tensor - its output has a second consumer (fuse_input_bn=True is only valid for "

@@ -55,14 +55,54 @@ def _side_stream(dev):
 
 
 
+# CU partition of the last backward phase (round 6).  MaskFuse's late weight-gradient products (ops/maskfuse_pair.py: launches of one
+# 256 x 256 tile per CU, ~110 us each, 128 KB of LDS: the workgroup owns its CU) and the body's data- / weight-gradient chains
+# (~100 latency-bound launches that fill a fraction of the chip each) used to take the SUM of their times: a body launch got on the
+# chip between two launches of tiles and held all of it at a quarter of its MFMA rate.  With LATE_CUS > 0 the late products run on a
+# stream created with hipExtStreamCreateWithCUMask over the LAST `LATE_CUS` logical CUs (the driver deals mask bits round-robin over
+# the 8 XCDs: every XCD gives the same share), in launches of LATE_CUS workgroups; the body's launches - which cannot share a CU with
+# a tile anyway (LDS) - keep the other CUs to themselves the whole time.  The stream is the HOST's (the C library creates nothing);
+# 0: the late products run on the side stream over the whole chip (round 5's schedule).
+LATE_CUS = 0
+TOTAL_CUS = 256
+
+
+def _late_stream(dev):
+    """The stream of MaskFuse's late weight-gradient launches: the side stream, or - LATE_CUS > 0 - a stream confined to the
+    last LATE_CUS CUs."""
+    if not LATE_CUS:
+        return _side_stream(dev)
+    key = ("late", dev, LATE_CUS)
+    s = _SIDE.get(key)
+    if s is None:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        words = (TOTAL_CUS + 31) // 32
+        mask = (ctypes.c_uint32 * words)()
+        for i in range(TOTAL_CUS - LATE_CUS, TOTAL_CUS):
+            mask[i // 32] |= 1 << (i % 32)
+        raw = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), ctypes.c_uint32(words), mask)
+        if rc != 0 or not raw.value:
+            raise RuntimeError("cim_amd: hipExtStreamCreateWithCUMask failed (%d)" % rc)
+        s = _SIDE[key] = torch.cuda.ExternalStream(raw.value, device=dev)
+    return s
+
+
+def _extra_streams(dev):
+    """Every stream besides the side stream that deferred work may still run on (joined at the end of the backward pass)."""
+    return [st for key, st in _SIDE.items() if isinstance(key, tuple) and key[0] in ("body", "late") and key[1] == dev]
+
+
 HIGH_PRIO = False       # opt-in experiment: no measured gain (ops/maskfuse_pair.py)
 
 
 def main_stream_high_priority(dev):
     """A HIGH-priority HIP stream for the training step's main chain (Generalized_RCNN.forward runs on it, so does its
     backward): side-stream work - the deferred weight-gradient GEMMs - then only takes the CUs the main chain leaves, instead of
-    time-sharing them half and half with the data-gradient GEMMs.  Default off (CIM_HIGH_PRIO=1 to try): everything on the
-    caller's stream."""
+    time-sharing them half and half with the data-gradient GEMMs.  Default off (`gemm.HIGH_PRIO = True`, a module attribute, to
+    try): everything on the caller's stream."""
     s = _SIDE.get(("main", dev))
     if s is None:
         s = _SIDE[("main", dev)] = torch.cuda.Stream(device=dev, priority=-1)
@@ -81,7 +121,9 @@ def main_stream_high_priority(dev):
 # post-accumulate-grad hooks fire at the layer's backward although nothing was accumulated yet (gradient_is_deferred() tells) -
 # DataParallel, which counts ready gradients per bucket through such hooks, skips them and launches the bucket that holds
 # them at the end of the backward pass, after calling join_side() itself - and torch.autograd.grad() with such a weight
-# among its inputs does not see the gradient (use .backward(), or CIM_DEFER_DW=0).
+# among its inputs is served through autograd instead (ops/chain.py: restricted_pass - the layer's backward sees that the pass does not
+# accumulate into its weight and keeps everything on the caller's stream); `gemm.DEFER_DW = False` (a module attribute, no
+# environment switch) turns the deferral off altogether.
 # Measured at cfg2: 17.33 -> 16.62 ms per step.  Deferring the MaskFuse layers' weight gradients as well (fc1, fc2, the
 # Winograd convolution: they already run beside their layer's data gradient) changed nothing: 16.71 ms.
 DEFER_DW = OVERLAP and engine.HAS_ENGINE_CALLBACK
@@ -141,7 +183,7 @@ def fork_event(dev):
 
 def side_stream_for_backward(dev, param, node=None):
     """(side stream pointer or None, fork event, join event, join flag) for a backbone layer's backward whose weight is `param`:
-    deferred to the side stream (the caller joins later: no join event), or - HIP-graph capture, CIM_DEFER_DW=0, a weight that is
+    deferred to the side stream (the caller joins later: no join event), or - HIP-graph capture, gemm.DEFER_DW = False, a weight that is
     not a Parameter, a pass that is not a complete .backward() (torch.autograd.grad captures the gradient the node RETURNS: a
     deferred one, installed as .grad at the end of the pass, would be lost; `node` = the layer's ctx, ops/chain.py:
     restricted_pass) - everything on the caller's stream (a fork / join inside every layer measured SLOWER than that: 17.0-17.1 vs
@@ -235,7 +277,7 @@ def join_side(discard=False):
                         ent[1].extend(fn(recs))
             ent[3] = []
         if ent[1] or ent[2]:
-            streams = [_side_stream(dev)] + ([_SIDE[("body", dev)]] if ("body", dev) in _SIDE else [])
+            streams = [_side_stream(dev)] + _extra_streams(dev)
             for st in streams:
                 ent[0].wait_stream(st)
             cur = torch.cuda.current_stream(dev)

@@ -25,7 +25,7 @@ from . import gemm as G
 from . import pair
 
 NPOS = 121
-# Measured experiment (DEFER_DW with gemm.HIGH_PRIO, both module attributes): the node's weight-gradient GEMMs (fc2, fc1, conv: ~2.5 ms of MFMA
+# Measured experiment (maskfuse_pair.DEFER_DW with gemm.HIGH_PRIO, both MODULE ATTRIBUTES - no environment switches): the node's weight-gradient GEMMs (fc2, fc1, conv: ~2.5 ms of MFMA
 # work at cfg2) are only needed by the optimizer, so they can be joined once, at the end of the backward pass (ops/gemm.py:
 # defer_side_join), and keep running on the normal-priority side stream while a high-priority main chain
 # (model_builder.Generalized_RCNN.forward) goes on to the ROIAlign and backbone backward.  Measured at cfg2 (same box, interleaved,
@@ -289,9 +289,12 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
         if publisher is not None and chain.restricted_pass(ctx, (1 + ofs, 3 + ofs, 5 + ofs)):
             publisher = None                             # (torch.autograd.grad towards the weights: through autograd)
         late = []               # (slot, weight, closure) of the weight gradients launched at the end (DW_WGS > 0)
-        # (a pass that does not accumulate into the weights - torch.autograd.grad towards them - returns the gradients through autograd)
-        run_late = (overlap and DEFER_DW and G.DEFER_DW and DW_WGS > 0
-                    and not chain.restricted_pass(ctx, (1 + ofs, 3 + ofs, 5 + ofs)))
+        # A pass that does not accumulate into the weights - torch.autograd.grad(...) towards them, .backward(inputs=[...]) without them -
+        # CAPTURES what this node returns: there the weight gradients are neither launched late nor joined at the end of the pass (they
+        # would be lost, or written into a .grad the pass never asked for) - they go back through autograd, joined here.
+        restricted = chain.restricted_pass(ctx, (1 + ofs, 3 + ofs, 5 + ofs))
+        defer = DEFER_DW and G.DEFER_DW and not restricted
+        run_late = overlap and defer and DW_WGS > 0
 
         def side_grad(slot, w, fn):
             if run_late:
@@ -379,6 +382,8 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
             if overlap:
                 for t in dy_keep:
                     t.record_stream(side)
+        keep_alive = [t for t in (V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf, dY1p.scale, am)
+                      if t is not None] + dy_keep
         if late:
             # biggest first: with several ranks a gradient's all-reduce starts right behind its product (publish), and fc1's 822 MB
             # is the one that needs the rest of the backward pass to hide under
@@ -386,11 +391,18 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
 
             def launch(defer):
                 c2 = torch.cuda.current_stream(dev)
-                side.wait_stream(c2)
-                with torch.cuda.stream(side):
+                # (single process: the stream of the late launches may be confined to a part of the chip - ops/gemm.py: LATE_CUS -
+                # one workgroup per CU of that part per launch)
+                late_st = G._late_stream(dev) if publisher is None else side
+                late_st.wait_stream(c2)
+                if late_st is not side:
+                    late_st.wait_stream(side)        # (the operands' images, the weights' images: written on either)
+                    for t in keep_alive:
+                        t.record_stream(late_st)
+                with torch.cuda.stream(late_st):
                     # (several ranks: RCCL's all-reduce kernels hold CUs of their own while these products run - a launch of exactly
                     # one workgroup per CU would then need a second, nearly empty round each time: the products go out whole)
-                    limit = DW_WGS if publisher is None else 0
+                    limit = (G.LATE_CUS or DW_WGS) if publisher is None else 0
                     SCHEDULE["late_launches_chunked" if publisher is None else "late_launches_whole_products"] += 1
                     got = {slot: publish(w, fn(limit)) for slot, w, fn in late}
                 if defer:           # (postponed: this node has returned - the join bookkeeping of the block below happens here)
@@ -417,7 +429,7 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
             for t in [V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf, dY1p.scale, am] + dy_keep:
                 if t is not None:
                     t.record_stream(side)
-            if DEFER_DW and G.DEFER_DW:
+            if defer:
                 # the weight gradients keep running on the side stream while the main stream goes on to the ROIAlign and backbone
                 # backward: joined (and installed as .grad) once, at the end of the backward pass (ops/gemm.py: defer_side_join)
                 keep = [V.buf, Xp.buf, Y1p.buf, dY2p.buf, dY1p.buf] + dy_keep

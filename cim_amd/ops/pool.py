@@ -4,7 +4,7 @@
 VGG16, /root/reference/lib/modeling/vgg16.py:43,50,60), `upsample_nearest(x, module)` an `nn.Upsample(mode='nearest')` with an
 integer scale (HRNet fuse layers, /root/reference/lib/modeling/HRNet.py:201) - ATen's semantics (first maximum of a window wins,
 NaN propagates; block sums in row order), NCHW fp32.  CPU tensors take the module itself (host-side tests of the model code);
-a GPU tensor in a configuration the kernels do not take is a counted fallback (ops/fallback.py: an error under CIM_STRICT=1).
+a GPU tensor in a configuration the kernels do not take is a counted fallback (ops/fallback.py: an error unless allowed explicitly).
 """
 import torch
 from torch.autograd import Function

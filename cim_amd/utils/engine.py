@@ -7,8 +7,8 @@
 * `broadcast_coalesced(tensors, src, group)`: `dist._broadcast_coalesced`.
 
 When an internal is missing (a torch upgrade), `HAS_ENGINE_CALLBACK` is False and every user takes its documented
-synchronous form instead of failing: weight gradients travel through autograd on the caller's stream (CIM_DEFER_DW=0
-behaviour), the generator is settled inside the forward (CIM_MINING_SYNC=1 behaviour), DataParallel finishes its reduction
+synchronous form instead of failing: weight gradients travel through autograd on the caller's stream (the
+behaviour of `ops.gemm.DEFER_DW = False`), the generator is settled inside the forward, DataParallel finishes its reduction
 from a `torch.autograd.graph.register_multi_grad_hook` over its parameters; the broadcast falls back to one
 `dist.broadcast` per tensor.  CIM_NO_ENGINE_CALLBACK=1 forces the fallbacks (tests/test_dp_gloo.py runs both)."""
 import os

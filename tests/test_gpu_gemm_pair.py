@@ -537,6 +537,68 @@ def test_head_backward_with_and_without_the_fused_dy_launch_is_bit_identical(dev
         assert torch.equal(a, b), name
 
 
+def test_maskfuse_weight_gradients_in_restricted_passes(dev):
+    """torch.autograd.grad(...) towards MaskFuse's weights and .backward(inputs=[...]) are not complete passes: the node's weight
+    gradients must come back THROUGH autograd (not be launched late / installed as .grad at the end of the pass), and a pass that
+    does not ask for the weights must leave their .grad alone.  (the defer block used to run in such passes -
+    autograd.grad raised 'appears to not have been used', .backward(inputs=[cat]) wrote the weights' .grad.)"""
+    from cim_amd.ops import gemm, maskfuse_pair, pair
+    torch.manual_seed(11)
+    R, C = 37, 128
+    conv = torch.nn.Conv2d(2 * C, 256, 3, padding=1).to(dev)
+    fc1, fc2 = torch.nn.Linear(256 * 49, 128).to(dev), torch.nn.Linear(128, 96).to(dev)
+    params = [conv.weight, conv.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias]
+    cat0 = torch.randn(R, 2 * C, 7, 7, device=dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(R, 96, device=dev)
+    fa = pair.amax_of(cat0)
+
+    def fresh():
+        cat = cat0.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+        for t in params:
+            t.grad = None
+        return cat, maskfuse_pair.maskfuse_head(cat, conv, fc1, fc2, fa)
+
+    # the complete pass: the reference values
+    cat, out = fresh()
+    out.backward(dy)
+    gemm.join_side()
+    torch.cuda.synchronize()
+    want = dict(cat=cat.grad.clone(), wc=conv.weight.grad.clone(), w1=fc1.weight.grad.clone(), w2=fc2.weight.grad.clone(),
+                b1=fc1.bias.grad.clone())
+    # (a) torch.autograd.grad towards two of the weights (and the input): returned, equal, nothing installed or left pending
+    cat, out = fresh()
+    g1, gc, gcat = torch.autograd.grad(out, [fc1.weight, conv.weight, cat], dy)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, want["w1"]) and torch.equal(gc, want["wc"]) and torch.equal(gcat, want["cat"])
+    assert all(t.grad is None for t in params) and not gemm._PENDING_IDS
+    # (b) towards ONE weight only
+    cat, out = fresh()
+    g2, = torch.autograd.grad(out, [fc2.weight], dy)
+    torch.cuda.synchronize()
+    assert torch.equal(g2, want["w2"])
+    assert all(t.grad is None for t in params) and not gemm._PENDING_IDS
+    # (c) .backward(inputs=[cat]): only cat.grad is written
+    cat, out = fresh()
+    out.backward(dy, inputs=[cat])
+    gemm.join_side()
+    torch.cuda.synchronize()
+    assert torch.equal(cat.grad, want["cat"])
+    assert all(t.grad is None for t in params), [n for n, t in zip("wc bc w1 b1 w2 b2".split(), params) if t.grad is not None]
+    # (d) .backward(inputs=[fc1.weight, fc1.bias]): those two, nothing else
+    cat, out = fresh()
+    out.backward(dy, inputs=[fc1.weight, fc1.bias])
+    gemm.join_side()
+    torch.cuda.synchronize()
+    assert torch.equal(fc1.weight.grad, want["w1"]) and torch.equal(fc1.bias.grad, want["b1"])
+    assert cat.grad is None and conv.weight.grad is None and fc2.weight.grad is None
+    # and a complete pass afterwards still takes the deferred schedule and gives the same numbers
+    cat, out = fresh()
+    out.backward(dy)
+    gemm.join_side()
+    torch.cuda.synchronize()
+    assert torch.equal(conv.weight.grad, want["wc"]) and torch.equal(fc1.weight.grad, want["w1"]) and torch.equal(cat.grad, want["cat"])
+
+
 def test_scale_sources_of_abi_13(dev):
     """cim_pair_amax takes any n (tail elements), cim_pair_scales(reduce_all) takes the maximum of all words (a weight's row maxima ->
     its one scale), cim_wino7_pair_scales multiplies max |d| by max(1, max |mask|) (MaskFuse's concat: lib/modeling/resnet50.py:131-134)."""

@@ -15,7 +15,7 @@ def main():
     argv = sys.argv[1:]
     take = lambda flag: (argv.pop(argv.index(flag) + 1), argv.pop(argv.index(flag)))[0] if flag in argv else "hip"
     backbone, optim = take("--backbone"), take("--optim")
-    os.environ.pop("CIM_STRICT", None)                     # library branches are the point here
+    os.environ["CIM_ALLOW_FALLBACK"] = "*"                 # library branches are the point here (an error by default)
     import torch
     import bench
     if backbone == "aten":
