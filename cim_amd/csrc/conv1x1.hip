@@ -132,9 +132,9 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, float4 v, int 
 // partials, arrival counters in device memory - and measured it slower in the whole step: 17.92 / 16.41 ms against 14.87 ms with the
 // separate reduce; removed in round 5 together with its library-owned counter ring)
 // Epilogue of one output value (shared by the single-pass kernels, the in-kernel split-K combine and the reduce kernel)
-__device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int col, float v, float& s1, float& s2) {
+// (small_value: the epilogue's value without its stores - the vectorised reduce stores four of them at once)
+__device__ __forceinline__ float small_value(const SmallArgs& g, int row, int col, float v, float& s1, float& s2) {
     const size_t o = (size_t)row * g.ldc + col;
-    if (g.Xraw) g.Xraw[o] = v;
     float y = v;
     if (g.bn) {
         const float a = g.gamma[row] * rsqrtf(g.var[row] + g.eps);
@@ -154,7 +154,12 @@ __device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int co
         if (g.mpart && on) { s1 += y; s2 = fmaf(y, g.mxr[o] - g.mmean[row], s2); }
         y = on ? y * (g.mgamma[row] * rsqrtf(g.mvar[row] + g.meps)) : 0.0f;
     }
-    g.C[o] = y;
+    return y;
+}
+__device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int col, float v, float& s1, float& s2) {
+    const size_t o = (size_t)row * g.ldc + col;
+    if (g.Xraw) g.Xraw[o] = v;
+    g.C[o] = small_value(g, row, col, v, s1, s2);
 }
 __device__ __forceinline__ void small_finish(const SmallArgs& g, int row, int col, float v) {
     float s1 = 0.0f, s2 = 0.0f;
@@ -346,6 +351,36 @@ __global__ __launch_bounds__(256) void small_splitk_reduce_kernel(const SmallArg
     const size_t mn = (size_t)g.M * g.N;
     if (i >= mn) return;
     small_finish(g, (int)(i / g.N), (int)(i % g.N), splitk_sum(g.ws, i, mn, g.splits));
+}
+// Round 6: FOUR consecutive elements of the flat [M][N] result per thread (16-byte loads of the partial tiles, four of them in flight
+// per split batch) - the launch above has one 4-byte load per thread and split in flight and ran at 2.5 TB/s on 20 MB
+// (profiles/r6/gemm_small_ablation_kernel_trace.txt: 4.4-8.5 us).  Same sums in the same order: bit-identical.  Needs ldc == N,
+// M N % 4 == 0 and 16-byte aligned workspace (the launcher checks); the four elements may straddle a row.
+__global__ __launch_bounds__(256) void small_splitk_reduce4_kernel(const SmallArgs g) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t mn = (size_t)g.M * g.N;
+    const size_t i = q * 4;
+    if (i >= mn) return;
+    float4 v = *reinterpret_cast<const float4*>(g.ws + i);
+    for (int k0 = 1; k0 < g.splits; k0 += 4) {
+        float4 p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            p[j] = k0 + j < g.splits ? *reinterpret_cast<const float4*>(g.ws + (size_t)(k0 + j) * mn + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < g.splits) { v.x += p[j].x; v.y += p[j].y; v.z += p[j].z; v.w += p[j].w; }
+    }
+    int row = (int)(i / g.N), col = (int)(i - (size_t)row * g.N);
+    const float s[4] = {v.x, v.y, v.z, v.w};
+    float y[4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        y[j] = small_value(g, row, col, s[j], s1, s2);
+        if (++col == g.N) { col = 0; ++row; }
+    }
+    if (g.Xraw) *reinterpret_cast<float4*>(g.Xraw + i) = v;               // (ldc == N: element (row, col) is element i of the flat array)
+    *reinterpret_cast<float4*>(g.C + i) = make_float4(y[0], y[1], y[2], y[3]);
 }
 
 // the same with the producer's affine-gradient partial sums (SmallArgs.mpart): a block owns 256 consecutive columns of ONE row,
@@ -610,7 +645,13 @@ static void launch_splitk_reduce(const SmallArgs& g, hipStream_t st) {
         hipLaunchKernelGGL(small_splitk_reduce_rows_kernel, dim3((unsigned)((g.N + 255) / 256), (unsigned)g.M), dim3(256), 0, st, g);
     } else {
         const size_t n = (size_t)g.M * g.N;
-        hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
+        // (four elements per thread pay from ~0.5 M elements: 8.5 -> 6.8 us at 1.4 M, 7.5 -> 5.6 us at 1.45 M; small results with
+        // many splits - the weight gradients: 16 K elements x 64 splits - are a latency chain per thread and want MORE threads:
+        // 5.6 -> 9.5 us with four elements each)
+        if (n >= (1u << 19) && g.ldc == g.N && n % 4 == 0 && (((size_t)g.ws | (size_t)g.C | (size_t)g.Xraw) & 15) == 0)
+            hipLaunchKernelGGL(small_splitk_reduce4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, g);
+        else
+            hipLaunchKernelGGL(small_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
     }
 }
 
