@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--sustained", type=float, default=5.0, help="seconds of the extra sustained loop (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra loops (sustained, iter_size=4, upload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap-update", action="store_true", help="A/B aid: the whole SGD update on the step's own stream (round 5)")
+    ap.add_argument("--trail-wgs", type=int, default=None, help="A/B aid: workgroups of the side-stream update launch")
     ap.add_argument("--late-cus", type=int, default=None, help="A/B aid: CUs of the stream MaskFuse's late weight-gradient launches run on "
                     "(cim_amd/ops/gemm.py: LATE_CUS; 0 = the whole chip); default: the package's setting")
     ap.add_argument("--phases", type=int, default=0, help="extra: N more steps with HIP events at the phase boundaries of the "
@@ -135,6 +137,11 @@ def run(args):
     instrument(_lib, timer)
     dp = DataParallel(model, cpu_keywords=["im_info", "roidb"], minibatch=True)
     opt = make_optimizer(model, torch)
+    # opt-in of the headline loop (extra.settings): the update of the three big MaskFuse weights (96 % of the update's 5.1 GB) runs
+    # on the side stream UNDER the next step's backbone forward instead of in front of it (cim_amd/optim/sgd.py: overlap_update)
+    opt.overlap_update = not args.no_overlap_update
+    if args.trail_wgs is not None:
+        opt.trail_workgroups = args.trail_wgs
     if os.environ.get("CIM_EARLY_STEP", "0") == "1":
         dp.attach_optimizer(opt)     # opt-in: MaskFuse / heads update overlapped with the ROIAlign + backbone backward
                                      # (measured at 1 GPU: 17.36-17.47 ms with, 17.37 without - HBM time only moves)
@@ -328,8 +335,10 @@ def run(args):
         from cim_amd.ops import fallback as _fb
         extra["aten_fallbacks"] = {"%s: %s" % k: v for k, v in _fb.counts().items()}      # GPU tensors that took a library branch (none expected)
         extra["settings"] = dict(lazy_settle=bool(heads.LAZY_SETTLE), gc_freeze_after_warmup=True, differentiates="model's total_loss key",
-                                 retain_graph=False, note="the headline loop's three departures from the reference's literal driver loop; "
-                                 "extra.reference_loop measures that loop")
+                                 retain_graph=False, optimizer_overlap_update=bool(opt.overlap_update),
+                                 note="the headline loop's four departures from the reference's literal driver loop (the fourth: "
+                                 "cim_amd.optim.SGD.overlap_update - the big weights' update runs on the side stream under the next "
+                                 "backbone forward; same arithmetic, same weights bit for bit); extra.reference_loop measures that loop")
         line["extra"] = extra
         # what the process group itself reports (a SCALE run is checkable: ranks, backend, every rank's own rate)
         line["dist"] = dict(world_size=dist.get_world_size() if world > 1 else 1, backend=(dist.get_backend() if world > 1 else None),
@@ -347,10 +356,12 @@ def reference_loop(torch, np, heads, dp, opt, dev_batches, timed_fn, state, time
     forward and backward), as a user of the unchanged train.py gets it: per image the four losses are reduced with .mean(0), summed
     into `total_loss` by ATen adds, each read back with .cpu() (iter_size 1: five blocking reads between forward and backward;
     iter_size 4, the shipped scripts/train_CIM.sh: five reads per four images), backward(retain_graph=True); the product's default
-    generator settle (end of backward), no gc.freeze().  The headline loop differs in exactly these points (extra.settings)."""
+    generator settle (end of backward), no gc.freeze(), the whole optimizer update on the loop's stream.  The headline loop differs in
+    exactly these points (extra.settings)."""
     import gc
     lazy = heads.LAZY_SETTLE
     heads.LAZY_SETTLE = False
+    overlap, opt.overlap_update = opt.overlap_update, False          # (the whole update on the loop's own stream, as torch.optim.SGD)
     gc.unfreeze()
     stats = {"inner": {}, "log": []}
 
@@ -406,6 +417,7 @@ def reference_loop(torch, np, heads, dp, opt, dev_batches, timed_fn, state, time
             res["iter_size_%d" % it] = dict(images_per_s=k * it / el, ms_per_image=1e3 * el / (k * it), optimizer_steps=k)
     finally:
         heads.LAZY_SETTLE = lazy
+        opt.overlap_update = overlap
         dp.iter_size = 1
     res["vs_headline"] = res["iter_size_1"]["ms_per_image"] / headline_ms
     res["note"] = ("tools/train.py:418-438 + training_stats.UpdateIterStats restated: .mean(0) / ATen total / .cpu() reads between "

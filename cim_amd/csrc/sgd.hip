@@ -62,9 +62,14 @@ __device__ __forceinline__ float4 sgd_update4(float4& pv, const float4& gv, floa
     return pv;
 }
 
+// A launch of fewer workgroups than chunks WALKS over them (workgroup b takes chunks b, b + grid, ...): cim_sgd_multi's
+// max_workgroups - an update that runs beside another stream's latency-bound launches (cim_amd.optim.SGD.overlap_update: under the next
+// step's backbone forward) then holds ONE or TWO of a CU's workgroup slots instead of all of them, and those launches' workgroups
+// are placed at once instead of queueing behind 15 k chunk workgroups.
 __global__ __launch_bounds__(256) void sgd_multi_kernel(const cim_sgd_tensor* __restrict__ tensors,
-                                                        const cim_sgd_chunk* __restrict__ chunks, float momentum) {
-    const cim_sgd_chunk ch = chunks[blockIdx.x];
+                                                        const cim_sgd_chunk* __restrict__ chunks, int n_chunks, float momentum) {
+  for (int ci = blockIdx.x; ci < n_chunks; ci += gridDim.x) {
+    const cim_sgd_chunk ch = chunks[ci];
     const cim_sgd_tensor t = tensors[ch.tensor];
     const float lr = t.lr, wd = t.wd;
     if (t.cols > 0) {
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const cim_sgd_tensor* __
             atomicMax(col_amax + c, cm.x); atomicMax(col_amax + c + 1, cm.y);
             atomicMax(col_amax + c + 2, cm.z); atomicMax(col_amax + c + 3, cm.w);
         }
-        return;
+        continue;
     }
     float* __restrict__ p = reinterpret_cast<float*>(t.p) + ch.offset;
     const float* __restrict__ g = reinterpret_cast<const float*>(t.g) + ch.offset;
@@ -154,16 +159,18 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const cim_sgd_tensor* __
         b[i] = bv;
         p[i] = fmaf(-lr, bv, p[i]);
     }
+  }
 }
 
 }  // namespace
 
 extern "C" int cim_sgd_multi(const cim_sgd_tensor* tensors, const cim_sgd_chunk* chunks, int n_chunks, float momentum,
-                             void* stream) {
+                             int max_workgroups, void* stream) {
     CIM_CHECK_ARG((tensors != nullptr && chunks != nullptr) || n_chunks == 0);
-    CIM_CHECK_ARG(n_chunks >= 0);
+    CIM_CHECK_ARG(n_chunks >= 0 && max_workgroups >= 0);
     if (n_chunks == 0) return 0;
-    hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_chunks), dim3(256), 0, cim::as_stream(stream), tensors, chunks, momentum);
+    const int grid = max_workgroups > 0 && max_workgroups < n_chunks ? max_workgroups : n_chunks;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(grid), dim3(256), 0, cim::as_stream(stream), tensors, chunks, n_chunks, momentum);
     CIM_CHECK_LAUNCH();
     return 0;
 }

@@ -132,6 +132,10 @@ class Generalized_RCNN(nn.Module):
             for p in self.Conv_Body.parameters():
                 p.requires_grad = False
 
+    def state_dict(self, *args, **kwargs):
+        _gemm_ops.wait_pending_updates()        # (cim_amd.optim.SGD.overlap_update: big weights may still be updated on the side stream)
+        return super().state_dict(*args, **kwargs)
+
     def forward(self, data, rois, masks, labels, gtrois=None, mat=None, path=None, index=None,
                 iou_map=None, asy_iou_map=None):
         """model_builder.py:117-213.  With `ops.gemm.HIGH_PRIO = True` (a module attribute; opt-in experiment, no measured gain: ops/maskfuse_pair.py) the TRAINING step

@@ -95,6 +95,25 @@ def _extra_streams(dev):
     return [st for key, st in _SIDE.items() if isinstance(key, tuple) and key[0] in ("body", "late") and key[1] == dev]
 
 
+# ---- parameter updates still running on the side stream (cim_amd.optim.SGD with overlap_update: the big MaskFuse weights are
+# updated UNDER the next step's backbone forward).  Everything of this package that reads such a weight either runs on the side
+# stream behind the update (the weights' pair images, ops/maskfuse_pair.py: prefetch_weight_images) or calls wait_pending_updates()
+# first (an image built on the caller's stream, state_dict() of the model and of the optimizer).
+_PENDING_UPDATES = {}   # device -> (event recorded behind the update on the side stream, frozenset of parameter ids)
+
+
+def register_pending_update(dev, event, ids):
+    _PENDING_UPDATES[dev] = (event, frozenset(ids))
+
+
+def wait_pending_updates(dev=None):
+    """Make the CURRENT stream wait for parameter updates that are still running on the side stream (no-op when none are)."""
+    for d in ([dev] if dev is not None else list(_PENDING_UPDATES)):
+        ent = _PENDING_UPDATES.pop(d, None)
+        if ent is not None:
+            torch.cuda.current_stream(d).wait_event(ent[0])
+
+
 HIGH_PRIO = False       # opt-in experiment: no measured gain (ops/maskfuse_pair.py)
 
 

@@ -112,6 +112,7 @@ def weight_image(w, conv=False):
             torch.cuda.current_stream(w.device).wait_event(e[3])
             e[2].record_stream(torch.cuda.current_stream(w.device))
         return e[2]
+    G.wait_pending_updates(w.device)          # (built on the caller's stream: an update of w may still run on the side stream)
     with torch.no_grad():
         img = _conv_image(w.contiguous()) if conv else _fc_image(w.contiguous())
     _store(w, img, None)

@@ -31,6 +31,8 @@ _TENSOR = np.dtype([("p", "<u8"), ("g", "<u8"), ("buf", "<u8"), ("n", "<i8"), ("
                     ("rows", "<i4"), ("cols", "<i4"), ("row_amax", "<u8"), ("col_amax", "<u8")])
 _CHUNK = np.dtype([("tensor", "<i4"), ("n", "<i4"), ("offset", "<i8")])
 MATRIX_MIN = 1 << 20   # weights of at least this many elements are updated in matrix mode (row / column |max| by-product)
+TRAIL_MIN = 1 << 24    # overlap_update: weights of at least this many elements are updated on the side stream (at cfg2: fc1 205 M,
+                       # the MaskFuse convolution 18.9 M, fc2 16.8 M elements = 96 % of the update's 5.1 GB of traffic)
 TILE_ROWS, TILE_COLS = 64, 1024
 
 
@@ -59,7 +61,17 @@ class SGD(torch.optim.Optimizer):
             raise NotImplementedError("cim_amd.optim.SGD: dampening / Nesterov are not used by the reference and not provided")
         defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
         super().__init__(params, defaults)
-        self._passes = {}           # "all" | "early" | "rest" -> _Pass
+        # Opt-in (round 6; `optimizer.overlap_update = True`, bench.py sets it): the update of the BIG weights (>= TRAIL_MIN elements)
+        # leaves the caller's stream - step() enqueues it on the package's side stream, ordered behind everything the caller's stream
+        # has done, and returns without making the caller's stream wait.  The next forward's backbone (~1.9 ms of small latency-bound
+        # launches that leave HBM idle) then runs BESIDE the 0.8 ms HBM-bound update instead of behind it; the weights' pair images
+        # (all the forward and backward ever read of these weights) are built on the same side stream behind the update, and the
+        # caller's stream waits for them where MaskFuse starts - as before.  What the caller must know: between step() and the next
+        # forward's box head these weights (and their momentum buffers) are NOT ordered on the caller's stream; state_dict() of the
+        # model and of this optimizer wait by themselves, any other direct read needs `optimizer.wait_update()` first.
+        self.overlap_update = False
+        self.trail_workgroups = 256      # workgroups of the side-stream launch (one slot per CU; 0 / 256 / 512 / 1024 / 2048: 13.90 / 13.70 / 13.79 / 13.84 / 13.85 ms per step)
+        self._passes = {}           # "all" | "early" | "rest" | "trail" -> _Pass
         self._early = None          # (frozenset of parameter ids updated early in this optimizer step, stream, event)
         self._check_every_step = True    # re-count the parameters with gradients every step (a parameter that starts to
                                          # receive gradients must not be skipped silently; ~20 us)
@@ -198,7 +210,8 @@ class SGD(torch.optim.Optimizer):
             c["copied"] = torch.cuda.Event()
             c["copied"].record()
             c["sig"] = sig
-        _lib.call("cim_sgd_multi", c["table"].data_ptr(), ps.chunks.data_ptr(), ps.n_chunks, c["momentum"], _lib.stream_ptr())
+        _lib.call("cim_sgd_multi", c["table"].data_ptr(), ps.chunks.data_ptr(), ps.n_chunks, c["momentum"],
+                  self.trail_workgroups if key == "trail" else 0, _lib.stream_ptr())
         # the kernel wrote parameters and momentum buffers through raw pointers: tell autograd's version counters, so that
         # anything keyed by Tensor._version (saved-tensor checks, caches) sees the in-place update
         torch.autograd.graph.increment_version(c["touched"])
@@ -258,6 +271,37 @@ class SGD(torch.optim.Optimizer):
             self._early = None
             self._run("rest", lambda p: id(p) not in done)
             torch.cuda.current_stream().wait_event(ev)  # everything after the step sees the early update too
+        elif self.overlap_update and not torch.cuda.is_current_stream_capturing():
+            self._step_overlapped()
         else:
             self._run("all", lambda p: True)
         return loss
+
+    def _step_overlapped(self):
+        from ..ops import gemm
+        big = [p for g in self.param_groups for p in g["params"]
+               if p.grad is not None and p.is_cuda and p.numel() >= TRAIL_MIN and _matrix_shape(p) is not None]
+        ids = frozenset(id(p) for p in big)
+        self._run("rest", lambda p: id(p) not in ids)
+        if not big:
+            return
+        dev = big[0].device
+        cur, side = torch.cuda.current_stream(dev), gemm._side_stream(dev)
+        gemm.wait_pending_updates(dev)                   # (a previous trailing update nobody waited for: same stream order anyway)
+        side.wait_stream(cur)                            # gradients final, the small parameters' launch enqueued
+        with torch.cuda.stream(side):
+            self._run("trail", lambda p: id(p) in ids)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for p in big:                                    # zero_grad() drops these while the side stream may still read them
+            p.grad.record_stream(side)
+        gemm.register_pending_update(dev, ev, ids)
+
+    def wait_update(self):
+        """Make the current stream wait for an update that is still running on the side stream (overlap_update)."""
+        from ..ops import gemm
+        gemm.wait_pending_updates()
+
+    def state_dict(self):
+        self.wait_update()              # (momentum buffers of the big weights may still be written on the side stream)
+        return super().state_dict()

@@ -524,7 +524,10 @@ typedef struct cim_sgd_chunk {
     int32_t n;         /* elements of this chunk (clamped to the tensor's end in the kernel) */
     int64_t offset;    /* first element */
 } cim_sgd_chunk;
-int cim_sgd_multi(const cim_sgd_tensor* tensors, const cim_sgd_chunk* chunks, int n_chunks, float momentum, void* stream);
+/* max_workgroups (ABI 14): 0 = one workgroup per chunk; > 0: at most that many workgroups, each walking over chunks b, b + grid, ...
+ * (an update that runs beside another stream's latency-bound launches holds one or two workgroup slots per CU instead of all). */
+int cim_sgd_multi(const cim_sgd_tensor* tensors, const cim_sgd_chunk* chunks, int n_chunks, float momentum, int max_workgroups,
+                  void* stream);
 
 #ifdef __cplusplus
 }

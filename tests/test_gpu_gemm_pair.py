@@ -600,7 +600,7 @@ def test_fused_box_head_against_the_oracle_and_float64(dev, C, H, W, K, cout):
             e = float((a - b).norm() / b.norm())
         worst[name] = e
         assert e < 1e-5, "%s deviates from the oracle / float64 evaluation by %.3g" % (name, e)
-    from tests.golden.cases import record_deviation
+    from cases import record_deviation
     record_deviation("fused_box_head_vs_oracle_fp64[C=%d,%dx%d,K=%d]" % (C, H, W, K), worst)
 
 

@@ -633,7 +633,8 @@ def test_bn_act_matches_aten(dev, relu, with_res, affine_grad):
 
 def test_stream_scheduling_does_not_change_a_training_run(dev, monkeypatch):
     """The step's scheduling options - training forward / backward on a high-priority stream, MaskFuse's and the backbone's weight
-    gradients left on the side stream until the end of the backward pass, MaskFuse's launched late in chunks of 256 workgroups -
+    gradients left on the side stream until the end of the backward pass, MaskFuse's launched late in chunks of 256 workgroups,
+    the big weights' update on the side stream under the next forward (optim.SGD.overlap_update) -
     must not change a single bit of a training run:
     40 optimizer steps (fused SGD) with them ON (default) and OFF give the same loss trajectory, and every gradient stays finite.
     (A buffer the side stream still reads being handed out by the caching allocator showed up here as a NaN weight gradient
@@ -656,6 +657,7 @@ def test_stream_scheduling_does_not_change_a_training_run(dev, monkeypatch):
         bench.init_for_synthetic(model)
         model = model.to(dev).train()
         opt = bench.make_optimizer(model, torch)
+        opt.overlap_update = flag          # (round 6) the big weights' update on the side stream, under the next backbone forward
         inp = synthetic.make_image_inputs("resnet50_voc", seed=3, n=300)
         iou, asy = mask_iou.mask_iou_maps(torch.from_numpy(inp["full_masks"]).to(dev))
         t = lambda a: torch.from_numpy(a).unsqueeze(0).to(dev)
@@ -675,11 +677,19 @@ def test_stream_scheduling_does_not_change_a_training_run(dev, monkeypatch):
             opt.step()
             hist.append(float(loss))
         heads.settle_rng()
-        return hist
+        sd = model.state_dict()            # (waits for an update still running on the side stream by itself)
+        osd = opt.state_dict()
+        big = max(model.parameters(), key=lambda p: p.numel())
+        return hist, {k: v.detach().clone() for k, v in sd.items()}, osd["state"][max(osd["state"], key=lambda k: osd["state"][k]["momentum_buffer"].numel())]["momentum_buffer"].clone(), big.numel()
 
-    on, off = run(True), run(False)
+    (on, sd_on, mom_on, nbig), (off, sd_off, mom_off, _) = run(True), run(False)
     assert all(np.isfinite(on)) and on[-1] < on[0]
     assert on == off, [(i, a, b) for i, (a, b) in enumerate(zip(on, off)) if a != b][:3]
+    from cim_amd.optim import sgd as _sgd
+    assert nbig >= _sgd.TRAIL_MIN                                   # (the run did take the side-stream update)
+    for k in sd_on:
+        assert torch.equal(sd_on[k], sd_off[k]), k                  # the trained weights, bit for bit
+    assert torch.equal(mom_on, mom_off)
 
 
 # ------------------------------------------------------------------ optimizer (csrc/sgd.hip)
