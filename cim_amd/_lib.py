@@ -45,6 +45,7 @@ SIGNATURES = {
     "cim_conv3x3_nchw_f32": [_P, _P, _P] + [c_int] * 6 + [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P, _P],
     "cim_conv7x7_nchw_f32": [_P, _P, _P] + [c_int] * 5 + [_P, _P, _P, _P, c_float, c_int, _P],
     "cim_conv3x3_nchw_bwd_workspace": [c_int] * 6,
+    "cim_conv3x3_dx_parts": [c_int] * 3,
     "cim_conv3x3_nchw_bn_act_bwd": [_P] * 8 + [c_float, c_int] + [_P] * 5 + [c_int] * 7 + [_P, _P, _P, _P, _P, c_int] + [c_int, _P, _P, c_float] + [_P] * 4,
     "cim_conv3x3_wt_multi": [_P, c_int, _P],
     "cim_bn_act_fwd": [_P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, _P],
@@ -113,12 +114,12 @@ def load():
     return lib
 
 
-VALUE_RETURNING = {"cim_maxpool2d_out_size", "cim_mining_sync_bytes", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch"}      # return a count, not a status
+VALUE_RETURNING = {"cim_maxpool2d_out_size", "cim_conv3x3_dx_parts", "cim_mining_sync_bytes", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace", "cim_conv3x3_nchw_splits", "cim_gemm_small_splits", "cim_mining_lds_bytes", "cim_bn_act_bwd_chunks", "cim_gemm_pair_splits", "cim_roi_align_bwd_workspace", "cim_roi_align_bwd_scratch"}      # return a count, not a status
 
 
 # split counts / workspace sizes of the body's layers: pure functions of their integer arguments (their tuning switches are read
 # once per process), asked ~100 times per training step with the step's few dozen layer shapes
-PURE = {"cim_maxpool2d_out_size", "cim_gemm_small_splits", "cim_conv3x3_nchw_splits", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace",
+PURE = {"cim_maxpool2d_out_size", "cim_conv3x3_dx_parts", "cim_gemm_small_splits", "cim_conv3x3_nchw_splits", "cim_conv1x1_bwd_workspace", "cim_conv3x3_nchw_bwd_workspace",
         "cim_bn_act_bwd_chunks", "cim_gemm_pair_splits"}
 _PURE_VALUES = {}
 

@@ -603,6 +603,159 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, c
     small_epilogue(g, acc, m0 + wm * 32, n0 + wn * 32, lane, split);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 6: the data gradient of a STRIDE-2 3 x 3 convolution (the first bottleneck of res3 / res4: torchvision v1.5 puts the
+// stride on conv2) by PARITY CLASSES of the input pixels.  conv3x3_small_kernel<CONV_DX> walks all 9 taps for every input pixel
+// and gathers zeros for the taps whose parity does not match: (yi + 1 - ky) must be even, so an even row only sees ky = 1 and an
+// odd row ky = 0, 2 (likewise columns) - 9 of the 36 (tap, pixel class) pairs carry data, the other three quarters of the
+// MFMAs multiplied zeros (profiles/r6: 85-104 us against 33 us for the stride-1 layers of the same size).  Here the pixels are
+// enumerated class by class (py, px = parity of the row / column; tiles never mix classes) and a class contracts over ITS taps
+// only:  K' = cout x {1, 2, 2, 4},  k' = co T + j,  tap j of class -> (ky, kx);  the pixel (yc, xc) of a class is the input
+// pixel (2 yc + py, 2 xc + px) and reads dY[co][yc + oy][xc + ox] with oy = [py and ky == 0], ox = [px and kx == 0].
+// No split-K (the longest class walks 4 cout / 32 slabs: 16 / 32 at res3 / res4) and no reduce launch; the epilogue (producer's
+// BatchNorm + ReLU backward, its affine partial sums) is small_epilogue's with the column mapped back to the map:
+// partial-sum groups are numbered class by class (cim_conv3x3_dx_parts).
+struct Dx2Geom { int H, W, Ho, Wo, cin, cout; int first[5]; int tiles_n[4]; int group0[4]; };
+struct ColMap { int Wc, W, py, px, Nc, group0; };
+
+__device__ __forceinline__ void small_epilogue_mapped(const SmallArgs& g, const f32x16& acc, int row0, int col0, int lane, const ColMap& cm) {
+    const int nc = col0 + (lane & 31);
+    const bool in = nc < cm.Nc;
+    const int yc = nc / cm.Wc, xc = nc - yc * cm.Wc;
+    const int col = (2 * yc + cm.py) * cm.W + 2 * xc + cm.px;
+    if (g.mpart == nullptr) {
+        if (in) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (row < g.M) small_finish(g, row, col, acc[r]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        float s1 = 0.0f, s2 = 0.0f;
+        if (in && row < g.M) small_finish(g, row, col, acc[r], s1, s2);
+        small_put_part(g, row, cm.group0 + (col0 >> 5), lane, s1, s2);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3x3_dx2_kernel(const SmallArgs g, const Dx2Geom c) {
+    constexpr int NT = 256, PA = SBM * (CBK / 4) / NT, PB = SBN * (CBK / 4) / NT;
+    extern __shared__ __attribute__((aligned(16))) float d2_smem[];
+    float (*As)[CBK * SLD] = reinterpret_cast<float (*)[CBK * SLD]>(d2_smem);
+    float (*Bs)[CBK * SLD] = reinterpret_cast<float (*)[CBK * SLD]>(d2_smem + 2 * CBK * SLD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int cls = 0;
+    while (cls < 3 && (int)blockIdx.x >= c.first[cls + 1]) ++cls;
+    const int py = cls >> 1, px = cls & 1;
+    const int Wc = (c.W - px + 1) >> 1, Nc = ((c.H - py + 1) >> 1) * Wc;
+    const int local = (int)blockIdx.x - c.first[cls], tn = c.tiles_n[cls];
+    const int m0 = (local / tn) * SBM, n0 = (local % tn) * SBN;
+    const int nx = px ? 2 : 1, lgT = py + px, T = 1 << lgT;
+    const int K = c.cout << lgT;                       // k' = co T + j
+    const int nslab = (K + CBK - 1) / CBK;
+    const int how = c.Ho * c.Wo;
+    const rsrc_t RA_ = make_rsrc(g.A, tile_extent(true, g.M, 9 * c.cout, g.lda));
+    const rsrc_t RB_ = make_rsrc(g.B, (long long)c.cout * how);
+    // the four class pixels of each B piece (fixed over the K loop); yc < 0: behind the class
+    int yc[PB][4], xc[PB][4];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int p = tid + i * NT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nc = n0 + (p % 16) * 4 + j;
+            const int y = nc / Wc;
+            yc[i][j] = nc < Nc ? y : -(1 << 20);
+            xc[i][j] = nc - y * Wc;
+        }
+    }
+    // tap j of this class: (ky, kx) and the displacement of the output pixel it reads
+    auto tap_of = [&](int j, int& tap, int& oy, int& ox) {
+        const int jy = j / nx, jx = j - jy * nx;
+        const int ky = py ? 2 * jy : 1, kx = px ? 2 * jx : 1;
+        tap = ky * 3 + kx;
+        oy = (py && jy == 0) ? 1 : 0;
+        ox = (px && jx == 0) ? 1 : 0;
+    };
+    auto load_a = [&](int k0, float4 (&ra)[PA]) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {               // A = the weight transposed to [(co, tap)][ci]: rows of ci, k' -> row co 9 + tap
+            const int p = tid + i * NT;
+            const int k = k0 + p / (SBM / 4), r = m0 + (p % (SBM / 4)) * 4;
+            const int co = k >> lgT;
+            int tap, oy, ox;
+            tap_of(k & (T - 1), tap, oy, ox);
+            ra[i] = bld4(RA_, co < c.cout ? ((unsigned)(co * 9 + tap) * g.lda + r) * 4u : OOB);
+        }
+    };
+    auto load_b = [&](int k0, float4 (&rb)[PB]) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int p = tid + i * NT;
+            const int k = k0 + p / 16;
+            const int co = k >> lgT;
+            int tap, oy, ox;
+            tap_of(k & (T - 1), tap, oy, ox);
+            const int base = co * how;
+            unsigned off[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yo = yc[i][j] + oy, xo = xc[i][j] + ox;
+                const bool ok = co < c.cout && yo >= 0 && yo < c.Ho && xo < c.Wo;
+                off[j] = ok ? (unsigned)(base + yo * c.Wo + xo) * 4u : OOB;
+            }
+            rb[i] = make_float4(bld1(RB_, off[0]), bld1(RB_, off[1]), bld1(RB_, off[2]), bld1(RB_, off[3]));
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    float4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+#define D2_PUT(RA, RB, BUF)                                                                                         \
+    {                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i) tile_store<true, SBM>(As[BUF], RA[i], tid + i * NT);          \
+        _Pragma("unroll") for (int i = 0; i < PB; ++i) tile_store<true, SBN>(Bs[BUF], RB[i], tid + i * NT);          \
+    }
+#define D2_MMA(BUF)                                                                                                 \
+    {                                                                                                               \
+        const float* __restrict__ a = As[BUF] + (lane >> 5) * SLD + wm * 32 + (lane & 31);                          \
+        const float* __restrict__ b = Bs[BUF] + (lane >> 5) * SLD + wn * 32 + (lane & 31);                          \
+        float av[CBK / 2], bv[CBK / 2];                                                                             \
+        _Pragma("unroll") for (int t = 0; t < CBK / 2; ++t) { av[t] = a[2 * t * SLD]; bv[t] = b[2 * t * SLD]; }     \
+        _Pragma("unroll") for (int t = 0; t < CBK / 2; ++t)                                                         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);                                 \
+        asm volatile("" : "+a"(acc));                                                                               \
+    }
+    {
+        const int last = nslab - 1;      // (loads unconditional, the slab index clamped: see gemm_small_kernel)
+        load_a(0, ra0); load_b(0, rb0);
+        load_a(min(1, last) * CBK, ra1); load_b(min(1, last) * CBK, rb1);
+        D2_PUT(ra0, rb0, 0)
+        asm volatile("" : "+a"(acc));
+        __syncthreads();
+        for (int s = 0; s < nslab; s += 2) {
+            load_a(min(s + 2, last) * CBK, ra0); load_b(min(s + 2, last) * CBK, rb0);
+            D2_MMA(0)
+            if (s + 1 < nslab) D2_PUT(ra1, rb1, 1)
+            __syncthreads();
+            if (s + 1 >= nslab) break;
+            load_a(min(s + 3, last) * CBK, ra1); load_b(min(s + 3, last) * CBK, rb1);
+            D2_MMA(1)
+            if (s + 2 < nslab) D2_PUT(ra0, rb0, 0)
+            __syncthreads();
+        }
+    }
+#undef D2_PUT
+#undef D2_MMA
+    const ColMap cm{Wc, c.W, py, px, Nc, c.group0[cls]};
+    small_epilogue_mapped(g, acc, m0 + wm * 32, n0 + wn * 32, lane, cm);
+}
+
 // w [Cout][Cin][9] -> wt [Cout][9][Cin] (the data gradient's A operand, M-contiguous): one workgroup per output channel,
 // through LDS so that both sides are coalesced.  (Gathering W[co][ci][tap] in the GEMM's loader - 36-byte strides between
 // lanes - made the data gradient 1.7x slower than the forward: 69 vs 40 us.)
@@ -918,6 +1071,36 @@ extern "C" int cim_conv7x7_nchw_f32(const float* x, const float* w, float* y, in
     return 0;
 }
 
+namespace {
+// pixel classes of the stride-2 data gradient (conv3x3_dx2_kernel): class = 2 py + px
+Dx2Geom dx2_geom(int cin, int cout, int H, int W) {
+    Dx2Geom c{};
+    c.H = H; c.W = W; c.Ho = (H - 1) / 2 + 1; c.Wo = (W - 1) / 2 + 1; c.cin = cin; c.cout = cout;
+    const int tiles_m = (cin + SBM - 1) / SBM;
+    int first = 0, group = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int py = cls >> 1, px = cls & 1;
+        const int nc = ((H - py + 1) / 2) * ((W - px + 1) / 2);
+        c.first[cls] = first;
+        c.tiles_n[cls] = (nc + SBN - 1) / SBN;
+        c.group0[cls] = group;
+        first += tiles_m * c.tiles_n[cls];
+        group += 2 * c.tiles_n[cls];                // two 32-column groups per tile
+    }
+    c.first[4] = first;
+    return c;
+}
+}  // namespace
+
+// 32-pixel groups of the affine partial sums a data gradient's epilogue leaves per channel (in_part: [B][2][parts][cin]): stride 1 -
+// ceil(H W / 32) consecutive pixels; stride 2 - the groups of conv3x3_dx2_kernel's pixel classes (tile padded).
+extern "C" int cim_conv3x3_dx_parts(int H, int W, int stride) {
+    if (stride != 2) return (H * W + 31) / 32;
+    int parts = 0;
+    for (int cls = 0; cls < 4; ++cls) parts += 2 * ((((H - (cls >> 1) + 1) / 2) * ((W - (cls & 1) + 1) / 2) + SBN - 1) / SBN);
+    return parts;
+}
+
 extern "C" long long cim_conv3x3_nchw_bwd_workspace(int B, int cin, int cout, int H, int W, int stride) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long long dx = (long long)cim_gemm_small_splits(cin, H * W, 9 * cout) * cin * H * W;
@@ -1013,9 +1196,26 @@ extern "C" int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, cons
         }
     }
     if (dx && !wt_ready) hipLaunchKernelGGL(conv3x3_wt_kernel, dim3(cout), dim3(256), sizeof(float) * cin * 9, st, w, wt_own, cin);
+    const int parts = cim_conv3x3_dx_parts(H, W, dilation == 1 ? stride : 1);
     for (int b = 0; b < B && dx; ++b) {                        // dX[cin][H W] = sum over (co, tap) W[co][ci][tap] dconv[co][shifted]
         const InputBn ib{x + (size_t)b * cin * hw, in_gamma, in_var, in_eps, in_xr ? in_xr + (size_t)b * cin * hw : nullptr, in_mean,
-                         in_part ? in_part + (size_t)b * 2 * ((hw + 31) / 32) * cin : nullptr};
+                         in_part ? in_part + (size_t)b * 2 * parts * cin : nullptr};
+        if (stride == 2 && dilation == 1) {                    // by parity classes of the input pixels: a quarter of the MFMAs, no split-K
+            SmallArgs g{};
+            g.A = wt; g.B = dconv + (size_t)b * cout * hwo; g.C = dx + (size_t)b * cin * hw;
+            g.M = cin; g.N = hw; g.K = 9 * cout; g.lda = cin; g.ldb = 0; g.ldc = hw;
+            g.splits = 1;
+            set_input_bn(g, in_gamma ? &ib : nullptr);
+            g.mparts = parts;
+            const Dx2Geom c2 = dx2_geom(cin, cout, H, W);
+            const size_t lds = sizeof(float) * 4 * CBK * SLD;
+            if (lds > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_dx2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL(conv3x3_dx2_kernel, dim3((unsigned)c2.first[4]), dim3(256), lds, st, g, c2);
+            continue;
+        }
         conv3x3_launch(CONV_DX, wt, dconv + (size_t)b * cout * hwo, dx + (size_t)b * cin * hw, cin, hw, 9 * cout, cin, hw, cx, nullptr,
                        nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, cim_gemm_small_splits(cin, hw, 9 * cout), ws_dx, st, 3,
                        in_gamma ? &ib : nullptr);

@@ -122,7 +122,8 @@ class Conv3x3BnActFunction(Function):
         in_bn = ctx.in_bn if need_x else None
         if in_bn is not None and not chain.still_private(x, in_bn, ctx):
             in_bn = None                         # somebody looks at x's gradient / the producer's backward is not in this pass
-        in_part = torch.empty((B, 2, (H * W + 31) // 32, cin), dtype=torch.float32, device=dev) if in_bn is not None and in_bn.affine else None
+        parts = _lib.call("cim_conv3x3_dx_parts", H, W, stride if dilation == 1 else 1)    # (stride 2: groups of the data gradient's pixel classes)
+        in_part = torch.empty((B, 2, parts, cin), dtype=torch.float32, device=dev) if in_bn is not None and in_bn.affine else None
         side, ev_fork, ev_join, join = _gemm_mod.side_stream_for_backward(dev, ctx.param if (need_x and need_w) else None, ctx)
         wt = _transposed(ctx.param) if (need_x and ctx.param is not None) else None
         _lib.call("cim_conv3x3_nchw_bn_act_bwd", dy.data_ptr(), _lib.ptr(y), xr.data_ptr(), x.data_ptr(), w.data_ptr(),

@@ -323,6 +323,10 @@ int cim_conv7x7_nchw_f32(const float* x, const float* w, float* y, int cin, int 
  * workspace: cim_conv3x3_nchw_bwd_workspace(...) bytes.  cin % 4 == 0, cout % 4 == 0.  side_stream, fork_event, join_event, join,
  * dy_is_dconv and in_gamma / in_var / in_eps as in cim_conv1x1_bn_act_bwd. */
 long long cim_conv3x3_nchw_bwd_workspace(int B, int cin, int cout, int H, int W, int stride);
+/* cim_conv3x3_dx_parts (ABI 14): the number of 32-pixel groups `in_part` ([B][2][parts][cin]) must provide for this geometry - stride 1:
+ * ceil(H W / 32); stride 2 (dilation 1): the data gradient runs by parity classes of the input pixels (a class only contracts over
+ * the taps that reach it: 9 of the 36 (tap, class) pairs) and numbers its groups class by class, tile padded. */
+int cim_conv3x3_dx_parts(int H, int W, int stride);
 int cim_conv3x3_nchw_bn_act_bwd(const float* dy, const float* y, const float* x_raw, const float* x, const float* w,
                                 const float* gamma, const float* mean, const float* var, float eps, int relu, float* dres,
                                 float* dgamma, float* dbeta, float* dx, float* dw, int B, int cin, int cout, int H, int W,

@@ -41,5 +41,17 @@ python3 "$ROOT/tools/bench_mining.py" > "$OUT/bench_mining.txt" 2>&1
 python3 "$ROOT/tools/bench_mining.py" --config resnet50_coco2017 >> "$OUT/bench_mining.txt" 2>&1
 python3 "$ROOT/tools/bench_conv3x3.py" 2>/dev/null | grep "^{" > "$OUT/bench_conv3x3.json"
 python3 "$ROOT/tools/bench_gemm_small.py" 2>/dev/null | grep "^{" > "$OUT/bench_gemm_small.json"
+# round 6: SQ counters of the backbone's kernels (the micro-benchmarks above under --pmc), per-dispatch-run GPU durations of the same
+SQB="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"
+rocprofv3 --kernel-trace --pmc $SQB --output-format csv -d /tmp/pmc_gs -o r -- python3 "$ROOT/tools/bench_gemm_small.py" > "$OUT/pmc_gs.log" 2>&1
+python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_gs gemm_small small_splitk > "$OUT/pmc_sq_backbone_gemm_small.json"
+rocprofv3 --kernel-trace --pmc $SQB --output-format csv -d /tmp/pmc_c3 -o r -- python3 "$ROOT/tools/bench_conv3x3.py" > "$OUT/pmc_c3.log" 2>&1
+python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_c3 conv3x3_small small_splitk > "$OUT/pmc_sq_backbone_conv3x3.json"
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_gs -o r -- python3 "$ROOT/tools/bench_gemm_small.py" > /dev/null 2>&1
+python3 "$ROOT/tools/trace_by_dispatch.py" /tmp/kt_gs/r_kernel_trace.csv 20 > "$OUT/gemm_small_kernel_trace.txt"
+# same-box A/B of the round's scheduling changes
+for flag in "" "--no-overlap-update"; do
+  for rep in 1 2 3; do python3 "$ROOT/bench.py" $flag --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.load(sys.stdin); print('${flag:-overlap_update}', round(d['ms_per_step'],3))"; done
+done > "$OUT/overlap_update_ab_refresh.txt"
 (cd "$ROOT" && python3 -m pytest tests/test_gpu_tolerance.py tests/test_gpu_fullsize.py -q -m gpu > "$OUT/parity_tests.log" 2>&1; cp gpurun_out/parity_deviation.json "$OUT/parity_deviation.json" 2>/dev/null)
 ls -la "$OUT"

@@ -10,6 +10,9 @@ backward while the GPU is inside the fc / conv contractions.  The gaps after the
 that is the one point of a step where the host has to wait for the GPU.
 """
 import csv
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sys
 
 path = sys.argv[1]
@@ -18,7 +21,8 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if ("roi_align_fwd" in r["Kernel_Name"] or "roi_align_wino7_pair" in r["Kernel_Name"])]
 # one full step: from the optimizer launch before the second-last ROIAlign forward to the one before the last
-opt = [i for i, r in enumerate(rows) if "sgd_multi_kernel" in r["Kernel_Name"] or "multi_tensor_apply" in r["Kernel_Name"]]
+from _trace_util import step_marks
+opt = step_marks(rows)
 a = max(i for i in opt if i < marks[-2])
 b = max(i for i in opt if i < marks[-1])
 sel = rows[a + 1:b + 1]

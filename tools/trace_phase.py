@@ -6,12 +6,16 @@ optimizer launch (backbone backward), in time order with its duration and the id
     python3 tools/trace_phase.py /tmp/kt/r_kernel_trace.csv"""
 import collections
 import csv
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
-opt = [i for i, r in enumerate(rows) if "sgd_multi_kernel" in r["Kernel_Name"] or "multi_tensor_apply" in r["Kernel_Name"]]
+from _trace_util import step_marks
+opt = step_marks(rows)
 fwd = [i for i, r in enumerate(rows) if ("roi_align_fwd" in r["Kernel_Name"] or "roi_align_wino7_pair" in r["Kernel_Name"])]
 bwd = [i for i, r in enumerate(rows) if "roi_align_bwd" in r["Kernel_Name"] or "roi_partial_reduce" in r["Kernel_Name"]]
 last_fwd = fwd[-1]

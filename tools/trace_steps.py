@@ -9,6 +9,7 @@ A step is delimited by its (single) ROIAlign forward dispatch; everything before
 one-off mask-IoU maps) is dropped.  Columns mirror rocprofv3 --stats, plus per-step figures."""
 import collections
 import csv
+import os
 import sys
 
 
@@ -48,18 +49,15 @@ def main():
     first = marks[-steps]
     # walk back to the start of that step: the backbone's first kernel follows the previous step's optimizer
     # (multi_tensor_apply) - find the last optimizer dispatch before `first`
-    start = 0
-    for i in range(first, -1, -1):
-        if any(t in rows[i]["Kernel_Name"] for t in ("multi_tensor_apply", "FusedSgd", "sgd_multi_kernel")):
-            start = i + 1
-            break
+    # (a step BEGINS with its first optimizer dispatch - the previous step's update; with optim.SGD.overlap_update the big weights'
+    # launch follows on the side stream and runs under this step's backbone forward: it is counted with the step it overlaps)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _trace_util import step_marks
+    opt_marks = step_marks(rows)
+    start = max([m for m in opt_marks if m < first], default=0)
     # ... and end with the optimizer launch that closes the last step (what follows is bench.py's own end-of-run work: its check
     # that every parameter is finite - 2 launches per tensor - and the extra loops)
-    end = len(rows)
-    for i in range(len(rows) - 1, start, -1):
-        if any(t in rows[i]["Kernel_Name"] for t in ("multi_tensor_apply", "FusedSgd", "sgd_multi_kernel")):
-            end = i + 1
-            break
+    end = max([m for m in opt_marks if m > start], default=len(rows))           # the first optimizer dispatch behind the last step
     sel = rows[start:end]
     stat = collections.OrderedDict()
     for r in sel:

@@ -5,11 +5,15 @@ backbone backward (main stream) or the weight-gradient GEMMs (side stream) end t
 
     python3 tools/trace_tail.py /tmp/kt/r_kernel_trace.csv"""
 import csv
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-opt = [i for i, r in enumerate(rows) if "sgd_multi_kernel" in r["Kernel_Name"]]
+from _trace_util import step_marks
+opt = step_marks(rows)
 a, b = opt[-2], opt[-1]
 step = rows[a:b + 1]
 t0 = int(step[0]["Start_Timestamp"])

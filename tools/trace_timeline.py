@@ -6,6 +6,9 @@ to the first dispatch matching PAT .. the last matching PAT; --min-us hides shor
     python3 tools/trace_timeline.py /tmp/kt/r_kernel_trace.csv --from roi_align_fwd --to roi_align_bwd --min-us 20"""
 import argparse
 import csv
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import re
 
 ap = argparse.ArgumentParser()
@@ -16,7 +19,8 @@ ap.add_argument("--min-us", type=float, default=0.0)
 args = ap.parse_args()
 rows = list(csv.DictReader(open(args.trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-opt = [i for i, r in enumerate(rows) if "sgd_multi_kernel" in r["Kernel_Name"]]
+from _trace_util import step_marks
+opt = step_marks(rows)
 step = rows[opt[-2]:opt[-1] + 1]
 t0 = int(step[0]["Start_Timestamp"])
 lo, hi = 0, len(step) - 1
