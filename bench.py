@@ -618,7 +618,7 @@ def pmc_traffic(config):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs of this
     script, tools/pmc_traffic.py).  Only a profile of THIS workload counts: files are named per config and record the
     image mix they were taken on; anything else -> {} and `traffic: null`."""
-    for rnd in ("r5", "r4"):                       # the newest committed profile of this configuration
+    for rnd in ("r6", "r5", "r4"):                       # the newest committed profile of this configuration
         path = os.path.join(REPO, "profiles", rnd, "pmc_traffic_%s.json" % config)
         if os.path.exists(path):
             with open(path) as f:
@@ -778,7 +778,7 @@ def report(args, world, elapsed, images, timer, infos, feat, Cf, cfg, gemm_mod, 
                 dtype_note="fp32 tensors and accumulation everywhere; MaskFuse GEMM products evaluated on a scaled two-term fp16 operand "
                            "split written by the operands' producers (3 MFMA products, dropped term <= 2^-22, one power-of-two scale per "
                            "matrix) - measured deviation of losses / gradients from the reference in tests/test_gpu_tolerance.py "
-                           "(profiles/r5/parity_deviation.json); the TF32-class single-product line: extra.tf32_class",
+                           "(profiles/r6/parity_deviation.json); the TF32-class single-product line: extra.tf32_class",
                 config=dict(workload=workload, parallelism="dp%d" % world, inputs="resident in HBM (extra.with_h2d_upload: "
                             "uploaded from pinned host memory inside every step)"),
                 roofline=roofline, roofline_hbm=hbm)

@@ -44,9 +44,15 @@ typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
 #define CIM_PAIR_EXP 0          // ablation switches (tools/bench_gemm_pair.py); 0 = product
 #endif
 
+#ifndef CIM_PAIR_WAVES
+#define CIM_PAIR_WAVES 8        // waves of a workgroup: 8 = 2 (M) x 4 (N), wave tile 128 x 64, two waves per SIMD (product);
+#endif                          // 4 = 2 x 2, wave tile 128 x 128 (256 accumulator registers), ONE wave per SIMD (experiment, tools/build_alt.sh)
 constexpr int BM = 256, BN = 256, BK = 32;
-constexpr int NT = 512;
-constexpr int WM = 128, WN = 64, MI = 4, NI = 2;
+constexpr int NW = CIM_PAIR_WAVES;
+constexpr int NT = 64 * NW;
+constexpr int WNC = NW / 2;                         // waves along N
+constexpr int WM = 128, WN = BN / WNC, MI = 4, NI = WN / 32;
+constexpr int IPW = 32 / NW;                        // LDS-DMA instructions per wave, operand and slab (1 KiB each)
 constexpr int OPER = 256 * BK * 4;        // 32768 B per operand and slab
 constexpr int SLAB = 2 * OPER;
 constexpr int LDS_BYTES = 2 * SLAB;       // 131072
@@ -107,11 +113,11 @@ __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(
 // KC: instruction i (0..31) covers tile rows 8i .. 8i+7 = double rows 4i .. 4i+3; a wave issues i = 4w .. 4w+3.
 // LDS position (double row d, slot s) holds global (row 2d + (s >> 3), chunk (s & 7) ^ (d & 7)); chunk p = 2 * kgroup + plane.
 struct StageKC {
-    unsigned off[4];      // byte offsets of this lane's four source chunks relative to (base + k0 * 4)
+    unsigned off[IPW];    // byte offsets of this lane's source chunks relative to (base + k0 * 4)
     __device__ __forceinline__ void init(int row0, int rows, int ld, int wave, int lane) {
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int d = 4 * (wave * 4 + ii) + (lane >> 4);
+        for (int ii = 0; ii < IPW; ++ii) {
+            const int d = 4 * (wave * IPW + ii) + (lane >> 4);
             const int s = lane & 15;
             const int r = min(row0 + 2 * d + (s >> 3), rows - 1);
             const int p = (s & 7) ^ (d & 7);
@@ -119,25 +125,29 @@ struct StageKC {
         }
     }
     __device__ __forceinline__ void issue(const char* base_k, const char* lds_oper, int wave) const {
-        glds16x4(base_k, off[0], off[1], off[2], off[3], lds_addr(lds_oper) + wave * 4096);
+#pragma unroll
+        for (int q = 0; q < IPW; q += 4)
+            glds16x4(base_k, off[q], off[q + 1], off[q + 2], off[q + 3], lds_addr(lds_oper) + (wave * IPW + q) * 1024);
     }
     static __device__ __forceinline__ size_t k_step_bytes(int) { return (size_t)BK * 4; }
 };
 // MC: instruction i = k row i of the slab (1024 B = the 256 tile columns); lane q loads chunk q ^ swz(k),
 // swz(k) = (k & 1) | ((k >> 1) & 1) << 3 (k & 3 = ii for k = 4w + ii).
 struct StageMC {
-    unsigned off[4];
+    unsigned off[IPW];
     __device__ __forceinline__ void init(int col0, int cols, int ld, int wave, int lane) {
         const int maxchunk = ((cols - col0) * 4 - 16) / 16;       // last whole chunk of the row that belongs to the matrix
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int swz = (ii & 1) | ((ii >> 1) << 3);
+        for (int ii = 0; ii < IPW; ++ii) {
+            const int swz = (ii & 1) | (((ii >> 1) & 1) << 3);    // (k & 3 = ii & 3 for k = IPW w + ii)
             const int c = min(lane ^ swz, maxchunk);
-            off[ii] = (unsigned)(wave * 4 + ii) * (unsigned)ld * 4u + (unsigned)col0 * 4u + (unsigned)c * 16u;
+            off[ii] = (unsigned)(wave * IPW + ii) * (unsigned)ld * 4u + (unsigned)col0 * 4u + (unsigned)c * 16u;
         }
     }
     __device__ __forceinline__ void issue(const char* base_k, const char* lds_oper, int wave) const {
-        glds16x4(base_k, off[0], off[1], off[2], off[3], lds_addr(lds_oper) + wave * 4096);
+#pragma unroll
+        for (int q = 0; q < IPW; q += 4)
+            glds16x4(base_k, off[q], off[q + 1], off[q + 2], off[q + 3], lds_addr(lds_oper) + (wave * IPW + q) * 1024);
     }
     static __device__ __forceinline__ size_t k_step_bytes(int ld) { return (size_t)BK * ld * 4; }
 };
@@ -236,11 +246,11 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // argument of the entry points (products = 1); the step's default is the fp32-class three-product evaluation.  The l halves of
 // the images are still moved (they are interleaved with the h halves in memory) and ignored.
 template <int AL, int BL, bool ONEP>
-__global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
+__global__ __launch_bounds__(NT, NW / 4) void gemm_pair_kernel(const PairArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WNC, wn = wave % WNC;
     int tile_m, tile_n, zidx;
     pair_tile_map(g.M, g.N, g.tn, g.tm, g.tz, (int)blockIdx.x + g.tile0, tile_m, tile_n, zidx);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float bvj[NI];          // bias of this lane's two output columns (consumed in the epilogue)
+    float bvj[NI];          // bias of this lane's output columns (consumed in the epilogue)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * WN + j * 32 + (lane & 31);
@@ -443,7 +453,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(const PairArgs g) {
     // ITS row as 16 bytes - 32 stores per wave, no LDS: 1.33 vs 1.26 ms (32-byte pieces of 32 different rows per
     // instruction).  The stores themselves cost 4-8 % of a launch (ablation without them: 1.246 vs 1.303 ms).)
     const float inv = 1.0f / (g.a_scale[zb] * g.b_scale[zb]);
-    asm volatile("" : "+v"(bvj[0]), "+v"(bvj[1]));
+#pragma unroll
+    for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(bvj[j]));
     float* C = Cb + (size_t)zsplit * g.c_split_stride;
     const int lk = lane >> 5, l31 = lane & 31;
     unsigned amax = 0;
