@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
     }
 }
 
-// Forward, row-sum form of the same separable sum (default when P <= 7 and the map is at most 64 x 64):
+// Forward, row-sum form of the same separable sum (default when P <= 7 and the map is at most 128 x 128):
 //   out[ph,pw,c] = sum_x WX[pw][x] * ( sum_y WY[ph][y] / count * feat[y,x,c] ).
 // A workgroup still owns one (roi, bin row), but walks the COLUMNS of the ROI once: the inner sum t(x) over the bin row's
 // rows is formed once per column and fed to every bin whose WX[pw][x] is non-zero, so the pixels that neighbouring bins
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_agg_kernel(const float* __r
 // rows x (sum of the bins' column counts), ~23 % fewer at the benchmark's ROI sizes.  Two columns are in flight per
 // iteration (up to 8 loads per lane).  The 7 column weights of a column sit in LDS as one padded row (zero outside the
 // bin's range), so the bin update is 7 unconditional packed FMAs.
-constexpr int RS_MAXD = 64;      // rows / columns of the map
+constexpr int RS_MAXD = 128;     // rows / columns of the map (round 6: was 64 - the reference's largest training scale gives 57 x 75 maps)
 // Round 4, measured and dropped: workgroup = one ROI x one 256-channel slice (four waves = the four bin-row pairs) with the slices
 // pinned to XCDs, so that an XCD's L2 only sees its 1.45 MB of the 5.8 MB map (the calibrated FETCH_SIZE of this launch is 232 MB
 // for that map: 38x).  0.152 vs 0.140 ms at cfg2, 0.287 vs 0.279 at 2000 ROIs (tools/bench_roi.py, same box): the re-fetches are
@@ -674,16 +674,19 @@ __global__ __launch_bounds__(256) void roi_align_wino7_pair_kernel(const float* 
     {
         // the rows of the map with a non-zero weight in bin row ph0 or ph0 + 1, ascending (a wave-wide compaction of the loop
         // rowsum2's thread 0 runs: same list, same order)
-        const int y = ylo + lane;
-        float a = 0.0f, b = 0.0f;
-        if (y <= yhi) { a = wy0[y]; b = two ? wy1[y] : 0.0f; }
-        const bool on = y <= yhi && (a != 0.0f || b != 0.0f);
-        const unsigned long long m = __ballot(on);
-        if (on) {
-            const int n = __popcll(m & ((1ull << lane) - 1ull));
-            s_rows[wave][n] = y * W; s_wa[wave][n] = a * inv_count; s_wb[wave][n] = b * inv_count;
+        nrows = 0;
+        for (int y0 = ylo; y0 <= yhi; y0 += 64) {             // (an ROI spans up to RS_MAXD = 128 rows: two passes of the wave)
+            const int y = y0 + lane;
+            float a = 0.0f, b = 0.0f;
+            if (y <= yhi) { a = wy0[y]; b = two ? wy1[y] : 0.0f; }
+            const bool on = y <= yhi && (a != 0.0f || b != 0.0f);
+            const unsigned long long m = __ballot(on);
+            if (on) {
+                const int n = nrows + __popcll(m & ((1ull << lane) - 1ull));
+                s_rows[wave][n] = y * W; s_wa[wave][n] = a * inv_count; s_wb[wave][n] = b * inv_count;
+            }
+            nrows += __popcll(m);
         }
-        nrows = __popcll(m);
     }
     for (int e = tid; e < ncols * 8; e += 256) {
         const int xi = e >> 3, pw = e & 7;
@@ -1149,9 +1152,10 @@ int launch_fwd(const float* feat, const float* rois, const float* masks, float* 
                int P, float scale, int sr, int aligned, hipStream_t st, float* ws = nullptr) {
     if (K == 0) return 0;
     dim3 grid(K, P), block(256);
-    // table-driven kernels: need the table workspace, 16-byte channel rows and maps of <= 64 rows.  Row-sum kernel (two bin rows
-    // per workgroup) for maps up to 64 columns and P <= 7; the flat entry-list kernel otherwise.
-    if (ws != nullptr && C % 4 == 0 && P <= FW_MAXP && (long long)H * W * C < (1ll << 30) && H <= 64) {
+    // table-driven kernels: need the table workspace, 16-byte channel rows and bin rows of at most 64 map rows (maps of <= 64 rows,
+    // or <= 128 rows with P >= 4: H / P + 2 rows per bin).  Row-sum kernel (two bin rows per workgroup) for maps up to 128 columns
+    // and P <= 7; the flat entry-list kernel otherwise.
+    if (ws != nullptr && C % 4 == 0 && P <= FW_MAXP && (long long)H * W * C < (1ll << 30) && (H <= 64 || (P >= 4 && H <= RS_MAXD))) {
         hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), sizeof(float) * roi_rec_words(P, H, W), st, rois, ws, K, P, H, W, scale, sr, aligned);
         if (P <= 7 && W <= RS_MAXD) {
             const int nth = C >= 1024 ? 256 : ((C / 4 + 63) / 64) * 64;       // narrow maps: no idle waves
@@ -1295,7 +1299,7 @@ extern "C" int cim_roi_align_wino7_pair_fwd(const float* feat, const float* rois
                                            int sampling_ratio, int aligned, float* workspace, void* stream) {
     CIM_CHECK_ARG(feat && rois && masks && V && scale && workspace);
     CIM_CHECK_ARG(B > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0 && K > 0 && Rs >= K && P == 7);
-    CIM_CHECK_ARG(H <= 64 && W <= RS_MAXD && (long long)H * W * C < (1ll << 30));
+    CIM_CHECK_ARG(H <= RS_MAXD && W <= RS_MAXD && (long long)H * W * C < (1ll << 30));
     hipStream_t st = cim::as_stream(stream);
     hipLaunchKernelGGL(roi_tables_kernel, dim3(K), dim3(256), sizeof(float) * roi_rec_words(P, H, W), st, rois, workspace, K, P, H, W,
                        spatial_scale, sampling_ratio, aligned);

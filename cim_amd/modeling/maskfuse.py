@@ -71,13 +71,13 @@ class MaskFuse(nn.Module):
             # transform in one launch (the conv input `cat` is never stored), then conv -> flatten -> fc1 -> fc2 on pair images.
             # ROIAlign averages feature pixels and the masks are {0, 1}: max |cat| <= max |x| max(1, max |mask|)
             return maskfuse_pair.maskfuse_roi_head(x, rois, masks.detach(), conv, fc1, fc2, self._cat_amax(x, masks), self.spatial_scale, sr)
-        if FUSE_ROI_WINO and x.is_cuda and (x.shape[2] > 64 or x.shape[3] > 64) and not MaskFuse._told_big_map:
+        if FUSE_ROI_WINO and x.is_cuda and (x.shape[2] > 128 or x.shape[3] > 128) and not MaskFuse._told_big_map:
             # NOT a library fallback (both paths are this package's HIP kernels) - but the numbers quoted for the fused launch
-            # (33 x 43 maps) do not carry over to maps above 64 rows / columns: say so once
+            # (33 x 43 maps) do not carry over to maps above 128 rows / columns: say so once
             MaskFuse._told_big_map = True
             import logging
             logging.getLogger("cim_amd.maskfuse").warning(
-                "feature map %d x %d exceeds the fused ROIAlign -> Winograd launch's 64 x 64 table limit: the two-launch path "
+                "feature map %d x %d exceeds the fused ROIAlign -> Winograd launch's 128 x 128 table limit: the two-launch path "
                 "(roi_align_maskcat + wino7_input_pair, `cat` materialised) runs for such images", x.shape[2], x.shape[3])
         cat = roi_align_maskcat(x, rois, masks, res, self.spatial_scale, sr, aligned=True)
         if not maskfuse_pair.supported(cat, conv.weight, fc1.weight, fc2.weight):

@@ -458,7 +458,7 @@ def roi_supported(x, conv_w, fc1_w, fc2_w, resolution):
     """Shapes the fused ROIAlign -> Winograd-image launch takes (else: roi_align_maskcat + maskfuse_head)."""
     c, h, w = x.shape[1], x.shape[2], x.shape[3]
     cout = conv_w.shape[0]
-    return (x.is_cuda and x.dtype == torch.float32 and resolution == 7 and c % 32 == 0 and h <= 64 and w <= 64 and h * w * c < (1 << 30)
+    return (x.is_cuda and x.dtype == torch.float32 and resolution == 7 and c % 32 == 0 and h <= 128 and w <= 128 and h * w * c < (1 << 30)
             and cout % 64 == 0 and conv_w.shape[1] == 2 * c and fc1_w.shape[1] == cout * 49 and fc1_w.shape[0] % 32 == 0
             and fc2_w.shape[1] == fc1_w.shape[0] and fc2_w.shape[0] % 32 == 0)
 

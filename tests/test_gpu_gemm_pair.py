@@ -404,7 +404,8 @@ def test_maskfuse_pair_function_vs_per_layer_path(dev, r):
         assert float((a - b).norm() / b.norm()) < 2e-5, name
 
 
-@pytest.mark.parametrize("C,H,W,K", [(256, 33, 43, 70), (64, 20, 25, 33), (512, 45, 60, 40), (256, 7, 9, 3), (1024, 64, 64, 32), (8, 33, 43, 65)])
+@pytest.mark.parametrize("C,H,W,K", [(256, 33, 43, 70), (64, 20, 25, 33), (512, 45, 60, 40), (256, 7, 9, 3), (1024, 64, 64, 32), (8, 33, 43, 65),
+                                     (256, 57, 75, 40), (64, 100, 128, 12)])        # (the reference's largest training scale; the limit)
 def test_roi_align_wino7_pair_image_is_bit_identical_to_the_two_kernel_path(dev, C, H, W, K):
     """cim_roi_align_wino7_pair_fwd (round 5: ROIAlign + mask multiply + concat + the Winograd 4 + 3 input transform in one launch,
     lib/modeling/resnet50.py:121-135) writes the very pair image cim_roi_align_maskcat_fwd_ws + cim_wino7_input_pair write -
@@ -537,8 +538,8 @@ def test_head_backward_with_and_without_the_fused_dy_launch_is_bit_identical(dev
         assert torch.equal(a, b), name
 
 
-@pytest.mark.parametrize("C,H,W,K,cout", [(32, 7, 9, 5, 256), (512, 45, 60, 20, 512), (1024, 33, 43, 24, 1024)],
-                         ids=["tiny", "cfg1-shape", "cfg2-shape"])
+@pytest.mark.parametrize("C,H,W,K,cout", [(32, 7, 9, 5, 256), (512, 45, 60, 20, 512), (1024, 33, 43, 24, 1024), (256, 57, 75, 12, 256)],
+                         ids=["tiny", "cfg1-shape", "cfg2-shape", "scale-1200-map"])
 def test_fused_box_head_against_the_oracle_and_float64(dev, C, H, W, K, cout):
     """The four fused launches of round 5 - roi_align_wino7_pair (ROIAlign + mask + concat + Winograd input transform),
     wino7_flatten_bwd_dy_pair (flatten backward + ReLU mask + both dy transforms), wino7_dx_maskfold (adjoint output transform + the

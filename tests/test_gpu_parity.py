@@ -41,7 +41,8 @@ def _roi_case(seed, C, H, W, K, img_scale=16.0):
 
 @pytest.mark.parametrize("C,H,W,K,aligned", [(8, 13, 17, 24, True), (3, 9, 11, 16, True), (64, 33, 43, 40, True),
                                               (8, 13, 17, 24, False), (4, 13, 17, 24, True), (4, 13, 17, 24, False),
-                                              (16, 45, 60, 33, True), (16, 45, 60, 33, False)])
+                                              (16, 45, 60, 33, True), (16, 45, 60, 33, False),
+                                              (16, 57, 75, 33, True), (8, 100, 128, 20, True)])      # (maps beyond 64 x 64: round 6)
 def test_roi_align_fwd_bwd_vs_oracle(dev, C, H, W, K, aligned, monkeypatch):
     from cim_amd.ops import roi_align
     import sys
