@@ -261,6 +261,11 @@ def run(args):
     if world > 1:
         dp.comm_works = []
     elapsed = timed(args.steps, iter_size=args.iter_size)          # ---- THE timed region: exactly --steps steps
+    if os.environ.get("CIM_BENCH_WINDOWS") == "1" and rank == 0:    # debugging aid: further windows of the same length (is the first one special?)
+        timer.enabled = False
+        print("window 0: %.3f ms" % (1e3 * elapsed / args.steps), file=sys.stderr)
+        for w in range(1, 6):
+            print("window %d: %.3f ms" % (w, 1e3 * timed(args.steps, iter_size=args.iter_size) / args.steps), file=sys.stderr)
     timer.enabled = False
     rank_seconds = state.get("rank_seconds", [elapsed])
     comm_works = getattr(dp, "comm_works", None)

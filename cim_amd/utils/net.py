@@ -37,6 +37,8 @@ def _CorrectMomentum(optimizer, param_keys, correction):
     """V := mu * V + lr * grad carries the learning rate inside the history V, so a changed learning rate
     rescales V by new_lr / old_lr (net.py:65-82).  Parameters without a history yet are skipped."""
     logger.info("Scaling update history by %.6f (new lr / old lr)", correction)
+    if hasattr(optimizer, "wait_update"):
+        optimizer.wait_update()          # (cim_amd.optim.SGD.overlap_update: the big weights' histories may still be written on the side stream)
     for p in param_keys:
         buf = optimizer.state.get(p, {}).get("momentum_buffer")
         if buf is not None:
