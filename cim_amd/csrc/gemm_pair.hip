@@ -499,19 +499,28 @@ __global__ __launch_bounds__(NT, NW / 4) void gemm_pair_kernel(const PairArgs g)
     }
 }
 
-// split-K reduce: fixed order, bias, ReLU, optional max |C|
+// split-K reduce: fixed order, bias, ReLU, optional max |C|.  Round 6: a launch of at most 1024 workgroups that WALK over the result,
+// and ONE max |C| atomic per workgroup (through LDS) instead of one per wave of a launch with a workgroup per 1024 elements - the
+// fc1 forward's reduce (4 M elements: 16 k waves) took 54-77 us in the step for 80 MB: its first ~2000 resident waves all see a
+// zero word and fire their atomicMax on ONE address (~12 ns each in L2); the same kernel without max |C| takes 13 us.
 __global__ __launch_bounds__(256) void pair_splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
                                                                  const float* __restrict__ bias, int M, int N, int ldc,
                                                                  int splits, long long stride, int relu,
                                                                  unsigned* __restrict__ c_amax) {
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    __shared__ unsigned s_am[4];
+    const long long total = (long long)M * N;
     unsigned am = 0;
-    if (i < (long long)M * N) {
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * 1024) {
         const int m = (int)(i / N), n = (int)(i % N);
         float4 s = *reinterpret_cast<const float4*>(ws + i);
-        for (int k = 1; k < splits; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(ws + k * stride + i);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int k0 = 1; k0 < splits; k0 += 4) {          // four partial tiles in flight, added in split order
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] = k0 + j < splits ? *reinterpret_cast<const float4*>(ws + (long long)(k0 + j) * stride + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < splits) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
         }
         if (bias) {
             const float4 b = *reinterpret_cast<const float4*>(bias + n);
@@ -521,12 +530,14 @@ __global__ __launch_bounds__(256) void pair_splitk_reduce_kernel(const float* __
             s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
         }
         *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = s;
-        am = max(max(__float_as_uint(s.x) & 0x7fffffffu, __float_as_uint(s.y) & 0x7fffffffu),
-                 max(__float_as_uint(s.z) & 0x7fffffffu, __float_as_uint(s.w) & 0x7fffffffu));
+        am = max(am, max(max(__float_as_uint(s.x) & 0x7fffffffu, __float_as_uint(s.y) & 0x7fffffffu),
+                         max(__float_as_uint(s.z) & 0x7fffffffu, __float_as_uint(s.w) & 0x7fffffffu)));
     }
     if (c_amax != nullptr) {
         am = wave_max_u32(am);
-        if ((threadIdx.x & 63) == 0) cim::amax_publish(c_amax, am);
+        if ((threadIdx.x & 63) == 0) s_am[threadIdx.x >> 6] = am;
+        __syncthreads();
+        if (threadIdx.x == 0) cim::amax_publish(c_amax, max(max(s_am[0], s_am[1]), max(s_am[2], s_am[3])));
     }
 }
 
@@ -560,11 +571,15 @@ __global__ __launch_bounds__(256) void pair_masked_stats_kernel(const float* __r
             }
         }
     }
+    // ONE atomicMax per workgroup (round 6; was one per wave: the ~2000 waves that are resident when the launch starts all see a
+    // zero word and fire on one address at ~12 ns each - 65 / 35 us for the two 32 MB launches of the step)
+    __shared__ unsigned s_m[4];
     m = wave_max_u32(m);
-    if ((threadIdx.x & 63) == 0) cim::amax_publish(amax, m);
-    if (part == nullptr) return;
-    red[ry][cx] = s;
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    if (part != nullptr) red[ry][cx] = s;
     __syncthreads();
+    if (threadIdx.x == 0) cim::amax_publish(amax, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));
+    if (part == nullptr) return;
     if (ry == 0 && col < cols) {
         float4 t = red[0][cx];
 #pragma unroll
@@ -626,8 +641,11 @@ __global__ __launch_bounds__(256) void pair_amax_kernel(const float* __restrict_
         const uint4 v = *reinterpret_cast<const uint4*>(X + i * 4);
         m = max(m, max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
     }
+    __shared__ unsigned s_m[4];
     m = wave_max_u32(m);
-    if ((threadIdx.x & 63) == 0) cim::amax_publish(out, m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) cim::amax_publish(out, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));      // one atomic per workgroup
 }
 
 template <int AL, int BL>
@@ -666,7 +684,8 @@ int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st, int ma
     }
     if (splits > 1) {
         const long long quads = ((long long)g.M * g.N + 3) / 4;
-        hipLaunchKernelGGL(pair_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, workspace,
+        const long long rwgs = (quads + 255) / 256;
+        hipLaunchKernelGGL(pair_splitk_reduce_kernel, dim3((unsigned)(rwgs < 1024 ? rwgs : 1024)), dim3(256), 0, st, workspace,
                            out, bias, g.M, g.N, ldc, splits, g.c_split_stride, relu, g.c_amax);
     }
     return 0;

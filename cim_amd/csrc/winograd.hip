@@ -334,10 +334,14 @@ __global__ __launch_bounds__(256) void wino7_output_kernel(const float* __restri
         case 2: w7_output_tile<1, 0, CIM_W7_VOUT>(M, bias, y, r, R, C, relu, ymax); break;
         default: w7_output_tile<1, 1, CIM_W7_VOUT>(M, bias, y, r, R, C, relu, ymax); break;
     }
-    if (y_amax != nullptr) {
+    if (y_amax != nullptr) {             // (one atomicMax per workgroup: see pair_masked_stats_kernel)
+        __shared__ float s_ymax[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-        if ((threadIdx.x & 63) == 0) cim::amax_publish(y_amax, __float_as_uint(ymax));
+        if ((threadIdx.x & 63) == 0) s_ymax[threadIdx.x >> 6] = ymax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            cim::amax_publish(y_amax, __float_as_uint(fmaxf(fmaxf(s_ymax[0], s_ymax[1]), fmaxf(s_ymax[2], s_ymax[3]))));
     }
 }
 
