@@ -66,9 +66,11 @@ __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot)
     // pass 1 over rows: labelled class of each row, cls / iou numerators and counts
     float s_cls = 0.f, s_iou = 0.f, n_lab = 0.f, n_fg = 0.f;
     for (int n = tid; n < N; n += NT) {
+        // (the first non-zero column, WITHOUT an early exit: a `break` makes every load wait for the branch on the one before it -
+        // up to C1 dependent L2 round trips per row; walking down from the last column keeps the loads independent)
         int h = -1;
-        for (int c = 0; c < C1; ++c)
-            if (Y[(size_t)n * C1 + c] != 0.0f) { h = c; break; }
+        for (int c = C1 - 1; c >= 0; --c)
+            if (Y[(size_t)n * C1 + c] != 0.0f) h = c;
         hot[n] = h;
         if (h < 0) continue;
         const float wn = ws * w[n];
