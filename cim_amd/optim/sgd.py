@@ -297,6 +297,11 @@ class SGD(torch.optim.Optimizer):
             p.grad.record_stream(side)
         gemm.register_pending_update(dev, ev, ids)
 
+    def zero_grad(self, set_to_none=True):
+        if not set_to_none:
+            self.wait_update()          # (zeroing in place: the side stream may still read the big weights' gradients)
+        return super().zero_grad(set_to_none=set_to_none)
+
     def wait_update(self):
         """Make the current stream wait for an update that is still running on the side stream (overlap_update)."""
         from ..ops import gemm
