@@ -730,6 +730,49 @@ def test_fused_sgd_matches_torch_sgd(dev):
         SGD(hip_p, lr=0.1, momentum=0.9, nesterov=True)
 
 
+def test_fused_sgd_overlapped_update_is_the_same_update(dev):
+    """optim.SGD.overlap_update (round 6): the big weights (>= TRAIL_MIN elements, matrix mode) are updated by a WALKING launch
+    (cim_sgd_multi max_workgroups) on the package's side stream while the caller's stream goes on; the result - weights, momentum
+    buffers, the row / column |max| by-products - equals the plain one-stream update bit for bit, and every documented way to read the
+    weights afterwards (wait_update, state_dict, utils.net's momentum correction) is ordered behind the side stream's launch."""
+    from cim_amd.optim import SGD, sgd as sgd_mod
+    from cim_amd.ops import gemm
+    from cim_amd.utils import net as net_utils
+    g = torch.Generator().manual_seed(5)
+    rows, cols = 4096, sgd_mod.TRAIL_MIN // 4096                   # exactly TRAIL_MIN elements
+    base = [torch.randn(rows, cols, generator=g) * 0.1, torch.randn(1000, 50, generator=g), torch.randn(777, generator=g)]
+
+    def run(overlap, wgs):
+        ps = [b.clone().to(dev).requires_grad_(True) for b in base]
+        opt = SGD([dict(params=ps[:2], lr=0.05, weight_decay=0.01), dict(params=ps[2:], lr=0.1, weight_decay=0.0)], lr=0.05, momentum=0.9)
+        opt.overlap_update, opt.trail_workgroups = overlap, wgs
+        gg = torch.Generator().manual_seed(6)
+        scales = None
+        for step in range(3):
+            for p_ in ps:
+                p_.grad = torch.randn(p_.shape, generator=gg).to(dev)
+            if step == 2:                                           # lr change with momentum correction (lib/utils/net.py:65-82)
+                for grp in opt.param_groups:
+                    grp["lr"] *= 0.5
+                net_utils._CorrectMomentum(opt, [q for grp in opt.param_groups for q in grp["params"]], 0.5)
+            opt.step()
+            if overlap:
+                assert gemm._PENDING_UPDATES, "the big weight's update did not go to the side stream"
+            opt.zero_grad()
+            scales = gemm._registered_scales(ps[0], rows, cols)
+        sd = opt.state_dict()                                       # (waits for the side stream by itself)
+        assert not gemm._PENDING_UPDATES
+        out = [p_.detach().clone() for p_ in ps] + [sd["state"][i]["momentum_buffer"].clone() for i in range(3)]
+        torch.cuda.synchronize()
+        return out + [scales[0].clone(), scales[1].clone()]
+
+    ref = run(False, 0)
+    for wgs in (256, 7, 0):
+        got = run(True, wgs)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), (wgs, i)
+
+
 def test_fused_sgd_follows_replaced_state_and_storage(dev):
     """the fast path caches raw pointers of parameters and momentum buffers.  load_state_dict() replaces the
     buffer tensors and `p.data = ...` the parameter storage: the next step must use the NEW tensors (as torch.optim.SGD
