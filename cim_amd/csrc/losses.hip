@@ -18,6 +18,15 @@ namespace {
 
 constexpr int NT = 1024;
 constexpr float LO = 1e-6f, HI = 1.0f - 1e-6f;
+#ifndef CIM_LOSS_CLOCKS
+#define CIM_LOSS_CLOCKS 0            // 1: phase stamps (100 MHz wall clock) of the loss launch's jobs -> cim_debug_loss_clocks (tools/loss_clocks.py)
+#endif
+#if CIM_LOSS_CLOCKS
+__device__ unsigned long long g_loss_clk[8][16];                         // [job][stamp]
+#define LCLK(JOB, I) do { if (threadIdx.x == 0 && (JOB) < 8) g_loss_clk[JOB][I] = wall_clock64(); } while (0)
+#else
+#define LCLK(JOB, I) do { } while (0)
+#endif
 
 __device__ __forceinline__ float clampf(float x) { return fminf(fmaxf(x, LO), HI); }
 __device__ __forceinline__ float inrange(float x) { return (x >= LO && x <= HI) ? 1.0f : 0.0f; }
@@ -34,6 +43,21 @@ __device__ float block_sum(float v, float* red) {
     return s;
 }
 
+// four block sums behind ONE pair of barriers (buf: 64 floats of LDS nobody else uses until the next barrier)
+__device__ void block_sum4(float& v0, float& v1, float& v2, float& v3, float* buf) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); v2 += __shfl_xor(v2, o); v3 += __shfl_xor(v3, o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) { buf[wave * 4 + 0] = v0; buf[wave * 4 + 1] = v1; buf[wave * 4 + 2] = v2; buf[wave * 4 + 3] = v3; }
+    __syncthreads();
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int w = 0; w < NT / 64; ++w) { s0 += buf[w * 4 + 0]; s1 += buf[w * 4 + 1]; s2 += buf[w * 4 + 2]; s3 += buf[w * 4 + 3]; }
+    v0 = s0; v1 = s1; v2 = s2; v3 = s3;
+}
+
 // (value, index) max over the 64 lanes; ties -> lower index (first maximum)
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 #pragma unroll
@@ -44,7 +68,41 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
     }
 }
 
-__device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot) {
+// lanes per row of the column passes: the smallest power of two >= C1 (1024: one wave per column instead)
+__device__ __forceinline__ int loss_group(int C1) {
+    return C1 <= 32 ? 32 : C1 <= 64 ? 64 : C1 <= 128 ? 128 : C1 <= 256 ? 256 : 1024;
+}
+
+// loss_weight_bag_loss (heads.py:43-74) of ONE class column from its two arg-maxima: the column's term of the bag loss (returned) and
+// its gradient components (added in place: one thread per column, no two columns share an element)
+__device__ __forceinline__ float refine_column_finish(const cim_loss_args& a, int li, int c, float fv, int fi, float uv, int ui,
+                                                      const int* hot, const float* rc, const float* ri, const float* w, float ws,
+                                                      float* g_rc_bag, float* g_ri_bag, int LD) {
+    const int C1 = a.C1;
+    const float L = (c == 0) ? 1.0f : a.labels[c - 1];
+    const float raw = fv * L + uv * (1.0f - L);
+    const float agg = clampf(raw);
+    const bool seen = (L == 1.0f);
+    const int idx = seen ? fi : ui;
+    const float om = seen ? ws * w[idx] : 1.0f;
+    const float term = -(L * logf(agg) + (1.0f - L) * logf(1.0f - agg)) * om / (float)C1;
+    const float dagg = -(L / agg - (1.0f - L) / (1.0f - agg)) * om / (float)C1 * inrange(raw);
+    const float du_f = dagg * L * ((hot[fi] == c) ? 1.0f : 0.0f);
+    const float du_u = dagg * (1.0f - L);
+    if (du_f != 0.0f) {
+        const float xr = rc[(size_t)fi * LD + c], xi = ri[(size_t)fi * LD + c];
+        g_rc_bag[(size_t)fi * C1 + c] += du_f * clampf(xi) * inrange(xr);
+        g_ri_bag[(size_t)fi * C1 + c] += du_f * clampf(xr) * inrange(xi);
+    }
+    if (du_u != 0.0f) {
+        const float xr = rc[(size_t)ui * LD + c], xi = ri[(size_t)ui * LD + c];
+        g_rc_bag[(size_t)ui * C1 + c] += du_u * clampf(xi) * inrange(xr);
+        g_ri_bag[(size_t)ui * C1 + c] += du_u * clampf(xr) * inrange(xi);
+    }
+    return term;
+}
+
+__device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot, float* grp_scratch) {
     const int N = a.N, C1 = a.C1, LD = a.ld > 0 ? a.ld : a.C1, tid = threadIdx.x;
     (void)LD;
     const float* rc = a.rc[li];
@@ -59,6 +117,7 @@ __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot)
     float* g_ri_bag = a.grad + (size_t)(3 + 4 * li + 3) * N * C1;
     for (int i = tid; i < N * C1; i += NT) { g_rc_cls[i] = 0.f; g_rc_bag[i] = 0.f; g_ri_iou[i] = 0.f; g_ri_bag[i] = 0.f; }
     float* out = a.part + 4 * li;                  // [bag, pcl, cls, iou]
+    LCLK(li, 1);
     if (!a.layer_valid[li]) {                      // CIM_layer returned None: the layer contributes nothing
         if (tid < 4) out[tid] = 0.0f;
         return;
@@ -83,12 +142,11 @@ __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot)
             n_fg += 1.0f;
         }
     }
-    s_cls = block_sum(s_cls, red);
-    s_iou = block_sum(s_iou, red);
-    n_lab = block_sum(n_lab, red);
-    n_fg = block_sum(n_fg, red);
+    LCLK(li, 2);
+    block_sum4(s_cls, s_iou, n_lab, n_fg, grp_scratch);          // (one pair of barriers instead of four: same sums, same order)
     const float cls_loss = n_lab > 0.f ? s_cls / n_lab : 0.f;                  // heads.py:104-114
     const float iou_loss = n_fg > 0.f ? s_iou / n_fg : 0.f;                    // heads.py:116-136
+    LCLK(li, 3);
     // pass 2 over rows: gradient components of cls_loss / iou_loss
     for (int n = tid; n < N; n += NT) {
         const int h = hot[n];
@@ -105,63 +163,148 @@ __device__ void refine_job(const cim_loss_args& a, int li, float* red, int* hot)
     }
     __syncthreads();
     // column pass (loss_weight_bag_loss, heads.py:43-74): one wave per class column
-    const int wave = tid >> 6, lane = tid & 63;
+    LCLK(li, 4);
+    // column pass (round 6: lanes along the COLUMNS of a row).  The first form gave a wave one column and its lanes the rows: a lane's
+    // loads were LD floats apart (64 cache lines per instruction) - 25 us of the job's 47 (tools/loss_clocks.py).  Now a group of G
+    // lanes (G = power of two >= C1) reads one row's C1 consecutive scores, NT / G rows per pass; every lane keeps the running
+    // (maximum, first index) of ITS column over its rows, the groups meet in LDS in group order with ties to the lower row - the same
+    // arg-max as before (first maximum), whichever way the rows are dealt.
+    const int G = loss_group(C1), NG = NT / G, grp = tid / G, c = tid % G;
     float bag = 0.0f;
-    for (int c = wave; c < C1; c += NT / 64) {
+    if (G <= 256) {
         float fv = -INFINITY, uv = -INFINITY;
         int fi = INT_MAX, ui = INT_MAX;
-        for (int n = lane; n < N; n += 64) {
-            const float u = clampf(rc[(size_t)n * LD + c]) * clampf(ri[(size_t)n * LD + c]);
-            const float f = (hot[n] == c) ? u : 0.0f;                            // ind * predict * tmp_pseudo_label
-            if (f > fv) { fv = f; fi = n; }
-            if (u > uv) { uv = u; ui = n; }
+        if (c < C1)
+            for (int n0 = grp; n0 < N; n0 += 8 * NG) {      // eight rows' loads in flight (one round trip per iteration otherwise)
+                float xr[8], xi[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = min(n0 + j * NG, N - 1);
+                    xr[j] = rc[(size_t)n * LD + c];
+                    xi[j] = ri[(size_t)n * LD + c];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = n0 + j * NG;
+                    if (n < N) {
+                        const float u = clampf(xr[j]) * clampf(xi[j]);
+                        const float f = (hot[n] == c) ? u : 0.0f;                // ind * predict * tmp_pseudo_label
+                        if (f > fv) { fv = f; fi = n; }
+                        if (u > uv) { uv = u; ui = n; }
+                    }
+                }
+            }
+        float* gv = grp_scratch;                                                 // [4][NG][C1]: fv, fi, uv, ui
+        int* gi = reinterpret_cast<int*>(grp_scratch);
+        if (c < C1) {
+            gv[(0 * NG + grp) * C1 + c] = fv; gi[(1 * NG + grp) * C1 + c] = fi;
+            gv[(2 * NG + grp) * C1 + c] = uv; gi[(3 * NG + grp) * C1 + c] = ui;
         }
-        wave_argmax(fv, fi);
-        wave_argmax(uv, ui);
-        if (lane == 0) {
-            const float L = (c == 0) ? 1.0f : a.labels[c - 1];
-            const float raw = fv * L + uv * (1.0f - L);
-            const float agg = clampf(raw);
-            const bool seen = (L == 1.0f);
-            const int idx = seen ? fi : ui;
-            const float om = seen ? ws * w[idx] : 1.0f;
-            bag += -(L * logf(agg) + (1.0f - L) * logf(1.0f - agg)) * om / (float)C1;
-            const float dagg = -(L / agg - (1.0f - L) / (1.0f - agg)) * om / (float)C1 * inrange(raw);
-            const float du_f = dagg * L * ((hot[fi] == c) ? 1.0f : 0.0f);
-            const float du_u = dagg * (1.0f - L);
-            if (du_f != 0.0f) {
-                const float xr = rc[(size_t)fi * LD + c], xi = ri[(size_t)fi * LD + c];
-                g_rc_bag[(size_t)fi * C1 + c] += du_f * clampf(xi) * inrange(xr);
-                g_ri_bag[(size_t)fi * C1 + c] += du_f * clampf(xr) * inrange(xi);
+        __syncthreads();
+        if (tid < C1) {
+            const int cc = tid;
+            fv = gv[(0 * NG) * C1 + cc]; fi = gi[(1 * NG) * C1 + cc]; uv = gv[(2 * NG) * C1 + cc]; ui = gi[(3 * NG) * C1 + cc];
+            for (int k = 1; k < NG; ++k) {
+                const float ofv = gv[(0 * NG + k) * C1 + cc], ouv = gv[(2 * NG + k) * C1 + cc];
+                const int ofi = gi[(1 * NG + k) * C1 + cc], oui = gi[(3 * NG + k) * C1 + cc];
+                if (ofv > fv || (ofv == fv && ofi < fi)) { fv = ofv; fi = ofi; }
+                if (ouv > uv || (ouv == uv && oui < ui)) { uv = ouv; ui = oui; }
             }
-            if (du_u != 0.0f) {
-                const float xr = rc[(size_t)ui * LD + c], xi = ri[(size_t)ui * LD + c];
-                g_rc_bag[(size_t)ui * C1 + c] += du_u * clampf(xi) * inrange(xr);
-                g_ri_bag[(size_t)ui * C1 + c] += du_u * clampf(xr) * inrange(xi);
+            bag = refine_column_finish(a, li, cc, fv, fi, uv, ui, hot, rc, ri, w, ws, g_rc_bag, g_ri_bag, LD);
+        }
+    } else {                                      // (more than 256 classes: one wave per column, lanes over the rows)
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int cc = wave; cc < C1; cc += NT / 64) {
+            float fv = -INFINITY, uv = -INFINITY;
+            int fi = INT_MAX, ui = INT_MAX;
+            for (int n = lane; n < N; n += 64) {
+                const float u = clampf(rc[(size_t)n * LD + cc]) * clampf(ri[(size_t)n * LD + cc]);
+                const float f = (hot[n] == cc) ? u : 0.0f;
+                if (f > fv) { fv = f; fi = n; }
+                if (u > uv) { uv = u; ui = n; }
             }
+            wave_argmax(fv, fi);
+            wave_argmax(uv, ui);
+            if (lane == 0) bag += refine_column_finish(a, li, cc, fv, fi, uv, ui, hot, rc, ri, w, ws, g_rc_bag, g_ri_bag, LD);
         }
     }
+    LCLK(li, 5);
     bag = block_sum(bag, red);
     if (tid == 0) { out[0] = bag; out[1] = 0.f; out[2] = cls_loss; out[3] = iou_loss; }
 }
 
-__device__ void mil_job(const cim_loss_args& a, float* red) {
-    const int N = a.N, C1 = a.C1, LD = a.ld > 0 ? a.ld : a.C1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+__device__ void mil_job(const cim_loss_args& a, float* red, float* grp_scratch) {
+    const int N = a.N, C1 = a.C1, LD = a.ld > 0 ? a.ld : a.C1, tid = threadIdx.x;
     float* g_pc = a.grad;                                   // component 0: d bag / d predict_cls
     float* g_pd = a.grad + (size_t)2 * N * C1;              // component 2: d bag / d predict_det
     float bag = 0.0f;
-    for (int c = wave; c < C1; c += NT / 64) {              // heads.py:149-166
+    const int G = loss_group(C1), NG = NT / G, grp = tid / G, c = tid % G;
+    if (G <= 256) {
+        // heads.py:149-166 with lanes along the columns of a row (see refine_job's column pass: this job took 61 us with a wave per
+        // column - the longest of the launch): column dots as NG partial sums per column, added in group order; then the gradient
+        // components, rows coalesced
         float s = 0.0f;
-        for (int n = lane; n < N; n += 64) s += a.pc[(size_t)n * LD + c] * a.pd[(size_t)n * LD + c];
+        if (c < C1)
+            for (int n0 = grp; n0 < N; n0 += 8 * NG) {
+                float x[8], y[8];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float L = (c == 0) ? 1.0f : a.labels[c - 1];
-        const float p = clampf(s);
-        if (lane == 0) bag += -(L * logf(p) + (1.0f - L) * logf(1.0f - p)) / (float)C1;
-        const float ds = -(L / p - (1.0f - L) / (1.0f - p)) / (float)C1 * inrange(s);
-        for (int n = lane; n < N; n += 64) {
-            g_pc[(size_t)n * C1 + c] = ds * a.pd[(size_t)n * LD + c];
-            g_pd[(size_t)n * C1 + c] = ds * a.pc[(size_t)n * LD + c];
+                for (int j = 0; j < 8; ++j) {
+                    const int n = min(n0 + j * NG, N - 1);
+                    x[j] = a.pc[(size_t)n * LD + c];
+                    y[j] = a.pd[(size_t)n * LD + c];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (n0 + j * NG < N) s += x[j] * y[j];
+            }
+        float* part = grp_scratch;                          // [NG][C1]
+        float* dsv = grp_scratch + NG * C1;                 // [C1]
+        if (c < C1) part[grp * C1 + c] = s;
+        __syncthreads();
+        if (tid < C1) {
+            float t = part[tid];
+            for (int k = 1; k < NG; ++k) t += part[k * C1 + tid];
+            const float L = (tid == 0) ? 1.0f : a.labels[tid - 1];
+            const float p = clampf(t);
+            bag = -(L * logf(p) + (1.0f - L) * logf(1.0f - p)) / (float)C1;
+            dsv[tid] = -(L / p - (1.0f - L) / (1.0f - p)) / (float)C1 * inrange(t);
+        }
+        __syncthreads();
+        if (c < C1) {
+            const float ds = dsv[c];
+            for (int n0 = grp; n0 < N; n0 += 8 * NG) {
+                float x[8], y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = min(n0 + j * NG, N - 1);
+                    x[j] = a.pc[(size_t)n * LD + c];
+                    y[j] = a.pd[(size_t)n * LD + c];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = n0 + j * NG;
+                    if (n < N) {
+                        g_pc[(size_t)n * C1 + c] = ds * y[j];
+                        g_pd[(size_t)n * C1 + c] = ds * x[j];
+                    }
+                }
+            }
+        }
+    } else {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int cc = wave; cc < C1; cc += NT / 64) {
+            float s = 0.0f;
+            for (int n = lane; n < N; n += 64) s += a.pc[(size_t)n * LD + cc] * a.pd[(size_t)n * LD + cc];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float L = (cc == 0) ? 1.0f : a.labels[cc - 1];
+            const float p = clampf(s);
+            if (lane == 0) bag += -(L * logf(p) + (1.0f - L) * logf(1.0f - p)) / (float)C1;
+            const float ds = -(L / p - (1.0f - L) / (1.0f - p)) / (float)C1 * inrange(s);
+            for (int n = lane; n < N; n += 64) {
+                g_pc[(size_t)n * C1 + cc] = ds * a.pd[(size_t)n * LD + cc];
+                g_pd[(size_t)n * C1 + cc] = ds * a.pc[(size_t)n * LD + cc];
+            }
         }
     }
     bag = block_sum(bag, red);
@@ -233,7 +376,7 @@ __device__ int pcl_plan(const cim_loss_args& a, float* red, float* row_val, int1
     return K;
 }
 
-__device__ void pcl_job(const cim_loss_args& a, float* red, unsigned char* scratch) {
+__device__ void pcl_job(const cim_loss_args& a, float* red, unsigned char* scratch, float* grp_scratch) {
     const int N = a.N, C1 = a.C1, LD = a.ld > 0 ? a.ld : a.C1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     float* g = a.grad + (size_t)1 * N * C1;                 // component 1: d pcl / d predict_cls
     for (int i = tid; i < N * C1; i += NT) g[i] = 0.f;
@@ -242,44 +385,113 @@ __device__ void pcl_job(const cim_loss_args& a, float* red, unsigned char* scrat
     int16_t* row_cluster = row_col + N;                                       // [N]
     __shared__ int csize[CIM_PCL_MAX_CLUSTERS];
     int bg_cluster;
+    LCLK(a.R + 1, 1);
     const int K = pcl_plan(a, red, row_val, row_col, row_cluster, csize, &bg_cluster);
+    LCLK(a.R + 1, 2);
     float den = 1e-6f;                                      // heads.py:22
     for (int k = 0; k < K; ++k) den += (float)csize[k];
     const float scale = 12.0f / den;                        // heads.py:40-41
     float acc = 0.0f;
-    // (cluster, column) pairs over the 16 waves
-    for (int job = wave; job < K * C1; job += NT / 64) {
-        const int k = job / C1, c = job % C1;
-        const float nk = (float)csize[k];
-        if (k == bg_cluster) {                              // heads.py:33-38: every member row vs its own pattern
-            float s = 0.0f;
-            for (int n = lane; n < N; n += 64) {
-                if (row_cluster[n] != k) continue;
-                const float x = a.pc[(size_t)n * LD + c], p = clampf(x);
-                const float t = (row_col[n] == c) ? 1.0f : 0.0f;
-                s += -(t * logf(p) + (1.0f - t) * logf(1.0f - p));
-                g[(size_t)n * C1 + c] = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(x);
-            }
+    const int G = loss_group(C1), NG = NT / G, grp = tid / G, cg = tid % G;
+    if (G <= 256) {
+        // lanes along the columns of a row (see refine_job's column pass), one pass over the rows per cluster
+        float* part = grp_scratch;                                   // [NG][C1]
+        int* anyf = reinterpret_cast<int*>(grp_scratch) + NG * C1;   // [NG][C1]
+        float* dvv = grp_scratch + 2 * NG * C1;                      // [C1]
+        for (int k = 0; k < K; ++k) {
+            const float nk = (float)csize[k];
+            if (k == bg_cluster) {                          // heads.py:33-38: every member row vs its own pattern
+                if (cg < C1) {
+                    float sb = 0.0f;
+                    for (int n0 = grp; n0 < N; n0 += 8 * NG) {
+                        float xs[8];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) acc += s / (float)C1;            // = n_k * mean over (rows, cols)
-        } else {                                            // heads.py:25-31: mean row vector vs column indicator
-            float s = 0.0f;
-            int any = 0;
-            for (int n = lane; n < N; n += 64) {
-                if (row_cluster[n] != k) continue;
-                s += a.pc[(size_t)n * LD + c];
-                any |= (row_col[n] == c);
-            }
+                        for (int j = 0; j < 8; ++j) xs[j] = a.pc[(size_t)min(n0 + j * NG, N - 1) * LD + cg];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); any |= __shfl_xor(any, o); }
-            const float v = s / nk, p = clampf(v), t = any ? 1.0f : 0.0f;
-            if (lane == 0) acc += nk * (-(t * logf(p) + (1.0f - t) * logf(1.0f - p))) / (float)C1;
-            const float dv = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(v);   // n_k * (1/n_k)
-            for (int n = lane; n < N; n += 64)
-                if (row_cluster[n] == k) g[(size_t)n * C1 + c] = dv;
+                        for (int j = 0; j < 8; ++j) {
+                            const int n = n0 + j * NG;
+                            if (n >= N || row_cluster[n] != k) continue;
+                            const float x = xs[j], p = clampf(x);
+                            const float t = (row_col[n] == cg) ? 1.0f : 0.0f;
+                            sb += -(t * logf(p) + (1.0f - t) * logf(1.0f - p));
+                            g[(size_t)n * C1 + cg] = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(x);
+                        }
+                    }
+                    acc += sb / (float)C1;                  // = n_k * mean over (rows, cols)
+                }
+            } else {                                        // heads.py:25-31: mean row vector vs column indicator
+                float sc = 0.0f;
+                int any = 0;
+                if (cg < C1) {
+                    for (int n0 = grp; n0 < N; n0 += 8 * NG) {
+                        float xs[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xs[j] = a.pc[(size_t)min(n0 + j * NG, N - 1) * LD + cg];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int n = n0 + j * NG;
+                            if (n >= N || row_cluster[n] != k) continue;
+                            sc += xs[j];
+                            any |= (row_col[n] == cg);
+                        }
+                    }
+                    part[grp * C1 + cg] = sc;
+                    anyf[grp * C1 + cg] = any;
+                }
+                __syncthreads();
+                if (tid < C1) {
+                    float t_sum = part[tid];
+                    int t_any = anyf[tid];
+                    for (int q = 1; q < NG; ++q) { t_sum += part[q * C1 + tid]; t_any |= anyf[q * C1 + tid]; }
+                    const float v = t_sum / nk, p = clampf(v), t = t_any ? 1.0f : 0.0f;
+                    acc += nk * (-(t * logf(p) + (1.0f - t) * logf(1.0f - p))) / (float)C1;
+                    dvv[tid] = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(v);   // n_k * (1/n_k)
+                }
+                __syncthreads();
+                if (cg < C1) {
+                    const float dv = dvv[cg];
+                    for (int n = grp; n < N; n += NG)
+                        if (row_cluster[n] == k) g[(size_t)n * C1 + cg] = dv;
+                }
+                __syncthreads();                            // (part / anyf / dvv are rewritten by the next cluster)
+            }
+        }
+    } else {
+        // (cluster, column) pairs over the 16 waves
+        for (int job = wave; job < K * C1; job += NT / 64) {
+            const int k = job / C1, c = job % C1;
+            const float nk = (float)csize[k];
+            if (k == bg_cluster) {                              // heads.py:33-38: every member row vs its own pattern
+                float s = 0.0f;
+                for (int n = lane; n < N; n += 64) {
+                    if (row_cluster[n] != k) continue;
+                    const float x = a.pc[(size_t)n * LD + c], p = clampf(x);
+                    const float t = (row_col[n] == c) ? 1.0f : 0.0f;
+                    s += -(t * logf(p) + (1.0f - t) * logf(1.0f - p));
+                    g[(size_t)n * C1 + c] = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(x);
+                }
+    #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                if (lane == 0) acc += s / (float)C1;            // = n_k * mean over (rows, cols)
+            } else {                                            // heads.py:25-31: mean row vector vs column indicator
+                float s = 0.0f;
+                int any = 0;
+                for (int n = lane; n < N; n += 64) {
+                    if (row_cluster[n] != k) continue;
+                    s += a.pc[(size_t)n * LD + c];
+                    any |= (row_col[n] == c);
+                }
+    #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); any |= __shfl_xor(any, o); }
+                const float v = s / nk, p = clampf(v), t = any ? 1.0f : 0.0f;
+                if (lane == 0) acc += nk * (-(t * logf(p) + (1.0f - t) * logf(1.0f - p))) / (float)C1;
+                const float dv = scale * (-(t / p - (1.0f - t) / (1.0f - p))) / (float)C1 * inrange(v);   // n_k * (1/n_k)
+                for (int n = lane; n < N; n += 64)
+                    if (row_cluster[n] == k) g[(size_t)n * C1 + c] = dv;
+            }
         }
     }
+    LCLK(a.R + 1, 3);
     acc = block_sum(acc, red);
     float* out = a.part + 4 * (a.R + 1);
     if (tid == 0) { out[0] = 0.f; out[1] = scale * acc; out[2] = 0.f; out[3] = 0.f; }
@@ -289,13 +501,22 @@ __global__ __launch_bounds__(NT) void losses_kernel(const cim_loss_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red = reinterpret_cast<float*>(smem);            // [16]
     int* hot = reinterpret_cast<int*>(smem + 64);           // [N] (refinement jobs) / the PCL job's 8N bytes of row tables
+    float* grp_scratch = reinterpret_cast<float*>(smem + 64 + 8 * (size_t)a.N);     // [4][NT / G][C1] words: the column passes' group partials
     const int job = blockIdx.x;
-    if (job < a.R) refine_job(a, job, red, hot);
-    else if (job == a.R) mil_job(a, red);
-    else pcl_job(a, red, smem + 64);
+    LCLK(job, 0);
+    if (job < a.R) refine_job(a, job, red, hot, grp_scratch);
+    else if (job == a.R) mil_job(a, red, grp_scratch);
+    else pcl_job(a, red, smem + 64, grp_scratch);
+    LCLK(job, 7);
 }
 
 }  // namespace
+
+#if CIM_LOSS_CLOCKS
+extern "C" int cim_debug_loss_clocks(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_loss_clk), sizeof(g_loss_clk)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int cim_losses_fwd(const cim_loss_args* args, void* stream) {
     CIM_CHECK_ARG(args != nullptr);
@@ -304,7 +525,8 @@ extern "C" int cim_losses_fwd(const cim_loss_args* args, void* stream) {
     CIM_CHECK_ARG(a.pc && a.pd && a.labels && a.part && a.grad && a.mat && (a.R == 0 || a.layer_valid));
     for (int i = 0; i < a.R; ++i)
         CIM_CHECK_ARG(a.rc[i] && a.ri[i] && a.pseudo_labels[i] && a.pseudo_iou_f16[i] && a.loss_weights[i]);
-    const size_t lds = 64 + 8 * (size_t)a.N;
+    const int lg = a.C1 <= 32 ? 32 : a.C1 <= 64 ? 64 : a.C1 <= 128 ? 128 : a.C1 <= 256 ? 256 : 1024;
+    const size_t lds = 64 + 8 * (size_t)a.N + (lg <= 256 ? 16 * (size_t)(NT / lg) * a.C1 + 16 : 0) + 256;      // (+ block_sum4's 64 floats)
     if (lds > 64 * 1024)
         CIM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(losses_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
