@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-update", action="store_true", help="A/B aid: the whole SGD update on the step's own stream (round 5)")
     ap.add_argument("--trail-wgs", type=int, default=None, help="A/B aid: workgroups of the side-stream update launch")
+    ap.add_argument("--dw-form", type=int, default=None, help="A/B aid: kernel form of MaskFuse's late weight-gradient products "
+                    "(cim_amd/ops/maskfuse_pair.py: DW_FORM; 0 = 256 x 256 tiles that own their CU, 1 = the co-resident 128 x 256 form)")
+    ap.add_argument("--dw-wgs", type=int, default=None, help="A/B aid: workgroups per launch of those products (DW_WGS / DW_FORM1_WGS)")
     ap.add_argument("--late-cus", type=int, default=None, help="A/B aid: CUs of the stream MaskFuse's late weight-gradient launches run on "
                     "(cim_amd/ops/gemm.py: LATE_CUS; 0 = the whole chip); default: the package's setting")
     ap.add_argument("--phases", type=int, default=0, help="extra: N more steps with HIP events at the phase boundaries of the "
@@ -110,6 +113,15 @@ def run(args):
     heads.LAZY_SETTLE = True
     if args.late_cus is not None:
         gemm_mod.LATE_CUS = args.late_cus
+    if args.dw_form is not None or args.dw_wgs is not None:
+        from cim_amd.ops import maskfuse_pair as _mp
+        if args.dw_form is not None:
+            _mp.DW_FORM = args.dw_form
+        if args.dw_wgs is not None:
+            if _mp.DW_FORM == 1:
+                _mp.DW_FORM1_WGS = args.dw_wgs
+            else:
+                _mp.DW_WGS = args.dw_wgs
     if os.environ.get("CIM_BENCH_WATCHDOG"):        # debugging aid: dump all thread stacks if a phase stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["CIM_BENCH_WATCHDOG"]), repeat=True)

@@ -53,9 +53,9 @@ SIGNATURES = {
     "cim_bn_act_bwd": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cim_sgd_multi": [_P, _P, c_int, c_float, c_int, _P],
     "cim_gemm_pair_splits": [c_int, c_int, c_int],
-    "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P],
+    "cim_gemm_pair": [_P, _P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cim_gemm_pair_batched": [_P, _P, _P] + [c_int] * 6 + [c_int, c_int, c_int, c_longlong, c_longlong, c_longlong,
-                              _P, _P, c_int, c_int, _P],
+                              _P, _P, c_int, c_int, c_int, _P],
     "cim_pair_scales": [_P, c_int, _P, _P, c_int, c_int, _P],
     "cim_pair_split": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, _P, _P, _P],
     "cim_pair_amax": [_P, c_longlong, _P, _P],
@@ -79,7 +79,7 @@ SIGNATURES = {
     "cim_head_act_bwd": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
 }
 
-ABI_VERSION = 14         # cim_abi_version() of include/cim_hip.h this binding was written against
+ABI_VERSION = 15         # cim_abi_version() of include/cim_hip.h this binding was written against
 _lib = None
 
 

@@ -15,4 +15,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace cim
 
 extern "C" const char* cim_last_error(void) { return cim::g_err; }
-extern "C" int cim_abi_version(void) { return 14; }
+extern "C" int cim_abi_version(void) { return 15; }

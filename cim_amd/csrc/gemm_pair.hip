@@ -40,22 +40,36 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
 
+#ifndef CIM_RING_SCHED
+#define CIM_RING_SCHED 1
+#endif
+#ifndef CIM_RING_DBG
+#define CIM_RING_DBG 0
+#endif
 #ifndef CIM_PAIR_EXP
 #define CIM_PAIR_EXP 0          // ablation switches (tools/bench_gemm_pair.py); 0 = product
 #endif
 
-#ifndef CIM_PAIR_WAVES
-#define CIM_PAIR_WAVES 8        // waves of a workgroup: 8 = 2 (M) x 4 (N), wave tile 128 x 64, two waves per SIMD (product);
-#endif                          // 4 = 2 x 2, wave tile 128 x 128 (256 accumulator registers), ONE wave per SIMD (experiment, tools/build_alt.sh)
+// Two kernels (wave tile 128 x 64 in both, four waves along N):
+//   gemm_pair_kernel: 256 x 256 tiles, eight waves = two per SIMD at <= 256 registers, two 64 KB slabs of 32 k in LDS: the workgroup OWNS
+//     its CU (every product of the forward / data-gradient chains; `form` = 0 of the entry points);
+//   gemm_pair_ring_kernel: 128 x 256 tiles, four waves = ONE per SIMD, a ring of five 24 KB slabs of 16 k (120 KB): half of a CU's
+//     registers and 40 KB of its LDS stay free, workgroups of other streams' kernels (the backbone's backward chains: 35 KB, 64 VGPRs)
+//     run on the same CU beside it - the form of MaskFuse's late weight gradients (`form` = 1; ops/maskfuse_pair.py).
+// (Round 6's other experiment - four waves of 128 x 128, 512 registers per wave - is recorded in profiles/r6/gemm_pair_four_wave_experiment.txt.)
 constexpr int BM = 256, BN = 256, BK = 32;
-constexpr int NW = CIM_PAIR_WAVES;
-constexpr int NT = 64 * NW;
-constexpr int WNC = NW / 2;                         // waves along N
+constexpr int NW = 8, NT = 64 * NW;
+constexpr int WNC = 4;                              // waves along N
 constexpr int WM = 128, WN = BN / WNC, MI = 4, NI = WN / 32;
 constexpr int IPW = 32 / NW;                        // LDS-DMA instructions per wave, operand and slab (1 KiB each)
 constexpr int OPER = 256 * BK * 4;        // 32768 B per operand and slab
 constexpr int SLAB = 2 * OPER;
 constexpr int LDS_BYTES = 2 * SLAB;       // 131072
+// the ring kernel
+constexpr int RBM = 128, RBK = 16, RNT = 256, RSTAGES = 5;
+constexpr int RSTAGE_A = RBM * RBK * 4, RSTAGE_B = BN * RBK * 4, RSTAGE = RSTAGE_A + RSTAGE_B;      // 8 KB + 16 KB
+constexpr int RIPA = RSTAGE_A / 1024 / 4, RIPB = RSTAGE_B / 1024 / 4;                                // LDS-DMA instructions per wave and slab: 2 + 4
+constexpr int RLDS_BYTES = RSTAGES * RSTAGE;      // 122880
 
 enum { L_KC = 0, L_MC = 1 };
 
@@ -85,7 +99,9 @@ typedef __attribute__((address_space(3))) char* lds_ptr_t;
 // Inline asm on purpose: through __builtin_amdgcn_global_load_lds hipcc treats every later ds_read as a possible reader of
 // the DMA's destination and puts s_waitcnt vmcnt(0) in front of it - the loads of slab t+2 would be waited for right
 // after their issue.  As an asm statement the DMA is invisible to that bookkeeping; the kernel waits with its own
-// s_waitcnt vmcnt(0) in front of the one barrier per slab.  M0 is saved and restored (compiler-reserved).
+// s_waitcnt vmcnt(0) in front of the one barrier per slab.  M0 is saved and restored (compiler-reserved); SCC is declared clobbered
+// (s_addk_i32 writes it: without the clobber the compiler carried the low / high halves of a 64-bit pointer increment ACROSS the
+// statement - s_add_u32 ... asm ... s_addc_u32 - and an operand that crossed a 4 GiB boundary faulted, found in round 6).
 __device__ __forceinline__ void glds16x4(const char* sbase, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
@@ -105,13 +121,29 @@ __device__ __forceinline__ void glds16x4(const char* sbase, unsigned o0, unsigne
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(sbase), "s"(lds_dst)
-        : "memory");
+        : "memory", "scc");
+}
+__device__ __forceinline__ void glds16x2(const char* sbase, unsigned o0, unsigned o1, unsigned lds_dst) {     // (two pieces)
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_addk_i32 m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(o0), "v"(o1), "s"(sbase), "s"(lds_dst)
+        : "memory", "scc");
 }
 __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
 
 // ---- staging ---------------------------------------------------------------------------------------
 // KC: instruction i (0..31) covers tile rows 8i .. 8i+7 = double rows 4i .. 4i+3; a wave issues i = 4w .. 4w+3.
 // LDS position (double row d, slot s) holds global (row 2d + (s >> 3), chunk (s & 7) ^ (d & 7)); chunk p = 2 * kgroup + plane.
+template <int W, int IPW, int KROWS = BK>
 struct StageKC {
     unsigned off[IPW];    // byte offsets of this lane's source chunks relative to (base + k0 * 4)
     __device__ __forceinline__ void init(int row0, int rows, int ld, int wave, int lane) {
@@ -131,25 +163,48 @@ struct StageKC {
     }
     static __device__ __forceinline__ size_t k_step_bytes(int) { return (size_t)BK * 4; }
 };
-// MC: instruction i = k row i of the slab (1024 B = the 256 tile columns); lane q loads chunk q ^ swz(k),
-// swz(k) = (k & 1) | ((k >> 1) & 1) << 3 (k & 3 = ii for k = 4w + ii).
+// MC, W = 256 tile columns: instruction i = k row i of the slab (1024 B); lane q loads chunk q ^ swz(k),
+// swz(k) = (k & 1) | ((k >> 1) & 1) << 3 (k & 3 = ii for k = 4w + ii).  W = 128 (a k row = 512 B = 32 chunks): instruction i = k rows
+// 2i and 2i + 1, lane q loads chunk (q & 31) ^ swz(k) of row k = 2i + (q >> 5) - the same LDS image at a row pitch of 512 B.
+template <int W, int IPW, int KROWS = BK>
 struct StageMC {
     unsigned off[IPW];
     __device__ __forceinline__ void init(int col0, int cols, int ld, int wave, int lane) {
         const int maxchunk = ((cols - col0) * 4 - 16) / 16;       // last whole chunk of the row that belongs to the matrix
 #pragma unroll
         for (int ii = 0; ii < IPW; ++ii) {
-            const int swz = (ii & 1) | (((ii >> 1) & 1) << 3);    // (k & 3 = ii & 3 for k = IPW w + ii)
-            const int c = min(lane ^ swz, maxchunk);
-            off[ii] = (unsigned)(wave * IPW + ii) * (unsigned)ld * 4u + (unsigned)col0 * 4u + (unsigned)c * 16u;
+            if constexpr (W == 256) {
+                const int swz = (ii & 1) | (((ii >> 1) & 1) << 3);    // (k & 3 = ii & 3 for k = IPW w + ii)
+                const int c = min(lane ^ swz, maxchunk);
+                off[ii] = (unsigned)(wave * IPW + ii) * (unsigned)ld * 4u + (unsigned)col0 * 4u + (unsigned)c * 16u;
+            } else {
+                const int k = 2 * (wave * IPW + ii) + (lane >> 5);
+                const int swz = (lane >> 5) | ((ii & 1) << 3);        // (k & 1, (k >> 1) & 1 = ii & 1: IPW is even)
+                const int c = min((lane & 31) ^ swz, maxchunk);
+                off[ii] = (unsigned)k * (unsigned)ld * 4u + (unsigned)col0 * 4u + (unsigned)c * 16u;
+            }
         }
     }
     __device__ __forceinline__ void issue(const char* base_k, const char* lds_oper, int wave) const {
+#if CIM_RING_DBG == 2
+        if constexpr (W == 128) return;
+#endif
+#if CIM_RING_DBG == 3
+        if constexpr (KROWS == 16 && W == 256) return;
+#endif
+        if constexpr (IPW == 2) {
+            glds16x2(base_k, off[0], off[1], lds_addr(lds_oper) + (wave * IPW) * 1024);
+        } else {
 #pragma unroll
-        for (int q = 0; q < IPW; q += 4)
-            glds16x4(base_k, off[q], off[q + 1], off[q + 2], off[q + 3], lds_addr(lds_oper) + (wave * IPW + q) * 1024);
+            for (int q = 0; q < IPW; q += 4)
+                glds16x4(base_k, off[q], off[q + 1], off[q + 2], off[q + 3], lds_addr(lds_oper) + (wave * IPW + q) * 1024);
+        }
     }
-    static __device__ __forceinline__ size_t k_step_bytes(int ld) { return (size_t)BK * ld * 4; }
+    // instructions 2h, 2h + 1 of this wave's IPW
+    __device__ __forceinline__ void issue_pair(const char* base_k, const char* lds_oper, int wave, int h) const {
+        glds16x2(base_k, off[2 * h], off[2 * h + 1], lds_addr(lds_oper) + (wave * IPW + 2 * h) * 1024);
+    }
+    static __device__ __forceinline__ size_t k_step_bytes(int ld) { return (size_t)KROWS * ld * 4; }
 };
 
 // ---- fragment reads ----------------------------------------------------------------------------------
@@ -173,13 +228,14 @@ struct FragKC {
 };
 // MC: lane supplies k row kb + (i16 >> 2) and 4 consecutive tile columns wbase + 32 i + 16 mg + 4 (i16 & 3); two reads
 // (k rows +0, +4) make the 8 k values of column wbase + 32 i + (lane & 31).
-template <int CNT>
+template <int CNT, int W = 256>
 struct FragMC {
+    static constexpr int ROW = W * 4;      // bytes per k row of the LDS image
     unsigned o[2][2];       // [i & 1][plane]
     __device__ __forceinline__ void init(int wbase, int lane) {
         const int i16 = lane & 15, mg = (lane >> 4) & 1, lk = lane >> 5;
         const int s = ((i16 >> 2) & 1) | (((i16 >> 3) & 1) << 3);
-        const unsigned base = (unsigned)(8 * lk + (i16 >> 2)) * 1024u + (unsigned)wbase * 4u + (unsigned)(i16 & 1) * 8u;
+        const unsigned base = (unsigned)(8 * lk + (i16 >> 2)) * (unsigned)ROW + (unsigned)wbase * 4u + (unsigned)(i16 & 1) * 8u;
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
@@ -187,18 +243,18 @@ struct FragMC {
                 o[ip][pl] = base + (unsigned)(((8 * ip + 4 * mg + 2 * ((i16 >> 1) & 1) + pl) ^ s) * 16);
     }
     __device__ __forceinline__ f16x8 read(const char* oper, int i, int ks, int pl) const {
-        const char* p = oper + o[i & 1][pl] + ks * 16384 + (i >> 1) * 256;
+        const char* p = oper + o[i & 1][pl] + ks * (16 * ROW) + (i >> 1) * 256;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4096));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * ROW));
         const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(f16x8, v);
     }
 };
 
-template <int L> struct StageSel { using type = StageKC; };
-template <> struct StageSel<L_MC> { using type = StageMC; };
-template <int L, int CNT> struct FragSel { using type = FragKC<CNT>; };
-template <int CNT> struct FragSel<L_MC, CNT> { using type = FragMC<CNT>; };
+template <int L, int W, int IPW> struct StageSel { using type = StageKC<W, IPW>; };
+template <int W, int IPW> struct StageSel<L_MC, W, IPW> { using type = StageMC<W, IPW>; };
+template <int L, int CNT, int W> struct FragSel { using type = FragKC<CNT>; };
+template <int CNT, int W> struct FragSel<L_MC, CNT, W> { using type = FragMC<CNT, W>; };
 
 // XCD-aware work order (same policy as gemm_f32.hip: xcd_tile_map): >= 8 z slices -> whole slices per XCD; otherwise a
 // contiguous run of tiles per XCD; inside a run the index walking the smaller operand's panels runs fastest.
@@ -240,6 +296,66 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return v;
 }
 
+template <int TBM>
+__device__ __forceinline__ void pair_epilogue(const PairArgs& g, f32x16 (&acc)[MI][NI], float (&bvj)[NI], float* Cb, int zsplit, int zb,
+                                              int m0, int n0, int wm, int wn, int lane) {
+    // epilogue: undo the two scales (powers of two: exact), bias, ReLU.  Nothing may be in flight on the vector-memory counter
+    // when the stores start: stores count on vmcnt as well, and a load whose completion the compiler cannot prove at a
+    // control-flow join draws an s_waitcnt vmcnt(0) in front of EVERY guarded store (128 per lane, each then waiting for
+    // the previous store's acknowledgement).  So the bias is loaded above the loop and consumed here once, and full tiles
+    // take a path without per-row guards.  (Tried: each wave passes its 32 x 64 blocks through its slice of the idle LDS and
+    // stores rows as 16 bytes per lane - 32 store instructions per wave instead of 128: SLOWER, 1.43 vs 1.26 ms on the
+    // Winograd-forward launch; a wave's 4-byte stores already cover two whole 128-byte row segments per instruction.  Also
+    // tried: MFMA operands swapped so that the accumulator tile is the transpose and a lane stores four consecutive columns of
+    // ITS row as 16 bytes - 32 stores per wave, no LDS: 1.33 vs 1.26 ms (32-byte pieces of 32 different rows per
+    // instruction).  The stores themselves cost 4-8 % of a launch (ablation without them: 1.246 vs 1.303 ms).)
+    const float inv = 1.0f / (g.a_scale[zb] * g.b_scale[zb]);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(bvj[j]));
+    float* C = Cb + (size_t)zsplit * g.c_split_stride;
+    const int lk = lane >> 5, l31 = lane & 31;
+    unsigned amax = 0;
+    const bool relu = g.relu != 0;
+    if (m0 + TBM <= g.M && n0 + BN <= g.N) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            float* cj = C + (size_t)(m0 + wm * WM + 4 * lk) * g.ldc + n0 + wn * WN + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * inv + bvj[j];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
+                    cj[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc] = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WN + j * 32 + l31;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (m >= g.M) continue;
+                    float v = acc[i][j][r] * inv + bvj[j];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
+                    C[(size_t)m * g.ldc + n] = v;
+                }
+            }
+        }
+    }
+    if (g.c_amax != nullptr && g.c_split_stride == 0) {
+        amax = wave_max_u32(amax);
+        if (lane == 0) cim::amax_publish(g.c_amax, amax);
+    }
+}
+
 // ONEP: the h * h product ALONE (one MFMA product per multiply-add instead of three): operands carry 11 significant bits - fp16
 // inputs with fp32 accumulation, the arithmetic class of TF32 (10 bits), which is what the reference's conv / matmul run in on
 // its own hardware (torch 1.10 defaults, tools/train.py:153-154 sets only cudnn.deterministic / benchmark).  An explicit
@@ -269,16 +385,18 @@ __global__ __launch_bounds__(NT, NW / 4) void gemm_pair_kernel(const PairArgs g)
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nslab = (kend - kbeg) / BK;
 
-    typename StageSel<AL>::type sa;
-    typename StageSel<BL>::type sb;
+    using StageA = typename StageSel<AL, BM, IPW>::type;
+    using StageB = typename StageSel<BL, BN, IPW>::type;
+    StageA sa;
+    StageB sb;
     sa.init(m0, g.M, g.lda, wave, lane);
     sb.init(n0, g.N, g.ldb, wave, lane);
     const char* ak = Ab + (AL == L_KC ? (size_t)kbeg * 4 : (size_t)kbeg * g.lda * 4);
     const char* bk = Bb + (BL == L_KC ? (size_t)kbeg * 4 : (size_t)kbeg * g.ldb * 4);
-    const size_t a_adv = StageSel<AL>::type::k_step_bytes(g.lda), b_adv = StageSel<BL>::type::k_step_bytes(g.ldb);
+    const size_t a_adv = StageA::k_step_bytes(g.lda), b_adv = StageB::k_step_bytes(g.ldb);
 
-    typename FragSel<AL, MI>::type fa;
-    typename FragSel<BL, NI>::type fb;
+    typename FragSel<AL, MI, BM>::type fa;
+    typename FragSel<BL, NI, BN>::type fb;
     fa.init(wm * WM, lane);
     fb.init(wn * WN, lane);
 
@@ -442,61 +560,173 @@ __global__ __launch_bounds__(NT, NW / 4) void gemm_pair_kernel(const PairArgs g)
 #endif
 
 
-    // epilogue: undo the two scales (powers of two: exact), bias, ReLU.  Nothing may be in flight on the vector-memory counter
-    // when the stores start: stores count on vmcnt as well, and a load whose completion the compiler cannot prove at a
-    // control-flow join draws an s_waitcnt vmcnt(0) in front of EVERY guarded store (128 per lane, each then waiting for
-    // the previous store's acknowledgement).  So the bias is loaded above the loop and consumed here once, and full tiles
-    // take a path without per-row guards.  (Tried: each wave passes its 32 x 64 blocks through its slice of the idle LDS and
-    // stores rows as 16 bytes per lane - 32 store instructions per wave instead of 128: SLOWER, 1.43 vs 1.26 ms on the
-    // Winograd-forward launch; a wave's 4-byte stores already cover two whole 128-byte row segments per instruction.  Also
-    // tried: MFMA operands swapped so that the accumulator tile is the transpose and a lane stores four consecutive columns of
-    // ITS row as 16 bytes - 32 stores per wave, no LDS: 1.33 vs 1.26 ms (32-byte pieces of 32 different rows per
-    // instruction).  The stores themselves cost 4-8 % of a launch (ablation without them: 1.246 vs 1.303 ms).)
-    const float inv = 1.0f / (g.a_scale[zb] * g.b_scale[zb]);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(bvj[j]));
-    float* C = Cb + (size_t)zsplit * g.c_split_stride;
-    const int lk = lane >> 5, l31 = lane & 31;
-    unsigned amax = 0;
-    const bool relu = g.relu != 0;
-    if (m0 + BM <= g.M && n0 + BN <= g.N) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            float* cj = C + (size_t)(m0 + wm * WM + 4 * lk) * g.ldc + n0 + wn * WN + j * 32 + l31;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] * inv + bvj[j];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
-                    cj[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc] = v;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * WN + j * 32 + l31;
-            if (n >= g.N) continue;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (m >= g.M) continue;
-                    float v = acc[i][j][r] * inv + bvj[j];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
-                    C[(size_t)m * g.ldc + n] = v;
-                }
-            }
-        }
+    pair_epilogue<BM>(g, acc, bvj, Cb, zsplit, zb, m0, n0, wm, wn, lane);
+}
+
+// The co-resident form (`form` = 1): C tile 128 x 256, four waves (wave tile 128 x 64, one wave per SIMD), both operands K-major (the
+// weight gradients' layout).  With one wave per SIMD and half the MFMA work per slab of the kernel above, two 32-k slabs do not cover
+// the LDS-DMA's latency (measured with them: 0.33 of the f16 peak against 0.47; 0.48 with the DMA taken out of the loop) - so the
+// operands go through a RING of five 16-k slabs (24 KB each): the DMA of slab t + 4 is issued at step t and is waited for at step
+// t + 3 (s_waitcnt vmcnt(12): the two younger slabs stay in flight), one barrier per step of four waves.  Per output element the same
+// MFMA products in the same order as the kernel above: same bits.
+template <bool ONEP>
+__global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g) {       // (2 waves per SIMD's worth of registers at most: <= 256)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wn = wave;
+    int tile_m, tile_n, zidx;
+    pair_tile_map(g.M, g.N, g.tn, g.tm, g.tz, (int)blockIdx.x + g.tile0, tile_m, tile_n, zidx);
+    const int m0 = tile_m * RBM, n0 = tile_n * BN;
+    const char* Ab = g.A;
+    const char* Bb = g.B;
+    float* Cb = g.C;
+    int zsplit = zidx, zb = 0;
+    if (g.batch > 1) {
+        Ab += (size_t)zidx * g.a_bs * 4;
+        Bb += (size_t)zidx * g.b_bs * 4;
+        Cb += (size_t)zidx * g.c_bs;
+        zsplit = 0;
+        zb = zidx;
     }
-    if (g.c_amax != nullptr && g.c_split_stride == 0) {
-        amax = wave_max_u32(amax);
-        if (lane == 0) cim::amax_publish(g.c_amax, amax);
+    const int kbeg = zsplit * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nslab = (kend - kbeg) / RBK;          // even (K and k_per_split are multiples of 32)
+
+    StageMC<RBM, RIPA, RBK> sa;
+    StageMC<BN, RIPB, RBK> sb;
+    sa.init(m0, g.M, g.lda, wave, lane);
+    sb.init(n0, g.N, g.ldb, wave, lane);
+    const char* ak = Ab + (size_t)kbeg * g.lda * 4;
+    const char* bk = Bb + (size_t)kbeg * g.ldb * 4;
+    const size_t a_adv = (size_t)RBK * g.lda * 4, b_adv = (size_t)RBK * g.ldb * 4;
+    FragMC<MI, RBM> fa;
+    FragMC<NI, BN> fb;
+    fa.init(0, lane);
+    fb.init(wn * WN, lane);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float bvj[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        bvj[j] = (g.bias != nullptr && n < g.N) ? g.bias[n] : 0.0f;
     }
+
+    // Every step issues exactly one slab's DMA (six instructions per wave), so the wait in front of a step's barrier is always
+    // vmcnt(12); past the last slab the source stays on the last one (re-read into buffers nobody consumes: 4 of K / 16 slabs) - no
+    // branch around the issue, the step is one basic block.  `left` = slabs the source pointers can still advance by.
+    int left = nslab - 1;
+    auto advance = [&]() {
+        const bool more = left > 0;
+        ak += more ? a_adv : 0;
+        bk += more ? b_adv : 0;
+        left -= more ? 1 : 0;
+    };
+    // prologue: slabs 0 .. 3 -> buffers 0 .. 3; slab 0 waited for
+#pragma unroll
+    for (int q = 0; q < RSTAGES - 1; ++q) {
+        sa.issue(ak, smem + q * RSTAGE, wave);
+        sb.issue(bk, smem + q * RSTAGE + RSTAGE_A, wave);
+        advance();
+    }
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    __syncthreads();
+
+    auto main_loop = [&](auto miv_c) {
+    constexpr int MIV = decltype(miv_c)::value;
+    f16x8 ah0[MIV], al0[MIV], bh0[NI], bl0[NI];
+    f16x8 ah1[MIV], al1[MIV], bh1[NI], bl1[NI];
+#define RING_READ_B(BH, BL_, BUF)                                                              \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                           \
+        BH[j] = fb.read((BUF) + RSTAGE_A, j, 0, 0);                                            \
+        if constexpr (!ONEP) BL_[j] = fb.read((BUF) + RSTAGE_A, j, 0, 1);                      \
+    }
+#define RING_READ_A(AF, BUF, PL)                                                               \
+    _Pragma("unroll") for (int i = 0; i < MIV; ++i) AF[i] = fa.read((BUF), i, 0, PL);
+#define RING_MMA(AF, BF)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < MIV; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i], BF[j], acc[i][j], 0, 0, 0)
+// With ONE wave per SIMD nothing else fills the matrix pipe while this wave issues LDS reads or DMA: a step is three groups of
+// MIV * NI MFMAs, each interleaved one to one with a third of the NEXT step's fragment reads (no dependence), and the step's six DMA
+// instructions go out in three pieces BETWEEN the groups (a piece issues while the group's last MFMA executes).  Fused ahead of the
+// MFMAs as a block (reads, then DMA) the same kernel ran at 0.36 of the f16 peak, interleaved 0.39+ (fc1's weight gradient).
+#if CIM_RING_SCHED == 0
+#define RING_SCHED(NREAD)
+#else
+#define RING_SCHED(NREAD)                                                                      \
+    _Pragma("unroll") for (int q = 0; q < MIV * NI; ++q) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+        if (q < (NREAD)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    \
+    }                                                                                          \
+    if ((NREAD) > MIV * NI) __builtin_amdgcn_sched_group_barrier(0x100, (NREAD) - MIV * NI, 0);\
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+// one 16-k step: slab T + 1 has landed behind the barrier and buffer (T - 1) % 5 is free (its fragments went into registers at
+// step T - 2): issue slab T + 4 into it, fetch the fragments of slab T + 1, multiply those of slab T
+#define RING_STEP(AH, AL_, BH, BL_, NAH, NAL, NBH, NBL)                                        \
+    {                                                                                          \
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                      \
+        __syncthreads();                                                                       \
+        const char* nxt = smem + rb * RSTAGE;                                                  \
+        const char* wbuf = smem + wb * RSTAGE;                                                 \
+        if constexpr (ONEP) {                                                                  \
+            sa.issue(ak, wbuf, wave);                                                          \
+            sb.issue(bk, wbuf + RSTAGE_A, wave);                                               \
+            RING_READ_B(NBH, NBL, nxt)                                                         \
+            RING_READ_A(NAH, nxt, 0)                                                           \
+            RING_MMA(AH, BH);                                                                  \
+            RING_SCHED(2 * NI + 2 * MIV)                                                       \
+        } else {                                                                               \
+            RING_READ_B(NBH, NBL, nxt)                                                         \
+            RING_MMA(AL_, BH);                                                                 \
+            RING_SCHED(4 * NI)                                                                 \
+            sa.issue(ak, wbuf, wave);                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            RING_READ_A(NAL, nxt, 1)                                                           \
+            RING_MMA(AH, BL_);                                                                 \
+            RING_SCHED(2 * MIV)                                                                \
+            sb.issue_pair(bk, wbuf + RSTAGE_A, wave, 0);                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            RING_READ_A(NAH, nxt, 0)                                                           \
+            RING_MMA(AH, BH);                                                                  \
+            RING_SCHED(2 * MIV)                                                                \
+            sb.issue_pair(bk, wbuf + RSTAGE_A, wave, 1);                                       \
+        }                                                                                      \
+        advance();                                                                             \
+        wb = wb == RSTAGES - 1 ? 0 : wb + 1;                                                   \
+        rb = rb == RSTAGES - 1 ? 0 : rb + 1;                                                   \
+    }
+    RING_READ_B(bh0, bl0, smem)
+    if constexpr (!ONEP) { RING_READ_A(al0, smem, 1) }
+    RING_READ_A(ah0, smem, 0)
+    int rb = 1, wb = RSTAGES - 1;           // buffers of slab t + 1 (read) and slab t + 4 (written)
+    for (int t = 0; t < nslab; t += 2) {
+        RING_STEP(ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
+        RING_STEP(ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
+    }
+#undef RING_STEP
+#undef RING_SCHED
+#undef RING_MMA
+#undef RING_READ_A
+#undef RING_READ_B
+    };
+    switch (__builtin_amdgcn_readfirstlane(min(MI, (g.M - m0 + 31) / 32))) {
+        case 1: main_loop(std::integral_constant<int, 1>{}); break;
+        case 2: main_loop(std::integral_constant<int, 2>{}); break;
+        case 3: main_loop(std::integral_constant<int, 3>{}); break;
+        default: main_loop(std::integral_constant<int, MI>{}); break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the re-read slabs of the last steps: nothing may be in flight when the stores start)
+#if CIM_RING_DBG != 1
+    pair_epilogue<RBM>(g, acc, bvj, Cb, zsplit, zb, m0, n0, 0, wn, lane);
+#endif
 }
 
 // split-K reduce: fixed order, bias, ReLU, optional max |C|.  Round 6: a launch of at most 1024 workgroups that WALK over the result,
@@ -648,11 +878,15 @@ __global__ __launch_bounds__(256) void pair_amax_kernel(const float* __restrict_
     if (threadIdx.x == 0) cim::amax_publish(out, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));      // one atomic per workgroup
 }
 
-template <int AL, int BL>
+template <int AL, int BL, bool RING>
 int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st, int max_workgroups, int products) {
-    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
-    auto kern = products == 1 ? gemm_pair_kernel<AL, BL, true> : gemm_pair_kernel<AL, BL, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static_assert(!RING || (AL == L_MC && BL == L_MC), "the ring kernel is the weight gradients' layout only");
+    constexpr int TBM = RING ? RBM : BM, LDSB = RING ? RLDS_BYTES : LDS_BYTES, THREADS = RING ? RNT : NT;
+    const int tm = (g.M + TBM - 1) / TBM, tn = (g.N + BN - 1) / BN;
+    void (*kern)(const PairArgs);
+    if constexpr (RING) kern = products == 1 ? gemm_pair_ring_kernel<true> : gemm_pair_ring_kernel<false>;
+    else kern = products == 1 ? gemm_pair_kernel<AL, BL, true> : gemm_pair_kernel<AL, BL, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     if (e != hipSuccess) return (int)e;
     const int slabs = g.K / BK;
     if (splits < 1) splits = 1;
@@ -680,7 +914,7 @@ int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st, int ma
     const long long chunk = max_workgroups > 0 ? max_workgroups : total;
     for (long long t0 = 0; t0 < total; t0 += chunk) {
         g.tile0 = (int)t0;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(total - t0 < chunk ? total - t0 : chunk)), dim3(NT), LDS_BYTES, st, g);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(total - t0 < chunk ? total - t0 : chunk)), dim3(THREADS), LDSB, st, g);
     }
     if (splits > 1) {
         const long long quads = ((long long)g.M * g.N + 3) / 4;
@@ -692,11 +926,15 @@ int launch_pair(PairArgs g, int splits, float* workspace, hipStream_t st, int ma
 }
 
 int dispatch_pair(const PairArgs& g, int a_mcontig, int b_kcontig, int splits, float* workspace, hipStream_t st, int max_workgroups,
-                  int products) {
-    if (!a_mcontig && !b_kcontig) return launch_pair<L_KC, L_MC>(g, splits, workspace, st, max_workgroups, products);
-    if (!a_mcontig && b_kcontig) return launch_pair<L_KC, L_KC>(g, splits, workspace, st, max_workgroups, products);
-    if (a_mcontig && !b_kcontig) return launch_pair<L_MC, L_MC>(g, splits, workspace, st, max_workgroups, products);
-    return launch_pair<L_MC, L_KC>(g, splits, workspace, st, max_workgroups, products);
+                  int products, int form) {
+    if (form == 1) {        // the co-resident form exists for the weight gradients' layout (both operands K-major)
+        if (a_mcontig && !b_kcontig) return launch_pair<L_MC, L_MC, true>(g, splits, workspace, st, max_workgroups, products);
+        return -3;
+    }
+    if (!a_mcontig && !b_kcontig) return launch_pair<L_KC, L_MC, false>(g, splits, workspace, st, max_workgroups, products);
+    if (!a_mcontig && b_kcontig) return launch_pair<L_KC, L_KC, false>(g, splits, workspace, st, max_workgroups, products);
+    if (a_mcontig && !b_kcontig) return launch_pair<L_MC, L_MC, false>(g, splits, workspace, st, max_workgroups, products);
+    return launch_pair<L_MC, L_KC, false>(g, splits, workspace, st, max_workgroups, products);
 }
 
 }  // namespace
@@ -716,7 +954,7 @@ static bool pair_dims_ok(int M, int N, int K, int lda, int ldb, int ldc, int a_m
 extern "C" int cim_gemm_pair_splits(int M, int N, int K) {
     // same model as pick_splits() of gemm_f32.hip at this engine's rate and slab depth
     const double CUS = 256.0;
-    const double tiles = (double)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const double tiles = (double)((M + 255) / 256) * ((N + BN - 1) / BN);
     const int slabs = K / BK;
     const double flops = 2.0 * M * (double)N * K;
     int best = 1;
@@ -735,12 +973,13 @@ extern "C" int cim_gemm_pair_splits(int M, int N, int K) {
 extern "C" int cim_gemm_pair(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda,
                              int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
                              const float* a_scale, const float* b_scale, uint32_t* c_amax, int max_workgroups, int products,
-                             void* stream) {
+                             int form, void* stream) {
     CIM_CHECK_ARG(A && B && C && a_scale && b_scale && max_workgroups >= 0 && (products == 3 || products == 1));
+    CIM_CHECK_ARG(form == 0 || (form == 1 && a_mcontig && !b_kcontig));
     CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
     CIM_CHECK_ARG(splits <= 1 || workspace != nullptr);
     PairArgs g{(const char*)A, (const char*)B, C, bias, M, N, K, lda, ldb, ldc, relu, 0, 0, 1, 0, 0, 0, a_scale, b_scale, c_amax, 0, 0, 0, 0};
-    int rc = dispatch_pair(g, a_mcontig, b_kcontig, splits, workspace, cim::as_stream(stream), max_workgroups, products);
+    int rc = dispatch_pair(g, a_mcontig, b_kcontig, splits, workspace, cim::as_stream(stream), max_workgroups, products, form);
     if (rc) { cim::set_error("cim_gemm_pair: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;
@@ -749,12 +988,13 @@ extern "C" int cim_gemm_pair(const void* A, const void* B, float* C, const float
 extern "C" int cim_gemm_pair_batched(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb,
                                      int ldc, int a_mcontig, int b_kcontig, int batch, long long a_bs, long long b_bs,
                                      long long c_bs, const float* a_scale, const float* b_scale, int max_workgroups, int products,
-                                     void* stream) {
+                                     int form, void* stream) {
     CIM_CHECK_ARG(A && B && C && a_scale && b_scale && batch > 0 && batch <= 65535 && max_workgroups >= 0 && (products == 3 || products == 1));
+    CIM_CHECK_ARG(form == 0 || (form == 1 && a_mcontig && !b_kcontig));
     CIM_CHECK_ARG(pair_dims_ok(M, N, K, lda, ldb, ldc, a_mcontig, b_kcontig));
     CIM_CHECK_ARG(a_bs % 8 == 0 && b_bs % 8 == 0 && c_bs % 4 == 0);
     PairArgs g{(const char*)A, (const char*)B, C, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, batch, a_bs, b_bs, c_bs, a_scale, b_scale, nullptr, 0, 0, 0, 0};
-    int rc = dispatch_pair(g, a_mcontig, b_kcontig, 1, nullptr, cim::as_stream(stream), max_workgroups, products);
+    int rc = dispatch_pair(g, a_mcontig, b_kcontig, 1, nullptr, cim::as_stream(stream), max_workgroups, products, form);
     if (rc) { cim::set_error("cim_gemm_pair_batched: launch setup failed (%d)", rc); return rc; }
     CIM_CHECK_LAUNCH();
     return 0;

@@ -45,6 +45,15 @@ DEFER_DW = True
 # 16.9 / 15.8 / 15.1 / 14.9 - the products are MFMA-bound, CUs withheld from them are simply lost.
 # 0: launched where their operands are ready, uncapped (beside the data-gradient products).
 DW_WGS = 256
+# Round 6: the late products run in the CO-RESIDENT form of the pair GEMM (include/cim_hip.h: `form` = 1 - 128 x 256 tiles of four waves, a
+# ring of five 16-k slabs: half of a CU's registers and 40 KB of its LDS stay free), as whole products (DW_FORM1_WGS = 0: no launch cap) -
+# the backbone's backward kernels (35 KB of LDS, 64 VGPRs) then run on the SAME CUs beside them instead of taking turns with
+# 256-workgroup launches that own the chip.  Alone the form is slower (0.40 against 0.44 of the f16 peak on the weight gradients), beside
+# the backbone's chains the last phase of the backward is shorter: 4.17 -> 3.86 ms (tools/diag_late.py: the chains end 0.9 ms earlier, the
+# late stream 0.12 ms earlier), step 14.41 -> 14.20 ms (same box, three interleaved runs each; bench.py --dw-form 0 | 1).  Same bits
+# (tests/test_gpu_gemm_pair.py).  0: the 256 x 256 form in launches of DW_WGS workgroups (round 4's schedule).
+DW_FORM = 1
+DW_FORM1_WGS = 0
 # which schedule the backward passes of this process took (counts per pass; bench.py prints it in extra.comm, the 2-rank tests
 # assert on it): the single-process schedule (late launches of DW_WGS workgroups, postponed behind the ROIAlign backward) and the
 # multi-rank one (whole products, handed to nn.DataParallel as soon as they are enqueued) are different code paths
@@ -313,13 +322,13 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
         db2 = pair.masked_stats(dY2, Y2, am[0:1], ctx.has_bias[2] and ctx.needs_input_grad[6 + ofs])
         dY2p = pair.split(dY2, r, h2, h2, scale=pair.scales_from(am[0:1], 1), relu_y=Y2)
         if need_w2:
-            dw2 = side_grad(2, w2_p, lambda limit=0: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False, limit=limit))
+            dw2 = side_grad(2, w2_p, lambda limit=0, form=0: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False, limit=limit, form=form))
         dY1 = pair.gemm(dY2p, W2p, r, h1, h2, False, False)
         # ---- fc1
         db1 = pair.masked_stats(dY1, Y1, am[1:2], ctx.has_bias[1] and ctx.needs_input_grad[4 + ofs])
         dY1p = pair.split(dY1, r, h1, h1, scale=pair.scales_from(am[1:2], 1), relu_y=Y1)
         if need_w1:
-            dw1 = side_grad(1, w1_p, lambda limit=0: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False, limit=limit))
+            dw1 = side_grad(1, w1_p, lambda limit=0, form=0: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False, limit=limit, form=form))
         if need_x or need_wc or (ctx.has_bias[0] and ctx.needs_input_grad[2 + ofs]):
             dX = pair.gemm(dY1p, W1p, r, cout * p * p, h1, False, False, c_amax=am[2:3], balance=True)
             # ---- flatten backward + ReLU mask of the conv; conv gradients
@@ -353,14 +362,14 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
             if want_dbc:
                 dbc = bpart.sum(dim=0)          # per-ROI partial sums from the flatten kernel: 4 MB instead of a pass over dy
             if need_wc:
-                def wgrad(limit=0, D=D):
+                def wgrad(limit=0, form=0, D=D):
                     st2 = _lib.stream_ptr()
                     if D is None:
                         sD = torch.empty(NPOS, dtype=torch.float32, device=dev)
                         _lib.call("cim_wino7_pair_scales", am[2:3].data_ptr(), 1, None, 2, sD.data_ptr(), st2)
                         D = pair.Pair(torch.empty((NPOS, rp, cout), dtype=torch.int32, device=dev), r, cout, NPOS, sD)
                         _lib.call("cim_wino7_dy_pair", dy.data_ptr(), D.buf.data_ptr(), sD.data_ptr(), r, rp, cout, 0, st2)
-                    dU = pair.gemm(V, D, cin, cout, rp, True, False, limit=limit)
+                    dU = pair.gemm(V, D, cin, cout, rp, True, False, limit=limit, form=form)
                     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
                     _lib.call("cim_wino_wgrad_output", dU.data_ptr(), dw.data_ptr(), cout, cin, 7, st2)
                     return dw
@@ -404,8 +413,11 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
                     # (several ranks: RCCL's all-reduce kernels hold CUs of their own while these products run - a launch of exactly
                     # one workgroup per CU would then need a second, nearly empty round each time: the products go out whole)
                     limit = (G.LATE_CUS or DW_WGS) if publisher is None else 0
+                    form = DW_FORM if publisher is None else 0
+                    if form == 1:
+                        limit = DW_FORM1_WGS
                     SCHEDULE["late_launches_chunked" if publisher is None else "late_launches_whole_products"] += 1
-                    got = {slot: publish(w, fn(limit)) for slot, w, fn in late}
+                    got = {slot: publish(w, fn(limit, form)) for slot, w, fn in late}
                 if defer:           # (postponed: this node has returned - the join bookkeeping of the block below happens here)
                     keep = [t for t in (V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf,
                                         dY1p.scale, am) if t is not None] + dy_keep

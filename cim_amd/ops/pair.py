@@ -129,12 +129,14 @@ PRODUCTS = 3
 
 
 def gemm(a, b, m, n, k, a_mcontig=False, b_kcontig=False, bias=None, relu=False, out=None, c_amax=None, balance=False, limit=0,
-         products=None):
+         products=None, form=0):
     """C[m,n] = A . B (+ bias)(ReLU) on pair images; k must be a multiple of 32 (the images' zero rows / columns pad it).
     Batched when a.batch > 1 (then no bias / ReLU / split-K).  balance=True: a short last round of tiles is run as its own
     split-K product over the last columns (tail_columns) / over the last batch entries (tail_entries).
     limit > 0: the product goes out as consecutive launches of at most `limit` workgroups (a workgroup of this engine owns its CU:
-    a capped product leaves the rest of the chip to concurrent streams - MaskFuse's late weight gradients, ops/maskfuse_pair.py)."""
+    a capped product leaves the rest of the chip to concurrent streams).
+    form = 1 (a_mcontig and not b_kcontig only): the co-resident form of the kernel (include/cim_hip.h) - 128 x 256 tiles whose workgroups
+    leave half a CU to other streams' kernels: MaskFuse's late weight gradients, ops/maskfuse_pair.py.  Same bits as form 0."""
     dev = a.buf.device
     products = PRODUCTS if products is None else products
     if a.batch > 1:
@@ -143,13 +145,13 @@ def gemm(a, b, m, n, k, a_mcontig=False, b_kcontig=False, bias=None, relu=False,
         main = a.batch - (tail[0] if tail else 0)
         _lib.call("cim_gemm_pair_batched", a.buf.data_ptr(), b.buf.data_ptr(), c.data_ptr(), m, n, k, a.ld, b.ld, n,
                   int(a_mcontig), int(b_kcontig), main, a.bs, b.bs, m * n, a.scale.data_ptr(), b.scale.data_ptr(),
-                  limit, products, _lib.stream_ptr())
+                  limit, products, form, _lib.stream_ptr())
         if tail:
             ws = torch.empty(tail[1] * m * n, dtype=torch.float32, device=dev)
             for z in range(main, a.batch):
                 _lib.call("cim_gemm_pair", a.buf.data_ptr() + 4 * z * a.bs, b.buf.data_ptr() + 4 * z * b.bs, c.data_ptr() + 4 * z * m * n,
                           None, m, n, k, a.ld, b.ld, n, int(a_mcontig), int(b_kcontig), 0, tail[1], ws.data_ptr(),
-                          a.scale.data_ptr() + 4 * z, b.scale.data_ptr() + 4 * z, None, limit, products, _lib.stream_ptr())
+                          a.scale.data_ptr() + 4 * z, b.scale.data_ptr() + 4 * z, None, limit, products, form, _lib.stream_ptr())
         return c
     c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=dev)
     splits = _lib.call("cim_gemm_pair_splits", m, n, k)
@@ -164,10 +166,10 @@ def gemm(a, b, m, n, k, a_mcontig=False, b_kcontig=False, bias=None, relu=False,
             _lib.call("cim_gemm_pair", a.buf.data_ptr(), b.buf.data_ptr() + boff, c.data_ptr() + 4 * col0,
                       (bias.data_ptr() + 4 * col0) if bias is not None else None, m, cols, k, a.ld, b.ld, n,
                       int(a_mcontig), int(b_kcontig), int(relu), sp, _lib.ptr(w), a.scale.data_ptr(), b.scale.data_ptr(),
-                      _lib.ptr(c_amax), limit, products, _lib.stream_ptr())
+                      _lib.ptr(c_amax), limit, products, form, _lib.stream_ptr())
         return c
     ws = torch.empty(splits * m * n, dtype=torch.float32, device=dev) if splits > 1 else None
     _lib.call("cim_gemm_pair", a.buf.data_ptr(), b.buf.data_ptr(), c.data_ptr(), _lib.ptr(bias), m, n, k, a.ld, b.ld, n,
               int(a_mcontig), int(b_kcontig), int(relu), splits, _lib.ptr(ws), a.scale.data_ptr(), b.scale.data_ptr(),
-              _lib.ptr(c_amax), limit, products, _lib.stream_ptr())
+              _lib.ptr(c_amax), limit, products, form, _lib.stream_ptr())
     return c

@@ -392,14 +392,20 @@ int cim_bn_act_bwd(const float* dy, const float* y, const float* x, const float*
  * with 11 significant bits, fp32 accumulation: the arithmetic class of TF32, which the reference's own convolutions / matmuls
  * run in on its hardware (torch 1.10 defaults; tools/train.py:153-154 touches cudnn.deterministic / benchmark only).  Reported
  * beside the headline as bench.py's extra.tf32_class, never used by default. */
+/* form: 0 = 256 x 256 tiles, eight waves, 128 KB of LDS - a workgroup owns its CU (every product of the forward / data-gradient
+ * chains); 1 = 128 x 256 tiles, four waves (one per SIMD, <= 256 registers each), 96 KB of LDS: half of the CU's registers and 64 KB of
+ * its LDS stay free, so workgroups of kernels on OTHER streams run on the same CU beside it - the form of the MaskFuse weight
+ * gradients that run beside the backbone's backward (a_mcontig = 1, b_kcontig = 0 only).  Same products in the same order per
+ * output element: same bits as form 0. */
 int cim_gemm_pair_splits(int M, int N, int K);
 int cim_gemm_pair(const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
                   int lda, int ldb, int ldc, int a_mcontig, int b_kcontig, int relu, int splits, float* workspace,
-                  const float* a_scale, const float* b_scale, uint32_t* c_amax, int max_workgroups, int products, void* stream);
+                  const float* a_scale, const float* b_scale, uint32_t* c_amax, int max_workgroups, int products, int form,
+                  void* stream);
 int cim_gemm_pair_batched(const void* A, const void* B, float* C, int M, int N, int K,
                           int lda, int ldb, int ldc, int a_mcontig, int b_kcontig,
                           int batch, long long a_bs, long long b_bs, long long c_bs,
-                          const float* a_scale, const float* b_scale, int max_workgroups, int products, void* stream);
+                          const float* a_scale, const float* b_scale, int max_workgroups, int products, int form, void* stream);
 int cim_pair_scales(const uint32_t* amax, int n_amax, const float* factor, float* scale, int n, int reduce_all, void* stream);
 int cim_pair_split(const float* X, void* P, int rows, int rows_pad, int cols, int ld, int ldp, int batch,
                    long long x_bs, long long p_bs, const float* scale, const float* relu_y, void* stream);

@@ -214,6 +214,35 @@ def test_pair_gemm_chunked_launches_are_bit_identical(dev):
         pair.gemm(px, pw, 300, 264, 8192, False, True, limit=-1)
 
 
+def test_pair_gemm_co_resident_form_is_bit_identical(dev):
+    """form = 1 of cim_gemm_pair* (128 x 256 tiles of four waves: the MaskFuse weight gradients beside the backbone's backward) - the
+    same products in the same order per output element as the 256 x 256 form: same bits, for a batched product (ragged last tiles both
+    ways), a split-K product, a plain one and chunked launches; only for the weight gradients' layout (both operands K-major)."""
+    from cim_amd import _lib
+    from cim_amd.ops import pair
+    g = torch.Generator().manual_seed(12)
+    nb, R, M, N = 9, 333, 520, 264
+    X, Y = torch.randn(nb, R, M, generator=g).to(dev), torch.randn(nb, R, N, generator=g).to(dev)
+    px, py = pair.split(X, R, M, M, batch=nb, x_bs=R * M), pair.split(Y, R, N, N, batch=nb, x_bs=R * N)
+    Xl, Yl = torch.randn(8192, 296, generator=g).to(dev), torch.randn(8192, 264, generator=g).to(dev)
+    pxl, pyl = pair.split(Xl), pair.split(Yl)
+    assert _lib.call("cim_gemm_pair_splits", 296, 264, 8192) > 1
+    Xs, Ys = torch.randn(1000, 1024, generator=g).to(dev), torch.randn(1000, 640, generator=g).to(dev)
+    pxs, pys = pair.split(Xs), pair.split(Ys)
+    cases = ((px, py, M, N, pair.pad32(R)), (pxl, pyl, 296, 264, 8192), (pxs, pys, 1024, 640, pair.pad32(1000)))
+    for a, b, m, n, k in cases:
+        ref = pair.gemm(a, b, m, n, k, True, False)
+        for limit in (0, 7):
+            assert torch.equal(ref, pair.gemm(a, b, m, n, k, True, False, limit=limit, form=1)), (m, n, k, limit)
+    want = Xs.double().t() @ Ys.double()
+    scale = Xs.double().abs().t() @ Ys.double().abs()
+    assert float(((pair.gemm(pxs, pys, 1024, 640, pair.pad32(1000), True, False, form=1).double() - want).abs() / scale).max()) < 2e-6
+    with pytest.raises(_lib.CimHipError):
+        pair.gemm(pxl, pyl, 8192, 8192, 264, False, True, form=1)        # (a forward product's layout)
+    with pytest.raises(_lib.CimHipError):
+        pair.gemm(pxs, pys, 1024, 640, pair.pad32(1000), True, False, form=2)
+
+
 @pytest.mark.parametrize("K", [2048, 50176])
 def test_pair_engine_error_class(dev, K):
     """One scale per matrix: on unit-variance data and on data with exponents spread over 2^+-10 the engine sits in the

@@ -98,18 +98,28 @@ PRODUCTS = 1 if args.one_product else 3      # --one-product: the h * h term alo
 sp = lambda m, n, k: lib.cim_gemm_pair_splits(m, n, k)
 fl_conv = NPOS * 2.0 * N * 2 * C * C
 fl_fc = 2.0 * N * K1 * 4096
-cases["pair wino_fwd   (KC x MC)"] = (lambda: lib.cim_gemm_pair_batched(P(pV.buf), P(pU.buf), P(M), N, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, pV.bs, pU.bs, N * C, P(pV.scale), P(pU.scale), 0, PRODUCTS, st), fl_conv)
-cases["pair wino_dgrad (KC x KC)"] = (lambda: lib.cim_gemm_pair_batched(P(pD.buf), P(pU.buf), P(M2), N, 2 * C, C, C, C, 2 * C, 0, 1, NPOS, pD.bs, pU.bs, N * 2 * C, P(pD.scale), P(pU.scale), 0, PRODUCTS, st), fl_conv)
-cases["pair wino_wgrad (MC x MC)"] = (lambda: lib.cim_gemm_pair_batched(P(pV.buf), P(pD.buf), P(dU), 2 * C, C, NP, 2 * C, C, C, 1, 0, NPOS, pV.bs, pD.bs, 2 * C * C, P(pV.scale), P(pD.scale), 0, PRODUCTS, st), fl_conv)
-cases["pair fc1_fwd    (KC x KC)"] = (lambda: lib.cim_gemm_pair(P(pX.buf), P(pW.buf), P(y1), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), P(ws), P(pX.scale), P(pW.scale), None, 0, PRODUCTS, st), fl_fc)
-cases["pair fc1_dgrad  (KC x MC)"] = (lambda: lib.cim_gemm_pair(P(pY.buf), P(pW.buf), P(dx1), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, 1, None, P(pY.scale), P(pW.scale), None, 0, PRODUCTS, st), fl_fc)
-cases["pair fc1_wgrad  (MC x MC)"] = (lambda: lib.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, 0, PRODUCTS, st), fl_fc)
+cases["pair wino_fwd   (KC x MC)"] = (lambda: lib.cim_gemm_pair_batched(P(pV.buf), P(pU.buf), P(M), N, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, pV.bs, pU.bs, N * C, P(pV.scale), P(pU.scale), 0, PRODUCTS, 0, st), fl_conv)
+cases["pair wino_dgrad (KC x KC)"] = (lambda: lib.cim_gemm_pair_batched(P(pD.buf), P(pU.buf), P(M2), N, 2 * C, C, C, C, 2 * C, 0, 1, NPOS, pD.bs, pU.bs, N * 2 * C, P(pD.scale), P(pU.scale), 0, PRODUCTS, 0, st), fl_conv)
+cases["pair wino_wgrad (MC x MC)"] = (lambda: lib.cim_gemm_pair_batched(P(pV.buf), P(pD.buf), P(dU), 2 * C, C, NP, 2 * C, C, C, 1, 0, NPOS, pV.bs, pD.bs, 2 * C * C, P(pV.scale), P(pD.scale), 0, PRODUCTS, 0, st), fl_conv)
+cases["pair fc1_fwd    (KC x KC)"] = (lambda: lib.cim_gemm_pair(P(pX.buf), P(pW.buf), P(y1), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), P(ws), P(pX.scale), P(pW.scale), None, 0, PRODUCTS, 0, st), fl_fc)
+cases["pair fc1_dgrad  (KC x MC)"] = (lambda: lib.cim_gemm_pair(P(pY.buf), P(pW.buf), P(dx1), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, 1, None, P(pY.scale), P(pW.scale), None, 0, PRODUCTS, 0, st), fl_fc)
+cases["pair fc1_wgrad  (MC x MC)"] = (lambda: lib.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, 0, PRODUCTS, 0, st), fl_fc)
+# the co-resident form (128 x 256 tiles of four waves) of the two weight-gradient products
+cases["form1 wino_wgrad"] = (lambda: lib.cim_gemm_pair_batched(P(pV.buf), P(pD.buf), P(dU), 2 * C, C, NP, 2 * C, C, C, 1, 0, NPOS, pV.bs, pD.bs, 2 * C * C, P(pV.scale), P(pD.scale), 0, PRODUCTS, 1, st), fl_conv)
+cases["form1 fc1_wgrad"] = (lambda: lib.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, 0, PRODUCTS, 1, st), fl_fc)
+if os.environ.get("CIM_BENCH_FORM1_LIMITS"):        # (diagnosis: per-CU latency or shared bandwidth?  launches of n workgroups)
+    for lim in (64, 128, 256, 512):
+        cases["form1 fc1_wgrad launches of %d" % lim] = (lambda lim=lim: lib.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, lim, PRODUCTS, 1, st), fl_fc)
+        cases["pair fc1_wgrad launches of %d" % lim] = (lambda lim=lim: lib.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, lim, PRODUCTS, 0, st), fl_fc)
 cases["split V (generic producer)"] = (lambda: lib.cim_pair_split(P(V), P(pV.buf), NP, NP, 2 * C, 2 * C, 2 * C, NPOS, NP * 2 * C, pV.bs, P(pV.scale), None, st), 0.0)
 for tag, al in alts.items():
-    cases["%-4s wino_fwd" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pV.buf), P(pU.buf), P(M), N, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, pV.bs, pU.bs, N * C, P(pV.scale), P(pU.scale), 0, PRODUCTS, st), fl_conv)
-    cases["%-4s wino_dgrad" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pD.buf), P(pU.buf), P(M2), N, 2 * C, C, C, C, 2 * C, 0, 1, NPOS, pD.bs, pU.bs, N * 2 * C, P(pD.scale), P(pU.scale), 0, PRODUCTS, st), fl_conv)
-    cases["%-4s wino_wgrad" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pV.buf), P(pD.buf), P(dU), 2 * C, C, NP, 2 * C, C, C, 1, 0, NPOS, pV.bs, pD.bs, 2 * C * C, P(pV.scale), P(pD.scale), 0, PRODUCTS, st), fl_conv)
-    cases["%-4s fc1_fwd" % tag] = (lambda al=al: al.cim_gemm_pair(P(pX.buf), P(pW.buf), P(y1), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), P(ws), P(pX.scale), P(pW.scale), None, 0, PRODUCTS, st), fl_fc)
+    cases["%-4s wino_fwd" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pV.buf), P(pU.buf), P(M), N, C, 2 * C, 2 * C, C, C, 0, 0, NPOS, pV.bs, pU.bs, N * C, P(pV.scale), P(pU.scale), 0, PRODUCTS, 0, st), fl_conv)
+    cases["%-4s wino_dgrad" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pD.buf), P(pU.buf), P(M2), N, 2 * C, C, C, C, 2 * C, 0, 1, NPOS, pD.bs, pU.bs, N * 2 * C, P(pD.scale), P(pU.scale), 0, PRODUCTS, 0, st), fl_conv)
+    cases["%-4s wino_wgrad" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pV.buf), P(pD.buf), P(dU), 2 * C, C, NP, 2 * C, C, C, 1, 0, NPOS, pV.bs, pD.bs, 2 * C * C, P(pV.scale), P(pD.scale), 0, PRODUCTS, 0, st), fl_conv)
+    cases["%-4s fc1_fwd" % tag] = (lambda al=al: al.cim_gemm_pair(P(pX.buf), P(pW.buf), P(y1), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), P(ws), P(pX.scale), P(pW.scale), None, 0, PRODUCTS, 0, st), fl_fc)
+    cases["%-4s form1 wino_wgrad" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pV.buf), P(pD.buf), P(dU), 2 * C, C, NP, 2 * C, C, C, 1, 0, NPOS, pV.bs, pD.bs, 2 * C * C, P(pV.scale), P(pD.scale), 0, PRODUCTS, 1, st), fl_conv)
+    cases["%-4s form1 fc1_wgrad" % tag] = (lambda al=al: al.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, 0, PRODUCTS, 1, st), fl_fc)
+    cases["%-4s fc1_wgrad" % tag] = (lambda al=al: al.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, 0, PRODUCTS, 0, st), fl_fc)
 if not args.no_old:
     Vr, Vc = _amax(V, NP, 2 * C, 2 * C, True, True, NPOS, NP * 2 * C)
     _, Uc = _amax(U, 2 * C, C, C, False, True, NPOS, 2 * C * C)
