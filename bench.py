@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--trail-wgs", type=int, default=None, help="A/B aid: workgroups of the side-stream update launch")
     ap.add_argument("--dw-form", type=int, default=None, help="A/B aid: kernel form of MaskFuse's late weight-gradient products "
                     "(cim_amd/ops/maskfuse_pair.py: DW_FORM; 0 = 256 x 256 tiles that own their CU, 1 = the co-resident 128 x 256 form)")
+    ap.add_argument("--no-postpone-dw", action="store_true", help="A/B aid: MaskFuse's late weight gradients are launched at the end of its "
+                    "backward node instead of behind the ROIAlign backward (cim_amd/ops/gemm.py: POSTPONE_DW)")
     ap.add_argument("--dw-wgs", type=int, default=None, help="A/B aid: workgroups per launch of those products (DW_WGS / DW_FORM1_WGS)")
     ap.add_argument("--late-cus", type=int, default=None, help="A/B aid: CUs of the stream MaskFuse's late weight-gradient launches run on "
                     "(cim_amd/ops/gemm.py: LATE_CUS; 0 = the whole chip); default: the package's setting")
@@ -113,6 +115,8 @@ def run(args):
     heads.LAZY_SETTLE = True
     if args.late_cus is not None:
         gemm_mod.LATE_CUS = args.late_cus
+    if args.no_postpone_dw:
+        gemm_mod.POSTPONE_DW = False
     if args.dw_form is not None or args.dw_wgs is not None:
         from cim_amd.ops import maskfuse_pair as _mp
         if args.dw_form is not None:

@@ -186,10 +186,10 @@ struct StageMC {
         }
     }
     __device__ __forceinline__ void issue(const char* base_k, const char* lds_oper, int wave) const {
-#if CIM_RING_DBG == 2
+#if CIM_RING_DBG == 2 || CIM_RING_DBG == 4 || CIM_RING_DBG == 6
         if constexpr (W == 128) return;
 #endif
-#if CIM_RING_DBG == 3
+#if CIM_RING_DBG == 3 || CIM_RING_DBG == 4 || CIM_RING_DBG == 6
         if constexpr (KROWS == 16 && W == 256) return;
 #endif
         if constexpr (IPW == 2) {
@@ -202,6 +202,9 @@ struct StageMC {
     }
     // instructions 2h, 2h + 1 of this wave's IPW
     __device__ __forceinline__ void issue_pair(const char* base_k, const char* lds_oper, int wave, int h) const {
+#if CIM_RING_DBG == 3 || CIM_RING_DBG == 4 || CIM_RING_DBG == 6
+        if constexpr (KROWS == 16 && W == 256) return;
+#endif
         glds16x2(base_k, off[2 * h], off[2 * h + 1], lds_addr(lds_oper) + (wave * IPW + 2 * h) * 1024);
     }
     static __device__ __forceinline__ size_t k_step_bytes(int ld) { return (size_t)KROWS * ld * 4; }
@@ -624,7 +627,11 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
     // branch around the issue, the step is one basic block.  `left` = slabs the source pointers can still advance by.
     int left = nslab - 1;
     auto advance = [&]() {
+#if CIM_RING_DBG == 7     /* ablation: the DMA re-reads slab 0 for ever (its mechanics with constant data) */
+        const bool more = false;
+#else
         const bool more = left > 0;
+#endif
         ak += more ? a_adv : 0;
         bk += more ? b_adv : 0;
         left -= more ? 1 : 0;
@@ -650,6 +657,13 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
     }
 #define RING_READ_A(AF, BUF, PL)                                                               \
     _Pragma("unroll") for (int i = 0; i < MIV; ++i) AF[i] = fa.read((BUF), i, 0, PL);
+#if CIM_RING_DBG == 5 || CIM_RING_DBG == 6      /* ablation: the loop's fragment reads are left out (registers keep the first slab's) */
+#define RING_LREAD_B(BH, BL_, BUF) asm volatile("" : "+v"(BH[0]), "+v"(BL_[0]));
+#define RING_LREAD_A(AF, BUF, PL) asm volatile("" : "+v"(AF[0]));
+#else
+#define RING_LREAD_B(BH, BL_, BUF) RING_READ_B(BH, BL_, BUF)
+#define RING_LREAD_A(AF, BUF, PL) RING_READ_A(AF, BUF, PL)
+#endif
 #define RING_MMA(AF, BF)                                                                       \
     _Pragma("unroll") for (int i = 0; i < MIV; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i], BF[j], acc[i][j], 0, 0, 0)
@@ -668,33 +682,43 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
     if ((NREAD) > MIV * NI) __builtin_amdgcn_sched_group_barrier(0x100, (NREAD) - MIV * NI, 0);\
     __builtin_amdgcn_sched_barrier(0);
 #endif
+// The step's barrier orders (i) every wave's part of slab T + 1 having landed (each wave waits for its own DMA in front of it) and (ii)
+// the DMA of this step against the fragment reads of the buffer it overwrites - those were issued two steps ago and consumed by the last
+// step's MFMAs.  The fragment reads still in flight (slab T's last ones) touch a buffer nobody writes before the NEXT barrier, by when this
+// step's MFMAs have consumed them: the bare s_barrier is enough, __syncthreads()'s s_waitcnt lgkmcnt(0) in front of it would expose
+// those reads' latency on every step (one wave per SIMD: nothing else runs meanwhile).
+#if CIM_RING_SCHED == 2
+#define RING_BARRIER() __syncthreads()
+#else
+#define RING_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 // one 16-k step: slab T + 1 has landed behind the barrier and buffer (T - 1) % 5 is free (its fragments went into registers at
 // step T - 2): issue slab T + 4 into it, fetch the fragments of slab T + 1, multiply those of slab T
 #define RING_STEP(AH, AL_, BH, BL_, NAH, NAL, NBH, NBL)                                        \
     {                                                                                          \
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                      \
-        __syncthreads();                                                                       \
+        RING_BARRIER();                                                                        \
         const char* nxt = smem + rb * RSTAGE;                                                  \
         const char* wbuf = smem + wb * RSTAGE;                                                 \
         if constexpr (ONEP) {                                                                  \
             sa.issue(ak, wbuf, wave);                                                          \
             sb.issue(bk, wbuf + RSTAGE_A, wave);                                               \
-            RING_READ_B(NBH, NBL, nxt)                                                         \
-            RING_READ_A(NAH, nxt, 0)                                                           \
+            RING_LREAD_B(NBH, NBL, nxt)                                                         \
+            RING_LREAD_A(NAH, nxt, 0)                                                           \
             RING_MMA(AH, BH);                                                                  \
             RING_SCHED(2 * NI + 2 * MIV)                                                       \
         } else {                                                                               \
-            RING_READ_B(NBH, NBL, nxt)                                                         \
+            RING_LREAD_B(NBH, NBL, nxt)                                                         \
             RING_MMA(AL_, BH);                                                                 \
             RING_SCHED(4 * NI)                                                                 \
             sa.issue(ak, wbuf, wave);                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                 \
-            RING_READ_A(NAL, nxt, 1)                                                           \
+            RING_LREAD_A(NAL, nxt, 1)                                                           \
             RING_MMA(AH, BL_);                                                                 \
             RING_SCHED(2 * MIV)                                                                \
             sb.issue_pair(bk, wbuf + RSTAGE_A, wave, 0);                                       \
             __builtin_amdgcn_sched_barrier(0);                                                 \
-            RING_READ_A(NAH, nxt, 0)                                                           \
+            RING_LREAD_A(NAH, nxt, 0)                                                           \
             RING_MMA(AH, BH);                                                                  \
             RING_SCHED(2 * MIV)                                                                \
             sb.issue_pair(bk, wbuf + RSTAGE_A, wave, 1);                                       \
@@ -706,15 +730,23 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
     RING_READ_B(bh0, bl0, smem)
     if constexpr (!ONEP) { RING_READ_A(al0, smem, 1) }
     RING_READ_A(ah0, smem, 0)
+#if CIM_RING_DBG == 5 || CIM_RING_DBG == 6
+    RING_READ_B(bh1, bl1, smem)
+    if constexpr (!ONEP) { RING_READ_A(al1, smem, 1) }
+    RING_READ_A(ah1, smem, 0)
+#endif
     int rb = 1, wb = RSTAGES - 1;           // buffers of slab t + 1 (read) and slab t + 4 (written)
     for (int t = 0; t < nslab; t += 2) {
         RING_STEP(ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
         RING_STEP(ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
     }
 #undef RING_STEP
+#undef RING_BARRIER
 #undef RING_SCHED
 #undef RING_MMA
 #undef RING_READ_A
+#undef RING_LREAD_A
+#undef RING_LREAD_B
 #undef RING_READ_B
     };
     switch (__builtin_amdgcn_readfirstlane(min(MI, (g.M - m0 + 31) / 32))) {
