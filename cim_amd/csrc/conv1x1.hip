@@ -20,6 +20,16 @@
 #include "common.h"
 #include "../../include/cim_hip.h"
 
+// The backbone's kernels run BESIDE MaskFuse's late weight-gradient products in the last phase of the backward pass (the co-resident form
+// of the pair GEMM, csrc/gemm_pair.hip: both on the same CUs) and they are the longer chain: their waves ask for the higher issue priority.
+#ifndef CIM_BODY_PRIO_LEVEL
+#define CIM_BODY_PRIO_LEVEL 3
+#endif
+#if CIM_BODY_PRIO_LEVEL > 0
+#define CIM_BODY_PRIO() __builtin_amdgcn_s_setprio(CIM_BODY_PRIO_LEVEL)
+#else
+#define CIM_BODY_PRIO()
+#endif
 namespace {
 
 #ifndef CIM_SMALL_BK
@@ -217,6 +227,7 @@ __device__ __forceinline__ void small_epilogue(const SmallArgs& g, const f32x16&
 // slabs and by how many tiles are in flight, not by operand traffic.
 template <bool AM, bool BKc, int WN>
 __global__ __launch_bounds__(128 * WN) void gemm_small_kernel(const SmallArgs g) {
+    CIM_BODY_PRIO();
     constexpr int NT = 128 * WN, BNT = 32 * WN;
     constexpr int PA = SBM * 8 / NT, PB = BNT * 8 / NT;          // 16-byte pieces per thread and slab: A 4 / 2, B 2 / 2
     __shared__ __attribute__((aligned(16))) float As[2][SBK * SLD];
@@ -347,6 +358,7 @@ __device__ __forceinline__ float splitk_sum(const float* __restrict__ ws, size_t
     return v;
 }
 __global__ __launch_bounds__(256) void small_splitk_reduce_kernel(const SmallArgs g) {
+    CIM_BODY_PRIO();
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t mn = (size_t)g.M * g.N;
     if (i >= mn) return;
@@ -357,6 +369,7 @@ __global__ __launch_bounds__(256) void small_splitk_reduce_kernel(const SmallArg
 // (profiles/r6/gemm_small_ablation_kernel_trace.txt: 4.4-8.5 us).  Same sums in the same order: bit-identical.  Needs ldc == N,
 // M N % 4 == 0 and 16-byte aligned workspace (the launcher checks); the four elements may straddle a row.
 __global__ __launch_bounds__(256) void small_splitk_reduce4_kernel(const SmallArgs g) {
+    CIM_BODY_PRIO();
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t mn = (size_t)g.M * g.N;
     const size_t i = q * 4;
@@ -386,6 +399,7 @@ __global__ __launch_bounds__(256) void small_splitk_reduce4_kernel(const SmallAr
 // the same with the producer's affine-gradient partial sums (SmallArgs.mpart): a block owns 256 consecutive columns of ONE row,
 // so that every half-wave is one 32-column group of that row.  grid (ceil(N / 256), M)
 __global__ __launch_bounds__(256) void small_splitk_reduce_rows_kernel(const SmallArgs g) {
+    CIM_BODY_PRIO();
     const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
     const size_t mn = (size_t)g.M * g.N;
     float s1 = 0.0f, s2 = 0.0f;
@@ -402,6 +416,7 @@ __global__ __launch_bounds__(256) void small_splitk_reduce_rows_kernel(const Sma
 // flight each -, then one fixed-order sum in LDS.
 struct BnPartTable { cim_bn_part_desc d[24]; int first[25]; int n; };
 __global__ __launch_bounds__(256) void bn_part_finish_kernel(const BnPartTable t) {
+    CIM_BODY_PRIO();
     __shared__ float sh[2][8][32];
     int e = 0;
     while (e + 1 < t.n && (int)blockIdx.x >= t.first[e + 1]) ++e;
@@ -455,6 +470,7 @@ struct ConvGeom { int H, W, Ho, Wo, stride, cin, cout; float inv_w; int dil; }; 
 constexpr int CBK = CIM_CONV3_BK;
 template <int MODE, int KS = 3>
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs g, const ConvGeom c) {
+    CIM_BODY_PRIO();
     constexpr int TAPS = KS * KS;
     constexpr int NT = 256, PA = SBM * (CBK / 4) / NT, PB = SBN * (CBK / 4) / NT;        // sixteen-byte pieces per thread and slab
     extern __shared__ __attribute__((aligned(16))) float c3_smem[];
@@ -643,6 +659,7 @@ __device__ __forceinline__ void small_epilogue_mapped(const SmallArgs& g, const 
 }
 
 __global__ __launch_bounds__(256) void conv3x3_dx2_kernel(const SmallArgs g, const Dx2Geom c) {
+    CIM_BODY_PRIO();
     constexpr int NT = 256, PA = SBM * (CBK / 4) / NT, PB = SBN * (CBK / 4) / NT;
     extern __shared__ __attribute__((aligned(16))) float d2_smem[];
     float (*As)[CBK * SLD] = reinterpret_cast<float (*)[CBK * SLD]>(d2_smem);

@@ -43,6 +43,11 @@ typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
 #ifndef CIM_RING_SCHED
 #define CIM_RING_SCHED 1
 #endif
+#ifndef CIM_RING_PRODUCER
+#define CIM_RING_PRODUCER 0     // 1: a fifth wave issues every LDS-DMA instruction of the workgroup, the four others hold MFMAs and fragment
+#endif                          // reads only.  FASTER ALONE (0.46-0.47 against 0.42-0.43 of the f16 peak: the 256 x 256 kernel's rate) and
+                                // SLOWER WHERE IT IS USED: beside the backbone's backward the last phase takes 3.69 ms with it, 3.60 without
+                                // (the chains' kernels get less of the CU: profiles/r6/gemm_pair_ring_kernel.txt) - not the product's build
 #ifndef CIM_RING_DBG
 #define CIM_RING_DBG 0
 #endif
@@ -66,7 +71,7 @@ constexpr int OPER = 256 * BK * 4;        // 32768 B per operand and slab
 constexpr int SLAB = 2 * OPER;
 constexpr int LDS_BYTES = 2 * SLAB;       // 131072
 // the ring kernel
-constexpr int RBM = 128, RBK = 16, RNT = 256, RSTAGES = 5;
+constexpr int RBM = 128, RBK = 16, RNT = 256 + 64 * CIM_RING_PRODUCER, RSTAGES = 5;
 constexpr int RSTAGE_A = RBM * RBK * 4, RSTAGE_B = BN * RBK * 4, RSTAGE = RSTAGE_A + RSTAGE_B;      // 8 KB + 16 KB
 constexpr int RIPA = RSTAGE_A / 1024 / 4, RIPB = RSTAGE_B / 1024 / 4;                                // LDS-DMA instructions per wave and slab: 2 + 4
 constexpr int RLDS_BYTES = RSTAGES * RSTAGE;      // 122880
@@ -596,13 +601,50 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nslab = (kend - kbeg) / RBK;          // even (K and k_per_split are multiples of 32)
 
+    const char* ak = Ab + (size_t)kbeg * g.lda * 4;
+    const char* bk = Bb + (size_t)kbeg * g.ldb * 4;
+    const size_t a_adv = (size_t)RBK * g.lda * 4, b_adv = (size_t)RBK * g.ldb * 4;
+#if CIM_RING_PRODUCER
+    // The producer wave: all 24 DMA instructions of a slab (8 of A, 16 of B), one slab per step behind the step's barrier; in front of
+    // the barrier of step t it waits for slab t + 1 (s_waitcnt vmcnt(48): slabs t + 2 and t + 3 stay in flight; the counter's 63 are
+    // exceeded right after an issue - the hardware holds the issue back, which only this wave waits for).
+    if (wave == 4) {
+        StageMC<RBM, 4 * RIPA, RBK> pa;
+        StageMC<BN, 4 * RIPB, RBK> pb;
+        pa.init(m0, g.M, g.lda, 0, lane);
+        pb.init(n0, g.N, g.ldb, 0, lane);
+        int left = nslab - 1;
+        for (int q = 0; q < RSTAGES - 1; ++q) {
+            pa.issue(ak, smem + q * RSTAGE, 0);
+            pb.issue(bk, smem + q * RSTAGE + RSTAGE_A, 0);
+            const bool more = left > 0;
+            ak += more ? a_adv : 0;
+            bk += more ? b_adv : 0;
+            left -= more ? 1 : 0;
+        }
+        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int wb = RSTAGES - 1;
+        for (int t = 0; t < nslab; ++t) {
+            asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            pa.issue(ak, smem + wb * RSTAGE, 0);
+            pb.issue(bk, smem + wb * RSTAGE + RSTAGE_A, 0);
+            const bool more = left > 0;
+            ak += more ? a_adv : 0;
+            bk += more ? b_adv : 0;
+            left -= more ? 1 : 0;
+            wb = wb == RSTAGES - 1 ? 0 : wb + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+#else
     StageMC<RBM, RIPA, RBK> sa;
     StageMC<BN, RIPB, RBK> sb;
     sa.init(m0, g.M, g.lda, wave, lane);
     sb.init(n0, g.N, g.ldb, wave, lane);
-    const char* ak = Ab + (size_t)kbeg * g.lda * 4;
-    const char* bk = Bb + (size_t)kbeg * g.ldb * 4;
-    const size_t a_adv = (size_t)RBK * g.lda * 4, b_adv = (size_t)RBK * g.ldb * 4;
+#endif
     FragMC<MI, RBM> fa;
     FragMC<NI, BN> fb;
     fa.init(0, lane);
@@ -625,6 +667,7 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
     // Every step issues exactly one slab's DMA (six instructions per wave), so the wait in front of a step's barrier is always
     // vmcnt(12); past the last slab the source stays on the last one (re-read into buffers nobody consumes: 4 of K / 16 slabs) - no
     // branch around the issue, the step is one basic block.  `left` = slabs the source pointers can still advance by.
+#if !CIM_RING_PRODUCER
     int left = nslab - 1;
     auto advance = [&]() {
 #if CIM_RING_DBG == 7     /* ablation: the DMA re-reads slab 0 for ever (its mechanics with constant data) */
@@ -645,6 +688,17 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
     }
     asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     __syncthreads();
+#define RING_WAIT() asm volatile("s_waitcnt vmcnt(12)" ::: "memory")
+#define RING_ISSUE_A() sa.issue(ak, wbuf, wave)
+#define RING_ISSUE_B(H) sb.issue_pair(bk, wbuf + RSTAGE_A, wave, H)
+#define RING_ADVANCE() advance()
+#else
+    __builtin_amdgcn_s_barrier();       // (slab 0 has landed: the producer waited for it)
+#define RING_WAIT()
+#define RING_ISSUE_A()
+#define RING_ISSUE_B(H)
+#define RING_ADVANCE()
+#endif
 
     auto main_loop = [&](auto miv_c) {
     constexpr int MIV = decltype(miv_c)::value;
@@ -696,13 +750,14 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
 // step T - 2): issue slab T + 4 into it, fetch the fragments of slab T + 1, multiply those of slab T
 #define RING_STEP(AH, AL_, BH, BL_, NAH, NAL, NBH, NBL)                                        \
     {                                                                                          \
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                      \
+        RING_WAIT();                                                                           \
         RING_BARRIER();                                                                        \
         const char* nxt = smem + rb * RSTAGE;                                                  \
         const char* wbuf = smem + wb * RSTAGE;                                                 \
         if constexpr (ONEP) {                                                                  \
-            sa.issue(ak, wbuf, wave);                                                          \
-            sb.issue(bk, wbuf + RSTAGE_A, wave);                                               \
+            RING_ISSUE_A();                                                                    \
+            RING_ISSUE_B(0);                                                                   \
+            RING_ISSUE_B(1);                                                                   \
             RING_LREAD_B(NBH, NBL, nxt)                                                         \
             RING_LREAD_A(NAH, nxt, 0)                                                           \
             RING_MMA(AH, BH);                                                                  \
@@ -711,19 +766,20 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
             RING_LREAD_B(NBH, NBL, nxt)                                                         \
             RING_MMA(AL_, BH);                                                                 \
             RING_SCHED(4 * NI)                                                                 \
-            sa.issue(ak, wbuf, wave);                                                          \
+            RING_ISSUE_A();                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                 \
             RING_LREAD_A(NAL, nxt, 1)                                                           \
             RING_MMA(AH, BL_);                                                                 \
             RING_SCHED(2 * MIV)                                                                \
-            sb.issue_pair(bk, wbuf + RSTAGE_A, wave, 0);                                       \
+            RING_ISSUE_B(0);                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                 \
             RING_LREAD_A(NAH, nxt, 0)                                                           \
             RING_MMA(AH, BH);                                                                  \
             RING_SCHED(2 * MIV)                                                                \
-            sb.issue_pair(bk, wbuf + RSTAGE_A, wave, 1);                                       \
+            RING_ISSUE_B(1);                                                                   \
         }                                                                                      \
-        advance();                                                                             \
+        RING_ADVANCE();                                                                        \
+        (void)wbuf;                                                                            \
         wb = wb == RSTAGES - 1 ? 0 : wb + 1;                                                   \
         rb = rb == RSTAGES - 1 ? 0 : rb + 1;                                                   \
     }
@@ -741,6 +797,10 @@ __global__ __launch_bounds__(RNT, 2) void gemm_pair_ring_kernel(const PairArgs g
         RING_STEP(ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
     }
 #undef RING_STEP
+#undef RING_WAIT
+#undef RING_ISSUE_A
+#undef RING_ISSUE_B
+#undef RING_ADVANCE
 #undef RING_BARRIER
 #undef RING_SCHED
 #undef RING_MMA
