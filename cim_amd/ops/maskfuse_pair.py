@@ -413,8 +413,8 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
                     # (several ranks: RCCL's all-reduce kernels hold CUs of their own while these products run - a launch of exactly
                     # one workgroup per CU would then need a second, nearly empty round each time: the products go out whole)
                     limit = (G.LATE_CUS or DW_WGS) if publisher is None else 0
-                    form = DW_FORM if publisher is None else 0
-                    if form == 1:
+                    form = DW_FORM          # (several ranks as well: whole products either way, and the co-resident form leaves RCCL's
+                    if form == 1:           # kernels and the backbone's chains room on every CU instead of whole CUs taken from a round)
                         limit = DW_FORM1_WGS
                     SCHEDULE["late_launches_chunked" if publisher is None else "late_launches_whole_products"] += 1
                     got = {slot: publish(w, fn(limit, form)) for slot, w, fn in late}
