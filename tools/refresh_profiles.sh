@@ -23,8 +23,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 "$ROOT/tools/pmc_traffic.py" /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE winograd7 f16x2p mix8 --calibrate /tmp/cal_FETCH_SIZE /tmp/cal_WRITE_SIZE > "$OUT/pmc_traffic_resnet50_voc.json"
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"
-rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d /tmp/pmc_mfma -o r -- python3 "$ROOT/tools/bench_gemm_pair.py" --no-old --no-alts --only "pair wino,pair fc1" > "$OUT/pmc_mfma.log" 2>&1
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d /tmp/pmc_mfma -o r -- python3 "$ROOT/tools/bench_gemm_pair.py" --no-old --no-alts --only "pair wino,pair fc1,form1" > "$OUT/pmc_mfma.log" 2>&1
 python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_mfma gemm_pair_kernel > "$OUT/pmc_mfma_gemm_pair.json"
+python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_mfma gemm_pair_ring_kernel > "$OUT/pmc_mfma_gemm_pair_ring.json"
 SQR="SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE"
 rocprofv3 --kernel-trace --pmc $SQR --output-format csv -d /tmp/pmc_roi -o r -- python3 "$ROOT/tools/bench_roi.py" > "$OUT/pmc_roi.log" 2>&1
 python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_roi roi_align roi_partial roi_tables wino7 > "$OUT/pmc_sq_roi_align.json"
@@ -49,9 +50,14 @@ rocprofv3 --kernel-trace --pmc $SQB --output-format csv -d /tmp/pmc_c3 -o r -- p
 python3 "$ROOT/tools/pmc_summary.py" /tmp/pmc_c3 conv3x3_small small_splitk > "$OUT/pmc_sq_backbone_conv3x3.json"
 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_gs -o r -- python3 "$ROOT/tools/bench_gemm_small.py" > /dev/null 2>&1
 python3 "$ROOT/tools/trace_by_dispatch.py" /tmp/kt_gs/r_kernel_trace.csv 20 > "$OUT/gemm_small_kernel_trace.txt"
-# same-box A/B of the round's scheduling changes
-for flag in "" "--no-overlap-update"; do
-  for rep in 1 2 3; do python3 "$ROOT/bench.py" $flag --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.load(sys.stdin); print('${flag:-overlap_update}', round(d['ms_per_step'],3))"; done
-done > "$OUT/overlap_update_ab_refresh.txt"
+# same-box A/B of the round's scheduling changes (interleaved)
+for rep in 1 2 3; do
+  for flag in "" "--no-overlap-update" "--dw-form 0"; do
+    python3 "$ROOT/bench.py" $flag --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.load(sys.stdin); print('${flag:-as shipped}', round(d['ms_per_step'],3))"
+  done
+done > "$OUT/schedule_ab_refresh.txt"
+for rep in 1 2 3; do
+  for flag in "--dw-form 1" "--dw-form 0"; do python3 "$ROOT/tools/diag_late.py" $flag 2>/dev/null | tail -8; done
+done > "$OUT/last_backward_phase_by_stream.txt"
 (cd "$ROOT" && python3 -m pytest tests/test_gpu_tolerance.py tests/test_gpu_fullsize.py -q -m gpu > "$OUT/parity_tests.log" 2>&1; cp gpurun_out/parity_deviation.json "$OUT/parity_deviation.json" 2>/dev/null)
 ls -la "$OUT"
