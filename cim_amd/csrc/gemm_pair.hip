@@ -503,6 +503,27 @@ __global__ __launch_bounds__(NT, NW / 4) void gemm_pair_kernel(const PairArgs g)
 #else
 #define PAIR_FENCE() if constexpr (AL == L_KC && BL == L_KC) __builtin_amdgcn_sched_barrier(0)
 #endif
+// Experiment switch (round 6): the half-step's fragment reads interleaved one to one with its MFMAs, as in the ring kernel, for the
+// instantiations with a K-contiguous A.  With two waves per SIMD the other wave already fills those issue slots: two interleaved runs of
+// tools/bench_gemm_pair.py gave +2.3 / 0 / +1.6 % and +0.4 / -0.2 / +0.9 % (Winograd forward / data gradient / fc1 forward), the
+// M-contiguous instantiations lose 1.7 % - within noise, not the product's build.
+#ifndef CIM_PAIR_SCHED
+#define CIM_PAIR_SCHED 0
+#endif
+#define PAIR_SCHED_ON (CIM_PAIR_SCHED && AL == L_KC)
+#if CIM_PAIR_SCHED
+#define PAIR_NREADS (((AL == L_KC ? 1 : 2) * MIV + (BL == L_KC ? 1 : 2) * NI) * (ONEP ? 1 : 2))
+#define PAIR_SCHED()                                                                           \
+    if constexpr (PAIR_SCHED_ON) {                                                             \
+        _Pragma("unroll") for (int q = 0; q < (ONEP ? 1 : 3) * MIV * NI; ++q) {                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+            if (q < PAIR_NREADS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+#else
+#define PAIR_SCHED()
+#endif
 #if CIM_PAIR_EXP == 3 || CIM_PAIR_EXP == 5       /* ablation: no LDS-DMA in the loop */
 #define PAIR_ISSUE(A, B)
 #else
@@ -529,6 +550,7 @@ __global__ __launch_bounds__(NT, NW / 4) void gemm_pair_kernel(const PairArgs g)
             PAIR_MMA(ah0, bl0);
         }
         PAIR_MMA(ah0, bh0);
+        PAIR_SCHED();
         PAIR_PRIO(0);
         PAIR_FENCE();
         // every wave holds its fragments of slab t and its share of slab t+1 has landed: slab t+1 is complete and
@@ -536,7 +558,8 @@ __global__ __launch_bounds__(NT, NW / 4) void gemm_pair_kernel(const PairArgs g)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 2 < nslab) PAIR_ISSUE(cur, cur + OPER)
-        if (t + 1 < nslab) {
+        if (PAIR_SCHED_ON || t + 1 < nslab) {       /* (unconditional with the interleave - reads and MFMAs in ONE basic block; past the
+                                                        last slab it reads a buffer nobody writes any more) */
             PAIR_READ_L(ah0, al0, bh0, bl0, nxt, 0)
         }
         PAIR_FENCE();
@@ -546,10 +569,12 @@ __global__ __launch_bounds__(NT, NW / 4) void gemm_pair_kernel(const PairArgs g)
             PAIR_MMA(ah1, bl1);
         }
         PAIR_MMA(ah1, bh1);
+        PAIR_SCHED();
         PAIR_PRIO(0);
         PAIR_FENCE();
     }
 #undef PAIR_READ_L
+#undef PAIR_SCHED
 #undef PAIR_ISSUE
 #undef PAIR_FENCE
 #undef PAIR_PRIO

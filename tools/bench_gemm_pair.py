@@ -119,6 +119,7 @@ for tag, al in alts.items():
     cases["%-4s fc1_fwd" % tag] = (lambda al=al: al.cim_gemm_pair(P(pX.buf), P(pW.buf), P(y1), None, N, 4096, K1, K1, K1, 4096, 0, 1, 0, sp(N, 4096, K1), P(ws), P(pX.scale), P(pW.scale), None, 0, PRODUCTS, 0, st), fl_fc)
     cases["%-4s form1 wino_wgrad" % tag] = (lambda al=al: al.cim_gemm_pair_batched(P(pV.buf), P(pD.buf), P(dU), 2 * C, C, NP, 2 * C, C, C, 1, 0, NPOS, pV.bs, pD.bs, 2 * C * C, P(pV.scale), P(pD.scale), 0, PRODUCTS, 1, st), fl_conv)
     cases["%-4s form1 fc1_wgrad" % tag] = (lambda al=al: al.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, 0, PRODUCTS, 1, st), fl_fc)
+    cases["%-4s fc1_dgrad" % tag] = (lambda al=al: al.cim_gemm_pair(P(pY.buf), P(pW.buf), P(dx1), None, N, K1, 4096, 4096, K1, K1, 0, 0, 0, 1, None, P(pY.scale), P(pW.scale), None, 0, PRODUCTS, 0, st), fl_fc)
     cases["%-4s fc1_wgrad" % tag] = (lambda al=al: al.cim_gemm_pair(P(pY.buf), P(pX.buf), P(dw1), None, 4096, K1, NP, 4096, K1, K1, 1, 0, 0, 1, None, P(pY.scale), P(pX.scale), None, 0, PRODUCTS, 0, st), fl_fc)
 if not args.no_old:
     Vr, Vc = _amax(V, NP, 2 * C, 2 * C, True, True, NPOS, NP * 2 * C)
