@@ -229,7 +229,12 @@ def test_pair_gemm_co_resident_form_is_bit_identical(dev):
     assert _lib.call("cim_gemm_pair_splits", 296, 264, 8192) > 1
     Xs, Ys = torch.randn(1000, 1024, generator=g).to(dev), torch.randn(1000, 640, generator=g).to(dev)
     pxs, pys = pair.split(Xs), pair.split(Ys)
-    cases = ((px, py, M, N, pair.pad32(R)), (pxl, pyl, 296, 264, 8192), (pxs, pys, 1024, 640, pair.pad32(1000)))
+    Xt, Yt = torch.randn(20, 8, generator=g).to(dev), torch.randn(20, 16, generator=g).to(dev)      # one ragged tile, two 16-k slabs
+    pxt, pyt = pair.split(Xt), pair.split(Yt)
+    Xu, Yu = torch.randn(90, 136, generator=g).to(dev), torch.randn(90, 520, generator=g).to(dev)   # six slabs: the ring wraps once
+    pxu, pyu = pair.split(Xu), pair.split(Yu)
+    cases = ((px, py, M, N, pair.pad32(R)), (pxl, pyl, 296, 264, 8192), (pxs, pys, 1024, 640, pair.pad32(1000)),
+             (pxt, pyt, 8, 16, 32), (pxu, pyu, 136, 520, 96))
     for a, b, m, n, k in cases:
         ref = pair.gemm(a, b, m, n, k, True, False)
         for limit in (0, 7):
