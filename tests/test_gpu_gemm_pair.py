@@ -239,6 +239,8 @@ def test_pair_gemm_co_resident_form_is_bit_identical(dev):
         ref = pair.gemm(a, b, m, n, k, True, False)
         for limit in (0, 7):
             assert torch.equal(ref, pair.gemm(a, b, m, n, k, True, False, limit=limit, form=1)), (m, n, k, limit)
+        one = pair.gemm(a, b, m, n, k, True, False, products=1)                    # (the one-product instantiation of both kernels)
+        assert torch.equal(one, pair.gemm(a, b, m, n, k, True, False, products=1, form=1)), (m, n, k, "products=1")
     want = Xs.double().t() @ Ys.double()
     scale = Xs.double().abs().t() @ Ys.double().abs()
     assert float(((pair.gemm(pxs, pys, 1024, 640, pair.pad32(1000), True, False, form=1).double() - want).abs() / scale).max()) < 2e-6
