@@ -238,7 +238,12 @@ def defer_side_join(dev, param, dw, *keep):
 def _deferred_entry(dev):
     ent = _DEFERRED.get(dev)
     if ent is None or not (ent[1] or ent[2] or ent[3]):
-        ent = _DEFERRED[dev] = [torch.cuda.current_stream(dev), [], [], []]
+        cur = torch.cuda.current_stream(dev)
+        # the first deferral of a pass names the stream that joins (and runs the finishers): the stream the backward runs on - a
+        # caller inside `with torch.cuda.stream(side)` would make the SIDE stream wait for itself and the pass's own stream for nothing
+        if any(cur == st for st in [_SIDE.get(dev)] + _extra_streams(dev) if st is not None):
+            raise RuntimeError("cim_amd: defer_side_join / defer_finisher called under a side stream's context")
+        ent = _DEFERRED[dev] = [cur, [], [], []]
         engine.queue_callback(join_side)
     return ent
 

@@ -179,6 +179,7 @@ def _head_forward(ctx, V, r, cin, p, wc, bc, w1, b1, w2, b2):
     ctx.dims = (r, cin, cout, h1, h2, p)
     ctx.has_bias = (bc is not None, b1 is not None, b2 is not None)
     ctx.weights = (wc, w1, w2)           # the Parameter objects: big gradients may be published early (see backward)
+    ctx.biases = (bc, b1, b2)            # (their gradients' last reduction may leave the critical chain with the late products)
     return Y2
 
 
@@ -314,18 +315,35 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
 
         wc_p, w1_p, w2_p = ctx.weights
         dcat = dwc = dbc = dw1 = db1 = dw2 = db2 = None
+        # The bias gradients are column sums whose partial sums fall out of kernels of the data-gradient chain; the LAST reduction of
+        # each (a 10 us launch + its boundary, three per step) leaves the chain with the postponed late products: it runs on their
+        # stream and the gradient is installed at the end-of-backward join like the weights' (same sums, same order).
+        needed = [w for w, need in ((w2_p, need_w2), (w1_p, need_w1), (wc_p, need_wc)) if need]
+        will_postpone = (run_late and G.POSTPONE_DW and publisher is None and len(needed) > 0
+                         and all(isinstance(w, torch.nn.Parameter) for w in needed))
+        bc_p, b1_p, b2_p = getattr(ctx, "biases", (None, None, None))
+        late_bias = []          # (bias Parameter, partial sums)
+
+        def bias_sum(b_p, part):
+            if part is None:
+                return None
+            if will_postpone and isinstance(b_p, torch.nn.Parameter):
+                # (the result belongs to the step's stream - the optimizer reads it there: allocated here, written on the late stream)
+                late_bias.append((b_p, part, torch.empty(part.shape[1], dtype=part.dtype, device=part.device)))
+                return None
+            return part.sum(dim=0)
         dy_keep = []
         am = torch.zeros(3, dtype=torch.int32, device=dev)
         # ---- fc2
         # (the ReLU mask is applied by the split; one launch gives max |dz| and the bias gradient's partial sums)
         dY2 = dY2.contiguous()
-        db2 = pair.masked_stats(dY2, Y2, am[0:1], ctx.has_bias[2] and ctx.needs_input_grad[6 + ofs])
+        db2 = bias_sum(b2_p, pair.masked_stats(dY2, Y2, am[0:1], ctx.has_bias[2] and ctx.needs_input_grad[6 + ofs], reduce=False))
         dY2p = pair.split(dY2, r, h2, h2, scale=pair.scales_from(am[0:1], 1), relu_y=Y2)
         if need_w2:
             dw2 = side_grad(2, w2_p, lambda limit=0, form=0: pair.gemm(dY2p, Y1p, h2, h1, rp, True, False, limit=limit, form=form))
         dY1 = pair.gemm(dY2p, W2p, r, h1, h2, False, False)
         # ---- fc1
-        db1 = pair.masked_stats(dY1, Y1, am[1:2], ctx.has_bias[1] and ctx.needs_input_grad[4 + ofs])
+        db1 = bias_sum(b1_p, pair.masked_stats(dY1, Y1, am[1:2], ctx.has_bias[1] and ctx.needs_input_grad[4 + ofs], reduce=False))
         dY1p = pair.split(dY1, r, h1, h1, scale=pair.scales_from(am[1:2], 1), relu_y=Y1)
         if need_w1:
             dw1 = side_grad(1, w1_p, lambda limit=0, form=0: pair.gemm(dY1p, Xp, h1, cout * p * p, rp, True, False, limit=limit, form=form))
@@ -360,7 +378,7 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
                 _lib.call("cim_flatten_chw_bwd_bias", dX.data_ptr(), y.data_ptr(), dy.data_ptr(), _lib.ptr(bpart), r, p * p, cout, st)
             del dX
             if want_dbc:
-                dbc = bpart.sum(dim=0)          # per-ROI partial sums from the flatten kernel: 4 MB instead of a pass over dy
+                dbc = bias_sum(bc_p, bpart)     # per-ROI partial sums from the flatten kernel: 4 MB instead of a pass over dy
             if need_wc:
                 def wgrad(limit=0, form=0, D=D):
                     st2 = _lib.stream_ptr()
@@ -418,7 +436,15 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
                         limit = DW_FORM1_WGS
                     SCHEDULE["late_launches_chunked" if publisher is None else "late_launches_whole_products"] += 1
                     got = {slot: publish(w, fn(limit, form)) for slot, w, fn in late}
+                    if defer:
+                        for b_p, part, out in late_bias:
+                            part.record_stream(late_st)
+                            out.record_stream(late_st)
+                            torch.sum(part, dim=0, out=out)
                 if defer:           # (postponed: this node has returned - the join bookkeeping of the block below happens here)
+                    # (OUTSIDE the late stream's context: the first deferral of a pass records the CURRENT stream as the one to join)
+                    for b_p, part, out in late_bias:
+                        G.defer_side_join(dev, b_p, out, part)
                     keep = [t for t in (V.buf, V.scale, Xp.buf, Xp.scale, Y1p.buf, Y1p.scale, dY2p.buf, dY2p.scale, dY1p.buf,
                                         dY1p.scale, am) if t is not None] + dy_keep
                     for slot, w, _ in late:
@@ -434,8 +460,11 @@ def _head_backward(ctx, dY2, ofs, fold_masks=None):
                 SCHEDULE["late_launches_postponed_behind_roi_align"] += 1
                 G.postpone(dev, lambda: launch(True))
             else:
+                assert not late_bias, "bias partial sums were left to a postponed launch that does not happen"
                 got = launch(False)
                 dwc, dw1, dw2 = got.get(0, dwc), got.get(1, dw1), got.get(2, dw2)
+        else:
+            assert not late_bias, "bias partial sums were left to a postponed launch that does not happen"
         if overlap:
             # operands the side stream's GEMMs read: the allocator must not hand their memory out before that work is done,
             # whichever way (join here, deferred join, DataParallel's all-reduce) the weight gradients leave this node

@@ -48,13 +48,16 @@ def amax_of(x, out=None):
     return out
 
 
-def masked_stats(dy, y, amax, want_colsum):
+def masked_stats(dy, y, amax, want_colsum, reduce=True):
     """ReLU backward in front of a split, dz = y > 0 ? dy : 0 (not stored: split(dy, relu_y=y) applies the same mask): max |dz| into
-    the zeroed int32[1] `amax`; -> column sums of dz (the layer's bias gradient) or None."""
+    the zeroed int32[1] `amax`; -> column sums of dz (the layer's bias gradient) or None.  reduce=False: the per-64-row partial sums
+    [ceil(rows / 64)][cols] instead (the caller sums them over dim 0 where it suits it: ops/maskfuse_pair.py, off the critical chain)."""
     rows, cols = dy.shape
     part = torch.empty(((rows + 63) // 64, cols), dtype=torch.float32, device=dy.device) if want_colsum else None
     _lib.call("cim_pair_masked_stats", dy.data_ptr(), y.data_ptr(), rows, cols, _lib.ptr(part), amax.data_ptr(), _lib.stream_ptr())
-    return part.sum(dim=0) if want_colsum else None
+    if not want_colsum:
+        return None
+    return part.sum(dim=0) if reduce else part
 
 
 def scales_from(amax, n=1, factor=None, reduce_all=False):
