@@ -251,9 +251,9 @@ class MaskFuseRoiPairFunction(Function):
             gcat = dbox.permute(0, 2, 3, 1)                  # [K,7,7,C] (channels-last): dcat's halves already combined with the masks
             assert gcat.is_contiguous()
             dfeat = RA._empty_nhwc(B, C, H, W, gcat)
+            scratch = RA._scratch(K, B, C, H, W, gcat.device)        # (a name, not a temporary inside the call: it must outlive the LAUNCH)
             _lib.call("cim_roi_align_bwd_ws", gcat.data_ptr(), rois.data_ptr(), dfeat.data_ptr(),
-                      B, C, H, W, K, P, scale, sr, aligned, tables.data_ptr(), 1,
-                      _lib.ptr(RA._scratch(K, B, C, H, W, gcat.device)), _lib.stream_ptr())
+                      B, C, H, W, K, P, scale, sr, aligned, tables.data_ptr(), 1, _lib.ptr(scratch), _lib.stream_ptr())
             G.run_postponed(gcat.device)         # this node's late weight gradients start behind the ROIAlign backward
         return dfeat, None, None, dwc, dbc, dw1, db1, dw2, db2, None, None, None
 

@@ -42,7 +42,8 @@ def _workspace(k, p, h, w, device):
 
 
 def _scratch(k, b, c, h, w, device):
-    """Per-ROI-group partial maps of the region-form backward (freed right after the call)."""
+    """Per-ROI-group partial maps of the region-form backward (the caller frees them after the launch: the caching allocator hands
+    the block out again in stream order)."""
     nbytes = _lib.call("cim_roi_align_bwd_scratch", k, b, c, h, w)
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device) if nbytes else None
 
@@ -77,9 +78,9 @@ class RoIAlignFunction(Function):
         grad_out = _nhwc(grad_out)
         grad_in = _empty_nhwc(B, C, H, W, grad_out)
         ws = ctx.tables if ctx.tables is not None else _workspace(K, P, H, W, grad_out.device)
+        scratch = _scratch(K, B, C, H, W, grad_out.device)      # (a name, not a temporary inside the call: it must outlive the LAUNCH)
         _lib.call("cim_roi_align_bwd_ws", grad_out.data_ptr(), rois.data_ptr(), grad_in.data_ptr(), B, C, H, W, K, P,
-                  scale, sr, aligned, ws.data_ptr(), int(ctx.tables is not None),
-                  _lib.ptr(_scratch(K, B, C, H, W, grad_out.device)), _lib.stream_ptr())
+                  scale, sr, aligned, ws.data_ptr(), int(ctx.tables is not None), _lib.ptr(scratch), _lib.stream_ptr())
         return grad_in, None, None, None, None, None
 
 
@@ -114,9 +115,10 @@ class RoIAlignMaskCatFunction(Function):
         grad_cat = _nhwc(grad_cat)
         grad_in = _empty_nhwc(B, C, H, W, grad_cat)
         ws = ctx.tables if ctx.tables is not None else _workspace(K, P, H, W, grad_cat.device)
+        scratch = _scratch(K, B, C, H, W, grad_cat.device)
         _lib.call("cim_roi_align_maskcat_bwd_ws", grad_cat.data_ptr(), rois.data_ptr(), masks.data_ptr(),
                   grad_in.data_ptr(), B, C, H, W, K, P, scale, sr, aligned, ws.data_ptr(), int(ctx.tables is not None),
-                  _lib.ptr(_scratch(K, B, C, H, W, grad_cat.device)), _lib.stream_ptr())
+                  _lib.ptr(scratch), _lib.stream_ptr())
         _gemm.run_postponed(grad_cat.device)        # MaskFuse's late weight gradients start behind this launch (ops/gemm.py)
         return grad_in, None, None, None, None, None, None
 

@@ -267,7 +267,8 @@ def test_pair_engine_error_class(dev, K):
         c32 = torch.empty(M, N, device=dev)          # the true-fp32 MFMA comparator: v_mfma_f32_32x32x2_f32 (csrc/conv1x1.hip)
         splits = _lib.call("cim_gemm_small_splits", M, N, K)
         ws = torch.empty(splits * M * N, device=dev)
-        _lib.call("cim_gemm_small_f32", A.to(dev).data_ptr(), B.to(dev).data_ptr(), c32.data_ptr(), M, N, K, K, N, N, 0, 0,
+        Ad, Bd = A.to(dev), B.to(dev)                # (names: the operands must outlive the launch)
+        _lib.call("cim_gemm_small_f32", Ad.data_ptr(), Bd.data_ptr(), c32.data_ptr(), M, N, K, K, N, N, 0, 0,
                   None, None, None, None, None, 0.0, None, 0, splits, ws.data_ptr(), _lib.stream_ptr())
         err_f32 = float(((c32.cpu().double() - ref).abs() / scale).max())
         assert err_pair < 2e-6 and err_pair < 2.0 * err_f32 + 1e-7, (spread, err_pair, err_f32)
